@@ -1,0 +1,177 @@
+"""Pins the CPU oracle against vectors produced by the reference itself (tools/make_golden.py).
+
+Tolerances: the fp32 noise floor of the whole path vs fp64 is 2.5e-6 rel on RGB and 3.2e-5 rel on
+Rho, and the oracle orders a few fp32 operations differently from the reference
+(exclusive cumsum, addmm), so fp32 comparisons use 2e-5 abs+rel; anything looser is stated inline.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import season_nerf_oracle as orc
+
+TOL = dict(rtol=2e-5, atol=2e-5)
+
+
+def load(golden_dir, name):
+    return dict(np.load(os.path.join(golden_dir, name), allow_pickle=False))
+
+
+def T(a):
+    return torch.tensor(np.asarray(a), dtype=torch.float32)
+
+
+def close(a, b, **kw):
+    kw = {**TOL, **kw}
+    a = a.detach().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    np.testing.assert_allclose(a.reshape(np.asarray(b).shape), b, **kw)
+
+
+def test_micro_known_answers(golden_dir):
+    g = load(golden_dir, "micro.npz")
+    close(orc.pe_encode(T(g["pe2_in"]), 2), g["pe2_out"], atol=1e-6)
+    # SURVEY A.8 literal
+    lit = [0.5, -1, 0.7071068, -4.37e-8, 0.7071068, 1.0, -4.37e-8, -1, -1, 8.74e-8]
+    close(orc.pe_encode(T([[0.5, -1.0]]), 2), np.array([lit], dtype=np.float32), atol=1e-6)
+    close(orc.pe_encode(T(g["pe10_in"]), 10), g["pe10_out"], atol=2e-6)
+    top, bot = T([[.1, .2, 1.]]), T([[.3, -.2, -1.]])
+    p, d = orc.sample_pt_coarse(top, bot, 4, True)
+    close(p, g["samp_pts"]); close(d, g["samp_delta"])
+    assert abs(float(d[0, 0, 0]) - 0.512348) < 1e-6
+    p, _ = orc.sample_pt_coarse(top, bot, 4, True, include_end_pt=True)
+    close(p, g["samp_pts_end"])
+    rho, dl = T([1, 2, .5, 3]).reshape(1, 4, 1), torch.full((1, 4, 1), 0.5)
+    close(orc.get_PV(rho, dl).reshape(-1), np.array([1, .606531, .223130, .173774], dtype=np.float32), atol=1e-6)
+    close((1 - torch.exp(-rho * dl)).reshape(-1), np.array([.393469, .632121, .221199, .776870], dtype=np.float32), atol=1e-6)
+    v = orc.world_angle_2_local_vec(60, 30, np.array([41.29, -95.9, 300]), np.eye(4))
+    np.testing.assert_allclose(v, g["wa2lv"], rtol=1e-12)
+    np.testing.assert_allclose(v, [0.0352731, -0.0819149, 0.99601494], atol=1e-7)
+    WC = np.array([41.29, -95.9, 300.0])
+    H4 = np.array([[310.0, 12.0, 0.0, -11650.0], [-9.0, 240.0, 0.0, 23390.0], [0.0, 0.0, 0.01, -3.0], [0, 0, 0, 1.0]])
+    np.testing.assert_allclose(orc.world_angle_2_local_vec(35, -100, WC, H4), g["wa2lv_H"], rtol=1e-12)
+    x, y, _ = orc.invert_P(g["P"], g["invP_row"], g["invP_col"], float(g["invP_h"]))
+    np.testing.assert_allclose(x, g["invP_x"], rtol=1e-10)
+    np.testing.assert_allclose(y, g["invP_y"], rtol=1e-10)
+
+
+def test_param_count():
+    n = lambda sd: sum(v.numel() for k, v in sd.items() if "running" not in k and "num_batches" not in k)
+    assert n(orc.init_weights(256, 4)) == 827884
+    assert n(orc.init_weights(512, 4)) == 3195820
+
+
+@pytest.mark.parametrize("name", ["net_W64_s0.npz", "net_W256_s1.npz"])
+def test_network_forwards(golden_dir, name):
+    g = load(golden_dir, name)
+    sd = orc.init_weights(int(g["W"]), int(g["C"]), int(g["seed"]))
+    X, sun, tim = T(g["X"]), T(g["sun"]), T(g["time"])
+    with torch.no_grad():
+        keys = ["Rho", "Col", "Solar_Vis", "Sky_Col", "Class", "Adjust"]
+        for k, v in zip(keys, orc.forward(sd, X, sun, tim)):
+            close(v, g["fwd_" + k])
+        for tag in ("sep", "full"):
+            for k, v in zip(keys, orc.forward_separate(sd, X, sun, tim)):
+                close(v, g[f"{tag}_{k}"])
+        r = orc.forward_solar(sd, X, sun, tim)
+        close(r[0], g["solar_Rho"]); close(r[1], g["solar_Solar_Vis"]); close(r[2], g["solar_Sky_raw"])
+        close(orc.forward_sigma_only(sd, X), g["sigma_only"])
+        close(orc.class_probs(sd, tim), g["class_only"])
+
+
+def rays(g):
+    return {k: T(g["in_" + k]) for k in ["Top", "Bot", "Sun_Angle", "Time_Encoded", "GT_Color"]}
+
+
+@pytest.mark.parametrize("name", ["eval_W256_R64_S96.npz", "eval_W64_R48_S64.npz"])
+def test_eval_rays(golden_dir, name):
+    g = load(golden_dir, name)
+    sd = orc.init_weights(int(g["W"]), int(g["C"]), int(g["seed"]))
+    S, data = int(g["S"]), rays(g)
+    with torch.no_grad():
+        out = orc.eval_rays(sd, data, S, train_mode=False)
+        for k in ["Rendered_Col", "Albedo_Color", "PE", "PV", "PS", "Rho", "Col", "Solar_Vis", "Sky_Col", "Classes",
+                  "Adjust", "deltas", "sample_pts"]:
+            close(out[k], g["eval_" + k])
+        loc, dist = orc.surface_depth(out["PS"], out["sample_pts"], out["deltas"])
+        close(loc, g["eval_surf_loc"], rtol=1e-4, atol=1e-5); close(dist, g["eval_surf_dist"], rtol=1e-4, atol=1e-5)
+        close(orc.eval_rays(sd, data, S, False, classic_solar=True)["Rendered_Col"], g["classic_Rendered_Col"])
+        o = orc.eval_rays(sd, data, S, train_mode=True, jitter=T(g["jitter"]))
+        close(o["sample_pts"], g["jit_sample_pts"], atol=1e-6)
+        close(o["Rendered_Col"], g["jit_Rendered_Col"]); close(o["Rho"], g["jit_Rho"])
+        o = orc.eval_rho_only(sd, data, S, train_mode=False)
+        for k in ["PE", "PV_Exact", "Solar_Vis", "Sky_Col"]:
+            close(o[k], g["rho_only_" + k])
+        if "hm" in g:
+            o = orc.eval_rays(sd, data, S, False, use_prior=True, hm=g["hm"],
+                              trust=int(g["prior_step"]) / int(g["prior_n_steps"]))
+            for k in ["Rendered_Col", "Rendered_Col_Supervised", "Rendered_Col_Merged", "PS_Supervised", "PS_Merged",
+                      "Rho_Merged", "Albedo_Color", "PE_Supervised"]:
+                close(o[k], g["prior_" + k], rtol=1e-4, atol=2e-5)
+
+
+def test_train_step_mse(golden_dir):
+    """get_loss (MSE) + backward + BN running stats + one Adam step, train-mode BatchNorm."""
+    g = load(golden_dir, "train_W64_R32_S32.npz")
+    sd = orc.init_weights(int(g["W"]), int(g["C"]), int(g["seed"]))
+    names = [k[5:] for k in g if k.startswith("grad_")]
+    for n in names:
+        sd[n] = sd[n].clone().requires_grad_(True)
+    data = rays(g)
+    solar = {k: T(g["solar_" + k]) for k in ["Top", "Bot", "Sun_Angle"]}
+    bn1, bn2 = orc.BNState(), orc.BNState()
+    loss, _ = orc.get_loss_mse(sd, data, solar, int(g["S"]), float(g["sc_lambda"]), train_mode=True, train_bn=True,
+                               jitter=T(g["jitter"]), jitter_solar=T(g["jitter_solar"]), bn_out=bn1, bn_out_solar=bn2)
+    for k, (v, w) in loss.items():
+        close(v, g["loss_" + k], rtol=1e-4, atol=1e-6)
+        assert abs(w - float(g["weight_" + k])) < 1e-9
+    total = orc.total_loss(loss)
+    close(total, g["total"], rtol=1e-4)
+    total.backward()
+    gmax = max(np.abs(g["grad_" + n]).max() for n in names)
+    for n in names:
+        ref = g["grad_" + n]
+        # a Linear bias in front of a train-mode BatchNorm has an exactly-zero gradient (pure rounding noise in
+        # both implementations), so scale by the layer's own magnitude but never below 1e-3 of the global one
+        scale = max(np.abs(ref).max(), 1e-3 * gmax)
+        np.testing.assert_allclose(sd[n].grad.numpy() / scale, ref / scale, atol=2e-3, err_msg=n)
+    # BN EMA: two passes per step (image rays then solar rays), Eval_Tools_2.py:347-352
+    for lname, (m1, v1) in bn1.updates.items():
+        sd2 = dict(sd); sd2[lname + ".norm.running_mean"], sd2[lname + ".norm.running_var"] = m1, v1
+        # second pass starts from the first pass's EMA
+        m_b = (bn2.updates[lname][0] - 0.99 * sd[lname + ".norm.running_mean"]) / 0.01
+        v_b = (bn2.updates[lname][1] - 0.99 * sd[lname + ".norm.running_var"]) / 0.01
+        close(0.99 * m1 + 0.01 * m_b, g["bn_" + lname + ".norm.running_mean"], rtol=1e-4, atol=1e-5)
+        close(0.99 * v1 + 0.01 * v_b, g["bn_" + lname + ".norm.running_var"], rtol=1e-4, atol=1e-5)
+    for n in names:
+        if np.abs(g["grad_" + n]).max() < 1e-3 * gmax:
+            continue        # zero-gradient biases: Adam turns rounding noise into +-lr steps, not comparable
+        p = sd[n].detach()
+        new, _, _ = orc.adam_step(p, sd[n].grad, torch.zeros_like(p), torch.zeros_like(p), 1, float(g["lr"]))
+        # first Adam step moves every weight by ~lr*sign(grad); compare the step itself
+        np.testing.assert_allclose((new - p).numpy(), g["adam_" + n] - p.numpy(), atol=0.05 * float(g["lr"]) + 1e-9,
+                                   err_msg=n)
+
+
+def test_renderers(golden_dir):
+    g = load(golden_dir, "render_W64_s2.npz")
+    sd = orc.init_weights(int(g["W"]), int(g["C"]), int(g["seed"]))
+    WC, H = g["WC"], g["H"]
+    imgs, mask, _ = orc.quick_run_render(sd, (60, 30), (45, 120), 0.25, 24, WC, H)
+    assert (mask == g["qr_mask"]).all()
+    close(imgs["Col_Img"], g["qr_Col_Img"]); close(imgs["Shadow_Mask"], g["qr_Shadow_Mask"])
+    np.testing.assert_allclose(orc.quick_run_dsm(sd, (16, 16), WC, H), g["qr_DSM"], rtol=1e-4, atol=2e-5)
+    size = (12, 12, 48)
+    d = orc.render_by_dir(sd, (80, 0), (30, 90), 0.25, size, WC, H)
+    for k in ["Rho", "Base_Col", "Est_Solar_Vis", "Deltas", "World_Points", "Adjust_col"]:
+        close(d[k], g["dir_" + k])
+    close(d["Output_class"][0, 0], g["dir_Output_class0"]); close(d["Sky_Col"][0, 0], g["dir_Sky_Col0"])
+    im = orc.images_from_dict(d, size)
+    for k in ["Base_Img", "Season_Adj_Img", "Shadow_Adjust", "Shadow_Mask", "Raw_Shadow_Mask"]:
+        np.testing.assert_allclose(im[k], g["img_" + k], rtol=1e-4, atol=2e-5)
+    with torch.no_grad():
+        cls = orc.class_probs(sd, T(np.stack([orc.encode_time(k / 12.0) for k in range(12)]))).numpy()
+    close(cls, g["sweep_classes"])
+    sw = orc.images_t_step(d, size, g["sweep_classes"].astype(np.float64))
+    np.testing.assert_allclose(sw, g["sweep_imgs"], rtol=1e-4, atol=2e-5)

@@ -1,0 +1,268 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running the REFERENCE itself.
+
+Runs only in the build container (needs /root/reference, which never travels to the GPU box).
+Nothing of the reference's source is copied: the reference is imported by path, fed weights from
+OUR deterministic generator (oracle.init_weights) through `load_state_dict`, and only arrays
+(inputs and the reference's outputs) are saved.  Recipe for the import stubs: SURVEY.md App. B.
+
+    python tools/make_golden.py            # rewrites tests/golden/*.npz
+"""
+import os
+import sys
+from types import SimpleNamespace
+from unittest.mock import MagicMock
+
+import numpy as np
+import scipy.stats  # noqa: F401  (import the real heavy deps before stubbing)
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+OUT = os.path.join(REPO, "tests", "golden")
+
+np.NaN = np.nan  # numpy 2.x removed the alias the reference uses (harness-side shim)
+for n in ['cv2', 'hsluv', 'gdal', 'rpcm', 'robust_loss_pytorch', 'sewar', 'sewar.full_ref', 'maxflow',
+          'pyfftw', 'pyfftw.interfaces', 'pyfftw.interfaces.scipy_fftpack',
+          'astropy', 'astropy.coordinates', 'astropy.time', 'astropy.units', 'torch.utils.tensorboard']:
+    m = MagicMock(name=n)
+    m.__path__ = []
+    sys.modules[n] = m
+sys.path.insert(0, REF)
+sys.path.insert(0, REPO)
+
+from T_NeRF_Full_2.T_NeRF_net_v2 import T_NeRF            # noqa: E402
+from T_NeRF_Full_2.Eval_Tools_2 import All_in_One_Eval    # noqa: E402
+from T_NeRF_Full_2.Quick_Run import Quick_Run_Net, encode_time  # noqa: E402
+from T_NeRF_Eval_Utils.mg_Img_Eval import (component_render_by_dir, get_imgs_from_Img_Dict,   # noqa: E402
+                                           get_imgs_from_Img_Dict_t_step)
+from all_NeRF.mg_unit_converter import world_angle_2_local_vec  # noqa: E402
+from pre_NeRF.P_Img import P_img_Pinhole                   # noqa: E402
+import misc                                                # noqa: E402
+
+from oracle import season_nerf_oracle as orc               # noqa: E402
+
+WC = np.array([41.29, -95.9, 300.0])
+H4 = np.array([[310.0, 12.0, 0.0, -11650.0], [-9.0, 240.0, 0.0, 23390.0], [0.0, 0.0, 0.01, -3.0], [0, 0, 0, 1.0]])
+
+
+def f32(x):
+    if isinstance(x, torch.Tensor):
+        x = x.detach().cpu().numpy()
+    return np.asarray(x, dtype=np.float32)
+
+
+def make_net(W, C, seed, hm=None, train=False):
+    sd = orc.init_weights(W, C, seed)
+    net = T_NeRF(W, C) if hm is None else T_NeRF(W, C, HM=hm)
+    missing = net.load_state_dict(sd, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    net.train(train)
+    return net, sd
+
+
+def synth_rays(R, seed, per_ray_time=True):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    top = np.concatenate([rng.uniform(-1, 1, (R, 2)), np.ones((R, 1))], 1)
+    bot = np.concatenate([rng.uniform(-1, 1, (R, 2)), -np.ones((R, 1))], 1)
+    sun = rng.uniform(0, 1, (R, 3))
+    sun /= np.linalg.norm(sun, axis=1, keepdims=True)
+    tau, d = rng.uniform(0, 1, R), rng.uniform(0, 1, R)
+    tim = np.stack([np.cos(2 * np.pi * tau), np.sin(2 * np.pi * tau), np.cos(2 * np.pi * d), np.sin(2 * np.pi * d)], 1)
+    gt = rng.uniform(0, 1, (R, 3))
+    t = lambda a: torch.tensor(a, dtype=torch.float32)
+    return {"Top": t(top), "Bot": t(bot), "Sun_Angle": t(sun), "Time_Encoded": t(tim), "GT_Color": t(gt)}
+
+
+def args_ns(S, classic=False):
+    return SimpleNamespace(n_samples=S, Use_Reg=True, Solar_Type_2=classic, Use_MSE_loss=True, Use_Solar=True,
+                           sc_lambda=0.03, number_low_frequency_cases=4)
+
+
+def gen_net(W, seed, N, tag):
+    net, _ = make_net(W, 4, seed)
+    rng = np.random.Generator(np.random.PCG64(100 + seed))
+    X = torch.tensor(rng.uniform(-1, 1, (N, 3)), dtype=torch.float32)
+    sun = rng.uniform(0, 1, (N, 3))
+    sun /= np.linalg.norm(sun, axis=1, keepdims=True)
+    sun = torch.tensor(sun, dtype=torch.float32)
+    tau = rng.uniform(0, 1, (N, 2))
+    tim = torch.tensor(np.concatenate([np.cos(2 * np.pi * tau[:, :1]), np.sin(2 * np.pi * tau[:, :1]),
+                                       np.cos(2 * np.pi * tau[:, 1:]), np.sin(2 * np.pi * tau[:, 1:])], 1),
+                       dtype=torch.float32)
+    out = {"W": W, "C": 4, "seed": seed, "X": f32(X), "sun": f32(sun), "time": f32(tim)}
+    with torch.no_grad():
+        for name, fn in [("fwd", net.forward), ("sep", net.forward_seperate), ("full", net.forward_full_eval)]:
+            r = fn(X, sun, tim)
+            for i, k in enumerate(["Rho", "Col", "Solar_Vis", "Sky_Col", "Class", "Adjust"]):
+                out[f"{name}_{k}"] = f32(r[i])
+        r = net.forward_Solar(X, sun, tim)
+        out["solar_Rho"], out["solar_Solar_Vis"], out["solar_Sky_raw"] = f32(r[0]), f32(r[1]), f32(r[2])
+        out["sigma_only"] = f32(net.forward_Classic_Sigma_Only(X))
+        out["class_only"] = f32(net.get_class_only(tim))
+    np.savez_compressed(os.path.join(OUT, f"net_{tag}.npz"), **out)
+
+
+EVAL_KEYS = ["Rendered_Col", "Albedo_Color", "PE", "PV", "PS", "Rho", "Col", "Solar_Vis", "Sky_Col", "Classes",
+             "Adjust", "deltas", "sample_pts"]
+
+
+def gen_eval(W, seed, R, S, tag, with_prior):
+    hm = None
+    if with_prior:
+        rng = np.random.Generator(np.random.PCG64(7))
+        hm = rng.uniform(-0.8, 0.6, (64, 64))
+    net, _ = make_net(W, 4, seed, hm=hm)
+    data = synth_rays(R, 200 + seed)
+    out = {"W": W, "C": 4, "seed": seed, "S": S}
+    for k, v in data.items():
+        out["in_" + k] = f32(v)
+    with torch.no_grad():
+        ev = All_in_One_Eval(args_ns(S), torch.device("cpu"), 10, False, None, H4, WC)
+        r = ev.eval(data, net, 0, False)
+        for k in EVAL_KEYS:
+            out["eval_" + k] = f32(r[k])
+        loc = torch.sum(r["PS"] * r["sample_pts"], 1) / (torch.sum(r["PS"], 1) + 1e-8)       # mg_run_NeRF.py:188
+        dist = torch.sum(torch.cumsum(r["deltas"], 1) * r["PS"], 1) / torch.sum(r["PS"], 1)   # mg_run_NeRF.py:189
+        out["eval_surf_loc"], out["eval_surf_dist"] = f32(loc), f32(dist)
+        evc = All_in_One_Eval(args_ns(S, classic=True), torch.device("cpu"), 10, False, None, H4, WC)
+        out["classic_Rendered_Col"] = f32(evc.eval(data, net, 0, False)["Rendered_Col"])
+        # train_mode sampling (shared jitter vector) with eval-mode BN
+        torch.manual_seed(1234 + seed)
+        jit = torch.rand(S)
+        torch.manual_seed(1234 + seed)
+        r = ev.eval(data, net, 0, True)
+        out["jitter"] = f32(jit)
+        out["jit_Rendered_Col"], out["jit_Rho"], out["jit_sample_pts"] = f32(r["Rendered_Col"]), f32(r["Rho"]), f32(r["sample_pts"])
+        # sun-ray pass (include_end_pt sampling), Eval_Tools_2.py:297
+        r = ev.eval_Rho_Only(data, net, False)
+        for k in ["PE", "PV_Exact", "Solar_Vis", "Sky_Col"]:
+            out["rho_only_" + k] = f32(r[k])
+        if with_prior:
+            evp = All_in_One_Eval(args_ns(S), torch.device("cpu"), 10, True, None, H4, WC)
+            r = evp.eval(data, net, 3, False)
+            out["hm"] = hm
+            out["prior_step"], out["prior_n_steps"] = 3, 10
+            for k in ["Rendered_Col", "Rendered_Col_Supervised", "Rendered_Col_Merged", "PS_Supervised", "PS_Merged",
+                      "Rho_Merged", "Albedo_Color", "PE_Supervised"]:
+                out["prior_" + k] = f32(r[k])
+    np.savez_compressed(os.path.join(OUT, f"eval_{tag}.npz"), **out)
+
+
+def gen_train(W, seed, R, S, tag):
+    net, sd0 = make_net(W, 4, seed, train=True)
+    data = synth_rays(R, 300 + seed)
+    rng = np.random.Generator(np.random.PCG64(400 + seed))
+    # explicit solar rays following the a11 law (Eval_Tools_2.py:72-108), drawn by OUR generator
+    az_el = rng.uniform(0, 1, (R, 2)) * np.array([[360, 89]]) + np.array([[-180, 1]])
+    vec = np.array([world_angle_2_local_vec(az_el[i][1], az_el[i][0], WC, H4) for i in range(R)])
+    starts = np.ones((R, 3))
+    starts[:, 0:2] = rng.uniform(-1, 1, (R, 2))
+    ends = starts - 2 * (vec / vec[:, 2:])
+    tt = lambda a: torch.tensor(a, dtype=torch.float32)
+    solar = {"Top": tt(starts), "Bot": tt(ends), "Sun_Angle": tt(vec)}
+    solar_time = tt(np.tile(encode_time(0.3, 0.1), (R, 1)))
+
+    ev = All_in_One_Eval(args_ns(S), torch.device("cpu"), 10, False, None, H4, WC)
+    ev.solar_creation_tool = lambda n, include_times=True: (solar["Top"], solar["Bot"], solar["Sun_Angle"], solar_time, az_el)
+    torch.manual_seed(77 + seed)
+    j1, j2 = torch.rand(S), torch.rand(S)
+    torch.manual_seed(77 + seed)
+    opt = torch.optim.Adam(net.parameters(), lr=10 ** -4.86)
+    opt.zero_grad()
+    loss = ev.get_loss(data, net, 0, True)
+    total = 0
+    for k in loss:
+        total = total + loss[k][0] * loss[k][1]
+    total.backward()
+    out = {"W": W, "C": 4, "seed": seed, "S": S, "lr": 10 ** -4.86, "sc_lambda": 0.03,
+           "jitter": f32(j1), "jitter_solar": f32(j2), "total": f32(total)}
+    for k, v in data.items():
+        out["in_" + k] = f32(v)
+    for k, v in solar.items():
+        out["solar_" + k] = f32(v)
+    for k in loss:
+        out["loss_" + k] = f32(loss[k][0])
+        out["weight_" + k] = np.float32(loss[k][1])
+    for n, p in net.named_parameters():
+        if p.grad is not None:
+            out["grad_" + n] = f32(p.grad)
+    opt.step()
+    new_sd = net.state_dict()
+    for n in new_sd:
+        if n.endswith("running_mean") or n.endswith("running_var"):
+            out["bn_" + n] = f32(new_sd[n])
+    for n, p in net.named_parameters():
+        if p.grad is not None:
+            out["adam_" + n] = f32(p)
+    np.savez_compressed(os.path.join(OUT, f"train_{tag}.npz"), **out)
+
+
+def gen_render(W, seed, tag):
+    net, _ = make_net(W, 4, seed)
+    out = {"W": W, "C": 4, "seed": seed, "WC": WC, "H": H4}
+    args = args_ns(96)
+    qr = Quick_Run_Net(net, args, WC, H4, torch.device("cpu"), use_full_solar=False)
+    imgs, mask = qr.render_img((60, 30), (45, 120), 0.25, 24)
+    out["qr_Col_Img"], out["qr_Shadow_Mask"], out["qr_mask"] = imgs["Col_Img"], imgs["Shadow_Mask"], mask
+    out["qr_DSM"] = qr.get_DSM((16, 16))   # get_DSM only works with a tuple size (Quick_Run.py:38)
+    size = (12, 12, 48)
+    d = component_render_by_dir(net, (80, 0), (30, 90), 0.25, size, WC, H4, torch.device("cpu"),
+                                include_exact_solar=False)
+    for k in ["Rho", "Base_Col", "Est_Solar_Vis", "Deltas", "World_Points"]:
+        out["dir_" + k] = f32(d[k])
+    out["dir_Adjust_col"] = f32(d["Adjust_col"])
+    out["dir_Output_class0"] = d["Output_class"][0, 0]
+    out["dir_Sky_Col0"] = d["Sky_Col"][0, 0]
+    im = get_imgs_from_Img_Dict(d, size, False)
+    for k in ["Base_Img", "Season_Adj_Img", "Shadow_Adjust", "Shadow_Mask", "Raw_Shadow_Mask"]:
+        out["img_" + k] = im[k]
+    taus = np.arange(12) / 12.0
+    with torch.no_grad():
+        cls = net.get_class_only(torch.tensor(np.stack([encode_time(t) for t in taus]), dtype=torch.float32)).numpy()
+    out["sweep_classes"] = cls
+    out["sweep_imgs"] = get_imgs_from_Img_Dict_t_step(d, size, cls.astype(np.float64))
+    # exact-solar secondary rays (mg_Img_Eval.py:57-70), tiny case
+    d2 = component_render_by_dir(net, (80, 0), (30, 90), 0.25, (4, 4, 24), WC, H4, torch.device("cpu"),
+                                 include_exact_solar=True)
+    out["exact_Exact_Solar"] = f32(d2["Exact_Solar"])
+    np.savez_compressed(os.path.join(OUT, f"render_{tag}.npz"), **out)
+
+
+def gen_micro():
+    out = {}
+    pe = misc.PE_Encode(2, True)
+    out["pe2_in"] = np.array([[0.5, -1.0]], dtype=np.float32)
+    out["pe2_out"] = f32(pe(torch.tensor(out["pe2_in"])))
+    pe10 = misc.PE_Encode(10, True)
+    x = torch.tensor([[0.123456, -0.98765, 0.5], [1.0, -1.0, 0.0]])
+    out["pe10_in"], out["pe10_out"] = f32(x), f32(pe10(x))
+    top, bot = torch.tensor([[.1, .2, 1.]]), torch.tensor([[.3, -.2, -1.]])
+    p, d = misc.sample_pt_coarse(top, bot, 4, True)
+    out["samp_pts"], out["samp_delta"] = f32(p), f32(d)
+    p, d = misc.sample_pt_coarse(top, bot, 4, True, include_end_pt=True)
+    out["samp_pts_end"] = f32(p)
+    out["wa2lv"] = world_angle_2_local_vec(60, 30, np.array([41.29, -95.9, 300]), np.eye(4))
+    out["wa2lv_H"] = world_angle_2_local_vec(35, -100, WC, H4)
+    P = np.array([[1200., 30., -40., 900.], [-25., 1100., 60., 1000.], [0.01, -0.02, 0.03, 1.0]])
+    cam = P_img_Pinhole.__new__(P_img_Pinhole)
+    cam.P = P
+    r, c = np.array([10., 500., 1999.]), np.array([0., 800., 1500.])
+    xs, ys, _ = cam.invert_P(r, c, 0.4)
+    out["P"], out["invP_row"], out["invP_col"], out["invP_h"] = P, r, c, 0.4
+    out["invP_x"], out["invP_y"] = xs, ys
+    np.savez_compressed(os.path.join(OUT, "micro.npz"), **out)
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    gen_micro()
+    gen_net(64, 0, 384, "W64_s0")
+    gen_net(256, 1, 768, "W256_s1")
+    gen_eval(256, 0, 64, 96, "W256_R64_S96", with_prior=False)
+    gen_eval(64, 1, 48, 64, "W64_R48_S64", with_prior=True)
+    gen_train(64, 0, 32, 32, "W64_R32_S32")
+    gen_render(64, 2, "W64_s2")
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))
