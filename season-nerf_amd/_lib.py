@@ -1,0 +1,68 @@
+"""ctypes binding of include/season_nerf_hip.h.  There is NO fallback: if the HIP library is missing or a call
+fails, a RuntimeError is raised - the product path never routes through a CPU implementation."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libseason_nerf_hip.so")
+
+_f = C.POINTER(C.c_float)
+
+
+class FieldOut(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in
+                ("d_rho", "d_solar_vis", "d_col_raw", "d_adjust", "d_col", "d_adjust_col", "d_points")]
+
+
+class CompositeOut(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in
+                ("d_rgb", "d_albedo", "d_pv", "d_pe", "d_ps", "d_delta", "d_shadow", "d_acc", "d_surf_loc", "d_surf_dist")]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"season_nerf_amd: HIP library not built ({LIB_PATH} missing). Run `python season-nerf_amd/build.py` "
+            "(needs hipcc, gfx950). There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, i64, i32 = C.c_void_p, C.c_int64, C.c_int
+    L.snerf_last_error.restype = C.c_char_p
+    L.snerf_abi_version.restype = i32
+    L.snerf_model_create.restype = vp
+    L.snerf_model_create.argtypes = [i32, i32]
+    L.snerf_model_set_tensor.argtypes = [vp, C.c_char_p, vp, C.c_size_t]
+    L.snerf_model_finalize.argtypes = [vp]
+    L.snerf_model_destroy.argtypes = [vp]
+    L.snerf_model_destroy.restype = None
+    L.snerf_model_width.argtypes = [vp]
+    L.snerf_model_classes.argtypes = [vp]
+    L.snerf_model_pack_host.argtypes = [vp, i32, vp, C.POINTER(C.c_size_t), vp, C.POINTER(C.c_size_t)]
+    L.snerf_group_forward.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp]
+    L.snerf_field_forward_points.argtypes = [vp, i32, i64, vp, i64, vp, vp, C.POINTER(FieldOut), vp]
+    L.snerf_field_forward_rays.argtypes = [vp, i32, i64, i32, vp, vp, vp, vp, vp, C.POINTER(FieldOut), vp]
+    L.snerf_composite_rays.argtypes = [i64, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, C.c_float,
+                                       C.POINTER(CompositeOut), vp]
+    L.snerf_render_workspace_bytes.restype = C.c_size_t
+    L.snerf_render_workspace_bytes.argtypes = [i64, i32, i32]
+    L.snerf_render_rays.argtypes = [vp, i64, i32, vp, vp, vp, vp, vp, i32, vp, C.POINTER(FieldOut),
+                                    C.POINTER(CompositeOut), vp, C.c_size_t, vp]
+    L.snerf_field_kernel_info.argtypes = [vp, i64, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+    _lib = L
+    return L
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"season_nerf_amd: {what} failed (code {rc}): {lib().snerf_last_error().decode()}")
+
+
+EXPORTS = ["snerf_last_error", "snerf_abi_version", "snerf_model_create", "snerf_model_set_tensor",
+           "snerf_model_finalize", "snerf_model_destroy", "snerf_model_width", "snerf_model_classes",
+           "snerf_model_pack_host", "snerf_group_forward", "snerf_field_forward_points", "snerf_field_forward_rays",
+           "snerf_composite_rays", "snerf_render_workspace_bytes", "snerf_render_rays", "snerf_field_kernel_info"]

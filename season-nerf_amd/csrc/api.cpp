@@ -1,0 +1,282 @@
+// C ABI of include/season_nerf_hip.h.  Host logic only: argument checking, model object, launch sequencing.
+#include "../../include/season_nerf_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "kernels.h"
+#include "pack.h"
+
+using namespace snerf;
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+static int fail_hip(hipError_t e, const char* what) {
+    return fail(SNERF_E_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+struct snerf_model {
+    int W = 0, C = 0;
+    Weights w;
+    bool finalized = false;
+    Packed host[2];
+    uint8_t* d_stream[2] = {nullptr, nullptr};
+    float* d_bias[2] = {nullptr, nullptr};
+    int n_cu = 0;
+};
+
+extern "C" {
+
+const char* snerf_last_error(void) { return g_err.c_str(); }
+int snerf_abi_version(void) { return 1; }
+
+snerf_model* snerf_model_create(int layer_width, int n_classes) {
+    if (layer_width != 64 && layer_width != 256) {
+        fail(SNERF_E_INVALID, "layer_width " + std::to_string(layer_width) +
+                                  " has no compiled kernel (built widths: 64, 256)");
+        return nullptr;
+    }
+    if (n_classes < 1 || n_classes > kMaxClasses) {
+        fail(SNERF_E_INVALID, "n_classes must be in [1," + std::to_string(kMaxClasses) + "]");
+        return nullptr;
+    }
+    snerf_model* m = new snerf_model();
+    m->W = layer_width;
+    m->C = n_classes;
+    return m;
+}
+
+int snerf_model_set_tensor(snerf_model* m, const char* key, const float* host_data, size_t numel) {
+    if (!m || !key || (!host_data && numel)) return fail(SNERF_E_INVALID, "snerf_model_set_tensor: NULL argument");
+    if (m->finalized) return fail(SNERF_E_STATE, "model already finalized");
+    Tensor t;
+    t.data.assign(host_data, host_data + numel);
+    m->w.t[key] = std::move(t);
+    return SNERF_OK;
+}
+
+static int pack_both(snerf_model* m) {
+    for (int p = 0; p < 2; ++p) {
+        if (!m->host[p].stream.empty()) continue;
+        std::string err;
+        if (!pack_program(m->w, p, m->W, m->C, /*fold_bn=*/true, &m->host[p], &err))
+            return fail(err.rfind("missing", 0) == 0 ? SNERF_E_MISSING : SNERF_E_INVALID, err);
+    }
+    return SNERF_OK;
+}
+
+int snerf_model_pack_host(snerf_model* m, int program, uint8_t* stream_out, size_t* stream_bytes, float* bias_out,
+                          size_t* bias_floats) {
+    if (!m || program < 0 || program > 1) return fail(SNERF_E_INVALID, "snerf_model_pack_host: bad argument");
+    int rc = pack_both(m);
+    if (rc) return rc;
+    const Packed& P = m->host[program];
+    if (stream_bytes) *stream_bytes = P.stream.size();
+    if (bias_floats) *bias_floats = P.bias.size();
+    if (stream_out) std::memcpy(stream_out, P.stream.data(), P.stream.size());
+    if (bias_out) std::memcpy(bias_out, P.bias.data(), P.bias.size() * 4);
+    return SNERF_OK;
+}
+
+int snerf_model_finalize(snerf_model* m) {
+    if (!m) return fail(SNERF_E_INVALID, "NULL model");
+    if (m->finalized) return SNERF_OK;
+    int rc = pack_both(m);
+    if (rc) return rc;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return fail_hip(e, "hipGetDevice (is a GPU visible?)");
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, dev);
+    if (e != hipSuccess) return fail_hip(e, "hipGetDeviceProperties");
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(SNERF_E_HIP, std::string("this library is built for gfx950 only, device is ") + prop.gcnArchName);
+    m->n_cu = prop.multiProcessorCount;
+    for (int p = 0; p < 2; ++p) {
+        const Packed& P = m->host[p];
+        if ((e = hipMalloc((void**)&m->d_stream[p], P.stream.size())) != hipSuccess) return fail_hip(e, "hipMalloc");
+        if ((e = hipMalloc((void**)&m->d_bias[p], P.bias.size() * 4)) != hipSuccess) return fail_hip(e, "hipMalloc");
+        if ((e = hipMemcpy(m->d_stream[p], P.stream.data(), P.stream.size(), hipMemcpyHostToDevice)) != hipSuccess)
+            return fail_hip(e, "hipMemcpy");
+        if ((e = hipMemcpy(m->d_bias[p], P.bias.data(), P.bias.size() * 4, hipMemcpyHostToDevice)) != hipSuccess)
+            return fail_hip(e, "hipMemcpy");
+    }
+    m->finalized = true;
+    return SNERF_OK;
+}
+
+void snerf_model_destroy(snerf_model* m) {
+    if (!m) return;
+    for (int p = 0; p < 2; ++p) {
+        if (m->d_stream[p]) (void)hipFree(m->d_stream[p]);
+        if (m->d_bias[p]) (void)hipFree(m->d_bias[p]);
+    }
+    delete m;
+}
+
+int snerf_model_width(const snerf_model* m) { return m ? m->W : 0; }
+int snerf_model_classes(const snerf_model* m) { return m ? m->C : 0; }
+
+static int check_ready(const snerf_model* m) {
+    if (!m) return fail(SNERF_E_INVALID, "NULL model");
+    if (!m->finalized) return fail(SNERF_E_STATE, "model not finalized (call snerf_model_finalize)");
+    return SNERF_OK;
+}
+
+int snerf_group_forward(const snerf_model* m, int64_t n_groups, const float* d_time, const float* d_sun,
+                        float* d_classes, float* d_sky_raw, float* d_sky, void* stream) {
+    int rc = check_ready(m);
+    if (rc) return rc;
+    if (n_groups == 0) return SNERF_OK;
+    if (n_groups < 0 || !d_time || !d_sun) return fail(SNERF_E_INVALID, "snerf_group_forward: bad argument");
+    MlpArgs a{};
+    a.stream = m->d_stream[PROG_GROUP];
+    a.stream_bytes = (uint32_t)m->host[PROG_GROUP].stream.size();
+    a.bias = m->d_bias[PROG_GROUP];
+    a.bias_floats = (int)m->host[PROG_GROUP].bias.size();
+    a.n = n_groups;
+    a.n_classes = m->C;
+    a.group_size = 1;
+    a.time = d_time;
+    a.sun = d_sun;
+    a.g_classes = d_classes;
+    a.g_sky_raw = d_sky_raw;
+    a.g_sky = d_sky;
+    hipError_t e = launch_mlp(PROG_GROUP, m->W, 0, a, m->n_cu, (hipStream_t)stream);
+    return e == hipSuccess ? SNERF_OK : fail_hip(e, "group kernel launch");
+}
+
+static int field_launch(const snerf_model* m, int variant, MlpArgs& a, const snerf_field_out* out, void* stream) {
+    if (variant < 0 || variant > 2) return fail(SNERF_E_INVALID, "variant must be 0, 1 or 2");
+    a.stream = m->d_stream[PROG_FIELD];
+    a.stream_bytes = (uint32_t)field_variant_chunks(m->W, m->C, variant) * kChunkBytes;
+    a.bias = m->d_bias[PROG_FIELD];
+    a.bias_floats = (int)m->host[PROG_FIELD].bias.size();
+    a.n_classes = m->C;
+    if (out) {
+        a.out.rho = out->d_rho; a.out.solar_vis = out->d_solar_vis; a.out.col_raw = out->d_col_raw;
+        a.out.adjust = out->d_adjust; a.out.col = out->d_col; a.out.adjust_col = out->d_adjust_col;
+        a.out.points = out->d_points;
+    }
+    if (variant <= 1 && !a.sun) return fail(SNERF_E_INVALID, "sun directions are required for variants 0 and 1");
+    hipError_t e = launch_mlp(PROG_FIELD, m->W, variant, a, m->n_cu, (hipStream_t)stream);
+    return e == hipSuccess ? SNERF_OK : fail_hip(e, "field kernel launch");
+}
+
+int snerf_field_forward_points(const snerf_model* m, int variant, int64_t n_points, const float* d_points,
+                               int64_t group_size, const float* d_sun, const float* d_classes,
+                               const snerf_field_out* out, void* stream) {
+    int rc = check_ready(m);
+    if (rc) return rc;
+    if (n_points == 0) return SNERF_OK;
+    if (n_points < 0 || !d_points || group_size < 1) return fail(SNERF_E_INVALID, "snerf_field_forward_points: bad argument");
+    MlpArgs a{};
+    a.n = n_points;
+    a.points = d_points;
+    a.n_samples = 1;
+    a.group_size = group_size;
+    a.sun = d_sun;
+    a.classes = d_classes;
+    return field_launch(m, variant, a, out, stream);
+}
+
+int snerf_field_forward_rays(const snerf_model* m, int variant, int64_t n_rays, int n_samples, const float* d_top,
+                             const float* d_bot, const float* d_tvals, const float* d_sun, const float* d_classes,
+                             const snerf_field_out* out, void* stream) {
+    int rc = check_ready(m);
+    if (rc) return rc;
+    if (n_rays == 0) return SNERF_OK;
+    if (n_rays < 0 || n_samples < 1 || !d_top || !d_bot || !d_tvals)
+        return fail(SNERF_E_INVALID, "snerf_field_forward_rays: bad argument");
+    MlpArgs a{};
+    a.n = n_rays * n_samples;
+    a.top = d_top;
+    a.bot = d_bot;
+    a.tvals = d_tvals;
+    a.n_samples = n_samples;
+    a.group_size = n_samples;
+    a.sun = d_sun;
+    a.classes = d_classes;
+    return field_launch(m, variant, a, out, stream);
+}
+
+int snerf_composite_rays(int64_t n_rays, int n_samples, const float* d_top, const float* d_bot, const float* d_tvals,
+                         const float* d_rho, const float* d_col, const float* d_solar_vis, const float* d_sky,
+                         int flags, const float* d_rho_prior, float trust, const snerf_composite_out* out, void* stream) {
+    if (n_rays == 0) return SNERF_OK;
+    if (n_rays < 0 || n_samples < 1 || !d_top || !d_bot || !d_tvals || !d_rho || !d_col || !d_solar_vis || !d_sky || !out)
+        return fail(SNERF_E_INVALID, "snerf_composite_rays: bad argument");
+    CompArgs a{};
+    a.n_rays = n_rays; a.n_samples = n_samples;
+    a.top = d_top; a.bot = d_bot; a.tvals = d_tvals;
+    a.rho = d_rho; a.col = d_col; a.solar_vis = d_solar_vis; a.sky = d_sky;
+    a.flags = flags; a.rho_prior = d_rho_prior; a.trust = trust;
+    a.out.rgb = out->d_rgb; a.out.albedo = out->d_albedo; a.out.pv = out->d_pv; a.out.pe = out->d_pe;
+    a.out.ps = out->d_ps; a.out.delta = out->d_delta; a.out.shadow = out->d_shadow; a.out.acc = out->d_acc;
+    a.out.surf_loc = out->d_surf_loc; a.out.surf_dist = out->d_surf_dist;
+    hipError_t e = launch_composite(a, (hipStream_t)stream);
+    return e == hipSuccess ? SNERF_OK : fail_hip(e, "composite kernel launch");
+}
+
+// workspace layout of snerf_render_rays: classes [R,C] | sky_raw [R,3] | sky [R,3] | rho [N] | sv [N] | col [N,3]
+static size_t align256(size_t x) { return (x + 255) / 256 * 256; }
+size_t snerf_render_workspace_bytes(int64_t n_rays, int n_samples, int n_classes) {
+    const size_t R = (size_t)n_rays, N = R * (size_t)n_samples;
+    return align256(R * n_classes * 4) + 2 * align256(R * 3 * 4) + 2 * align256(N * 4) + align256(N * 3 * 4);
+}
+
+int snerf_render_rays(const snerf_model* m, int64_t n_rays, int n_samples, const float* d_top, const float* d_bot,
+                      const float* d_tvals, const float* d_sun, const float* d_time, int flags, float* d_rgb,
+                      const snerf_field_out* field_out, const snerf_composite_out* comp_out, void* d_workspace,
+                      size_t workspace_bytes, void* stream) {
+    int rc = check_ready(m);
+    if (rc) return rc;
+    if (n_rays == 0) return SNERF_OK;
+    if (n_rays < 0 || n_samples < 1 || !d_top || !d_bot || !d_tvals || !d_sun || !d_time || !d_workspace)
+        return fail(SNERF_E_INVALID, "snerf_render_rays: bad argument");
+    if (workspace_bytes < snerf_render_workspace_bytes(n_rays, n_samples, m->C))
+        return fail(SNERF_E_INVALID, "snerf_render_rays: workspace too small");
+    if (n_rays == 0) return SNERF_OK;
+    const size_t R = (size_t)n_rays, N = R * (size_t)n_samples;
+    char* ws = (char*)d_workspace;
+    float* cls = (float*)ws; ws += align256(R * m->C * 4);
+    float* sky_raw = (float*)ws; ws += align256(R * 3 * 4);
+    float* sky = (float*)ws; ws += align256(R * 3 * 4);
+    float* rho = (float*)ws; ws += align256(N * 4);
+    float* sv = (float*)ws; ws += align256(N * 4);
+    float* col = (float*)ws;
+    rc = snerf_group_forward(m, n_rays, d_time, d_sun, cls, sky_raw, sky, stream);
+    if (rc) return rc;
+    snerf_field_out fo{};
+    if (field_out) fo = *field_out;
+    if (!fo.d_rho) fo.d_rho = rho;
+    if (!fo.d_solar_vis) fo.d_solar_vis = sv;
+    if (!fo.d_col) fo.d_col = col;
+    rc = snerf_field_forward_rays(m, 0, n_rays, n_samples, d_top, d_bot, d_tvals, d_sun, cls, &fo, stream);
+    if (rc) return rc;
+    snerf_composite_out co{};
+    if (comp_out) co = *comp_out;
+    if (d_rgb) co.d_rgb = d_rgb;
+    return snerf_composite_rays(n_rays, n_samples, d_top, d_bot, d_tvals, fo.d_rho, fo.d_col, fo.d_solar_vis, sky, flags,
+                                nullptr, 1.f, &co, stream);
+}
+
+int snerf_field_kernel_info(const snerf_model* m, int64_t n_points, int* grid, int* block, int* lds_bytes) {
+    if (!m) return fail(SNERF_E_INVALID, "NULL model");
+    int rc = pack_both(const_cast<snerf_model*>(m));
+    if (rc) return rc;
+    const int64_t tiles = (n_points + mlp_tile_points() - 1) / mlp_tile_points();
+    const int ncu = m->n_cu ? m->n_cu : 256;
+    if (grid) *grid = (int)(tiles < ncu ? tiles : ncu);
+    if (block) *block = 256;
+    if (lds_bytes) *lds_bytes = mlp_lds_bytes((int)m->host[PROG_FIELD].bias.size());
+    return SNERF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,64 @@
+// Kernel argument blocks and launch entry points (internal; the public surface is include/season_nerf_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace snerf {
+
+struct snerf_field_out_dev {
+    float* rho;
+    float* solar_vis;
+    float* col_raw;
+    float* adjust;
+    float* col;
+    float* adjust_col;
+    float* points;
+};
+
+struct MlpArgs {
+    const uint8_t* stream;     // packed fragment stream (device)
+    uint32_t stream_bytes;     // bytes consumed per tile = length of the cyclic DMA stream
+    const float* bias;         // bias table (device)
+    int bias_floats;
+    int64_t n;                 // points (field program) or groups (group program)
+    int n_classes;
+    // field program inputs
+    const float* points;       // [n,3] or NULL -> generate from rays
+    const float* top;          // [R,3]
+    const float* bot;          // [R,3]
+    const float* tvals;        // [S]
+    int n_samples;
+    int64_t group_size;        // points per sun/classes row
+    const float* sun;          // [G,3]
+    const float* classes;      // [G,C] or NULL
+    snerf_field_out_dev out;
+    // group program inputs / outputs
+    const float* time;         // [G,4]
+    float* g_classes;          // [G,C]
+    float* g_sky_raw;          // [G,3]
+    float* g_sky;              // [G,3]
+};
+
+struct CompOutDev {
+    float *rgb, *albedo, *pv, *pe, *ps, *delta, *shadow, *acc, *surf_loc, *surf_dist;
+};
+
+struct CompArgs {
+    int64_t n_rays;
+    int n_samples;
+    const float *top, *bot, *tvals;
+    const float *rho, *col, *solar_vis, *sky;
+    int flags;
+    const float* rho_prior;
+    float trust;
+    CompOutDev out;
+};
+
+hipError_t launch_mlp(int prog, int W, int variant, const MlpArgs& a, int n_cu, hipStream_t st);
+hipError_t launch_composite(const CompArgs& a, hipStream_t st);
+int mlp_lds_bytes(int bias_floats);
+int mlp_tile_points();
+int field_variant_chunks(int W, int C, int variant);
+const char* mlp_kernel_name();
+
+}  // namespace snerf

@@ -1,0 +1,575 @@
+// gfx950 (MI355X / CDNA4) kernels of the Season-NeRF per-ray hot path.  See program.h for the data layout.
+//
+//  mlp_kernel<PROG, W, VARIANT>   fused register-resident MFMA chain (field program: one sample point per lane
+//                                 column, 32 points per wave, 128 per workgroup; group program: time/sun groups)
+//  composite_kernel               exclusive-prefix transmittance + shading, one wavefront per ray
+//
+// Structure of mlp_kernel (persistent, 4 waves = 1 wave per SIMD, up to 512 VGPR+AGPR per lane):
+//   * weights stream L2 -> LDS through a ring of 16 KiB chunks filled by LDS-DMA (global_load_lds_dwordx4),
+//     RING_D-1 chunks in flight, one counted s_waitcnt vmcnt + one s_barrier per chunk (24 MFMAs);
+//   * each wave reads the A fragments (weights) with conflict-free lane-linear ds_read_b128 and multiplies them
+//     against its own 32 points, whose activations stay in registers from the positional encoding to the heads;
+//   * 3 bf16 MFMAs per product (hi*hi + lo*hi + hi*lo, fp32 accumulate) keep the result within ~1e-5 of fp32,
+//     the parity bar (1e-4 rel) being out of reach of plain bf16 on an omega_0 = 30 SIREN.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "program.h"
+#include "kernels.h"
+
+namespace snerf {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(3))) char lds_char;
+typedef const __attribute__((address_space(3))) float lds_cfloat;
+typedef const __attribute__((address_space(3))) u32x4 lds_cu32x4;
+typedef const __attribute__((address_space(3))) f32x4 lds_cf32x4;
+typedef const __attribute__((address_space(1))) void glb_void;
+
+constexpr int RING_D = 6;                       // ring slots (16 KiB each)
+constexpr int RING_BYTES = RING_D * kChunkBytes;
+constexpr int TILE_PTS = 128;                   // points per workgroup tile (4 waves x 32)
+
+struct Frag {          // B operand of one k-step: 8 bf16 hi + 8 bf16 lo of this lane's point
+    u32x4 hi, lo;
+};
+
+struct Ring {
+    uint32_t rd;       // LDS offset of the slot the NEXT ring_step hands to the consumers
+    uint32_t wr;       // LDS offset of the slot the next DMA fills
+    uint32_t cur;      // LDS offset of the chunk being consumed
+    uint32_t goff;     // byte offset in the (cyclic) global stream of the next chunk to fetch
+};
+
+__device__ __forceinline__ float sin2pi(float r) { return __builtin_amdgcn_sinf(r); }   // v_sin_f32: revolutions,
+__device__ __forceinline__ float cos2pi(float r) { return __builtin_amdgcn_cosf(r); }   // 1.25e-7 abs err (probe_hw)
+
+// two fp32 -> packed bf16 hi and packed bf16 lo (x = hi + lo to ~2^-17 relative)
+__device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t& lo) {
+    bf16x2 hv;
+    hv[0] = (__bf16)a;
+    hv[1] = (__bf16)b;
+    hi = __builtin_bit_cast(uint32_t, hv);
+    const float ha = __builtin_bit_cast(float, hi << 16);
+    const float hb = __builtin_bit_cast(float, hi & 0xffff0000u);
+    bf16x2 lv;
+    lv[0] = (__bf16)(a - ha);
+    lv[1] = (__bf16)(b - hb);
+    lo = __builtin_bit_cast(uint32_t, lv);
+}
+
+// 8 consecutive values -> one Frag
+__device__ __forceinline__ void pack8(const float* v, Frag& f) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        uint32_t h, l;
+        split2(v[2 * q], v[2 * q + 1], h, l);
+        f.hi[q] = h;
+        f.lo[q] = l;
+    }
+}
+
+__device__ __forceinline__ f32x16 mfma3(const u32x4& a_hi, const u32x4& a_lo, const Frag& b, f32x16 acc) {
+    const bf16x8 ah = __builtin_bit_cast(bf16x8, a_hi), al = __builtin_bit_cast(bf16x8, a_lo);
+    const bf16x8 bh = __builtin_bit_cast(bf16x8, b.hi), bl = __builtin_bit_cast(bf16x8, b.lo);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+    return acc;
+}
+
+__device__ __forceinline__ void dma_chunk(const uint8_t* stream, uint32_t goff, lds_char* lds, uint32_t wr, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int piece = wave + 4 * i;                      // 16 pieces of 1 KiB, 4 per wave
+        const uint8_t* src = stream + goff + piece * kFragBytes + lane * 16;
+        __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(lds + wr + piece * kFragBytes), 16, 0, 0);
+    }
+}
+
+__device__ __forceinline__ uint32_t ring_next(uint32_t off) {
+    off += kChunkBytes;
+    return off == RING_BYTES ? 0u : off;
+}
+
+// Hand the next chunk to the consumers and refill the slot that was just released.
+//  - vmcnt((D-2)*4): all but the (D-2) youngest chunks this wave fetched have landed  => chunk `rd` is complete
+//    (the count is in DMA instructions of THIS wave; extra older loads/stores only make the wait stricter);
+//  - lgkmcnt(0) + s_barrier: every wave's pieces have landed and every wave has finished reading slot `wr`.
+__device__ __forceinline__ void ring_step(Ring& rg, const uint8_t* stream, uint32_t stream_bytes, lds_char* lds, int wave, int lane) {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((RING_D - 2) * 4) : "memory");
+    dma_chunk(stream, rg.goff, lds, rg.wr, wave, lane);
+    rg.goff += kChunkBytes;
+    if (rg.goff >= stream_bytes) rg.goff = 0;
+    rg.cur = rg.rd;
+    rg.rd = ring_next(rg.rd);
+    rg.wr = ring_next(rg.wr);
+}
+
+// One fused layer: out^T[n x 32 pts] = act(W[n x k] * in^T[k x 32 pts] + b), activations in registers.
+//   in0/in1: B fragments of the (concatenated) input blocks; out: 2 fragments per 32-row output block;
+//   raw: fp32 accumulator of block 0 for OUT_RAW layers.
+template <int NB, int KS0, int KS1, bool SIN>
+__device__ __forceinline__ void run_layer(Ring& rg, const uint8_t* stream, uint32_t stream_bytes, lds_char* lds,
+                                          lds_cfloat* bias_l, const Frag* in0, const Frag* in1, Frag* out,
+                                          f32x16* raw, int wave, int lane) {
+    constexpr int KS = KS0 + KS1;
+    const int h = lane >> 5;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        lds_cf32x4* bp = (lds_cf32x4*)(bias_l + b * 32 + h * 16);
+        f32x16 acc;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 t = bp[q];
+            acc[4 * q] = t[0]; acc[4 * q + 1] = t[1]; acc[4 * q + 2] = t[2]; acc[4 * q + 3] = t[3];
+        }
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int p = b * KS + s;
+            if (p % kChunkPairs == 0) ring_step(rg, stream, stream_bytes, lds, wave, lane);
+            lds_char* ap = lds + rg.cur + (p % kChunkPairs) * kPairBytes + lane * 16;
+            const u32x4 a_hi = *(lds_cu32x4*)ap;
+            const u32x4 a_lo = *(lds_cu32x4*)(ap + kFragBytes);
+            acc = mfma3(a_hi, a_lo, s < KS0 ? in0[s] : in1[s - KS0], acc);
+        }
+        if (SIN) {
+            float v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = sin2pi(acc[i]);
+            pack8(v, out[2 * b]);
+            pack8(v + 8, out[2 * b + 1]);
+        } else if (b == 0) {
+            *raw = acc;
+        }
+    }
+}
+
+// sin/cos of k_j * x exactly as the reference evaluates them (misc.py:109,127-131): the fp32 argument is
+// 2^j * fl32(fl32(pi/2) * x); it is reduced in fp64 (exact power-of-two scaling, exact fract) before v_sin/v_cos.
+struct PeArg {
+    double u;   // fl32(fl32(pi/2)*x) / (2*pi), revolutions at j = 0
+};
+__device__ __forceinline__ PeArg pe_arg(float x) {
+    const float a0 = __fmul_rn(x, 1.57079637050628662109375f);
+    PeArg r;
+    r.u = (double)a0 * 0.15915494309189533576888;
+    return r;
+}
+__device__ __forceinline__ void pe_sincos(const PeArg& a, double scale, float& c, float& s) {
+    const double r = a.u * scale;                 // exact: scale = 2^j
+    const float f = (float)(r - __builtin_floor(r));
+    c = cos2pi(f);
+    s = sin2pi(f);
+}
+
+// PE(pos): 32 slots per lane-half, see slot_feature_PEPOS
+__device__ __forceinline__ void make_pe_pos(float x0, float x1, float x2, int h, Frag* pe) {
+    float v[32];
+    const float xs[3] = {x0, x1, x2};
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const PeArg a = pe_arg(xs[d]);
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            const double scale = h ? (double)(1 << (5 + q)) : (double)(1 << q);
+            pe_sincos(a, scale, v[10 * d + 2 * q], v[10 * d + 2 * q + 1]);
+        }
+    }
+    v[30] = h ? x2 : x0;
+    v[31] = h ? 0.f : x1;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) pack8(v + 8 * s, pe[s]);
+}
+
+// PE(sun): 16 slots per lane-half, see slot_feature_PESUN
+__device__ __forceinline__ void make_pe_sun(float x0, float x1, float x2, int h, Frag* pe) {
+    float v[16];
+    const float xs[3] = {x0, x1, x2};
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const PeArg a = pe_arg(xs[d]);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const double scale = h ? (double)(1 << (2 + q)) : (double)(1 << q);
+            pe_sincos(a, scale, v[4 * d + 2 * q], v[4 * d + 2 * q + 1]);
+        }
+    }
+    v[12] = h ? x2 : x0;
+    v[13] = h ? 0.f : x1;
+    v[14] = 0.f;
+    v[15] = 0.f;
+    pack8(v, pe[0]);
+    pack8(v + 8, pe[1]);
+}
+
+// PE(time[:,0:2]): lane-half h owns coordinate h, see slot_feature_PETIME
+__device__ __forceinline__ void make_pe_time(float t0, float t1, int h, Frag* pe) {
+    float v[8];
+    const float x = h ? t1 : t0;
+    const PeArg a = pe_arg(x);
+    v[0] = x;
+    pe_sincos(a, 1.0, v[1], v[2]);
+    pe_sincos(a, 2.0, v[3], v[4]);
+    v[5] = v[6] = v[7] = 0.f;
+    pack8(v, pe[0]);
+    pe[1].hi = u32x4{0, 0, 0, 0};
+    pe[1].lo = u32x4{0, 0, 0, 0};
+}
+
+__device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }   // torch Softplus(beta 1, thr 20)
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
+
+// =====================================================================================================
+template <int PROG, int W, int VARIANT>
+__global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int C_MAX = kMaxClasses;
+    constexpr int W2 = W / 2;
+    lds_char* lds = (lds_char*)smem;
+    __attribute__((address_space(3))) float* bias_lds = (__attribute__((address_space(3))) float*)(lds + RING_BYTES);
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = lane >> 5;
+    const int C = A.n_classes;
+
+    // bias table -> LDS (once per workgroup)
+    for (int i = threadIdx.x; i < A.bias_floats; i += 256) bias_lds[i] = A.bias[i];
+
+    // prologue: RING_D-1 chunks in flight
+    Ring rg;
+    rg.rd = 0;
+    rg.cur = 0;
+    rg.goff = 0;
+    {
+        uint32_t wr = 0;
+#pragma unroll
+        for (int c = 0; c < RING_D - 1; ++c) {
+            dma_chunk(A.stream, rg.goff, lds, wr, wave, lane);
+            rg.goff += kChunkBytes;
+            if (rg.goff >= A.stream_bytes) rg.goff = 0;
+            wr += kChunkBytes;
+        }
+        rg.wr = wr;   // = (RING_D-1)*chunk, the slot "before" slot 0
+    }
+    __syncthreads();   // bias table visible (drains the prologue DMAs once; harmless)
+
+    const int64_t n_tiles = (A.n + TILE_PTS - 1) / TILE_PTS;
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t n = tile * TILE_PTS + wave * 32 + (lane & 31);
+        const bool valid = n < A.n;
+        const int64_t nc = valid ? n : A.n - 1;
+        const int64_t g = nc / A.group_size;
+
+        if constexpr (PROG == PROG_FIELD) {
+            // ---- sample position (misc.py:234-247 fused): top*(1-t) + bot*t, two roundings + one add, no fma
+            float x0, x1, x2;
+            if (A.points) {
+                x0 = A.points[nc * 3]; x1 = A.points[nc * 3 + 1]; x2 = A.points[nc * 3 + 2];
+            } else {
+                const int64_t r = nc / A.n_samples;
+                const int s = (int)(nc - r * A.n_samples);
+                const float t = A.tvals[s], omt = __fsub_rn(1.f, t);
+                x0 = __fadd_rn(__fmul_rn(A.top[r * 3], omt), __fmul_rn(A.bot[r * 3], t));
+                x1 = __fadd_rn(__fmul_rn(A.top[r * 3 + 1], omt), __fmul_rn(A.bot[r * 3 + 1], t));
+                x2 = __fadd_rn(__fmul_rn(A.top[r * 3 + 2], omt), __fmul_rn(A.bot[r * 3 + 2], t));
+            }
+            // every per-tile input is loaded here, before the MFMA chain: a plain load in the middle of the chain
+            // makes hipcc drain the LDS-DMA pipeline with vmcnt(0)
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+            float pcls[C_MAX];
+#pragma unroll
+            for (int c = 0; c < C_MAX; ++c) pcls[c] = 0.f;
+            if constexpr (VARIANT <= 1) { s0 = A.sun[g * 3]; s1 = A.sun[g * 3 + 1]; s2 = A.sun[g * 3 + 2]; }
+            if constexpr (VARIANT == 0) {
+                if (A.classes) {
+#pragma unroll
+                    for (int c = 0; c < C_MAX; ++c) if (c < C) pcls[c] = A.classes[g * C + c];
+                }
+            }
+            Frag pe[PEPOS_KS];
+            make_pe_pos(x0, x1, x2, h, pe);
+
+            constexpr int KW = W / 16, KW2 = W2 / 16;
+            Frag hA[KW], hB[KW];
+            f32x16 raw;
+#define LAYER(L, NBv, K0, K1, SINv, IN0, IN1, OUT, RAW)                                                              \
+    run_layer<NBv, K0, K1, SINv>(rg, A.stream, A.stream_bytes, lds, bias_lds + prog_bias_start(PROG_FIELD, W, C_MAX, L), \
+                                 IN0, IN1, OUT, RAW, wave, lane)
+            // trunk (G_NeRF.py:80-91)
+            LAYER(F_FC1, W / 32, PEPOS_KS, 0, true, pe, nullptr, hA, nullptr);
+            LAYER(F_FC2, W / 32, KW, 0, true, hA, nullptr, hB, nullptr);
+            LAYER(F_FC3, W / 32, KW, 0, true, hB, nullptr, hA, nullptr);
+            LAYER(F_FC4, W / 32, KW, 0, true, hA, nullptr, hB, nullptr);
+            LAYER(F_FC5, W / 32, KW, PEPOS_KS, true, hB, pe, hA, nullptr);
+            LAYER(F_FC6, W / 32, KW, 0, true, hA, nullptr, hB, nullptr);
+            LAYER(F_FC7, W / 32, KW, 0, true, hB, nullptr, hA, nullptr);
+            LAYER(F_FC8, W / 32, KW, 0, true, hA, nullptr, hB, nullptr);
+            Frag x1f[KW2];
+            LAYER(F_FC9, W2 / 32, KW, 0, true, hB, nullptr, x1f, nullptr);
+            // sigma / colour head (G_NeRF.py:93-98): regs 0..2 colour, 3 density (lane-half 0)
+            LAYER(F_HEAD, 1, KW2, 0, false, x1f, nullptr, nullptr, &raw);
+            const float col_r = raw[0], col_g = raw[1], col_b = raw[2], rho_raw = raw[3];
+            float sv_raw = 0.f;
+            float adj[3 * C_MAX];
+#pragma unroll
+            for (int i = 0; i < 3 * C_MAX; ++i) adj[i] = 0.f;
+            if constexpr (VARIANT <= 1) {
+                // solar visibility branch (G_NeRF.py:100-108)
+                Frag ps[PESUN_KS];
+                make_pe_sun(s0, s1, s2, h, ps);
+                Frag sA[KW2], sB[KW2];
+                LAYER(F_S1, W2 / 32, KW2, PESUN_KS, true, x1f, ps, sA, nullptr);
+                LAYER(F_S2, W2 / 32, KW2, 0, true, sA, nullptr, sB, nullptr);
+                LAYER(F_S3, W2 / 32, KW2, 0, true, sB, nullptr, sA, nullptr);
+                LAYER(F_S4, 1, KW2, 0, false, sA, nullptr, nullptr, &raw);
+                sv_raw = raw[0];
+            }
+            if constexpr (VARIANT == 0) {
+                // seasonal colour-adjust branch (T_NeRF_net_v2.py:83-87)
+                LAYER(F_A1, W / 32, KW2, 0, true, x1f, nullptr, hA, nullptr);
+                LAYER(F_A2, W / 32, KW, 0, true, hA, nullptr, hB, nullptr);
+                LAYER(F_A3, W / 32, KW, 0, true, hB, nullptr, hA, nullptr);
+                LAYER(F_AC, 1, KW, 0, false, hA, nullptr, nullptr, &raw);
+#pragma unroll
+                for (int i = 0; i < 3 * C_MAX; ++i) adj[i] = raw[i];
+            }
+#undef LAYER
+            // ---- output non-linearities (T_NeRF_net_v2.py:91-98), lane-half 0 holds the head rows
+            if (h == 0 && valid) {
+                const snerf_field_out_dev& O = A.out;
+                if (O.rho) O.rho[n] = softplus_f(rho_raw);
+                if (O.points) { O.points[n * 3] = x0; O.points[n * 3 + 1] = x1; O.points[n * 3 + 2] = x2; }
+                if constexpr (VARIANT <= 1) {
+                    if (O.solar_vis) O.solar_vis[n] = sigmoid_f(sv_raw);
+                }
+                if constexpr (VARIANT == 0) {
+                    if (O.col_raw) { O.col_raw[n * 3] = col_r; O.col_raw[n * 3 + 1] = col_g; O.col_raw[n * 3 + 2] = col_b; }
+                    float ac0 = 0.f, ac1 = 0.f, ac2 = 0.f;
+#pragma unroll
+                    for (int c = 0; c < C_MAX; ++c) {
+                        if (c < C) {
+                            if (O.adjust) {
+                                O.adjust[(n * C + c) * 3] = adj[3 * c];
+                                O.adjust[(n * C + c) * 3 + 1] = adj[3 * c + 1];
+                                O.adjust[(n * C + c) * 3 + 2] = adj[3 * c + 2];
+                            }
+                            const float pc = pcls[c];
+                            ac0 = __fadd_rn(ac0, __fmul_rn(adj[3 * c], pc));
+                            ac1 = __fadd_rn(ac1, __fmul_rn(adj[3 * c + 1], pc));
+                            ac2 = __fadd_rn(ac2, __fmul_rn(adj[3 * c + 2], pc));
+                        }
+                    }
+                    if (O.adjust_col) { O.adjust_col[n * 3] = ac0; O.adjust_col[n * 3 + 1] = ac1; O.adjust_col[n * 3 + 2] = ac2; }
+                    if (O.col) {
+                        O.col[n * 3] = sigmoid_f(col_r + ac0);
+                        O.col[n * 3 + 1] = sigmoid_f(col_g + ac1);
+                        O.col[n * 3 + 2] = sigmoid_f(col_b + ac2);
+                    }
+                }
+            }
+        } else {
+            // ---- group program: class softmax (T_NeRF_net_v2.py:77-78) and sky colour (G_NeRF.py:110-111)
+            constexpr int KW = W / 16, W4P = pad32(W / 4), KW4 = W4P / 16;
+            f32x16 raw;
+#define LAYER(L, NBv, K0, K1, SINv, IN0, IN1, OUT, RAW)                                                              \
+    run_layer<NBv, K0, K1, SINv>(rg, A.stream, A.stream_bytes, lds, bias_lds + prog_bias_start(PROG_GROUP, W, C_MAX, L), \
+                                 IN0, IN1, OUT, RAW, wave, lane)
+            const float t0 = A.time[nc * 4], t1 = A.time[nc * 4 + 1];
+            const float s0 = A.sun[nc * 3], s1 = A.sun[nc * 3 + 1], s2 = A.sun[nc * 3 + 2];
+            Frag pt[PETIME_KS];
+            make_pe_time(t0, t1, h, pt);
+            Frag hA[KW], hB[KW];
+            LAYER(G_T1, W / 32, PETIME_KS, 0, true, pt, nullptr, hA, nullptr);
+            LAYER(G_T2, W / 32, KW, 0, true, hA, nullptr, hB, nullptr);
+            LAYER(G_CL, 1, KW, 0, false, hB, nullptr, nullptr, &raw);
+            float logit[C_MAX];
+#pragma unroll
+            for (int c = 0; c < C_MAX; ++c) logit[c] = raw[c];
+            Frag ps[PESUN_KS];
+            make_pe_sun(s0, s1, s2, h, ps);
+            Frag kA[KW4];
+            LAYER(G_K1, W4P / 32, PESUN_KS, 0, true, ps, nullptr, kA, nullptr);
+            LAYER(G_K2, 1, KW4, 0, false, kA, nullptr, nullptr, &raw);
+#undef LAYER
+            if (h == 0 && valid) {
+                float m = -3.0e38f;
+#pragma unroll
+                for (int c = 0; c < C_MAX; ++c) if (c < C) m = fmaxf(m, logit[c]);
+                float e[C_MAX], sum = 0.f;
+#pragma unroll
+                for (int c = 0; c < C_MAX; ++c) { e[c] = c < C ? expf(logit[c] - m) : 0.f; sum += e[c]; }
+#pragma unroll
+                for (int c = 0; c < C_MAX; ++c) if (c < C && A.g_classes) A.g_classes[n * C + c] = e[c] / sum;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    if (A.g_sky_raw) A.g_sky_raw[n * 3 + k] = raw[k];
+                    if (A.g_sky) A.g_sky[n * 3 + k] = sigmoid_f(raw[k]);
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup
+}
+
+// =====================================================================================================
+// compositing: one wavefront per ray (Eval_Tools_2.py:13-16,187-215; mg_run_NeRF.py:188-189)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_incl_scan(float v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float t = __shfl_up(v, o, 64);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(256) void composite_kernel(const CompArgs A) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= A.n_rays) return;
+    const int S = A.n_samples;
+    const float tx = A.top[r * 3], ty = A.top[r * 3 + 1], tz = A.top[r * 3 + 2];
+    const float bx = A.bot[r * 3], by = A.bot[r * 3 + 1], bz = A.bot[r * 3 + 2];
+    const float dx = tx - bx, dy = ty - by, dz = tz - bz;
+    // deltas = sqrt(sum((top-bot)^2)) / S   (misc.py:243)
+    const float delta_ray = __fdiv_rn(__fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz))), (float)S);
+    const bool classic = A.flags & 1, zero_oob = A.flags & 2;
+    const float sky0 = A.sky[r * 3], sky1 = A.sky[r * 3 + 1], sky2 = A.sky[r * 3 + 2];
+
+    float carry = 0.f, carry_m = 0.f;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, svsum = 0.f, acc = 0.f, l0 = 0.f, l1 = 0.f, l2 = 0.f, dist = 0.f;
+    float c0 = 0.f, c1 = 0.f, c2 = 0.f;          // classic-solar colour
+    float m0 = 0.f, m1 = 0.f, m2 = 0.f;          // prior-merged albedo
+    for (int base = 0; base < S; base += 64) {
+        const int s = base + lane;
+        const bool in = s < S;
+        const int64_t idx = r * S + (in ? s : S - 1);
+        const float t = A.tvals[in ? s : S - 1], omt = __fsub_rn(1.f, t);
+        const float px = __fadd_rn(__fmul_rn(tx, omt), __fmul_rn(bx, t));
+        const float py = __fadd_rn(__fmul_rn(ty, omt), __fmul_rn(by, t));
+        const float pz = __fadd_rn(__fmul_rn(tz, omt), __fmul_rn(bz, t));
+        float delta = delta_ray;
+        if (zero_oob && (px > 1.f || px < -1.f || py > 1.f || py < -1.f || pz > 1.f || pz < -1.f)) delta = 0.f;
+        const float rho = in ? A.rho[idx] : 0.f;
+        const float y = in ? rho * delta : 0.f;
+        const float incl = wave_incl_scan(y, lane);
+        const float excl = carry + (incl - y);
+        carry += __shfl(incl, 63, 64);
+        const float pv = expf(-excl);
+        const float pe = 1.f - expf(-y);
+        const float ps = in ? pv * pe : 0.f;
+        const float sv = in ? A.solar_vis[idx] : 0.f;
+        const float k0 = in ? A.col[idx * 3] : 0.f, k1 = in ? A.col[idx * 3 + 1] : 0.f, k2 = in ? A.col[idx * 3 + 2] : 0.f;
+        if (in) {
+            if (A.out.pv) A.out.pv[idx] = pv;
+            if (A.out.pe) A.out.pe[idx] = pe;
+            if (A.out.ps) A.out.ps[idx] = ps;
+            if (A.out.delta) A.out.delta[idx] = delta;
+        }
+        a0 += ps * k0; a1 += ps * k1; a2 += ps * k2;
+        svsum += ps * sv;
+        acc += ps;
+        l0 += ps * px; l1 += ps * py; l2 += ps * pz;
+        dist += ps * (delta_ray * (float)(s + 1));
+        if (classic) {
+            c0 += ps * k0 * (sv + (1.f - sv) * sky0);
+            c1 += ps * k1 * (sv + (1.f - sv) * sky1);
+            c2 += ps * k2 * (sv + (1.f - sv) * sky2);
+        }
+        if (A.rho_prior) {
+            const float rm = in ? (rho * A.trust + A.rho_prior[idx] * (1.f - A.trust)) : 0.f;
+            const float ym = rm * delta;
+            const float incl_m = wave_incl_scan(ym, lane);
+            const float excl_m = carry_m + (incl_m - ym);
+            carry_m += __shfl(incl_m, 63, 64);
+            const float psm = in ? expf(-excl_m) * (1.f - expf(-ym)) : 0.f;
+            if (classic) {
+                m0 += psm * k0 * (sv + (1.f - sv) * sky0);
+                m1 += psm * k1 * (sv + (1.f - sv) * sky1);
+                m2 += psm * k2 * (sv + (1.f - sv) * sky2);
+            } else {
+                m0 += psm * k0; m1 += psm * k1; m2 += psm * k2;
+            }
+        }
+    }
+    a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2);
+    svsum = wave_sum(svsum); acc = wave_sum(acc);
+    l0 = wave_sum(l0); l1 = wave_sum(l1); l2 = wave_sum(l2); dist = wave_sum(dist);
+    if (classic) { c0 = wave_sum(c0); c1 = wave_sum(c1); c2 = wave_sum(c2); }
+    if (A.rho_prior) { m0 = wave_sum(m0); m1 = wave_sum(m1); m2 = wave_sum(m2); }
+    if (lane == 0) {
+        const float sv3 = sigmoid_f((svsum - 0.2f) * 30.f);                 // Eval_Tools_2.py:214 (un-merged PS)
+        const float f0 = sv3 + (1.f - sv3) * sky0, f1 = sv3 + (1.f - sv3) * sky1, f2 = sv3 + (1.f - sv3) * sky2;
+        float r0, r1, r2, al0 = a0, al1 = a1, al2 = a2;
+        if (A.rho_prior) {                                                  // Rendered_Col_Merged, :243-248
+            if (classic) { r0 = m0; r1 = m1; r2 = m2; } else { r0 = m0 * f0; r1 = m1 * f1; r2 = m2 * f2; al0 = m0; al1 = m1; al2 = m2; }
+        } else if (classic) { r0 = c0; r1 = c1; r2 = c2; }
+        else { r0 = a0 * f0; r1 = a1 * f1; r2 = a2 * f2; }
+        if (A.out.rgb) { A.out.rgb[r * 3] = r0; A.out.rgb[r * 3 + 1] = r1; A.out.rgb[r * 3 + 2] = r2; }
+        if (A.out.albedo) { A.out.albedo[r * 3] = al0; A.out.albedo[r * 3 + 1] = al1; A.out.albedo[r * 3 + 2] = al2; }
+        if (A.out.shadow) A.out.shadow[r] = svsum;
+        if (A.out.acc) A.out.acc[r] = acc;
+        if (A.out.surf_loc) {
+            A.out.surf_loc[r * 3] = l0 / (acc + 1e-8f); A.out.surf_loc[r * 3 + 1] = l1 / (acc + 1e-8f); A.out.surf_loc[r * 3 + 2] = l2 / (acc + 1e-8f);
+        }
+        if (A.out.surf_dist) A.out.surf_dist[r] = dist / acc;
+    }
+}
+
+// =====================================================================================================
+// launchers
+template <int PROG, int W, int VARIANT>
+static hipError_t launch_mlp_t(const MlpArgs& a, int n_cu, hipStream_t st) {
+    const int lds_bytes = RING_BYTES + a.bias_floats * 4;
+    const int64_t n_tiles = (a.n + TILE_PTS - 1) / TILE_PTS;
+    int grid = (int)(n_tiles < n_cu ? n_tiles : n_cu);
+    if (grid < 1) grid = 1;
+    auto k = mlp_kernel<PROG, W, VARIANT>;
+    hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds_bytes, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_mlp(int prog, int W, int variant, const MlpArgs& a, int n_cu, hipStream_t st) {
+#define CASE(Wv)                                                                                  \
+    if (W == Wv) {                                                                                \
+        if (prog == PROG_GROUP) return launch_mlp_t<PROG_GROUP, Wv, 0>(a, n_cu, st);              \
+        if (variant == 0) return launch_mlp_t<PROG_FIELD, Wv, 0>(a, n_cu, st);                    \
+        if (variant == 1) return launch_mlp_t<PROG_FIELD, Wv, 1>(a, n_cu, st);                    \
+        return launch_mlp_t<PROG_FIELD, Wv, 2>(a, n_cu, st);                                      \
+    }
+    CASE(64)
+    CASE(256)
+#undef CASE
+    return hipErrorInvalidValue;
+}
+
+int mlp_lds_bytes(int bias_floats) { return RING_BYTES + bias_floats * 4; }
+int mlp_tile_points() { return TILE_PTS; }
+const char* mlp_kernel_name() { return "mlp_kernel"; }
+
+// chunks consumed per tile by a variant of the field program (the DMA stream is cyclic over exactly these)
+int field_variant_chunks(int W, int C, int variant) {
+    const int last = variant == 0 ? (int)F_NUM : variant == 1 ? (int)F_A1 : (int)F_S1;
+    return prog_chunk_start(PROG_FIELD, W, C, last);
+}
+
+hipError_t launch_composite(const CompArgs& a, hipStream_t st) {
+    const int grid = (int)((a.n_rays + 3) / 4);
+    hipLaunchKernelGGL(composite_kernel, dim3(grid), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+}  // namespace snerf

@@ -1,0 +1,184 @@
+// Host-side weight packer: reference state_dict tensors -> the MFMA fragment streams of program.h.
+//
+// What is folded at pack time (fp64 arithmetic, then one rounding):
+//   * eval-mode BatchNorm1d (misc.py:169-170,188-189):  sin(BN(30*(Wx+b)))  ==  sin(2*pi*(W''x + b''))
+//       a = gamma/sqrt(running_var+eps),  W'' = a*30*W/(2*pi),  b'' = (a*(30*b - running_mean) + beta)/(2*pi)
+//     (v_sin_f32 takes revolutions, so the 1/(2*pi) is free);
+//   * the k-order permutation of the register-resident chain and the row maps of the head layers;
+//   * the bf16 hi/lo split  w = hi + lo  (hi = RNE bf16(w), lo = RNE bf16(w - hi)).
+// Pure host code: no HIP calls, usable (and unit-tested) on a machine without a GPU.
+#include "pack.h"
+
+#include <cmath>
+#include <cstring>
+
+namespace snerf {
+
+static inline uint16_t bf16_rne(float f) {
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    if ((u & 0x7f800000u) == 0x7f800000u) return (uint16_t)(u >> 16);   // inf / nan: truncate
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+static inline float bf16_to_f32(uint16_t b) {
+    uint32_t u = (uint32_t)b << 16;
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+
+const Tensor* Weights::find(const std::string& k) const {
+    auto it = t.find(k);
+    return it == t.end() ? nullptr : &it->second;
+}
+
+// ---- reference layer sources --------------------------------------------------------------------------
+struct Src {
+    const char* prefix;   // state_dict key prefix
+    bool sine;            // SineLayer (weights under ".linear.") vs plain Linear
+};
+
+static const char* field_prefix(int l) {
+    static const char* p[F_NUM] = {
+        "G_NeRF_net.fc1", "G_NeRF_net.fc2", "G_NeRF_net.fc3", "G_NeRF_net.fc4", "G_NeRF_net.fc5", "G_NeRF_net.fc6",
+        "G_NeRF_net.fc7", "G_NeRF_net.fc8", "G_NeRF_net.fc9", nullptr /*head: two sources*/,
+        "G_NeRF_net.fc_solar_1", "G_NeRF_net.fc_solar_2", "G_NeRF_net.fc_solar_3", "G_NeRF_net.fc_solar_4",
+        "adjust_layer_1", "adjust_layer_2", "adjust_layer_3", "adjust_col"};
+    return p[l];
+}
+static const char* group_prefix(int l) {
+    static const char* p[G_NUM] = {"time_layer_1", "time_layer_2", "get_class_layer", "G_NeRF_net.fc_sky_color_1",
+                                   "G_NeRF_net.fc_sky_color_2"};
+    return p[l];
+}
+
+// Dense folded layer in *reference* feature order: Wd[n_ref][k_ref], bd[n_ref]
+struct Dense {
+    int n = 0, k = 0;
+    std::vector<double> W, b;
+};
+
+static bool fetch(const Weights& w, const std::string& key, size_t numel, const float** out, std::string* err) {
+    const Tensor* t = w.find(key);
+    if (!t) { *err = "missing tensor: " + key; return false; }
+    if (t->data.size() != numel) {
+        *err = "tensor " + key + " has " + std::to_string(t->data.size()) + " elements, expected " + std::to_string(numel);
+        return false;
+    }
+    *out = t->data.data();
+    return true;
+}
+
+static bool dense_sine(const Weights& w, const std::string& pre, int n, int k, bool fold_bn, Dense* d, std::string* err) {
+    const float *W, *b;
+    if (!fetch(w, pre + ".linear.weight", (size_t)n * k, &W, err)) return false;
+    if (!fetch(w, pre + ".linear.bias", (size_t)n, &b, err)) return false;
+    const bool has_bn = w.find(pre + ".norm.weight") != nullptr;
+    const float *g = nullptr, *beta = nullptr, *mu = nullptr, *var = nullptr;
+    if (has_bn) {
+        if (!fold_bn) { *err = "layer " + pre + " has BatchNorm; only the folded (eval-mode) program is packed"; return false; }
+        if (!fetch(w, pre + ".norm.weight", n, &g, err) || !fetch(w, pre + ".norm.bias", n, &beta, err) ||
+            !fetch(w, pre + ".norm.running_mean", n, &mu, err) || !fetch(w, pre + ".norm.running_var", n, &var, err))
+            return false;
+    }
+    const double inv2pi = 1.0 / (2.0 * M_PI);
+    d->n = n; d->k = k;
+    d->W.assign((size_t)n * k, 0.0); d->b.assign(n, 0.0);
+    for (int r = 0; r < n; ++r) {
+        double a = 1.0, shift = 0.0, off = 0.0;
+        if (has_bn) { a = (double)g[r] / std::sqrt((double)var[r] + 1e-5); shift = mu[r]; off = beta[r]; }
+        for (int c = 0; c < k; ++c) d->W[(size_t)r * k + c] = a * 30.0 * (double)W[(size_t)r * k + c] * inv2pi;
+        d->b[r] = (a * (30.0 * (double)b[r] - shift) + off) * inv2pi;
+    }
+    return true;
+}
+
+static bool dense_linear(const Weights& w, const std::string& pre, int n, int k, Dense* d, std::string* err) {
+    const float *W, *b;
+    if (!fetch(w, pre + ".weight", (size_t)n * k, &W, err)) return false;
+    if (!fetch(w, pre + ".bias", (size_t)n, &b, err)) return false;
+    d->n = n; d->k = k;
+    d->W.assign(W, W + (size_t)n * k);
+    d->b.assign(b, b + n);
+    return true;
+}
+
+// padded output row -> reference row (or -1)
+static int ref_row(const LayerShape& s, int n) {
+    const int b = n / 32, r = n % 32;
+    switch (s.row_map) {
+        case ROWS_ID: return n < s.n_ref ? n : -1;
+        case ROWS_HEAD: return (b == 0 && r < 4) ? r : -1;               // col r,g,b, sigma -> acc regs 0..3 of lane-half 0
+        case ROWS_SV: case ROWS_SKY: return (b == 0 && r < s.n_ref) ? r : -1;
+        case ROWS_ADJ: case ROWS_CLASS:                                      // output i -> acc reg i of lane-half 0
+            if (b != 0) return -1;
+            for (int i = 0; i < s.n_ref && i < 16; ++i) if (acc_row(i, 0) == r) return i;
+            return -1;
+    }
+    return -1;
+}
+
+bool pack_program(const Weights& w, int prog, int W, int C, bool fold_bn, Packed* out, std::string* err) {
+    if (W < 64 || W % 64 != 0) { *err = "layer width must be a multiple of 64 (got " + std::to_string(W) + ")"; return false; }
+    if (C < 1 || C > kMaxClasses) { *err = "n_classes must be in [1," + std::to_string(kMaxClasses) + "]"; return false; }
+    const int L = prog_layers(prog);
+    out->stream.assign((size_t)prog_chunks(prog, W, C) * kChunkBytes, 0);
+    out->bias.assign((size_t)prog_bias_floats(prog, W, C), 0.f);
+    for (int l = 0; l < L; ++l) {
+        const LayerShape s = prog_layer(prog, W, C, l);
+        // ---- dense folded reference layer
+        Dense d;
+        const int k_ref = kind_features(s.kind0, s.ks0) + kind_features(s.kind1, s.ks1);
+        if (prog == PROG_FIELD && l == F_HEAD) {
+            Dense c3, s1;
+            if (!dense_linear(w, "G_NeRF_net.fc10Col", 3, k_ref, &c3, err)) return false;
+            if (!dense_linear(w, "G_NeRF_net.fc10Sigma", 1, k_ref, &s1, err)) return false;
+            d.n = 4; d.k = k_ref; d.W = c3.W; d.b = c3.b;
+            d.W.insert(d.W.end(), s1.W.begin(), s1.W.end()); d.b.push_back(s1.b[0]);
+        } else {
+            const std::string pre = prog == PROG_FIELD ? field_prefix(l) : group_prefix(l);
+            // input width of the reference layer: an IN_H block narrower than its k-steps means zero-padded features
+            int kr = k_ref;
+            if (prog == PROG_GROUP && l == G_K2) kr = W / 4;          // fc_sky_color_2 reads W/4 features (padded to 32)
+            if (s.out_kind == OUT_SIN) { if (!dense_sine(w, pre, s.n_ref, kr, fold_bn, &d, err)) return false; }
+            else { if (!dense_linear(w, pre, s.n_ref, kr, &d, err)) return false; }
+        }
+        // ---- bias table in accumulator order: [block][lane-half][reg]
+        float* bias = out->bias.data() + prog_bias_start(prog, W, C, l);
+        for (int b = 0; b < s.nb(); ++b)
+            for (int h = 0; h < 2; ++h)
+                for (int i = 0; i < 16; ++i) {
+                    const int rr = ref_row(s, 32 * b + acc_row(i, h));
+                    bias[b * 32 + h * 16 + i] = rr >= 0 ? (float)d.b[rr] : 0.f;
+                }
+        // ---- fragments
+        uint8_t* base = out->stream.data() + (size_t)prog_chunk_start(prog, W, C, l) * kChunkBytes;
+        const int f0 = kind_features(s.kind0, s.ks0);
+        for (int b = 0; b < s.nb(); ++b)
+            for (int ks = 0; ks < s.ks(); ++ks) {
+                uint16_t* hi = (uint16_t*)(base + (size_t)(b * s.ks() + ks) * kPairBytes);
+                uint16_t* lo = hi + kFragBytes / 2;
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int r = lane & 31, h = lane >> 5;
+                    const int rr = ref_row(s, 32 * b + r);
+                    for (int j = 0; j < 8; ++j) {
+                        double v = 0.0;
+                        if (rr >= 0) {
+                            int col = -1;
+                            if (ks < s.ks0) { const int f = slot_feature(s.kind0, 16 * ks + 8 * h + j); if (f >= 0) col = f; }
+                            else { const int f = slot_feature(s.kind1, 16 * (ks - s.ks0) + 8 * h + j); if (f >= 0) col = f0 + f; }
+                            if (col >= 0 && col < d.k) v = d.W[(size_t)rr * d.k + col];
+                        }
+                        const float vf = (float)v;
+                        const uint16_t vh = bf16_rne(vf);
+                        hi[lane * 8 + j] = vh;
+                        lo[lane * 8 + j] = bf16_rne((float)(v - (double)bf16_to_f32(vh)));
+                    }
+                }
+            }
+    }
+    return true;
+}
+
+}  // namespace snerf

@@ -1,0 +1,152 @@
+// Shared description of the fused-MLP "programs" (host packer + device kernels).
+//
+// The Season-NeRF network (reference: T_NeRF_Full_2/T_NeRF_net_v2.py:20-105, T_NeRF_Full_2/G_NeRF.py:42-111)
+// is run as two register-resident MFMA chains:
+//   FIELD program  - per sample point: PE(pos) -> fc1..fc9 -> {sigma/colour head, solar branch, adjust branch}
+//   GROUP program  - per (time, sun) group (a ray, or one per image): time->class softmax, sun->sky colour
+//
+// Data layout contract (gfx950, v_mfma_f32_32x32x16_bf16, computed transposed:  H_out^T[n x pts] = W[n x k] * H_in^T[k x pts]):
+//   * weights are the MFMA A operand: one "fragment" = 32 output rows x 16 k-slots of bf16 = 1 KiB, stored
+//     lane-linear (lane l = 32*h + r holds row r, k-slots 8h..8h+7 as 16 contiguous bytes), so a
+//     global_load_lds_dwordx4 / ds_read_b128 pair moves it with no swizzle and no bank conflicts;
+//   * every fragment exists twice, hi = bf16(w) and lo = bf16(w - hi) (3-term error-compensated product
+//     hi*hi + lo*hi + hi*lo, fp32 accumulate) - a "pair" = 2 KiB, a DMA "chunk" = 8 pairs = 16 KiB;
+//   * activations are the MFMA B operand and never leave registers: the 32x32 fp32 accumulator of output
+//     block b (point on the lane, 16 rows in registers) becomes, after sin() and the bf16 hi/lo split, the
+//     B fragments of k-steps 2b and 2b+1 of the next layer.  The price is a fixed permutation of the k order,
+//     paid for at pack time:  k-slot (s, 8h+j)  <->  feature 32*(s>>1) + 16*(s&1) + 8*(j>>2) + 4*h + (j&3).
+#pragma once
+#include <stdint.h>
+
+namespace snerf {
+
+constexpr int kFragBytes = 1024;
+constexpr int kPairBytes = 2 * kFragBytes;
+constexpr int kChunkPairs = 8;
+constexpr int kChunkBytes = kChunkPairs * kPairBytes;   // 16 KiB
+constexpr int kMaxClasses = 5;                           // 3*C adjust rows must fit the 16 rows one lane owns
+
+constexpr int PE_POS_N = 10, PE_SUN_N = 4, PE_TIME_N = 2;     // G_NeRF.py:7, T_NeRF_net_v2.py:36
+constexpr int PE_POS_F = 3 * (2 * PE_POS_N + 1);              // 63
+constexpr int PE_SUN_F = 3 * (2 * PE_SUN_N + 1);              // 27
+constexpr int PE_TIME_F = 2 * (2 * PE_TIME_N + 1);            // 10
+constexpr int PEPOS_KS = 4, PESUN_KS = 2, PETIME_KS = 2;      // k-steps (16 slots each) of the encodings
+
+enum InKind : int { IN_NONE = 0, IN_H = 1, IN_PEPOS = 2, IN_PESUN = 3, IN_PETIME = 4 };
+enum OutKind : int { OUT_SIN = 0, OUT_RAW = 1 };
+enum RowMap : int { ROWS_ID = 0, ROWS_HEAD = 1, ROWS_SV = 2, ROWS_ADJ = 3, ROWS_CLASS = 4, ROWS_SKY = 5 };
+
+enum FieldLayer : int { F_FC1 = 0, F_FC2, F_FC3, F_FC4, F_FC5, F_FC6, F_FC7, F_FC8, F_FC9, F_HEAD,
+                        F_S1, F_S2, F_S3, F_S4, F_A1, F_A2, F_A3, F_AC, F_NUM };
+enum GroupLayer : int { G_T1 = 0, G_T2, G_CL, G_K1, G_K2, G_NUM };
+
+struct LayerShape {
+    int n_ref;      // output rows in the reference layer (before padding)
+    int n_out;      // padded to a multiple of 32
+    int ks0, kind0; // first input block: k-steps and kind
+    int ks1, kind1; // optional second block (concatenated after the first, as the reference's torch.cat)
+    int out_kind;   // OUT_SIN: sin(2*pi*acc) -> bf16 hi/lo fragments;  OUT_RAW: fp32 accumulator rows
+    int row_map;
+    __host__ __device__ constexpr int ks() const { return ks0 + ks1; }
+    __host__ __device__ constexpr int nb() const { return n_out / 32; }
+    __host__ __device__ constexpr int pairs() const { return nb() * ks(); }
+    __host__ __device__ constexpr int chunks() const { return (pairs() + kChunkPairs - 1) / kChunkPairs; }
+};
+
+__host__ __device__ constexpr int pad32(int x) { return (x + 31) / 32 * 32; }
+
+// W must be a multiple of 64 (so W/2 is a multiple of 32).  C = number of season classes.
+__host__ __device__ constexpr LayerShape field_layer(int W, int C, int l) {
+    const int W2 = W / 2;
+    switch (l) {
+        case F_FC1: return {W, W, PEPOS_KS, IN_PEPOS, 0, IN_NONE, OUT_SIN, ROWS_ID};
+        case F_FC2: case F_FC3: case F_FC4: case F_FC6: case F_FC7: case F_FC8:
+            return {W, W, W / 16, IN_H, 0, IN_NONE, OUT_SIN, ROWS_ID};
+        case F_FC5: return {W, W, W / 16, IN_H, PEPOS_KS, IN_PEPOS, OUT_SIN, ROWS_ID};
+        case F_FC9: return {W2, W2, W / 16, IN_H, 0, IN_NONE, OUT_SIN, ROWS_ID};
+        case F_HEAD: return {4, 32, W2 / 16, IN_H, 0, IN_NONE, OUT_RAW, ROWS_HEAD};
+        case F_S1: return {W2, W2, W2 / 16, IN_H, PESUN_KS, IN_PESUN, OUT_SIN, ROWS_ID};
+        case F_S2: case F_S3: return {W2, W2, W2 / 16, IN_H, 0, IN_NONE, OUT_SIN, ROWS_ID};
+        case F_S4: return {1, 32, W2 / 16, IN_H, 0, IN_NONE, OUT_RAW, ROWS_SV};
+        case F_A1: return {W, W, W2 / 16, IN_H, 0, IN_NONE, OUT_SIN, ROWS_ID};
+        case F_A2: case F_A3: return {W, W, W / 16, IN_H, 0, IN_NONE, OUT_SIN, ROWS_ID};
+        case F_AC: return {3 * C, 32, W / 16, IN_H, 0, IN_NONE, OUT_RAW, ROWS_ADJ};
+        default: return {0, 0, 0, 0, 0, 0, 0, 0};
+    }
+}
+
+__host__ __device__ constexpr LayerShape group_layer(int W, int C, int l) {
+    const int W4 = W / 4;
+    switch (l) {
+        case G_T1: return {W, W, PETIME_KS, IN_PETIME, 0, IN_NONE, OUT_SIN, ROWS_ID};
+        case G_T2: return {W, W, W / 16, IN_H, 0, IN_NONE, OUT_SIN, ROWS_ID};
+        case G_CL: return {C, 32, W / 16, IN_H, 0, IN_NONE, OUT_RAW, ROWS_CLASS};
+        case G_K1: return {W4, pad32(W4), PESUN_KS, IN_PESUN, 0, IN_NONE, OUT_SIN, ROWS_ID};
+        case G_K2: return {3, 32, pad32(W4) / 16, IN_H, 0, IN_NONE, OUT_RAW, ROWS_SKY};
+        default: return {0, 0, 0, 0, 0, 0, 0, 0};
+    }
+}
+
+enum Program : int { PROG_FIELD = 0, PROG_GROUP = 1 };
+__host__ __device__ constexpr int prog_layers(int prog) { return prog == PROG_FIELD ? (int)F_NUM : (int)G_NUM; }
+__host__ __device__ constexpr LayerShape prog_layer(int prog, int W, int C, int l) {
+    return prog == PROG_FIELD ? field_layer(W, C, l) : group_layer(W, C, l);
+}
+// chunk index at which layer l starts (every layer starts on a chunk boundary), and bias-table offset (floats)
+__host__ __device__ constexpr int prog_chunk_start(int prog, int W, int C, int l) {
+    int c = 0;
+    for (int i = 0; i < l; ++i) c += prog_layer(prog, W, C, i).chunks();
+    return c;
+}
+__host__ __device__ constexpr int prog_bias_start(int prog, int W, int C, int l) {
+    int c = 0;
+    for (int i = 0; i < l; ++i) c += prog_layer(prog, W, C, i).n_out;
+    return c;
+}
+__host__ __device__ constexpr int prog_chunks(int prog, int W, int C) { return prog_chunk_start(prog, W, C, prog_layers(prog)); }
+__host__ __device__ constexpr int prog_bias_floats(int prog, int W, int C) { return prog_bias_start(prog, W, C, prog_layers(prog)); }
+
+// ---- k-slot -> input feature maps.  kk = 16*s + 8*h + j is the K index inside a block.  -1 = zero padding.
+__host__ __device__ constexpr int slot_feature_H(int kk) {
+    const int s = kk / 16, h = (kk % 16) / 8, j = kk % 8;
+    return 32 * (s >> 1) + 16 * (s & 1) + 8 * (j >> 2) + 4 * h + (j & 3);
+}
+// PE(pos), reference feature order (misc.py:114-139): [x0 x1 x2 | per d: cos(k_0..k_9 x_d), sin(k_0..k_9 x_d)].
+// lane-half h evaluates frequencies 5h..5h+4 of all three coordinates: e = 8s + j in [0,32):
+//   e < 30: d = e/10, r = e%10, freq = 5h + r/2, (r&1 ? sin : cos);  e = 30,31: raw x (h=0: x0,x1; h=1: x2, pad)
+__host__ __device__ constexpr int slot_feature_PEPOS(int kk) {
+    const int s = kk / 16, h = (kk % 16) / 8, j = kk % 8, e = 8 * s + j;
+    if (e < 30) { const int d = e / 10, r = e % 10; return 3 + 20 * d + 10 * (r & 1) + 5 * h + r / 2; }
+    if (e == 30) return h == 0 ? 0 : 2;
+    return h == 0 ? 1 : -1;
+}
+// PE(sun), n = 4: e = 8s + j in [0,16): e < 12: d = e/4, r = e%4, freq = 2h + r/2; e = 12,13 raw; 14,15 pad
+__host__ __device__ constexpr int slot_feature_PESUN(int kk) {
+    const int s = kk / 16, h = (kk % 16) / 8, j = kk % 8, e = 8 * s + j;
+    if (e < 12) { const int d = e / 4, r = e % 4; return 3 + 8 * d + 4 * (r & 1) + 2 * h + r / 2; }
+    if (e == 12) return h == 0 ? 0 : 2;
+    if (e == 13) return h == 0 ? 1 : -1;
+    return -1;
+}
+// PE(time[:, 0:2]), n = 2: only k-step 0 is used; lane-half h owns coordinate d = h:
+//   j = 0 raw, 1 cos k0, 2 sin k0, 3 cos k1, 4 sin k1, 5..7 pad
+__host__ __device__ constexpr int slot_feature_PETIME(int kk) {
+    const int s = kk / 16, h = (kk % 16) / 8, j = kk % 8;
+    if (s != 0 || j > 4) return -1;
+    if (j == 0) return h;
+    const int q = j - 1;                       // 0 cos k0, 1 sin k0, 2 cos k1, 3 sin k1
+    return 2 + 4 * h + 2 * (q & 1) + (q >> 1);
+}
+__host__ __device__ constexpr int slot_feature(int kind, int kk) {
+    return kind == IN_H ? slot_feature_H(kk) : kind == IN_PEPOS ? slot_feature_PEPOS(kk)
+         : kind == IN_PESUN ? slot_feature_PESUN(kk) : kind == IN_PETIME ? slot_feature_PETIME(kk) : -1;
+}
+__host__ __device__ constexpr int kind_features(int kind, int ks) {
+    return kind == IN_H ? 16 * ks : kind == IN_PEPOS ? PE_POS_F : kind == IN_PESUN ? PE_SUN_F
+         : kind == IN_PETIME ? PE_TIME_F : 0;
+}
+
+// accumulator register i of lane-half h  <->  row of the 32-row output block
+__host__ __device__ constexpr int acc_row(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
+
+}  // namespace snerf

@@ -1,0 +1,148 @@
+"""Host-side mirror of `All_in_One_Eval` (T_NeRF_Full_2/Eval_Tools_2.py:111-459): same constructor, same
+`eval / eval_Rho_Only / full_eval` signatures and result-dict keys, computed by the HIP kernels
+(group network -> fused field network with in-kernel ray sampling -> wave-scan compositing).
+
+Deviation (documented in INTEGRATION.md): tensors of the result dict stay on the GPU, including `sample_pts`
+(the reference leaves that one on the CPU); no host<->device copies happen inside `eval`.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .network import T_NeRF
+
+
+def sample_parameters(n_samples, eval_mode, include_end_pt=False):
+    """The sample-parameter vector of misc.sample_pt_coarse (misc.py:236-241), built with the same torch CPU ops
+    (and the same CPU RNG draw `t.rand(n)` - one jitter vector shared by all rays) so seeds reproduce."""
+    if (not include_end_pt) or (not eval_mode):
+        ts = torch.linspace(0, 1, n_samples + 1)[0:-1]
+    else:
+        ts = torch.linspace(0, 1, n_samples)
+    if not eval_mode:
+        ts = ts + 1 / n_samples * torch.rand(n_samples)
+    return ts.float().contiguous()
+
+
+class All_in_One_Eval:
+    def __init__(self, args, device, n_steps, use_prior, ada_loss, H, WC, base_solar_vecs=None):
+        self.device = torch.device(device)
+        self.args = args
+        self.n_steps = n_steps
+        self.use_prior = use_prior
+        self.use_reg = args.Use_Reg
+        self.use_classic_solar = args.Solar_Type_2
+        self.use_MSE_loss = args.Use_MSE_loss
+        self.ada_loss = ada_loss
+        self.H, self.WC = H, WC
+
+    # -------------------------------------------------------------------------------------------------
+    def _check(self, Network):
+        if not isinstance(Network, T_NeRF):
+            raise TypeError("season_nerf_amd.All_in_One_Eval needs a season_nerf_amd.T_NeRF network")
+        if self.device.type != "cuda":
+            raise RuntimeError("season_nerf_amd.All_in_One_Eval runs on an MI355X only (device must be cuda)")
+
+    def _inputs(self, data_dict, Network):
+        dev = self.device
+        f = lambda k: data_dict[k].to(device=dev, dtype=torch.float32).contiguous()
+        return f("Top"), f("Bot"), f("Sun_Angle"), f("Time_Encoded")
+
+    def eval(self, data_dict, Network, current_step, train_mode):
+        """Eval_Tools_2.py:165-252.  Keys: Rendered_Col, PE, PV, PS, Solar_Vis, Sky_Col, Classes, Adjust, Rho, Col,
+        Col_Adj, deltas, sample_pts, Albedo_Color (+ the *_Supervised / *_Merged family with use_prior)."""
+        self._check(Network)
+        (top, bot, sun, tim) = Network._prep(*self._inputs(data_dict, Network))
+        dev = top.device
+        R, S, Cn = top.shape[0], self.args.n_samples, Network.n_classes
+        N = R * S
+        L = _lib.lib()
+        st = Network._stream()
+        tv = sample_parameters(S, eval_mode=not train_mode).to(dev)
+        cls, _, sky = Network._groups(tim, sun)
+        e = lambda *s: torch.empty(*s, device=dev)
+        rho, sv, col, adjc, pts = e(R, S, 1), e(R, S, 1), e(R, S, 3), e(R, S, 3), e(R, S, 3)
+        fo = _lib.FieldOut(d_rho=rho.data_ptr(), d_solar_vis=sv.data_ptr(), d_col=col.data_ptr(),
+                           d_adjust_col=adjc.data_ptr(), d_points=pts.data_ptr())
+        _lib.check(L.snerf_field_forward_rays(Network.device_model(), 0, R, S, top.data_ptr(), bot.data_ptr(),
+                                              tv.data_ptr(), sun.data_ptr(), cls.data_ptr(), C.byref(fo), st),
+                   "field_forward_rays")
+        flags = 1 if self.use_classic_solar else 0
+
+        def composite(rho_t, prior=None, trust=1.0):
+            rgb, alb, pv, pe, ps, dl = e(R, 3), e(R, 3), e(R, S, 1), e(R, S, 1), e(R, S, 1), e(R, S, 1)
+            co = _lib.CompositeOut(d_rgb=rgb.data_ptr(), d_albedo=alb.data_ptr(), d_pv=pv.data_ptr(),
+                                   d_pe=pe.data_ptr(), d_ps=ps.data_ptr(), d_delta=dl.data_ptr())
+            _lib.check(L.snerf_composite_rays(R, S, top.data_ptr(), bot.data_ptr(), tv.data_ptr(), rho_t.data_ptr(),
+                                              col.data_ptr(), sv.data_ptr(), sky.data_ptr(), flags,
+                                              prior.data_ptr() if prior is not None else None, float(trust),
+                                              C.byref(co), st), "composite_rays")
+            return rgb, alb, pv, pe, ps, dl
+
+        rgb, alb, pv, pe, ps, dl = composite(rho)
+        res = {"Rendered_Col": rgb, "PE": pe, "PV": pv, "PS": ps, "Solar_Vis": sv,
+               "Sky_Col": sky.unsqueeze(1).expand(R, S, 3), "Classes": cls.unsqueeze(1).expand(R, S, Cn),
+               "Adjust": adjc, "Rho": rho, "Col": col, "Col_Adj": -1, "deltas": dl, "sample_pts": pts,
+               "Albedo_Color": alb}
+        if self.use_prior:                                                     # :218-248
+            trust = current_step / self.n_steps
+            rs = Network.Supervised_Sample(pts.reshape(-1, 3), dl.reshape(-1, 1)).reshape(R, S, 1).float().contiguous()
+            # supervised composite: PS from the prior density, solar term from the network's own PS (:229)
+            _, _, pv_s, pe_s, ps_s, _ = composite(rs)
+            svs = torch.sigmoid(((sv * ps).sum(1) - 0.2) * 30)
+            if self.use_classic_solar:
+                rgb_s = (ps_s * col * (sv + (1 - sv) * res["Sky_Col"])).sum(1)
+            else:
+                rgb_s = (ps_s * col).sum(1) * (svs + (1 - svs) * sky)
+            rgb_m, alb_m, pv_m, pe_m, ps_m, _ = composite(rho, prior=rs, trust=trust)
+            # the kernel's merged pass reports only rgb/albedo; per-sample merged terms via a plain composite
+            rho_m = rho * trust + rs * (1 - trust)
+            _, _, pv_m, pe_m, ps_m, _ = composite(rho_m)
+            res.update({"PV_Supervised": pv_s, "PE_Supervised": pe_s, "PS_Supervised": ps_s,
+                        "Rendered_Col_Supervised": rgb_s, "PV_Merged": pv_m, "PE_Merged": pe_m, "PS_Merged": ps_m,
+                        "Rendered_Col_Merged": rgb_m, "Rho_Merged": rho_m, "Albedo_Color": alb_m})
+        return res
+
+    def full_eval(self, data_dict, Network, current_step):
+        """Eval_Tools_2.py:127-163: eval-mode sampling, no prior; same keys minus Albedo/Col_Adj."""
+        saved = self.use_prior
+        self.use_prior = False
+        try:
+            r = self.eval(data_dict, Network, current_step, False)
+        finally:
+            self.use_prior = saved
+        r.pop("Albedo_Color"), r.pop("Col_Adj")
+        return r
+
+    def eval_Rho_Only(self, data_dict, Network, train_mode, current_step=0):
+        """Eval_Tools_2.py:297-337 (no-prior branch): density + solar visibility along sun rays, end-point sampling.
+        Keys: PE, PV_Exact, Solar_Vis, Sky_Col (raw, not sigmoided - T_NeRF_net_v2.py:154-157)."""
+        self._check(Network)
+        if self.use_prior:
+            raise NotImplementedError("eval_Rho_Only with use_prior is not implemented by the HIP path yet")
+        dev = self.device
+        top, bot, sun = Network._prep(*[data_dict[k].to(dev) for k in ("Top", "Bot", "Sun_Angle")])
+        R, S = top.shape[0], self.args.n_samples
+        L = _lib.lib()
+        st = Network._stream()
+        tv = sample_parameters(S, eval_mode=not train_mode, include_end_pt=True).to(dev)
+        tim = torch.zeros(R, 4, device=dev)
+        _, sky_raw, sky = Network._groups(tim, sun)
+        e = lambda *s: torch.empty(*s, device=dev)
+        rho, sv = e(R, S, 1), e(R, S, 1)
+        fo = _lib.FieldOut(d_rho=rho.data_ptr(), d_solar_vis=sv.data_ptr())
+        _lib.check(L.snerf_field_forward_rays(Network.device_model(), 1, R, S, top.data_ptr(), bot.data_ptr(),
+                                              tv.data_ptr(), sun.data_ptr(), None, C.byref(fo), st), "field_forward_rays")
+        pv, pe = e(R, S, 1), e(R, S, 1)
+        col0 = torch.zeros(R, S, 3, device=dev)
+        co = _lib.CompositeOut(d_pv=pv.data_ptr(), d_pe=pe.data_ptr())
+        _lib.check(L.snerf_composite_rays(R, S, top.data_ptr(), bot.data_ptr(), tv.data_ptr(), rho.data_ptr(),
+                                          col0.data_ptr(), sv.data_ptr(), sky.data_ptr(), 0, None, 1.0, C.byref(co), st),
+                   "composite_rays")
+        return {"PE": pe, "PV_Exact": pv, "Solar_Vis": sv, "Sky_Col": sky_raw.unsqueeze(1).expand(R, S, 3)}
+
+    def get_loss(self, *a, **k):
+        raise NotImplementedError("season_nerf_amd: the training step (get_loss/backward) is not implemented on the "
+                                  "HIP path yet - SURVEY 8 row a9, next round")

@@ -1,0 +1,197 @@
+"""Host-side mirror of the reference network class `T_NeRF` (T_NeRF_Full_2/T_NeRF_net_v2.py:20-204) on top of the
+HIP C-ABI.  Same constructor, same `state_dict` keys/shapes (SURVEY App. C - `Final_Model.nn` loads unchanged), same
+forward variants and return conventions; the arithmetic runs in the gfx950 kernels, never in PyTorch.
+
+Training-mode BatchNorm / autograd through the kernels is not implemented yet: calling a forward while
+`self.training` is True raises instead of silently computing something else.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _lib
+
+OMEGA0 = 30.0
+
+
+class SineLayer(nn.Module):
+    """Parameter container with the reference's key layout `<name>.linear.{weight,bias}`, `<name>.norm.*`
+    (misc.py:148-186).  Init law: first layers U(+-1/in), others U(+-sqrt(6/in)/omega_0); biases torch default."""
+
+    def __init__(self, in_features, out_features, is_first=False, use_norm=False):
+        super().__init__()
+        self.linear = nn.Linear(in_features, out_features)
+        bound = 1.0 / in_features if is_first else math.sqrt(6.0 / in_features) / OMEGA0
+        with torch.no_grad():
+            self.linear.weight.uniform_(-bound, bound)
+        self.norm = nn.BatchNorm1d(out_features, momentum=0.01) if (use_norm and not is_first) else nn.Identity()
+
+
+class _GNeRF(nn.Module):
+    """Key layout of G_NeRF_Net_Classic (G_NeRF.py:42-64)."""
+
+    def __init__(self, W):
+        super().__init__()
+        W2, W4 = max(W // 2, 1), max(W // 4, 1)
+        self.fc1 = SineLayer(63, W, is_first=True)
+        for i in (2, 3, 4, 6, 7, 8):
+            setattr(self, f"fc{i}", SineLayer(W, W, use_norm=True))
+        self.fc5 = SineLayer(W + 63, W, use_norm=True)
+        self.fc9 = SineLayer(W, W2, use_norm=True)
+        self.fc10Col = nn.Linear(W2, 3)
+        self.fc10Sigma = nn.Linear(W2, 1)
+        self.fc_solar_1 = SineLayer(27 + W2, W2, is_first=True)
+        self.fc_solar_2 = SineLayer(W2, W2)
+        self.fc_solar_3 = SineLayer(W2, W2)
+        self.fc_solar_4 = nn.Linear(W2, 1)
+        self.fc_sky_color_1 = SineLayer(27, W4, is_first=True)
+        self.fc_sky_color_2 = nn.Linear(W4, 3)
+
+
+class T_NeRF(nn.Module):
+    def __init__(self, layer_width, n_classes=4, HM=np.array([[0], [0]])):
+        super().__init__()
+        W = layer_width
+        self.layer_width = W
+        self.n_classes = n_classes
+        self.hm = torch.tensor(HM, requires_grad=False)
+        self._hm_const = torch.tensor(self.hm.shape).reshape([1, 2]) - 1
+        self.G_NeRF_net = _GNeRF(W)
+        self.time_layer_1 = SineLayer(10, W, is_first=True)
+        self.time_layer_2 = SineLayer(W, W)
+        self.get_class_layer = nn.Linear(W, n_classes)
+        self.adjust_layer_1 = SineLayer(W // 2, W)
+        self.adjust_layer_2 = SineLayer(W, W)
+        self.adjust_layer_3 = SineLayer(W, W)
+        self.adjust_col = nn.Linear(W, n_classes * 3)
+        # constructed but never used by the reference either (T_NeRF_net_v2.py:49-51); serialised in checkpoints
+        self.adjust_rho = nn.Linear(W, n_classes)
+        self.adjust_solar_vis = nn.Linear(W, n_classes)
+        self.adjust_sky_col = nn.Linear(W, n_classes * 3)
+        self._handle = None
+        self._sig = None
+
+    # ------------------------------------------------------------------ device model management
+    def _signature(self):
+        return tuple((k, v._version, v.data_ptr()) for k, v in self.state_dict(keep_vars=True).items())
+
+    def device_model(self):
+        """Packed weights on the GPU, re-packed whenever a parameter or BN statistic changed."""
+        sig = self._signature()
+        if self._handle is not None and sig == self._sig:
+            return self._handle
+        L = _lib.lib()
+        self.release()
+        h = L.snerf_model_create(self.layer_width, self.n_classes)
+        if not h:
+            raise RuntimeError("season_nerf_amd: " + L.snerf_last_error().decode())
+        try:
+            for k, v in self.state_dict().items():
+                if not v.is_floating_point():
+                    continue
+                a = np.ascontiguousarray(v.detach().float().cpu().numpy())
+                _lib.check(L.snerf_model_set_tensor(h, k.encode(), a.ctypes.data, a.size), "set_tensor " + k)
+            _lib.check(L.snerf_model_finalize(h), "model_finalize")
+        except Exception:
+            L.snerf_model_destroy(h)
+            raise
+        self._handle, self._sig = h, sig
+        return h
+
+    def release(self):
+        if self._handle is not None:
+            _lib.lib().snerf_model_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+    @property
+    def device(self):
+        return self.get_class_layer.weight.device
+
+    def _prep(self, *tensors):
+        if self.training:
+            raise NotImplementedError(
+                "season_nerf_amd.T_NeRF: train-mode (batch-statistics BatchNorm + autograd) forward is not implemented "
+                "by the HIP path yet; call .eval() first")
+        dev = self.device
+        if dev.type != "cuda":
+            raise RuntimeError("season_nerf_amd.T_NeRF runs on an MI355X only: move the module with .to('cuda')")
+        return [t.to(device=dev, dtype=torch.float32).contiguous() for t in tensors]
+
+    @staticmethod
+    def _stream():
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    # ------------------------------------------------------------------ kernels
+    def _groups(self, time, sun):
+        G = time.shape[0]
+        dev = time.device
+        cls = torch.empty(G, self.n_classes, device=dev)
+        sky_raw = torch.empty(G, 3, device=dev)
+        sky = torch.empty(G, 3, device=dev)
+        _lib.check(_lib.lib().snerf_group_forward(self.device_model(), G, time.data_ptr(), sun.data_ptr(), cls.data_ptr(),
+                                                  sky_raw.data_ptr(), sky.data_ptr(), self._stream()), "group_forward")
+        return cls, sky_raw, sky
+
+    def _field_points(self, variant, X, sun, cls, want):
+        N = X.shape[0]
+        dev = X.device
+        shapes = {"d_rho": (N, 1), "d_solar_vis": (N, 1), "d_col_raw": (N, 3), "d_adjust": (N, self.n_classes, 3),
+                  "d_col": (N, 3), "d_adjust_col": (N, 3)}
+        out = {k: torch.empty(shapes[k], device=dev) for k in want}
+        fo = _lib.FieldOut(**{k: v.data_ptr() for k, v in out.items()})
+        _lib.check(_lib.lib().snerf_field_forward_points(
+            self.device_model(), variant, N, X.data_ptr(), 1, sun.data_ptr() if sun is not None else None,
+            cls.data_ptr() if cls is not None else None, C.byref(fo), self._stream()), "field_forward_points")
+        return out
+
+    # ------------------------------------------------------------------ reference API (T_NeRF_net_v2.py)
+    def _process_time(self, Time):
+        return Time[:, 0:2]
+
+    def forward(self, X, Solar_Angle, Time):
+        """-> Rho[N,1], Col[N,3], Solar_Vis[N,1], Sky_Col[N,3], output_class[N,C], Adjust_col[N,3]  (:75-105)"""
+        X, sun, tim = self._prep(X, Solar_Angle, Time)
+        cls, _, sky = self._groups(tim, sun)
+        o = self._field_points(0, X, sun, cls, ["d_rho", "d_col", "d_solar_vis", "d_adjust_col"])
+        return o["d_rho"], o["d_col"], o["d_solar_vis"], sky, cls, o["d_adjust_col"]
+
+    def forward_seperate(self, X, Solar_Angle, Time):
+        """Col raw and Adjust[N,C,3] unmixed (:131-151)."""
+        X, sun, tim = self._prep(X, Solar_Angle, Time)
+        cls, _, sky = self._groups(tim, sun)
+        o = self._field_points(0, X, sun, cls, ["d_rho", "d_col_raw", "d_solar_vis", "d_adjust"])
+        return o["d_rho"], o["d_col_raw"], o["d_solar_vis"], sky, cls, o["d_adjust"]
+
+    forward_full_eval = forward_seperate      # identical outputs (:184-204)
+
+    def forward_Solar(self, X, Solar_Angle, Time):
+        """-> softplus(Rho), sigmoid(Solar_Vis), Sky raw (:154-157)."""
+        X, sun, tim = self._prep(X, Solar_Angle, Time)
+        _, sky_raw, _ = self._groups(tim, sun)
+        o = self._field_points(1, X, sun, None, ["d_rho", "d_solar_vis"])
+        return o["d_rho"], o["d_solar_vis"], sky_raw
+
+    def forward_Classic_Sigma_Only(self, X):
+        (X,) = self._prep(X)
+        return self._field_points(2, X, None, None, ["d_rho"])["d_rho"]
+
+    def get_class_only(self, Time):
+        (tim,) = self._prep(Time)
+        sun = torch.zeros(tim.shape[0], 3, device=tim.device)
+        return self._groups(tim, sun)[0]
+
+    def Supervised_Sample(self, world_pts, delta):
+        """DSM prior density (:175-181); tiny gather, done with torch ops on whatever device the points live on."""
+        hm = self.hm.to(world_pts.device)
+        xy = ((world_pts[:, 0:2] + 1) / 2 * self._hm_const.to(world_pts.device)).long()
+        p = (hm[xy[:, 0], xy[:, 1]] >= world_pts[:, 2]).float().clamp(max=0.99)
+        return -torch.log(1 - p.unsqueeze(1)) / delta
