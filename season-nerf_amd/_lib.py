@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libseason_nerf_hip.so")
+LIB_PATH = os.environ.get("SNERF_LIB", os.path.join(HERE, "libseason_nerf_hip.so"))   # SNERF_LIB: A/B builds (tools/)
 
 _f = C.POINTER(C.c_float)
 

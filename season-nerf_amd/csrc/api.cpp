@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -159,6 +160,9 @@ static int field_launch(const snerf_model* m, int variant, MlpArgs& a, const sne
     a.bias = m->d_bias[PROG_FIELD];
     a.bias_floats = (int)m->host[PROG_FIELD].bias.size();
     a.n_classes = m->C;
+#ifdef SNERF_ABLATE
+    if (const char* e = getenv("SNERF_ABLATE")) a.debug = (uint32_t)atoi(e);
+#endif
     if (out) {
         a.out.rho = out->d_rho; a.out.solar_vis = out->d_solar_vis; a.out.col_raw = out->d_col_raw;
         a.out.adjust = out->d_adjust; a.out.col = out->d_col; a.out.adjust_col = out->d_adjust_col;

@@ -37,6 +37,7 @@ struct MlpArgs {
     float* g_classes;          // [G,C]
     float* g_sky_raw;          // [G,3]
     float* g_sky;              // [G,3]
+    uint32_t debug;            // only read by -DSNERF_ABLATE builds
 };
 
 struct CompOutDev {

@@ -16,6 +16,9 @@
 
 #include "program.h"
 #include "kernels.h"
+#if defined(SNERF_ABLATE) && !defined(ABL)
+#define ABL 0
+#endif
 
 namespace snerf {
 
@@ -44,6 +47,9 @@ struct Ring {
     uint32_t wr;       // LDS offset of the slot the next DMA fills
     uint32_t cur;      // LDS offset of the chunk being consumed
     uint32_t goff;     // byte offset in the (cyclic) global stream of the next chunk to fetch
+#ifdef SNERF_ABLATE
+    uint32_t debug;
+#endif
 };
 
 __device__ __forceinline__ float sin2pi(float r) { return __builtin_amdgcn_sinf(r); }   // v_sin_f32: revolutions,
@@ -83,13 +89,35 @@ __device__ __forceinline__ f32x16 mfma3(const u32x4& a_hi, const u32x4& a_lo, co
     return acc;
 }
 
+// Fetch one 16 KiB chunk: 16 pieces of 1 KiB, wave w moves pieces w, w+4, w+8, w+12 (LDS-DMA: each lane's 16 bytes land
+// at M0 + lane*16).  Issued through inline asm on purpose: the __builtin_amdgcn_global_load_lds form is FLAT-encoded
+// and makes hipcc (ROCm 7.2) treat every later LDS read as dependent on a "pending flat" access, i.e. it emits
+// s_waitcnt lgkmcnt(0) in front of every MFMA instead of counted waits (measured: 685 of 685 waits).  hipcc neither
+// counts these loads nor waits for them; ring_step's hand-counted vmcnt does (cdna_hip_programming.md 5.7).
+// M0 is written and restored inside the one statement; saddr form: address = sgpr base + lane*16.
 __device__ __forceinline__ void dma_chunk(const uint8_t* stream, uint32_t goff, lds_char* lds, uint32_t wr, int wave, int lane) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int piece = wave + 4 * i;                      // 16 pieces of 1 KiB, 4 per wave
-        const uint8_t* src = stream + goff + piece * kFragBytes + lane * 16;
-        __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(lds + wr + piece * kFragBytes), 16, 0, 0);
-    }
+    const uint8_t* b0 = stream + goff + wave * kFragBytes;                    // wave-uniform
+    const uint32_t dst = (uint32_t)(uintptr_t)(lds + wr + wave * kFragBytes); // wave-uniform LDS byte address
+    const uint32_t voff = lane * 16;
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %3\n\t"
+        "s_add_u32 m0, m0, 0x1000\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %4\n\t"
+        "s_add_u32 m0, m0, 0x1000\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %5\n\t"
+        "s_add_u32 m0, m0, 0x1000\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %6\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(dst), "s"(b0), "s"(b0 + 4 * kFragBytes), "s"(b0 + 8 * kFragBytes), "s"(b0 + 12 * kFragBytes)
+        : "memory", "scc");
 }
 
 __device__ __forceinline__ uint32_t ring_next(uint32_t off) {
@@ -102,7 +130,16 @@ __device__ __forceinline__ uint32_t ring_next(uint32_t off) {
 //    (the count is in DMA instructions of THIS wave; extra older loads/stores only make the wait stricter);
 //  - lgkmcnt(0) + s_barrier: every wave's pieces have landed and every wave has finished reading slot `wr`.
 __device__ __forceinline__ void ring_step(Ring& rg, const uint8_t* stream, uint32_t stream_bytes, lds_char* lds, int wave, int lane) {
+#if defined(SNERF_ABLATE) && (ABL & 4)     // timing-only: no ring at all
+    return;
+#endif
+#ifdef SNERF_ABLATE      // timing-only ablation builds (tools/ablate.sh); results are garbage by construction
+    if (!(rg.debug & 2)) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((RING_D - 2) * 4) : "memory");
+    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (!(rg.debug & 1))
+#else
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((RING_D - 2) * 4) : "memory");
+#endif
     dma_chunk(stream, rg.goff, lds, rg.wr, wave, lane);
     rg.goff += kChunkBytes;
     if (rg.goff >= stream_bytes) rg.goff = 0;
@@ -114,39 +151,112 @@ __device__ __forceinline__ void ring_step(Ring& rg, const uint8_t* stream, uint3
 // One fused layer: out^T[n x 32 pts] = act(W[n x k] * in^T[k x 32 pts] + b), activations in registers.
 //   in0/in1: B fragments of the (concatenated) input blocks; out: 2 fragments per 32-row output block;
 //   raw: fp32 accumulator of block 0 for OUT_RAW layers.
+// Software pipelining, all at source level (every index is static after unrolling):
+//   * the A fragments (weights) are read PF pairs ahead of the MFMAs that consume them, and the ring step that
+//     publishes a chunk runs PF pairs before the chunk's first MFMA: LDS latency and the barrier hide behind MFMAs;
+//   * accumulators ping-pong between blocks and the epilogue of block b-1 (bias, sin, bf16 hi/lo split) is emitted
+//     in four slices inside block b's MFMA sequence, so VALU/transcendental work fills the MFMA shadow instead
+//     of serialising at every block boundary.
+#ifndef SNERF_PF
+#define SNERF_PF 3
+#endif
+constexpr int PF = SNERF_PF;
+
+// epilogue of element pair e (0..7): accumulator elements 2e, 2e+1 -> one packed word of the output fragments
+__device__ __forceinline__ void epilogue_pair(const f32x16& acc, const f32x4* biasq, int e, Frag* out2) {
+    const int i0 = 2 * e, i1 = 2 * e + 1;
+#if defined(SNERF_ABLATE) && (ABL & 1)     // timing-only: no sin / split
+    out2[e >> 2].hi[e & 3] = __builtin_bit_cast(uint32_t, acc[i0] + biasq[i0 >> 2][i0 & 3]);
+    out2[e >> 2].lo[e & 3] = __builtin_bit_cast(uint32_t, acc[i1] + biasq[i1 >> 2][i1 & 3]);
+#else
+    const float v0 = sin2pi(acc[i0] + biasq[i0 >> 2][i0 & 3]);
+    const float v1 = sin2pi(acc[i1] + biasq[i1 >> 2][i1 & 3]);
+    uint32_t hh, ll;
+    split2(v0, v1, hh, ll);
+    out2[e >> 2].hi[e & 3] = hh;
+    out2[e >> 2].lo[e & 3] = ll;
+#endif
+}
+
+// LLVM SchedGroupMask bits
+#define SG_VALU 0x002
+#define SG_MFMA 0x008
+#define SG_DSREAD 0x100
+#define SG_TRANS 0x400
+
 template <int NB, int KS0, int KS1, bool SIN>
 __device__ __forceinline__ void run_layer(Ring& rg, const uint8_t* stream, uint32_t stream_bytes, lds_char* lds,
                                           lds_cfloat* bias_l, const Frag* in0, const Frag* in1, Frag* out,
                                           f32x16* raw, int wave, int lane) {
-    constexpr int KS = KS0 + KS1;
+    constexpr int KS = KS0 + KS1, NP = NB * KS;
     const int h = lane >> 5;
+    u32x4 fh[PF], fl[PF];
+#pragma unroll
+    for (int q = 0; q < PF; ++q) {
+        if (q < NP) {
+            if (q % kChunkPairs == 0) ring_step(rg, stream, stream_bytes, lds, wave, lane);
+            lds_char* ap = lds + rg.cur + (q % kChunkPairs) * kPairBytes + lane * 16;
+            fh[q] = *(lds_cu32x4*)ap;
+            fl[q] = *(lds_cu32x4*)(ap + kFragBytes);
+        }
+    }
+    f32x16 accs[2];
+    f32x4 biasq[2][4];
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         lds_cf32x4* bp = (lds_cf32x4*)(bias_l + b * 32 + h * 16);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) biasq[b & 1][i] = bp[i];
         f32x16 acc;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 t = bp[q];
-            acc[4 * q] = t[0]; acc[4 * q + 1] = t[1]; acc[4 * q + 2] = t[2]; acc[4 * q + 3] = t[3];
-        }
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            const int p = b * KS + s;
-            if (p % kChunkPairs == 0) ring_step(rg, stream, stream_bytes, lds, wave, lane);
-            lds_char* ap = lds + rg.cur + (p % kChunkPairs) * kPairBytes + lane * 16;
-            const u32x4 a_hi = *(lds_cu32x4*)ap;
-            const u32x4 a_lo = *(lds_cu32x4*)(ap + kFragBytes);
+            const int q = b * KS + s;
+            const u32x4 a_hi = fh[q % PF], a_lo = fl[q % PF];
+            if (q + PF < NP) {
+                const int qn = q + PF;
+                if (qn % kChunkPairs == 0) ring_step(rg, stream, stream_bytes, lds, wave, lane);
+#if defined(SNERF_ABLATE) && (ABL & 2)     // timing-only: A fragments stay in registers, no LDS reads
+                asm volatile("" : "+v"(fh[q % PF]), "+v"(fl[q % PF]));
+#else
+                lds_char* ap = lds + rg.cur + (qn % kChunkPairs) * kPairBytes + lane * 16;
+                fh[q % PF] = *(lds_cu32x4*)ap;
+                fl[q % PF] = *(lds_cu32x4*)(ap + kFragBytes);
+#endif
+            }
             acc = mfma3(a_hi, a_lo, s < KS0 ? in0[s] : in1[s - KS0], acc);
-        }
-        if (SIN) {
-            float v[16];
+            if (SIN && b > 0) {
+                // previous block's epilogue, one element pair at a time, spread evenly over this block's k-steps
 #pragma unroll
-            for (int i = 0; i < 16; ++i) v[i] = sin2pi(acc[i]);
-            pack8(v, out[2 * b]);
-            pack8(v + 8, out[2 * b + 1]);
-        } else if (b == 0) {
-            *raw = acc;
+                for (int e = 0; e < 8; ++e)
+                    if ((e * KS) / 8 == s) epilogue_pair(accs[(b - 1) & 1], biasq[(b - 1) & 1], e, out + 2 * (b - 1));
+            }
+#ifndef SNERF_NO_SCHED_GROUPS
+            // pin the interleave: each MFMA gets at most 1 LDS read, 1 transcendental and 3 plain VALU in its shadow
+            // (an MFMA holds vector issue for 8 of its 32 cycles: <= 6 plain-VALU-equivalents hide per gap)
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(SG_DSREAD, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(SG_TRANS, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(SG_VALU, 3, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#endif
         }
+        accs[b & 1] = acc;
+    }
+    if (SIN) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) epilogue_pair(accs[(NB - 1) & 1], biasq[(NB - 1) & 1], e, out + 2 * (NB - 1));
+    } else {
+        f32x16 acc = accs[0];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            acc[i] += biasq[0][0][i]; acc[4 + i] += biasq[0][1][i]; acc[8 + i] += biasq[0][2][i]; acc[12 + i] += biasq[0][3][i];
+        }
+        *raw = acc;
     }
 }
 
@@ -247,6 +357,9 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpArgs A) {
     rg.rd = 0;
     rg.cur = 0;
     rg.goff = 0;
+#ifdef SNERF_ABLATE
+    rg.debug = A.debug;
+#endif
     {
         uint32_t wr = 0;
 #pragma unroll
