@@ -109,7 +109,7 @@ def main():
         if i is not None:
             ev0[i].record()
         sn._lib.check(L.snerf_field_forward_rays(model, 0, R, S, top.data_ptr(), bot.data_ptr(), tv.data_ptr(),
-                                                 sun.data_ptr(), cls.data_ptr(), C.byref(fo), st), "field")
+                                                 1, sun.data_ptr(), cls.data_ptr(), C.byref(fo), st), "field")
         if i is not None:
             ev1[i].record()
         sn._lib.check(L.snerf_composite_rays(R, S, top.data_ptr(), bot.data_ptr(), tv.data_ptr(), rho.data_ptr(),

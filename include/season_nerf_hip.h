@@ -81,10 +81,11 @@ int snerf_field_forward_points(const snerf_model* m, int variant, int64_t n_poin
 /* ---- the same on rays: fuses misc.sample_pt_coarse (misc.py:234-247) into the kernel prologue.
  * Rays r = 0..R-1, samples s = 0..S-1, point (r,s) = top[r]*(1-t[s]) + bot[r]*t[s]; d_tvals [S] is the sample
  * parameter vector (linspace + optional shared jitter, built by the caller exactly as the reference does).
- * sun and classes are per ray ([R,3], [R,C]). */
+ * Ray r uses sun/classes row r / rays_per_group: 1 = per-ray sun and time (training batches), n_rays = one
+ * (sun, time) for the whole image (novel-view renders). */
 int snerf_field_forward_rays(const snerf_model* m, int variant, int64_t n_rays, int n_samples,
                              const float* d_top, const float* d_bot, const float* d_tvals,
-                             const float* d_sun, const float* d_classes,
+                             int64_t rays_per_group, const float* d_sun, const float* d_classes,
                              const snerf_field_out* out, void* stream);
 
 /* ---- compositing: Eval_Tools_2.get_PV (:13-16) + PE/PS + albedo / solar shading (:187-215) + depth
@@ -118,6 +119,26 @@ int snerf_render_rays(const snerf_model* m, int64_t n_rays, int n_samples, const
                       const float* d_tvals, const float* d_sun, const float* d_time, int flags,
                       float* d_rgb, const snerf_field_out* field_out, const snerf_composite_out* comp_out,
                       void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* ---- seasonal sweep: mg_Img_Eval.get_imgs_from_Img_Dict (:123-190) and get_imgs_from_Img_Dict_t_step (:192-228).
+ * The MLP is NOT re-run: from the per-sample tensors of one render (forward_seperate outputs) produce, for every class
+ * vector t of d_class_vecs [T,C]:  season[t,r] = sum_s PS*sigmoid(col_raw + class_t @ adjust)  and
+ * shaded[t,r] = season[t,r] * (shadow + (1-shadow)*sky), shadow = sigmoid(30*(sum_s PS*solar_vis - 0.2)).
+ * d_sky is ONE vector [3] (the reference uses Sky_Col[0,0]); d_solar_vis may be the estimated or the exact visibility.
+ * flags bit1 = zero delta outside the cube.  Also: base [R,3] = sum PS*sigmoid(col_raw), shadow_adjust [R,3],
+ * raw_shadow [R].  All outputs optional. */
+typedef struct snerf_sweep_out {
+    float* d_season;         /* [T,R,3] */
+    float* d_shaded;         /* [T,R,3] */
+    float* d_base;           /* [R,3] */
+    float* d_shadow_adjust;  /* [R,3] */
+    float* d_raw_shadow;     /* [R] */
+} snerf_sweep_out;
+
+int snerf_composite_sweep(int64_t n_rays, int n_samples, int n_classes, int n_times, const float* d_top,
+                          const float* d_bot, const float* d_tvals, const float* d_rho, const float* d_col_raw,
+                          const float* d_adjust, const float* d_solar_vis, const float* d_sky, const float* d_class_vecs,
+                          int flags, const snerf_sweep_out* out, void* stream);
 
 /* Name and launch geometry of the dominant kernel (for profiling scripts): fills grid/block/lds bytes. */
 int snerf_field_kernel_info(const snerf_model* m, int64_t n_points, int* grid, int* block, int* lds_bytes);

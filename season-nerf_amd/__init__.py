@@ -4,5 +4,9 @@ call boundary: `T_NeRF` (network), `All_in_One_Eval` (ray evaluator).  All arith
 from . import _lib
 from .network import T_NeRF, SineLayer
 from .evaluator import All_in_One_Eval, sample_parameters
+from .render import (Quick_Run_Net, component_render_by_dir, get_imgs_from_Img_Dict, get_imgs_from_Img_Dict_t_step,
+                     render_season_sweep, world_angle_2_local_vec, encode_time)
 
-__all__ = ["T_NeRF", "SineLayer", "All_in_One_Eval", "sample_parameters", "_lib"]
+__all__ = ["T_NeRF", "SineLayer", "All_in_One_Eval", "sample_parameters", "Quick_Run_Net", "component_render_by_dir",
+           "get_imgs_from_Img_Dict", "get_imgs_from_Img_Dict_t_step", "render_season_sweep", "world_angle_2_local_vec",
+           "encode_time", "_lib"]

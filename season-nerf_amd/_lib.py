@@ -19,6 +19,10 @@ class CompositeOut(C.Structure):
                 ("d_rgb", "d_albedo", "d_pv", "d_pe", "d_ps", "d_delta", "d_shadow", "d_acc", "d_surf_loc", "d_surf_dist")]
 
 
+class SweepOut(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("d_season", "d_shaded", "d_base", "d_shadow_adjust", "d_raw_shadow")]
+
+
 _lib = None
 
 
@@ -45,13 +49,14 @@ def lib():
     L.snerf_model_pack_host.argtypes = [vp, i32, vp, C.POINTER(C.c_size_t), vp, C.POINTER(C.c_size_t)]
     L.snerf_group_forward.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp]
     L.snerf_field_forward_points.argtypes = [vp, i32, i64, vp, i64, vp, vp, C.POINTER(FieldOut), vp]
-    L.snerf_field_forward_rays.argtypes = [vp, i32, i64, i32, vp, vp, vp, vp, vp, C.POINTER(FieldOut), vp]
+    L.snerf_field_forward_rays.argtypes = [vp, i32, i64, i32, vp, vp, vp, i64, vp, vp, C.POINTER(FieldOut), vp]
     L.snerf_composite_rays.argtypes = [i64, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, C.c_float,
                                        C.POINTER(CompositeOut), vp]
     L.snerf_render_workspace_bytes.restype = C.c_size_t
     L.snerf_render_workspace_bytes.argtypes = [i64, i32, i32]
     L.snerf_render_rays.argtypes = [vp, i64, i32, vp, vp, vp, vp, vp, i32, vp, C.POINTER(FieldOut),
                                     C.POINTER(CompositeOut), vp, C.c_size_t, vp]
+    L.snerf_composite_sweep.argtypes = [i64, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, C.POINTER(SweepOut), vp]
     L.snerf_field_kernel_info.argtypes = [vp, i64, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     _lib = L
     return L
@@ -65,4 +70,4 @@ def check(rc, what):
 EXPORTS = ["snerf_last_error", "snerf_abi_version", "snerf_model_create", "snerf_model_set_tensor",
            "snerf_model_finalize", "snerf_model_destroy", "snerf_model_width", "snerf_model_classes",
            "snerf_model_pack_host", "snerf_group_forward", "snerf_field_forward_points", "snerf_field_forward_rays",
-           "snerf_composite_rays", "snerf_render_workspace_bytes", "snerf_render_rays", "snerf_field_kernel_info"]
+           "snerf_composite_rays", "snerf_composite_sweep", "snerf_render_workspace_bytes", "snerf_render_rays", "snerf_field_kernel_info"]

@@ -35,7 +35,7 @@ struct snerf_model {
 extern "C" {
 
 const char* snerf_last_error(void) { return g_err.c_str(); }
-int snerf_abi_version(void) { return 1; }
+int snerf_abi_version(void) { return 2; }
 
 snerf_model* snerf_model_create(int layer_width, int n_classes) {
     if (layer_width != 64 && layer_width != 256) {
@@ -66,8 +66,10 @@ static int pack_both(snerf_model* m) {
     for (int p = 0; p < 2; ++p) {
         if (!m->host[p].stream.empty()) continue;
         std::string err;
-        if (!pack_program(m->w, p, m->W, m->C, /*fold_bn=*/true, &m->host[p], &err))
+        Packed tmp;
+        if (!pack_program(m->w, p, m->W, m->C, /*fold_bn=*/true, &tmp, &err))
             return fail(err.rfind("missing", 0) == 0 ? SNERF_E_MISSING : SNERF_E_INVALID, err);
+        m->host[p] = std::move(tmp);
     }
     return SNERF_OK;
 }
@@ -191,12 +193,12 @@ int snerf_field_forward_points(const snerf_model* m, int variant, int64_t n_poin
 }
 
 int snerf_field_forward_rays(const snerf_model* m, int variant, int64_t n_rays, int n_samples, const float* d_top,
-                             const float* d_bot, const float* d_tvals, const float* d_sun, const float* d_classes,
-                             const snerf_field_out* out, void* stream) {
+                             const float* d_bot, const float* d_tvals, int64_t rays_per_group, const float* d_sun,
+                             const float* d_classes, const snerf_field_out* out, void* stream) {
     int rc = check_ready(m);
     if (rc) return rc;
     if (n_rays == 0) return SNERF_OK;
-    if (n_rays < 0 || n_samples < 1 || !d_top || !d_bot || !d_tvals)
+    if (n_rays < 0 || n_samples < 1 || rays_per_group < 1 || !d_top || !d_bot || !d_tvals)
         return fail(SNERF_E_INVALID, "snerf_field_forward_rays: bad argument");
     MlpArgs a{};
     a.n = n_rays * n_samples;
@@ -204,7 +206,7 @@ int snerf_field_forward_rays(const snerf_model* m, int variant, int64_t n_rays, 
     a.bot = d_bot;
     a.tvals = d_tvals;
     a.n_samples = n_samples;
-    a.group_size = n_samples;
+    a.group_size = (int64_t)n_samples * rays_per_group;
     a.sun = d_sun;
     a.classes = d_classes;
     return field_launch(m, variant, a, out, stream);
@@ -262,13 +264,31 @@ int snerf_render_rays(const snerf_model* m, int64_t n_rays, int n_samples, const
     if (!fo.d_rho) fo.d_rho = rho;
     if (!fo.d_solar_vis) fo.d_solar_vis = sv;
     if (!fo.d_col) fo.d_col = col;
-    rc = snerf_field_forward_rays(m, 0, n_rays, n_samples, d_top, d_bot, d_tvals, d_sun, cls, &fo, stream);
+    rc = snerf_field_forward_rays(m, 0, n_rays, n_samples, d_top, d_bot, d_tvals, 1, d_sun, cls, &fo, stream);
     if (rc) return rc;
     snerf_composite_out co{};
     if (comp_out) co = *comp_out;
     if (d_rgb) co.d_rgb = d_rgb;
     return snerf_composite_rays(n_rays, n_samples, d_top, d_bot, d_tvals, fo.d_rho, fo.d_col, fo.d_solar_vis, sky, flags,
                                 nullptr, 1.f, &co, stream);
+}
+
+int snerf_composite_sweep(int64_t n_rays, int n_samples, int n_classes, int n_times, const float* d_top,
+                          const float* d_bot, const float* d_tvals, const float* d_rho, const float* d_col_raw,
+                          const float* d_adjust, const float* d_solar_vis, const float* d_sky, const float* d_class_vecs,
+                          int flags, const snerf_sweep_out* out, void* stream) {
+    if (n_rays == 0 || n_times == 0) return SNERF_OK;
+    if (n_rays < 0 || n_samples < 1 || n_times < 0 || n_classes < 1 || n_classes > kMaxClasses || !d_top || !d_bot ||
+        !d_tvals || !d_rho || !d_col_raw || !d_adjust || !d_solar_vis || !d_sky || !d_class_vecs || !out)
+        return fail(SNERF_E_INVALID, "snerf_composite_sweep: bad argument");
+    SweepArgs a{};
+    a.n_rays = n_rays; a.n_samples = n_samples; a.n_classes = n_classes; a.n_times = n_times; a.flags = flags;
+    a.top = d_top; a.bot = d_bot; a.tvals = d_tvals; a.rho = d_rho; a.col_raw = d_col_raw; a.adjust = d_adjust;
+    a.solar_vis = d_solar_vis; a.sky = d_sky; a.class_vecs = d_class_vecs;
+    a.season = out->d_season; a.shaded = out->d_shaded; a.base = out->d_base; a.shadow_adjust = out->d_shadow_adjust;
+    a.raw_shadow = out->d_raw_shadow;
+    hipError_t e = launch_sweep(a, (hipStream_t)stream);
+    return e == hipSuccess ? SNERF_OK : fail_hip(e, "sweep kernel launch");
 }
 
 int snerf_field_kernel_info(const snerf_model* m, int64_t n_points, int* grid, int* block, int* lds_bytes) {

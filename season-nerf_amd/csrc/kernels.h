@@ -55,6 +55,17 @@ struct CompArgs {
     CompOutDev out;
 };
 
+struct SweepArgs {
+    int64_t n_rays;
+    int n_samples, n_classes, n_times, flags;
+    const float *top, *bot, *tvals;
+    const float *rho, *col_raw, *adjust, *solar_vis;
+    const float* sky;          // [3]
+    const float* class_vecs;   // [T,C]
+    float *season, *shaded;    // [T,R,3]
+    float *base, *shadow_adjust, *raw_shadow;   // [R,3], [R,3], [R]
+};
+hipError_t launch_sweep(const SweepArgs& a, hipStream_t st);
 hipError_t launch_mlp(int prog, int W, int variant, const MlpArgs& a, int n_cu, hipStream_t st);
 hipError_t launch_composite(const CompArgs& a, hipStream_t st);
 int mlp_lds_bytes(int bias_floats);

@@ -641,6 +641,94 @@ __global__ __launch_bounds__(256) void composite_kernel(const CompArgs A) {
 }
 
 // =====================================================================================================
+// seasonal sweep (mg_Img_Eval.py:123-228): the MLP ran once; for every class vector t recompute only
+//   img[t,r] = sum_s PS * sigmoid(Col_raw + class_t @ Adjust)  * (shadow + (1-shadow) * sky)
+// One wavefront per ray; PS by the same shuffle scan; T_CHUNK class vectors per pass (accumulators in registers).
+// HBM-bound: reads 17 floats per sample once per T_CHUNK time-steps.
+constexpr int T_CHUNK = 12;
+__global__ __launch_bounds__(256) void sweep_kernel(const SweepArgs A) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= A.n_rays) return;
+    const int S = A.n_samples, C = A.n_classes;
+    const float tx = A.top[r * 3], ty = A.top[r * 3 + 1], tz = A.top[r * 3 + 2];
+    const float bx = A.bot[r * 3], by = A.bot[r * 3 + 1], bz = A.bot[r * 3 + 2];
+    const float dx = tx - bx, dy = ty - by, dz = tz - bz;
+    const float delta_ray = __fdiv_rn(__fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz))), (float)S);
+    const bool zero_oob = A.flags & 2;
+    for (int t0 = 0; t0 < A.n_times; t0 += T_CHUNK) {
+        float cw[T_CHUNK][kMaxClasses];
+#pragma unroll
+        for (int t = 0; t < T_CHUNK; ++t)
+#pragma unroll
+            for (int c = 0; c < kMaxClasses; ++c) cw[t][c] = (t0 + t < A.n_times && c < C) ? A.class_vecs[(t0 + t) * C + c] : 0.f;
+        float acc[T_CHUNK][3];
+#pragma unroll
+        for (int t = 0; t < T_CHUNK; ++t) acc[t][0] = acc[t][1] = acc[t][2] = 0.f;
+        float carry = 0.f, svsum = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f;
+        for (int base = 0; base < S; base += 64) {
+            const int s = base + lane;
+            const bool in = s < S;
+            const int64_t idx = r * S + (in ? s : S - 1);
+            const float tt = A.tvals[in ? s : S - 1], omt = __fsub_rn(1.f, tt);
+            float delta = delta_ray;
+            if (zero_oob) {
+                const float px = __fadd_rn(__fmul_rn(tx, omt), __fmul_rn(bx, tt));
+                const float py = __fadd_rn(__fmul_rn(ty, omt), __fmul_rn(by, tt));
+                const float pz = __fadd_rn(__fmul_rn(tz, omt), __fmul_rn(bz, tt));
+                if (px > 1.f || px < -1.f || py > 1.f || py < -1.f || pz > 1.f || pz < -1.f) delta = 0.f;
+            }
+            const float y = in ? A.rho[idx] * delta : 0.f;
+            const float incl = wave_incl_scan(y, lane);
+            const float excl = carry + (incl - y);
+            carry += __shfl(incl, 63, 64);
+            const float ps = in ? expf(-excl) * (1.f - expf(-y)) : 0.f;
+            svsum += ps * (in ? A.solar_vis[idx] : 0.f);
+            const float k0 = A.col_raw[idx * 3], k1 = A.col_raw[idx * 3 + 1], k2 = A.col_raw[idx * 3 + 2];
+            b0 += ps * sigmoid_f(k0); b1 += ps * sigmoid_f(k1); b2 += ps * sigmoid_f(k2);
+            float ad[kMaxClasses][3];
+#pragma unroll
+            for (int c = 0; c < kMaxClasses; ++c)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) ad[c][k] = c < C ? A.adjust[(idx * C + c) * 3 + k] : 0.f;
+#pragma unroll
+            for (int t = 0; t < T_CHUNK; ++t) {
+                float m0 = 0.f, m1 = 0.f, m2 = 0.f;
+#pragma unroll
+                for (int c = 0; c < kMaxClasses; ++c) { m0 += cw[t][c] * ad[c][0]; m1 += cw[t][c] * ad[c][1]; m2 += cw[t][c] * ad[c][2]; }
+                acc[t][0] += ps * sigmoid_f(k0 + m0);
+                acc[t][1] += ps * sigmoid_f(k1 + m1);
+                acc[t][2] += ps * sigmoid_f(k2 + m2);
+            }
+        }
+        svsum = wave_sum(svsum);
+        b0 = wave_sum(b0); b1 = wave_sum(b1); b2 = wave_sum(b2);
+        const float mask = sigmoid_f((svsum - 0.2f) * 30.f);
+        const float f0 = mask + (1.f - mask) * A.sky[0], f1 = mask + (1.f - mask) * A.sky[1], f2 = mask + (1.f - mask) * A.sky[2];
+#pragma unroll
+        for (int t = 0; t < T_CHUNK; ++t) {
+            const float v0 = wave_sum(acc[t][0]), v1 = wave_sum(acc[t][1]), v2 = wave_sum(acc[t][2]);
+            if (lane == 0 && t0 + t < A.n_times) {
+                const int64_t o = ((int64_t)(t0 + t) * A.n_rays + r) * 3;
+                if (A.season) { A.season[o] = v0; A.season[o + 1] = v1; A.season[o + 2] = v2; }
+                if (A.shaded) { A.shaded[o] = v0 * f0; A.shaded[o + 1] = v1 * f1; A.shaded[o + 2] = v2 * f2; }
+            }
+        }
+        if (lane == 0 && t0 == 0) {
+            if (A.raw_shadow) A.raw_shadow[r] = svsum;
+            if (A.shadow_adjust) { A.shadow_adjust[r * 3] = f0; A.shadow_adjust[r * 3 + 1] = f1; A.shadow_adjust[r * 3 + 2] = f2; }
+            if (A.base) { A.base[r * 3] = b0; A.base[r * 3 + 1] = b1; A.base[r * 3 + 2] = b2; }
+        }
+    }
+}
+
+hipError_t launch_sweep(const SweepArgs& a, hipStream_t st) {
+    const int grid = (int)((a.n_rays + 3) / 4);
+    hipLaunchKernelGGL(sweep_kernel, dim3(grid), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+// =====================================================================================================
 // launchers
 template <int PROG, int W, int VARIANT>
 static hipError_t launch_mlp_t(const MlpArgs& a, int n_cu, hipStream_t st) {

@@ -67,7 +67,7 @@ class All_in_One_Eval:
         fo = _lib.FieldOut(d_rho=rho.data_ptr(), d_solar_vis=sv.data_ptr(), d_col=col.data_ptr(),
                            d_adjust_col=adjc.data_ptr(), d_points=pts.data_ptr())
         _lib.check(L.snerf_field_forward_rays(Network.device_model(), 0, R, S, top.data_ptr(), bot.data_ptr(),
-                                              tv.data_ptr(), sun.data_ptr(), cls.data_ptr(), C.byref(fo), st),
+                                              tv.data_ptr(), 1, sun.data_ptr(), cls.data_ptr(), C.byref(fo), st),
                    "field_forward_rays")
         flags = 1 if self.use_classic_solar else 0
 
@@ -134,7 +134,7 @@ class All_in_One_Eval:
         rho, sv = e(R, S, 1), e(R, S, 1)
         fo = _lib.FieldOut(d_rho=rho.data_ptr(), d_solar_vis=sv.data_ptr())
         _lib.check(L.snerf_field_forward_rays(Network.device_model(), 1, R, S, top.data_ptr(), bot.data_ptr(),
-                                              tv.data_ptr(), sun.data_ptr(), None, C.byref(fo), st), "field_forward_rays")
+                                              tv.data_ptr(), 1, sun.data_ptr(), None, C.byref(fo), st), "field_forward_rays")
         pv, pe = e(R, S, 1), e(R, S, 1)
         col0 = torch.zeros(R, S, 3, device=dev)
         co = _lib.CompositeOut(d_pv=pv.data_ptr(), d_pe=pe.data_ptr())

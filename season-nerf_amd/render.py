@@ -1,0 +1,323 @@
+"""Host-side mirrors of the reference's two novel-view render paths, on top of the HIP kernels.
+
+  * path A  `Quick_Run_Net`  (T_NeRF_Full_2/Quick_Run.py:61-226): parallel rays from (el, az), cube culling,
+    `render_img` / `get_DSM`; with `use_full_solar` the per-sample exact sun visibility of
+    `All_in_One_Eval.eval_exact_solar` (Eval_Tools_2.py:255-295) - O(R*S^2) density-only evaluations;
+  * path B  `component_render_by_dir` (T_NeRF_Eval_Utils/mg_Img_Eval.py:96-115 + `_internal_render` :17-72),
+    `get_imgs_from_Img_Dict` (:123-190) and the seasonal sweep `get_imgs_from_Img_Dict_t_step` (:192-228),
+    plus `render_season_sweep`, the same pipeline without the float64 host round trip (BASELINE config 5).
+
+Ray-grid geometry is float64 numpy on the host exactly as in the reference (a few kFLOP per image); everything
+per-sample runs on the GPU.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from .evaluator import All_in_One_Eval, sample_parameters
+from .network import T_NeRF
+
+
+# ------------------------------------------------------------------------------------------------ geometry
+def world_angle_2_local_vec(world_el, world_az, world_center, World2Local_H):
+    """(el, az) in degrees -> unit vector in cube coordinates (all_NeRF/mg_unit_converter.py:5-9,59-68,29-34)."""
+    Y, X = math.cos(math.radians(world_az)), math.sin(math.radians(world_az))
+    Z = math.tan(math.radians(world_el)) * math.sqrt(X * X + Y * Y)
+    n = math.sqrt(X * X + Y * Y + Z * Z) / 1000.0
+    X, Y, Z = X / n, Y / n, Z / n
+    R_km = 6378.137
+    lat = world_center[0] + np.rad2deg(Y / (1000.0 * R_km))
+    lon = world_center[1] + np.rad2deg(X / (1000.0 * R_km * np.cos(np.deg2rad(world_center[0]))))
+    p = np.asarray(World2Local_H, dtype=np.float64) @ np.array([lat, lon, world_center[2] + Z, 1.0])
+    v = p[0:3]
+    return v / np.sqrt(np.sum(v ** 2))
+
+
+def encode_time(time_frac_year, time_frac_day=0):
+    """Quick_Run.py:9-12."""
+    a, b = time_frac_year * 2 * np.pi, time_frac_day * 2 * np.pi
+    return np.array([np.cos(a), np.sin(a), np.cos(b), np.sin(b)])
+
+
+def _f32(a, dev):
+    return torch.tensor(np.asarray(a), dtype=torch.float32, device=dev).contiguous()
+
+
+def _exact_solar_visibility(net: T_NeRF, pts, sun_vec, S, zero_oob, chunk_rays=65536, sun64=None):
+    """Transmittance from every sample point towards the sun: secondary rays Top = p + (1-p_z)/sun_z * sun, Bot = p,
+    S end-point-inclusive samples, density only; visibility = exp(-sum_{j<S-1} rho_j delta_j), i.e. PV at the last
+    sample (Eval_Tools_2.py:255-271 / mg_Img_Eval.py:57-70).  pts [M,3] (device), sun_vec [3] or [M,3] (device).
+    sun64 (float64 numpy [3]): path B forms the tops in float64 (fp32 tensor * float64 numpy vector, then .float(),
+    mg_Img_Eval.py:58-60) - mirrored exactly because the out-of-cube test of the first sample depends on the last bit."""
+    dev = pts.device
+    L = _lib.lib()
+    st = net._stream()
+    M = pts.shape[0]
+    tv = sample_parameters(S, eval_mode=True, include_end_pt=True).to(dev)
+    sun = sun_vec if sun_vec.dim() == 2 else sun_vec.unsqueeze(0).expand(M, 3)
+    K = (1.0 - pts[:, 2]) / sun[:, 2]
+    if sun64 is None:
+        tops = (pts + K.unsqueeze(1) * sun).contiguous()
+    else:
+        s64 = torch.tensor(np.asarray(sun64, dtype=np.float64), device=dev).reshape(1, 3)
+        tops = (pts.double() + K.double().unsqueeze(1) * s64).float().contiguous()
+    vis = torch.empty(M, device=dev)
+    model = net.device_model()
+    for i in range(0, M, chunk_rays):
+        j = min(M, i + chunk_rays)
+        n = j - i
+        t_, b_ = tops[i:j].contiguous(), pts[i:j].contiguous()
+        rho = torch.empty(n, S, device=dev)
+        fo = _lib.FieldOut(d_rho=rho.data_ptr())
+        _lib.check(L.snerf_field_forward_rays(model, 2, n, S, t_.data_ptr(), b_.data_ptr(), tv.data_ptr(), 1, None, None,
+                                              C.byref(fo), st), "field_forward_rays(sigma)")
+        pv = torch.empty(n, S, device=dev)
+        z1, z3 = torch.zeros(n, S, device=dev), torch.zeros(n, S, 3, device=dev)
+        sky0 = torch.zeros(n, 3, device=dev)
+        co = _lib.CompositeOut(d_pv=pv.data_ptr())
+        _lib.check(L.snerf_composite_rays(n, S, t_.data_ptr(), b_.data_ptr(), tv.data_ptr(), rho.data_ptr(), z3.data_ptr(),
+                                          z1.data_ptr(), sky0.data_ptr(), 2 if zero_oob else 0, None, 1.0, C.byref(co), st),
+                   "composite_rays")
+        vis[i:j] = pv[:, -1]
+    return vis
+
+
+# ------------------------------------------------------------------------------------------------ path A
+class Quick_Run_Net:
+    def __init__(self, network, args, world_center_LLA, World_2_Local_H, device, max_input_size=50000, use_tqdm=False,
+                 use_full_solar=True):
+        self.eval_tool = All_in_One_Eval(args, device, 5, False, False, World_2_Local_H, world_center_LLA)
+        self.network = network
+        self.world_center_LLA = world_center_LLA
+        self.W2L_H = World_2_Local_H
+        self.n_samples = args.n_samples
+        self.n_classes = args.number_low_frequency_cases
+        self.use_tqdm = use_tqdm
+        self.use_full_solar = use_full_solar
+        self.device = torch.device(device)
+        self.max_input_size = max_input_size      # kept for API compatibility; one launch renders the whole image
+
+    def _get_input_dict(self, camera_el_az, solar_el_az, time_frac, out_img_size, region):
+        """Quick_Run.py:77-109."""
+        is_tuple = isinstance(out_img_size, tuple)
+        hw = out_img_size if is_tuple else (out_img_size, out_img_size)
+        X, Y = np.meshgrid(np.arange(0, hw[0]), np.arange(0, hw[1]), indexing="ij")
+        XY = np.stack([X, Y], 2).reshape([-1, 2])
+        mids = np.concatenate([XY * 2. / (np.array([[hw[0], hw[1]]]) - 1) - 1, np.zeros([XY.shape[0], 1])], 1)
+        if region is not None:
+            mids[:, 0] = (mids[:, 0] + 1) / 2 * (region[1] - region[0]) + region[0]
+            mids[:, 1] = (mids[:, 1] + 1) / 2 * (region[3] - region[2]) + region[2]
+        cam = world_angle_2_local_vec(camera_el_az[0], camera_el_az[1], self.world_center_LLA, self.W2L_H)
+        tops, bots = mids + cam / cam[2], mids - cam / cam[2]
+        good = np.all((bots <= 1) * (bots >= -1) * (tops <= 1) * (tops >= -1), 1)
+        XY = XY[good]
+        if not is_tuple:
+            XY[:, 0] = out_img_size - XY[:, 0] - 1
+        n = XY.shape[0]
+        sun = world_angle_2_local_vec(solar_el_az[0], solar_el_az[1], self.world_center_LLA, self.W2L_H)
+        dev = self.device
+        return {"Top": _f32(tops[good], dev), "Bot": _f32(bots[good], dev), "XY": XY,
+                "Sun_Angle": _f32(np.tile(sun, (n, 1)), dev), "Time_Encoded": _f32(np.tile(encode_time(time_frac), (n, 1)), dev)}
+
+    def _eval(self, d, exact):
+        out = self.eval_tool.eval(d, self.network, -1, False)
+        if exact and d["Top"].shape[0] > 0:                                   # eval_exact_solar, Eval_Tools_2.py:273-295
+            R, S = out["PS"].shape[0], self.n_samples
+            out["Est_Solar_Vis"] = out["Solar_Vis"].clone()
+            sun = d["Sun_Angle"].unsqueeze(1).expand(R, S, 3).reshape(-1, 3)
+            vis = _exact_solar_visibility(self.network, out["sample_pts"].reshape(-1, 3), sun, S, zero_oob=False)
+            sv = vis.reshape(R, S, 1)
+            out["Solar_Vis"] = sv
+            sky = out["Sky_Col"]
+            if self.eval_tool.use_classic_solar:
+                out["Rendered_Col"] = (out["PS"] * out["Col"] * (sv + (1 - sv) * sky)).sum(1)
+            else:
+                sv3 = torch.sigmoid(((sv * out["PS"]).sum(1) - .2) * 30)
+                out["Rendered_Col"] = (out["PS"] * out["Col"]).sum(1) * (sv3 + (1 - sv3) * sky.mean(1))
+        return out
+
+    def render_img(self, camera_el_and_az, solar_el_and_az, time_frac, out_img_size, region=None):
+        """-> ({"Col_Img", "Shadow_Mask"[, "Estimated_Shadow_Mask"]}, mask)   (Quick_Run.py:173-205, :14-35)"""
+        with torch.no_grad():
+            d = self._get_input_dict(camera_el_and_az, solar_el_and_az, time_frac, out_img_size, region)
+            out = self._eval(d, self.use_full_solar)
+            hw = out_img_size if isinstance(out_img_size, tuple) else (out_img_size, out_img_size)
+            XY = d["XY"]
+            img = np.zeros([hw[0], hw[1], 3])
+            mask = np.zeros([hw[0], hw[1]], dtype=bool)
+            img[XY[:, 0], XY[:, 1]] = out["Rendered_Col"].cpu().numpy()
+            mask[XY[:, 0], XY[:, 1]] = True
+            imgs = {"Col_Img": img}
+            shadow = np.zeros([hw[0], hw[1]])
+            shadow[XY[:, 0], XY[:, 1]] = (out["PS"] * out["Solar_Vis"]).sum(1)[:, 0].cpu().numpy()
+            imgs["Shadow_Mask"] = shadow
+            if "Est_Solar_Vis" in out:
+                est = np.zeros([hw[0], hw[1]])
+                est[XY[:, 0], XY[:, 1]] = (out["PS"] * out["Est_Solar_Vis"]).sum(1)[:, 0].cpu().numpy()
+                imgs["Estimated_Shadow_Mask"] = est
+        return imgs, mask
+
+    def get_DSM(self, out_img_size, region=None):
+        """Nadir rays; height = sum_s PS * linspace(1, -1, 96)  (Quick_Run.py:207-226, :37-40; 96 hard-coded there)."""
+        with torch.no_grad():
+            d = self._get_input_dict([90, 0], [90, 0], 0.0, out_img_size, region)
+            out = self.eval_tool.eval(d, self.network, -1, False)
+            hw = out_img_size if isinstance(out_img_size, tuple) else (out_img_size, out_img_size)
+            img = np.full([hw[0], hw[1]], np.nan)
+            z = torch.linspace(1, -1, 96, device=out["PS"].device, dtype=torch.float64).reshape(1, -1, 1)
+            img[d["XY"][:, 0], d["XY"][:, 1]] = (out["PS"].double() * z).sum(1)[:, 0].cpu().numpy()
+        return img
+
+
+# ------------------------------------------------------------------------------------------------ path B
+class ImgDict(dict):
+    """The float64 numpy dict of the reference (`_internal_render`, mg_Img_Eval.py:17-72) plus, under `.dev`, the fp32
+    device tensors it was copied from, so the image-assembly functions below run on the GPU without re-upload."""
+    dev = None
+
+
+def _render_by_dir_device(net, view_el_az, sun_el_az, time_frac, out_img_size, W2C, W2L_H, device, include_exact_solar):
+    Hh, Ww, S = out_img_size
+    dev = torch.device(device)
+    g = np.stack(np.meshgrid(np.linspace(1, -1, Hh), np.linspace(-1, 1, Ww), indexing="ij"), -1).reshape([-1, 2])
+    g = np.concatenate([g, np.zeros([g.shape[0], 1])], 1)
+    v = world_angle_2_local_vec(view_el_az[0], view_el_az[1], W2C, W2L_H)
+    sunv = world_angle_2_local_vec(sun_el_az[0], sun_el_az[1], W2C, W2L_H)
+    top, bot = _f32(g + np.expand_dims(v / v[2], 0), dev), _f32(g - np.expand_dims(v / v[2], 0), dev)
+    R, Cn = top.shape[0], net.n_classes
+    (top, bot) = net._prep(top, bot)
+    L = _lib.lib()
+    st = net._stream()
+    tv = sample_parameters(S, eval_mode=True, include_end_pt=True).to(dev)
+    sun1, tim1 = _f32(sunv.reshape(1, 3), dev), _f32(encode_time(time_frac).reshape(1, 4), dev)
+    cls, _, sky = net._groups(tim1, sun1)                                  # one (time, sun) group for the whole image
+    e = lambda *s: torch.empty(*s, device=dev)
+    rho, sv, col_raw, adj, pts = e(R, S, 1), e(R, S, 1), e(R, S, 3), e(R, S, Cn, 3), e(R, S, 3)
+    fo = _lib.FieldOut(d_rho=rho.data_ptr(), d_solar_vis=sv.data_ptr(), d_col_raw=col_raw.data_ptr(),
+                       d_adjust=adj.data_ptr(), d_points=pts.data_ptr())
+    model = net.device_model()
+    # one (sun, time) group for all rays: rays_per_group = R
+    _lib.check(L.snerf_field_forward_rays(model, 0, R, S, top.data_ptr(), bot.data_ptr(), tv.data_ptr(), R, sun1.data_ptr(),
+                                          cls.data_ptr(), C.byref(fo), st), "field_forward_rays")
+    dl = e(R, S, 1)
+    z3 = torch.zeros(R, S, 3, device=dev)
+    sky_r = sky.expand(R, 3).contiguous()
+    co = _lib.CompositeOut(d_delta=dl.data_ptr())
+    _lib.check(L.snerf_composite_rays(R, S, top.data_ptr(), bot.data_ptr(), tv.data_ptr(), rho.data_ptr(), z3.data_ptr(),
+                                      sv.data_ptr(), sky_r.data_ptr(), 2, None, 1.0, C.byref(co), st), "composite_rays")
+    devd = {"top": top, "bot": bot, "tv": tv, "World_Points": pts, "Deltas": dl, "Rho": rho, "Base_Col": col_raw,
+            "Est_Solar_Vis": sv, "Sky": sky[0].contiguous(), "Class": cls[0].contiguous(), "Adjust_col": adj}
+    if include_exact_solar:
+        sun_d = _f32(sunv, dev)
+        devd["Exact_Solar"] = _exact_solar_visibility(net, pts.reshape(-1, 3), sun_d, S, zero_oob=True,
+                                                      sun64=sunv).reshape(R, S, 1)
+    return devd
+
+
+def component_render_by_dir(the_network, view_el_az, sun_el_az, time_frac, out_img_size: tuple, W2C, W2L_H, device,
+                            max_batch_size=150000, include_exact_solar=True):
+    """mg_Img_Eval.py:96-115.  Returns the reference's dict of float64 arrays (World_Points, Deltas, Rho, Base_Col,
+    Est_Solar_Vis, Sky_Col, Output_class, Adjust_col[, Exact_Solar], Image_Points)."""
+    with torch.no_grad():
+        Hh, Ww, S = out_img_size
+        d = _render_by_dir_device(the_network, view_el_az, sun_el_az, time_frac, out_img_size, W2C, W2L_H, device,
+                                  include_exact_solar)
+        R, Cn = d["Rho"].shape[0], the_network.n_classes
+        f = lambda t: t.cpu().numpy().astype(np.float64)
+        res = ImgDict()
+        for k in ["World_Points", "Deltas", "Rho", "Base_Col", "Est_Solar_Vis", "Adjust_col"]:
+            res[k] = f(d[k])
+        res["Sky_Col"] = np.broadcast_to(f(d["Sky"]).reshape(1, 1, 3), (R, S, 3)).copy()
+        res["Output_class"] = np.broadcast_to(f(d["Class"]).reshape(1, 1, Cn), (R, S, Cn)).copy()
+        if include_exact_solar:
+            res["Exact_Solar"] = f(d["Exact_Solar"])
+        res["Image_Points"] = np.stack(np.meshgrid(np.arange(Hh), np.arange(Ww), indexing="ij"), -1).reshape([-1, 2])
+        res.dev = d
+    return res
+
+
+def _sweep(d, class_vecs, solar_key):
+    """Run the sweep kernel on a device dict; class_vecs [T,C] numpy.  Returns dict of device tensors."""
+    dev = d["Rho"].device
+    L = _lib.lib()
+    R, S = d["Rho"].shape[0], d["Rho"].shape[1]
+    Cn = d["Adjust_col"].shape[2]
+    cv = _f32(class_vecs, dev)
+    T = cv.shape[0]
+    e = lambda *s: torch.empty(*s, device=dev)
+    season, shaded, base, sadj, raw = e(T, R, 3), e(T, R, 3), e(R, 3), e(R, 3), e(R)
+    so = _lib.SweepOut(d_season=season.data_ptr(), d_shaded=shaded.data_ptr(), d_base=base.data_ptr(),
+                       d_shadow_adjust=sadj.data_ptr(), d_raw_shadow=raw.data_ptr())
+    sv = d[solar_key].contiguous()
+    _lib.check(L.snerf_composite_sweep(R, S, Cn, T, d["top"].data_ptr(), d["bot"].data_ptr(), d["tv"].data_ptr(),
+                                       d["Rho"].data_ptr(), d["Base_Col"].data_ptr(), d["Adjust_col"].data_ptr(),
+                                       sv.data_ptr(), d["Sky"].data_ptr(), cv.data_ptr(), 2, C.byref(so),
+                                       C.c_void_p(torch.cuda.current_stream().cuda_stream)), "composite_sweep")
+    return {"season": season, "shaded": shaded, "base": base, "shadow_adjust": sadj, "raw_shadow": raw}
+
+
+def _device_dict(Img_Dict, device="cuda"):
+    if getattr(Img_Dict, "dev", None) is not None:
+        return Img_Dict.dev
+    raise TypeError("season_nerf_amd: image assembly needs the dict returned by season_nerf_amd.component_render_by_dir "
+                    "(it carries the device tensors); a plain numpy dict would require a CPU path, which this package "
+                    "does not provide")
+
+
+def _scatter(vals, ij, hw, k=None):
+    img = np.full([hw[0], hw[1]] + ([k] if k else []), np.nan)
+    img[ij[:, 0], ij[:, 1]] = vals
+    return img
+
+
+def get_imgs_from_Img_Dict(Img_Dict, out_img_size: tuple, use_classic_shadows: bool = False):
+    """mg_Img_Eval.py:123-190 (use_classic_shadows=False branch).  Keys: Base_Img, Season_Adj_Img, Extreme_Imgs,
+    Shadow_Adjust, Shadow_Mask, Raw_Shadow_Mask, Sky_Col, Time_Class (+ the *_Exact family)."""
+    if use_classic_shadows:
+        raise NotImplementedError("use_classic_shadows=True is not implemented on the HIP path")
+    d = _device_dict(Img_Dict)
+    ij, hw = Img_Dict["Image_Points"], out_img_size
+    Cn = d["Adjust_col"].shape[2]
+    cv = np.concatenate([d["Class"].cpu().numpy().reshape(1, Cn), np.eye(Cn)], 0)        # season class + the C extremes
+    o = _sweep(d, cv, "Est_Solar_Vis")
+    f = lambda t: t.cpu().numpy().astype(np.float64)
+    raw = _scatter(f(o["raw_shadow"]), ij, hw)
+    mask = 1 / (1 + np.exp(-(raw - .2) * 30))
+    sky = f(d["Sky"])
+    res = {"Base_Img": _scatter(f(o["base"]), ij, hw, 3), "Season_Adj_Img": _scatter(f(o["season"][0]), ij, hw, 3),
+           "Extreme_Imgs": [_scatter(f(o["season"][1 + i]), ij, hw, 3) for i in range(Cn)],
+           "Shadow_Adjust": np.expand_dims(mask, -1) + np.expand_dims(1 - mask, -1) * sky.reshape([1, 1, 3]),
+           "Shadow_Mask": mask, "Raw_Shadow_Mask": raw, "Sky_Col": sky, "Time_Class": f(d["Class"])}
+    if "Exact_Solar" in d:
+        oe = _sweep(d, cv[:1], "Exact_Solar")
+        raw_e = _scatter(f(oe["raw_shadow"]), ij, hw)
+        mask_e = 1 / (1 + np.exp(-(raw_e - .2) * 30))
+        res["Shadow_Adjust_Exact"] = np.expand_dims(mask_e, -1) + np.expand_dims(1 - mask_e, -1) * sky.reshape([1, 1, 3])
+        res["Shadow_Mask_Exact"], res["Raw_Shadow_Mask_Exact"] = mask_e, raw_e
+    return res
+
+
+def get_imgs_from_Img_Dict_t_step(Img_Dict, out_img_size: tuple, class_vecs_array):
+    """mg_Img_Eval.py:192-228: [T, H, W, 3] shaded images for T class vectors; exact solar visibility wins if present."""
+    d = _device_dict(Img_Dict)
+    o = _sweep(d, np.asarray(class_vecs_array), "Exact_Solar" if "Exact_Solar" in d else "Est_Solar_Vis")
+    ij, hw = Img_Dict["Image_Points"], out_img_size
+    sh = o["shaded"].cpu().numpy().astype(np.float64)
+    return np.array([_scatter(sh[t], ij, hw, 3) for t in range(sh.shape[0])])
+
+
+def render_season_sweep(the_network, view_el_az, sun_el_az, time_fracs, out_img_size: tuple, W2C, W2L_H, device,
+                        include_exact_solar=False, render_time_frac=None):
+    """BASELINE config 5 in one GPU pipeline: one component render + class vectors of all `time_fracs` + sweep kernel
+    (what mg_merge_seasons.merge_season_walk does through the float64 host dict, mg_merge_seasons.py:270-273).
+    Returns a [T, H, W, 3] float32 tensor on the GPU."""
+    with torch.no_grad():
+        tf0 = time_fracs[0] if render_time_frac is None else render_time_frac
+        d = _render_by_dir_device(the_network, view_el_az, sun_el_az, tf0, out_img_size, W2C, W2L_H, device, include_exact_solar)
+        times = _f32(np.stack([encode_time(t) for t in time_fracs]), d["Rho"].device)
+        cls = the_network.get_class_only(times)
+        o = _sweep(d, cls.cpu().numpy(), "Exact_Solar" if include_exact_solar else "Est_Solar_Vis")
+        return o["shaded"].reshape(len(time_fracs), out_img_size[0], out_img_size[1], 3)

@@ -1,0 +1,221 @@
+"""CPU-only checks of the C-ABI library: it builds/loads, exports every symbol include/season_nerf_hip.h declares,
+its host-side error behaviour, and the host packer (no compute calls - those need a GPU)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import season_nerf_oracle as orc
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="session")
+def lib():
+    import __graft_entry__ as g
+    g.build()                      # no-op when the .so is up to date; hipcc cross-compiles without a GPU
+    import season_nerf_amd as sn
+    return sn._lib.lib()
+
+
+def test_exports_match_header(lib):
+    hdr = open(os.path.join(REPO, "include", "season_nerf_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(snerf_[a-z_]+)\s*\(", hdr)))
+    assert len(declared) >= 15
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in the header but not exported"
+    import season_nerf_amd as sn
+    assert sorted(sn._lib.EXPORTS) == declared
+    assert lib.snerf_abi_version() == 2
+
+
+def test_error_paths(lib):
+    assert not lib.snerf_model_create(96, 4)                       # no kernel compiled for this width
+    assert b"96" in lib.snerf_last_error()
+    assert not lib.snerf_model_create(64, 9)
+    m = lib.snerf_model_create(64, 4)
+    assert m
+    n = C.c_size_t()
+    rc = lib.snerf_model_pack_host(m, 0, None, C.byref(n), None, None)
+    assert rc == -2 and b"missing tensor" in lib.snerf_last_error()       # SNERF_E_MISSING
+    a = np.zeros(5, dtype=np.float32)
+    assert lib.snerf_model_set_tensor(m, b"G_NeRF_net.fc1.linear.weight", a.ctypes.data, a.size) == 0
+    rc = lib.snerf_model_pack_host(m, 0, None, C.byref(n), None, None)
+    assert rc == -1 and b"elements" in lib.snerf_last_error()             # wrong shape -> SNERF_E_INVALID
+    # forward before finalize
+    assert lib.snerf_group_forward(m, 4, None, None, None, None, None, None) == -4
+    if not torch.cuda.is_available():
+        sd = orc.init_weights(64, 4, 0)
+        for k, v in sd.items():
+            if v.is_floating_point():
+                arr = np.ascontiguousarray(v.numpy())
+                assert lib.snerf_model_set_tensor(m, k.encode(), arr.ctypes.data, arr.size) == 0
+        assert lib.snerf_model_finalize(m) == -3                    # SNERF_E_HIP: no device here
+    lib.snerf_model_destroy(m)
+
+
+def test_product_fails_loudly_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import season_nerf_amd as sn
+    net = sn.T_NeRF(64, 4).eval()
+    with pytest.raises(RuntimeError):
+        net.forward(torch.zeros(2, 3), torch.ones(2, 3), torch.ones(2, 4))
+
+
+# ------------------------------------------------------------------------------------------------------------
+# Double-entry check of the packer: decode the fragment streams with an independent Python statement of the layout
+# rules (program.h) and evaluate the folded network in float64.  Must reproduce the oracle's forward.
+def bf16_to_f64(u16):
+    return (u16.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+
+
+def slot_H(kk):
+    s, h, j = kk // 16, (kk % 16) // 8, kk % 8
+    return 32 * (s >> 1) + 16 * (s & 1) + 8 * (j >> 2) + 4 * h + (j & 3)
+
+
+def slot_pepos(kk):
+    s, h, j = kk // 16, (kk % 16) // 8, kk % 8
+    e = 8 * s + j
+    if e < 30:
+        d, r = divmod(e, 10)
+        return 3 + 20 * d + 10 * (r & 1) + 5 * h + r // 2
+    return (0 if h == 0 else 2) if e == 30 else (1 if h == 0 else -1)
+
+
+def slot_pesun(kk):
+    s, h, j = kk // 16, (kk % 16) // 8, kk % 8
+    e = 8 * s + j
+    if e < 12:
+        d, r = divmod(e, 4)
+        return 3 + 8 * d + 4 * (r & 1) + 2 * h + r // 2
+    if e == 12:
+        return 0 if h == 0 else 2
+    return (1 if h == 0 else -1) if e == 13 else -1
+
+
+def slot_petime(kk):
+    s, h, j = kk // 16, (kk % 16) // 8, kk % 8
+    if s != 0 or j > 4:
+        return -1
+    if j == 0:
+        return h
+    q = j - 1
+    return 2 + 4 * h + 2 * (q & 1) + (q >> 1)
+
+
+def acc_row(i, h):
+    return (i & 3) + 8 * (i >> 2) + 4 * h
+
+
+class Decoder:
+    def __init__(self, lib, model, prog):
+        ns, nb = C.c_size_t(), C.c_size_t()
+        assert lib.snerf_model_pack_host(model, prog, None, C.byref(ns), None, C.byref(nb)) == 0
+        self.stream = np.zeros(ns.value, dtype=np.uint8)
+        self.bias = np.zeros(nb.value, dtype=np.float32)
+        assert lib.snerf_model_pack_host(model, prog, self.stream.ctypes.data, C.byref(ns), self.bias.ctypes.data, C.byref(nb)) == 0
+        self.chunk, self.boff = 0, 0
+
+    def layer(self, n_out, ks):
+        """dense folded matrix [n_out, 16*ks] in slot order and bias [n_out] of the next layer of the stream"""
+        nbk = n_out // 32
+        base = self.chunk * 16384
+        Wd = np.zeros((n_out, 16 * ks))
+        u16 = self.stream.view(np.uint16)
+        for b in range(nbk):
+            for s in range(ks):
+                o = (base + (b * ks + s) * 2048) // 2
+                hi = bf16_to_f64(u16[o:o + 512]).reshape(64, 8)
+                lo = bf16_to_f64(u16[o + 512:o + 1024]).reshape(64, 8)
+                v = hi + lo
+                for lane in range(64):
+                    r, h = lane & 31, lane >> 5
+                    Wd[32 * b + r, 16 * s + 8 * h:16 * s + 8 * h + 8] = v[lane]
+        bias = np.zeros(n_out)
+        for b in range(nbk):
+            for h in range(2):
+                for i in range(16):
+                    bias[32 * b + acc_row(i, h)] = self.bias[self.boff + b * 32 + h * 16 + i]
+        self.chunk += (nbk * ks + 7) // 8
+        self.boff += n_out
+        return Wd, bias
+
+
+def gather(feat, slot_fn, n_slots):
+    """activation/encoding vector in slot order: [N, n_slots]"""
+    out = np.zeros((feat.shape[0], n_slots))
+    for kk in range(n_slots):
+        f = slot_fn(kk)
+        if 0 <= f < feat.shape[1]:
+            out[:, kk] = feat[:, f]
+    return out
+
+
+@pytest.mark.parametrize("W", [64, 256])
+def test_packed_streams_reproduce_the_network(lib, W):
+    Cn = 4
+    sd = orc.init_weights(W, Cn, seed=7)
+    m = lib.snerf_model_create(W, Cn)
+    for k, v in sd.items():
+        if v.is_floating_point():
+            arr = np.ascontiguousarray(v.numpy())
+            assert lib.snerf_model_set_tensor(m, k.encode(), arr.ctypes.data, arr.size) == 0
+    rng = np.random.Generator(np.random.PCG64(3))
+    N = 48
+    X = torch.tensor(rng.uniform(-1, 1, (N, 3)))
+    sun = rng.uniform(0, 1, (N, 3)); sun /= np.linalg.norm(sun, axis=1, keepdims=True)
+    sun = torch.tensor(sun)
+    tim = torch.tensor(rng.uniform(-1, 1, (N, 4)))
+    sd64 = orc.cast_weights(sd, torch.float64)
+    with torch.no_grad():
+        ref = orc.forward_separate(sd64, X, sun, tim)
+        pe_pos = orc.pe_encode(X, 10).numpy()
+        pe_sun = orc.pe_encode(sun, 4).numpy()
+        pe_tim = orc.pe_encode(tim[:, 0:2], 2).numpy()
+    act = lambda z: np.sin(2 * np.pi * z)
+    W2 = W // 2
+    # ---------------- field program
+    D = Decoder(lib, m, 0)
+    P = gather(pe_pos, slot_pepos, 64)
+    Wd, b = D.layer(W, 4); h = act(P @ Wd.T + b)
+    for _ in range(3):
+        Wd, b = D.layer(W, W // 16); h = act(gather(h, slot_H, W) @ Wd.T + b)
+    Wd, b = D.layer(W, W // 16 + 4); h = act(np.concatenate([gather(h, slot_H, W), P], 1) @ Wd.T + b)
+    for _ in range(3):
+        Wd, b = D.layer(W, W // 16); h = act(gather(h, slot_H, W) @ Wd.T + b)
+    Wd, b = D.layer(W2, W // 16); x1 = act(gather(h, slot_H, W) @ Wd.T + b)
+    Wd, b = D.layer(32, W2 // 16); head = gather(x1, slot_H, W2) @ Wd.T + b
+    S_ = gather(pe_sun, slot_pesun, 32)
+    Wd, b = D.layer(W2, W2 // 16 + 2); a = act(np.concatenate([gather(x1, slot_H, W2), S_], 1) @ Wd.T + b)
+    for _ in range(2):
+        Wd, b = D.layer(W2, W2 // 16); a = act(gather(a, slot_H, W2) @ Wd.T + b)
+    Wd, b = D.layer(32, W2 // 16); sv = gather(a, slot_H, W2) @ Wd.T + b
+    Wd, b = D.layer(W, W2 // 16); y = act(gather(x1, slot_H, W2) @ Wd.T + b)
+    for _ in range(2):
+        Wd, b = D.layer(W, W // 16); y = act(gather(y, slot_H, W) @ Wd.T + b)
+    Wd, b = D.layer(32, W // 16); adj = gather(y, slot_H, W) @ Wd.T + b
+    tol = dict(rtol=2e-4, atol=3e-5)      # bf16 hi+lo weights carry ~2^-17 relative representation error
+    np.testing.assert_allclose(head[:, 0:3], ref[1].numpy(), **tol)                                   # Col_raw
+    np.testing.assert_allclose(np.log1p(np.exp(head[:, 3:4])), ref[0].numpy(), **tol)                 # Rho
+    np.testing.assert_allclose(1 / (1 + np.exp(-sv[:, 0:1])), ref[2].numpy(), **tol)                  # Solar_Vis
+    adj_rows = np.stack([adj[:, acc_row(i, 0)] for i in range(3 * Cn)], 1).reshape(N, Cn, 3)
+    np.testing.assert_allclose(adj_rows, ref[5].numpy(), **tol)
+    # ---------------- group program
+    D = Decoder(lib, m, 1)
+    Wd, b = D.layer(W, 2); t1 = act(gather(pe_tim, slot_petime, 32) @ Wd.T + b)
+    Wd, b = D.layer(W, W // 16); t2 = act(gather(t1, slot_H, W) @ Wd.T + b)
+    Wd, b = D.layer(32, W // 16); logits = gather(t2, slot_H, W) @ Wd.T + b
+    lg = np.stack([logits[:, acc_row(i, 0)] for i in range(Cn)], 1)
+    pr = np.exp(lg - lg.max(1, keepdims=True)); pr /= pr.sum(1, keepdims=True)
+    np.testing.assert_allclose(pr, ref[4].numpy(), **tol)
+    W4p = max(32, (W // 4 + 31) // 32 * 32)
+    Wd, b = D.layer(W4p, 2); k1 = act(gather(pe_sun, slot_pesun, 32) @ Wd.T + b)
+    Wd, b = D.layer(32, W4p // 16); sky = gather(k1, slot_H, W4p) @ Wd.T + b
+    np.testing.assert_allclose(1 / (1 + np.exp(-sky[:, 0:3])), ref[3].numpy(), **tol)
+    lib.snerf_model_destroy(m)

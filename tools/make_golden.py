@@ -205,6 +205,10 @@ def gen_render(W, seed, tag):
     qr = Quick_Run_Net(net, args, WC, H4, torch.device("cpu"), use_full_solar=False)
     imgs, mask = qr.render_img((60, 30), (45, 120), 0.25, 24)
     out["qr_Col_Img"], out["qr_Shadow_Mask"], out["qr_mask"] = imgs["Col_Img"], imgs["Shadow_Mask"], mask
+    qrx = Quick_Run_Net(net, args_ns(96), WC, H4, torch.device("cpu"), use_full_solar=True)   # exact solar, O(R*S^2)
+    imx, maskx = qrx.render_img((70, 200), (50, 100), 0.6, 7)
+    out["qrx_Col_Img"], out["qrx_Shadow_Mask"], out["qrx_Est_Shadow_Mask"], out["qrx_mask"] = \
+        imx["Col_Img"], imx["Shadow_Mask"], imx["Estimated_Shadow_Mask"], maskx
     out["qr_DSM"] = qr.get_DSM((16, 16))   # get_DSM only works with a tuple size (Quick_Run.py:38)
     size = (12, 12, 48)
     d = component_render_by_dir(net, (80, 0), (30, 90), 0.25, size, WC, H4, torch.device("cpu"),
