@@ -139,6 +139,11 @@ def main():
     if rank == 0:
         value = world * R * S * a.steps / dt
         achieved = FLOP_PER_SAMPLE * R * S / (field_ms * 1e-3)
+        traffic = None          # HBM bytes per launch from the committed PMC passes of this same command (profiles/)
+        try:
+            traffic = json.load(open(os.path.join(REPO, "profiles", "r1", "c_traffic.json")))["bytes_per_launch"]
+        except Exception:
+            pass
         out = {
             "metric": "ray-samples/sec (4096 rays x 96 samples forward render, T_NeRF 8x256)",
             "value": value, "unit": "ray-samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -150,7 +155,7 @@ def main():
             "per_gpu_value": value / world,
             "image_512x512x96_ms_est": 512 * 512 * S / (value / world) * 1e3,
             "roofline": {"bound": "mfma", "achieved": achieved / 1e12, "peak": PEAK_BF16_DENSE / 1e12, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_BF16_DENSE, "traffic": None,
+                         "frac": achieved / PEAK_BF16_DENSE, "traffic": traffic,
                          "kernel": "snerf::mlp_kernel<0,256,0> (fused field network)", "kernel_ms": field_ms,
                          "note": "achieved = algorithmic 1.489 MFLOP/ray-sample x 393216 / kernel time; the kernel "
                                  "executes 3 bf16 MFMAs per algorithmic product (error-compensated split) plus padding: "

@@ -2,6 +2,7 @@
 call boundary: `T_NeRF` (network), `All_in_One_Eval` (ray evaluator).  All arithmetic runs in the HIP kernels of
 `csrc/` through the C ABI of `include/season_nerf_hip.h`; importing this package never falls back to a CPU path."""
 from . import _lib
+from . import parallel
 from .network import T_NeRF, SineLayer
 from .evaluator import All_in_One_Eval, sample_parameters
 from .render import (Quick_Run_Net, component_render_by_dir, get_imgs_from_Img_Dict, get_imgs_from_Img_Dict_t_step,
@@ -9,4 +10,4 @@ from .render import (Quick_Run_Net, component_render_by_dir, get_imgs_from_Img_D
 
 __all__ = ["T_NeRF", "SineLayer", "All_in_One_Eval", "sample_parameters", "Quick_Run_Net", "component_render_by_dir",
            "get_imgs_from_Img_Dict", "get_imgs_from_Img_Dict_t_step", "render_season_sweep", "world_angle_2_local_vec",
-           "encode_time", "_lib"]
+           "encode_time", "parallel", "_lib"]

@@ -24,6 +24,7 @@ def build(force=False, verbose=True):
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "-std=c++17", "-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-ffp-contract=off",
+           "-mllvm", "-amdgpu-mfma-vgpr-form=1",    # MFMA accumulators in VGPRs: no v_accvgpr_read per epilogue element
            "-Wno-unused-command-line-argument",
            "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:

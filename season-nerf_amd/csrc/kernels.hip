@@ -162,20 +162,39 @@ __device__ __forceinline__ void ring_step(Ring& rg, const uint8_t* stream, uint3
 #endif
 constexpr int PF = SNERF_PF;
 
-// epilogue of element pair e (0..7): accumulator elements 2e, 2e+1 -> one packed word of the output fragments
-__device__ __forceinline__ void epilogue_pair(const f32x16& acc, const f32x4* biasq, int e, Frag* out2) {
+// Epilogue of element pair e (0..7) of a 32x32 accumulator block, cut into three phases that run in three
+// consecutive k-steps, so that the VALU work sharing an MFMA shadow is always three *independent* short chains
+// (a single in-order wave cannot hide a 7-deep add->sin->cvt->shift->sub->cvt chain behind 3 MFMAs: measured -25 %):
+//   A: t = acc + bias, v = sin(2*pi*t)        B: hi = bf16x2(v), ha/hb = hi as fp32        C: lo = bf16x2(v - h)
+struct EpiTmp {
+    float v0, v1, ha, hb;
+};
+__device__ __forceinline__ void epi_A(const f32x16& acc, const f32x4* biasq, int e, EpiTmp& t) {
     const int i0 = 2 * e, i1 = 2 * e + 1;
-#if defined(SNERF_ABLATE) && (ABL & 1)     // timing-only: no sin / split
-    out2[e >> 2].hi[e & 3] = __builtin_bit_cast(uint32_t, acc[i0] + biasq[i0 >> 2][i0 & 3]);
-    out2[e >> 2].lo[e & 3] = __builtin_bit_cast(uint32_t, acc[i1] + biasq[i1 >> 2][i1 & 3]);
+#if defined(SNERF_ABLATE) && (ABL & 8)      // timing-only: no transcendental
+    t.v0 = (acc[i0] + biasq[i0 >> 2][i0 & 3]) * 0.5f;
+    t.v1 = (acc[i1] + biasq[i1 >> 2][i1 & 3]) * 0.5f;
 #else
-    const float v0 = sin2pi(acc[i0] + biasq[i0 >> 2][i0 & 3]);
-    const float v1 = sin2pi(acc[i1] + biasq[i1 >> 2][i1 & 3]);
-    uint32_t hh, ll;
-    split2(v0, v1, hh, ll);
-    out2[e >> 2].hi[e & 3] = hh;
-    out2[e >> 2].lo[e & 3] = ll;
+    t.v0 = sin2pi(acc[i0] + biasq[i0 >> 2][i0 & 3]);
+    t.v1 = sin2pi(acc[i1] + biasq[i1 >> 2][i1 & 3]);
 #endif
+}
+__device__ __forceinline__ void epi_B(int e, EpiTmp& t, Frag* out2) {
+    // compiler-generated VALU only: an inline-asm v_cvt_pk/v_sub here read stale v_sin results (wrong low parts,
+    // 7e-4 instead of 7e-6 on Rho) - hipcc pads the transcendental-use hazard for its own instructions, not for asm
+    bf16x2 hv;
+    hv[0] = (__bf16)t.v0;
+    hv[1] = (__bf16)t.v1;
+    const uint32_t hi = __builtin_bit_cast(uint32_t, hv);
+    t.ha = __builtin_bit_cast(float, hi << 16);
+    t.hb = __builtin_bit_cast(float, hi & 0xffff0000u);
+    out2[e >> 2].hi[e & 3] = hi;
+}
+__device__ __forceinline__ void epi_C(int e, const EpiTmp& t, Frag* out2) {
+    bf16x2 lv;
+    lv[0] = (__bf16)(t.v0 - t.ha);
+    lv[1] = (__bf16)(t.v1 - t.hb);
+    out2[e >> 2].lo[e & 3] = __builtin_bit_cast(uint32_t, lv);
 }
 
 // LLVM SchedGroupMask bits
@@ -189,6 +208,7 @@ __device__ __forceinline__ void run_layer(Ring& rg, const uint8_t* stream, uint3
                                           lds_cfloat* bias_l, const Frag* in0, const Frag* in1, Frag* out,
                                           f32x16* raw, int wave, int lane) {
     constexpr int KS = KS0 + KS1, NP = NB * KS;
+    constexpr bool PIPE = KS >= 4;      // tiny layers (2 k-steps per block) run the previous epilogue in one piece
     const int h = lane >> 5;
     u32x4 fh[PF], fl[PF];
 #pragma unroll
@@ -202,6 +222,7 @@ __device__ __forceinline__ void run_layer(Ring& rg, const uint8_t* stream, uint3
     }
     f32x16 accs[2];
     f32x4 biasq[2][4];
+    EpiTmp et[8];
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         lds_cf32x4* bp = (lds_cf32x4*)(bias_l + b * 32 + h * 16);
@@ -227,10 +248,20 @@ __device__ __forceinline__ void run_layer(Ring& rg, const uint8_t* stream, uint3
             }
             acc = mfma3(a_hi, a_lo, s < KS0 ? in0[s] : in1[s - KS0], acc);
             if (SIN && b > 0) {
-                // previous block's epilogue, one element pair at a time, spread evenly over this block's k-steps
+                // previous block's epilogue: pair e runs phase A at step sA(e) = e*(KS-2)/8, B at sA+1, C at sA+2
 #pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    if ((e * KS) / 8 == s) epilogue_pair(accs[(b - 1) & 1], biasq[(b - 1) & 1], e, out + 2 * (b - 1));
+                for (int e = 0; e < 8; ++e) {
+                    if (PIPE) {
+                        const int sA = (e * (KS - 2)) / 8;
+                        if (s == sA + 2) epi_C(e, et[e], out + 2 * (b - 1));
+                        if (s == sA + 1) epi_B(e, et[e], out + 2 * (b - 1));
+                        if (s == sA) epi_A(accs[(b - 1) & 1], biasq[(b - 1) & 1], e, et[e]);
+                    } else if (s == 0) {
+                        epi_A(accs[(b - 1) & 1], biasq[(b - 1) & 1], e, et[e]);
+                        epi_B(e, et[e], out + 2 * (b - 1));
+                        epi_C(e, et[e], out + 2 * (b - 1));
+                    }
+                }
             }
 #ifndef SNERF_NO_SCHED_GROUPS
             // pin the interleave: each MFMA gets at most 1 LDS read, 1 transcendental and 3 plain VALU in its shadow
@@ -249,7 +280,11 @@ __device__ __forceinline__ void run_layer(Ring& rg, const uint8_t* stream, uint3
     }
     if (SIN) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) epilogue_pair(accs[(NB - 1) & 1], biasq[(NB - 1) & 1], e, out + 2 * (NB - 1));
+        for (int e = 0; e < 8; ++e) epi_A(accs[(NB - 1) & 1], biasq[(NB - 1) & 1], e, et[e]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) epi_B(e, et[e], out + 2 * (NB - 1));
+#pragma unroll
+        for (int e = 0; e < 8; ++e) epi_C(e, et[e], out + 2 * (NB - 1));
     } else {
         f32x16 acc = accs[0];
 #pragma unroll

@@ -1,0 +1,54 @@
+"""Ray-parallel execution over the GPUs of one node: one process per GPU, `torch.distributed` (backend "nccl" = RCCL
+over xGMI on the GPU box, "gloo" in the CPU tests).
+
+Rays are independent given the weights, so the path shards with NO collective inside the data path:
+every rank holds a replica of the 3.3 MB weights, renders a contiguous block of rays, and the only exchange is one
+all-gather of the rendered rows (RGB tiles: 12 B/ray) - latency-bound, a few tens of microseconds over xGMI.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n, world):
+    """Contiguous, balanced ray ranges: the first n % world ranks get one extra ray."""
+    q, r = divmod(n, world)
+    out, lo = [], 0
+    for k in range(world):
+        hi = lo + q + (1 if k < r else 0)
+        out.append((lo, hi))
+        lo = hi
+    return out
+
+
+def shard_dict(data_dict, rank, world):
+    """Slice every per-ray tensor of a reference-style data dict (Top, Bot, Sun_Angle, Time_Encoded, ...)."""
+    n = data_dict["Top"].shape[0]
+    lo, hi = shard_bounds(n, world)[rank]
+    return {k: (v[lo:hi] if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == n else v) for k, v in data_dict.items()}
+
+
+def gather_rows(local, n_total, group=None):
+    """All-gather row blocks of unequal length (shard_bounds order) into the full [n_total, ...] tensor on every rank.
+    One collective: blocks are padded to the largest shard."""
+    world = dist.get_world_size(group)
+    bounds = shard_bounds(n_total, world)
+    mx = max(hi - lo for lo, hi in bounds)
+    pad = torch.zeros((mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    buf = torch.empty((world * mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(buf, pad, group=group)
+    return torch.cat([buf[k * mx: k * mx + (hi - lo)] for k, (lo, hi) in enumerate(bounds)], 0)
+
+
+class ShardedEval:
+    """Wraps an evaluator's `eval`: each rank evaluates its ray shard, per-ray results are all-gathered."""
+
+    def __init__(self, eval_tool, network, group=None, keys=("Rendered_Col",)):
+        self.eval_tool, self.network, self.group, self.keys = eval_tool, network, group, keys
+
+    def eval(self, data_dict, current_step, train_mode):
+        world = dist.get_world_size(self.group)
+        rank = dist.get_rank(self.group)
+        n = data_dict["Top"].shape[0]
+        out = self.eval_tool.eval(shard_dict(data_dict, rank, world), self.network, current_step, train_mode)
+        return {k: gather_rows(out[k].contiguous(), n, self.group) for k in self.keys}
