@@ -140,6 +140,46 @@ int snerf_composite_sweep(int64_t n_rays, int n_samples, int n_classes, int n_ti
                           const float* d_adjust, const float* d_solar_vis, const float* d_sky, const float* d_class_vecs,
                           int flags, const snerf_sweep_out* out, void* stream);
 
+/* ---- training engine: the device side of Net_tool.train_step (mg_run_NeRF.py:288-326) = All_in_One_Eval.get_loss
+ * (Eval_Tools_2.py:340-459) forward passes in .train() mode, backward, Adam.  Layer-wise fp32 (exact-fp32 MFMA GEMMs),
+ * batch-statistics BatchNorm1d (momentum 0.01, misc.py:170) with running-stat EMA, activations stashed in HBM.
+ * Two passes per step, as the reference: image rays (everything gets a gradient except the solar branch, whose output
+ * is detached, Eval_Tools_2.py:214) and random sun rays (forward_Solar: trunk without gradient, :297-337).
+ * The caller owns all memory: a flat parameter arena and same-sized gradient / Adam arenas (layout from
+ * snerf_trainer_tensor_info: state_dict keys -> offset), the BatchNorm running-stat arena, and the workspace.
+ * The scalar loss terms stay with the caller: forward returns Rendered_Col / Albedo / Sky_Col / Solar_Vis ..., backward
+ * takes dL/d(those). */
+typedef struct snerf_trainer snerf_trainer;
+snerf_trainer* snerf_trainer_create(int layer_width, int n_classes);
+void snerf_trainer_destroy(snerf_trainer* t);
+int64_t snerf_trainer_param_floats(const snerf_trainer* t);
+int64_t snerf_trainer_buffer_floats(const snerf_trainer* t);
+int snerf_trainer_tensor_count(const snerf_trainer* t);
+int snerf_trainer_tensor_info(const snerf_trainer* t, int index, char* key, int key_cap, int* is_buffer, int64_t* offset,
+                              int64_t* numel, int* rows, int* cols);
+size_t snerf_trainer_workspace_bytes(snerf_trainer* t, int64_t n_rays, int64_t n_solar_rays, int n_samples);
+int snerf_trainer_bind(snerf_trainer* t, float* d_params, float* d_grads, float* d_adam_m, float* d_adam_v, float* d_buffers,
+                       void* d_workspace, size_t workspace_bytes, int64_t n_rays, int64_t n_solar_rays, int n_samples);
+/* image-ray pass: T_NeRF.forward + compositing.  train_bn: 1 = batch statistics + EMA update, 0 = running statistics. */
+int snerf_trainer_forward_image(snerf_trainer* t, int64_t n_rays, int n_samples, const float* d_top, const float* d_bot,
+                                const float* d_tvals, const float* d_sun, const float* d_time, int train_bn, int flags,
+                                const snerf_composite_out* out, float* d_sky, float* d_classes,
+                                const snerf_field_out* per_sample, void* stream);
+/* gradients of the image pass: dL/dRendered_Col [R,3], dL/dAlbedo_Color [R,3] (opt), dL/dSky_Col per ray [R,3] (opt),
+ * dL/dPE [R*S] (opt); ACCUMULATES into the gradient arena. */
+int snerf_trainer_backward_image(snerf_trainer* t, const float* d_g_rgb, const float* d_g_albedo, const float* d_g_sky,
+                                 const float* d_g_pe, void* stream);
+/* sun-ray pass: T_NeRF.forward_Solar + PV_Exact / PE (end-point sampling is the caller's d_tvals). */
+int snerf_trainer_forward_solar(snerf_trainer* t, int64_t n_rays, int n_samples, const float* d_top, const float* d_bot,
+                                const float* d_tvals, const float* d_sun, int train_bn, float* d_solar_vis, float* d_pv,
+                                float* d_pe, float* d_sky_raw, void* stream);
+int snerf_trainer_backward_solar(snerf_trainer* t, const float* d_g_solar_vis, void* stream);
+int snerf_trainer_zero_grad(snerf_trainer* t, void* stream);
+/* test introspection: synchronous copy of an internal buffer ("d_rho", "d_col", "d_head", "d_sky", ...) to the host */
+int snerf_trainer_debug_read(snerf_trainer* t, const char* name, float* host_out, int64_t n_floats);
+/* torch.optim.Adam semantics (no weight decay) over the whole parameter arena in one launch; step counts from 1. */
+int snerf_trainer_adam_step(snerf_trainer* t, float lr, float beta1, float beta2, float eps, int step, void* stream);
+
 /* Name and launch geometry of the dominant kernel (for profiling scripts): fills grid/block/lds bytes. */
 int snerf_field_kernel_info(const snerf_model* m, int64_t n_points, int* grid, int* block, int* lds_bytes);
 

@@ -57,6 +57,29 @@ def lib():
     L.snerf_render_rays.argtypes = [vp, i64, i32, vp, vp, vp, vp, vp, i32, vp, C.POINTER(FieldOut),
                                     C.POINTER(CompositeOut), vp, C.c_size_t, vp]
     L.snerf_composite_sweep.argtypes = [i64, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, C.POINTER(SweepOut), vp]
+    f32p = vp
+    L.snerf_trainer_create.restype = vp
+    L.snerf_trainer_create.argtypes = [i32, i32]
+    L.snerf_trainer_destroy.argtypes = [vp]
+    L.snerf_trainer_destroy.restype = None
+    L.snerf_trainer_param_floats.restype = i64
+    L.snerf_trainer_param_floats.argtypes = [vp]
+    L.snerf_trainer_buffer_floats.restype = i64
+    L.snerf_trainer_buffer_floats.argtypes = [vp]
+    L.snerf_trainer_tensor_count.argtypes = [vp]
+    L.snerf_trainer_tensor_info.argtypes = [vp, i32, C.c_char_p, i32, C.POINTER(i32), C.POINTER(i64), C.POINTER(i64),
+                                            C.POINTER(i32), C.POINTER(i32)]
+    L.snerf_trainer_workspace_bytes.restype = C.c_size_t
+    L.snerf_trainer_workspace_bytes.argtypes = [vp, i64, i64, i32]
+    L.snerf_trainer_bind.argtypes = [vp, f32p, f32p, f32p, f32p, f32p, vp, C.c_size_t, i64, i64, i32]
+    L.snerf_trainer_forward_image.argtypes = [vp, i64, i32, vp, vp, vp, vp, vp, i32, i32, C.POINTER(CompositeOut), vp, vp,
+                                              C.POINTER(FieldOut), vp]
+    L.snerf_trainer_backward_image.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.snerf_trainer_forward_solar.argtypes = [vp, i64, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp]
+    L.snerf_trainer_backward_solar.argtypes = [vp, vp, vp]
+    L.snerf_trainer_zero_grad.argtypes = [vp, vp]
+    L.snerf_trainer_debug_read.argtypes = [vp, C.c_char_p, vp, i64]
+    L.snerf_trainer_adam_step.argtypes = [vp, C.c_float, C.c_float, C.c_float, C.c_float, i32, vp]
     L.snerf_field_kernel_info.argtypes = [vp, i64, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     _lib = L
     return L
@@ -70,4 +93,8 @@ def check(rc, what):
 EXPORTS = ["snerf_last_error", "snerf_abi_version", "snerf_model_create", "snerf_model_set_tensor",
            "snerf_model_finalize", "snerf_model_destroy", "snerf_model_width", "snerf_model_classes",
            "snerf_model_pack_host", "snerf_group_forward", "snerf_field_forward_points", "snerf_field_forward_rays",
-           "snerf_composite_rays", "snerf_composite_sweep", "snerf_render_workspace_bytes", "snerf_render_rays", "snerf_field_kernel_info"]
+           "snerf_composite_rays", "snerf_composite_sweep", "snerf_render_workspace_bytes", "snerf_render_rays", "snerf_field_kernel_info",
+           "snerf_trainer_create", "snerf_trainer_destroy", "snerf_trainer_param_floats", "snerf_trainer_buffer_floats",
+           "snerf_trainer_tensor_count", "snerf_trainer_tensor_info", "snerf_trainer_workspace_bytes", "snerf_trainer_bind",
+           "snerf_trainer_forward_image", "snerf_trainer_backward_image", "snerf_trainer_forward_solar",
+           "snerf_trainer_backward_solar", "snerf_trainer_zero_grad", "snerf_trainer_adam_step", "snerf_trainer_debug_read"]

@@ -8,8 +8,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libseason_nerf_hip.so")
-SOURCES = ["kernels.hip", "api.cpp", "pack.cpp"]
-DEPS = SOURCES + ["kernels.h", "pack.h", "program.h", os.path.join("..", "..", "include", "season_nerf_hip.h")]
+SOURCES = ["kernels.hip", "api.cpp", "pack.cpp", "gemm.hip", "train_kernels.hip", "train.cpp"]
+DEPS = SOURCES + ["kernels.h", "pack.h", "program.h", "train.h", os.path.join("..", "..", "include", "season_nerf_hip.h")]
 
 
 def needs_build():

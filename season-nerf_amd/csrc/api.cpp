@@ -18,6 +18,7 @@ static int fail(int code, const std::string& msg) {
     g_err = msg;
     return code;
 }
+int snerf_set_error(int code, const std::string& msg) { return fail(code, msg); }   // used by train.cpp
 static int fail_hip(hipError_t e, const char* what) {
     return fail(SNERF_E_HIP, std::string(what) + ": " + hipGetErrorString(e));
 }

@@ -1,0 +1,545 @@
+// Layer-wise training engine: forward with batch-statistics BatchNorm (+ running-stat EMA), backward, Adam.
+// Reference semantics: T_NeRF.forward / forward_Solar in .train() mode (T_NeRF_net_v2.py:75-157, misc.py:148-189),
+// Eval_Tools_2.py:165-215 (compositing) and :297-337 (sun-ray pass, trunk under no_grad), mg_run_NeRF.py:288-326.
+// The caller (PyTorch) owns every buffer: parameter / gradient / Adam arenas and the activation workspace.
+#include "../../include/season_nerf_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+#include "train.h"
+
+using namespace snerf;
+
+extern int snerf_set_error(int code, const std::string& msg);   // api.cpp
+
+namespace {
+
+struct LayerP {
+    std::string name;
+    int n_out, n_in;
+    bool sine, bn;
+    int64_t w, b, g, beta;     // offsets (floats) in the parameter arena; g/beta only with bn
+    int64_t rm, rv;            // offsets in the buffer arena (running mean/var); only with bn
+};
+
+enum L {
+    L_FC1, L_FC2, L_FC3, L_FC4, L_FC5, L_FC6, L_FC7, L_FC8, L_FC9, L_COL, L_SIG, L_S1, L_S2, L_S3, L_S4, L_K1, L_K2,
+    L_T1, L_T2, L_CL, L_A1, L_A2, L_A3, L_AC, L_DEAD0, L_DEAD1, L_DEAD2, L_NUM
+};
+
+struct Act {           // a [rows, cols] fp32 matrix inside the workspace
+    float* p = nullptr;
+    int64_t ld = 0;
+};
+
+}  // namespace
+
+struct snerf_trainer {
+    int W, C, W2, W4;
+    std::vector<LayerP> layers;
+    int64_t n_params = 0, n_buffers = 0;
+    float *params = nullptr, *grads = nullptr, *adam_m = nullptr, *adam_v = nullptr, *buffers = nullptr;
+    char* ws = nullptr;
+    size_t ws_bytes = 0;
+    // state of the last forward passes (needed by backward)
+    int64_t R = 0, Rs = 0;
+    int S = 0;
+    // workspace carve (set by carve())
+    struct Pass {
+        int64_t R = 0, N = 0;
+        Act E, In5, Z[9], H[9], head, Za[3], Ha[3], adj, In_s1, Zs[3], Hs[3], sv_raw, tmpA, tmpB;
+        float *pts, *rho, *col, *sv, *pe_sun, *pe_time, *Zt1, *Ht1, *Zt2, *Ht2, *logits, *cls, *Zk1, *Hk1, *sky_raw, *sky;
+        float* bn;             // [8 layers][4][W]: colsum, m2, mean, istd
+        float *top, *bot, *tvals;   // engine-owned copies: the caller's tensors may be recycled before backward
+    } img, sol;
+    Act dA, dB, dX1;
+    float *d_head, *d_adj, *d_rho, *d_col, *d_sky, *d_cls, *d_sv_raw, *rayA, *rayB, *bn_bwd;   // bn_bwd: [2][W]
+};
+
+static int64_t align64(int64_t x) { return (x + 63) / 64 * 64; }
+
+static void build_layers(snerf_trainer* t) {
+    const int W = t->W, C = t->C, W2 = t->W2, W4 = t->W4;
+    auto add = [&](const char* name, int n_out, int n_in, bool sine, bool bn) {
+        LayerP l;
+        l.name = name; l.n_out = n_out; l.n_in = n_in; l.sine = sine; l.bn = bn;
+        l.w = t->n_params; t->n_params += (int64_t)n_out * n_in;
+        l.b = t->n_params; t->n_params += n_out;
+        l.g = l.beta = l.rm = l.rv = -1;
+        if (bn) {
+            l.g = t->n_params; t->n_params += n_out;
+            l.beta = t->n_params; t->n_params += n_out;
+            l.rm = t->n_buffers; t->n_buffers += n_out;
+            l.rv = t->n_buffers; t->n_buffers += n_out;
+        }
+        t->layers.push_back(l);
+    };
+    add("G_NeRF_net.fc1", W, 63, true, false);
+    add("G_NeRF_net.fc2", W, W, true, true);
+    add("G_NeRF_net.fc3", W, W, true, true);
+    add("G_NeRF_net.fc4", W, W, true, true);
+    add("G_NeRF_net.fc5", W, W + 63, true, true);
+    add("G_NeRF_net.fc6", W, W, true, true);
+    add("G_NeRF_net.fc7", W, W, true, true);
+    add("G_NeRF_net.fc8", W, W, true, true);
+    add("G_NeRF_net.fc9", W2, W, true, true);
+    add("G_NeRF_net.fc10Col", 3, W2, false, false);
+    add("G_NeRF_net.fc10Sigma", 1, W2, false, false);
+    add("G_NeRF_net.fc_solar_1", W2, W2 + 27, true, false);
+    add("G_NeRF_net.fc_solar_2", W2, W2, true, false);
+    add("G_NeRF_net.fc_solar_3", W2, W2, true, false);
+    add("G_NeRF_net.fc_solar_4", 1, W2, false, false);
+    add("G_NeRF_net.fc_sky_color_1", W4, 27, true, false);
+    add("G_NeRF_net.fc_sky_color_2", 3, W4, false, false);
+    add("time_layer_1", W, 10, true, false);
+    add("time_layer_2", W, W, true, false);
+    add("get_class_layer", C, W, false, false);
+    add("adjust_layer_1", W, W2, true, false);
+    add("adjust_layer_2", W, W, true, false);
+    add("adjust_layer_3", W, W, true, false);
+    add("adjust_col", 3 * C, W, false, false);
+    add("adjust_rho", C, W, false, false);            // dead heads: parameters only (never used, never get a gradient)
+    add("adjust_solar_vis", C, W, false, false);
+    add("adjust_sky_col", 3 * C, W, false, false);
+}
+
+// ---- workspace carving ------------------------------------------------------------------------------
+struct Carver {
+    char* base;
+    size_t off = 0;
+    float* take(int64_t floats) {
+        float* p = base ? (float*)(base + off) : nullptr;
+        off += (size_t)align64(floats) * 4;
+        return p;
+    }
+    Act mat(int64_t rows, int64_t ld) { Act a; a.p = take(rows * ld); a.ld = ld; return a; }
+};
+
+static size_t carve(snerf_trainer* t, char* base, int64_t R, int64_t Rs, int S) {
+    Carver c{base};
+    const int W = t->W, W2 = t->W2, W4 = t->W4, C = t->C;
+    for (int pass = 0; pass < 2; ++pass) {
+        snerf_trainer::Pass& P = pass == 0 ? t->img : t->sol;
+        const int64_t Rr = pass == 0 ? R : Rs, N = Rr * S;
+        P.R = Rr; P.N = N;
+        P.E = c.mat(N, 64);
+        P.In5 = c.mat(N, W + 64);
+        for (int l = 0; l < 9; ++l) {
+            const int w = l == 8 ? W2 : W;
+            P.Z[l] = c.mat(N, w);
+            if (l == 3) { P.H[l].p = P.In5.p; P.H[l].ld = W + 64; }     // fc4's output lives inside fc5's concat input
+            else P.H[l] = c.mat(N, w);
+        }
+        P.head = c.mat(N, 4);
+        for (int l = 0; l < 3; ++l) { P.Za[l] = c.mat(N, W); P.Ha[l] = c.mat(N, W); }
+        P.adj = c.mat(N, 3 * C);
+        P.In_s1 = c.mat(N, W2 + 28);
+        for (int l = 0; l < 3; ++l) { P.Zs[l] = c.mat(N, W2); P.Hs[l] = c.mat(N, W2); }
+        P.sv_raw = c.mat(N, 1);
+        P.pts = c.take(N * 3); P.rho = c.take(N); P.col = c.take(N * 3); P.sv = c.take(N);
+        P.pe_sun = c.take(Rr * 28); P.pe_time = c.take(Rr * 12);
+        P.Zt1 = c.take(Rr * W); P.Ht1 = c.take(Rr * W); P.Zt2 = c.take(Rr * W); P.Ht2 = c.take(Rr * W);
+        P.logits = c.take(Rr * C); P.cls = c.take(Rr * C);
+        P.Zk1 = c.take(Rr * W4); P.Hk1 = c.take(Rr * W4); P.sky_raw = c.take(Rr * 3); P.sky = c.take(Rr * 3);
+        P.bn = c.take(8 * 4 * W);
+        P.top = c.take(Rr * 3); P.bot = c.take(Rr * 3); P.tvals = c.take(S);
+    }
+    const int64_t Nmax = (R > Rs ? R : Rs) * S, Rmax = R > Rs ? R : Rs;
+    t->dA = c.mat(Nmax, W + 64);
+    t->dB = c.mat(Nmax, W + 64);
+    t->dX1 = c.mat(Nmax, W2);
+    t->d_head = c.take(Nmax * 4); t->d_adj = c.take(Nmax * 3 * C); t->d_rho = c.take(Nmax); t->d_col = c.take(Nmax * 3);
+    t->d_sky = c.take(Rmax * 3); t->d_cls = c.take(Rmax * C); t->d_sv_raw = c.take(Nmax);
+    t->rayA = c.take(Rmax * W); t->rayB = c.take(Rmax * W);
+    t->bn_bwd = c.take(2 * W);
+    return c.off;
+}
+
+// ---- building blocks ----------------------------------------------------------------------------------
+#define HIPCK(x)                                                                                   \
+    do {                                                                                           \
+        hipError_t _e = (x);                                                                       \
+        if (_e != hipSuccess) return snerf_set_error(SNERF_E_HIP, std::string(#x) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+// Z[M, n_out] = alpha * (In[M, K] W^T + b);  colsum optional
+static hipError_t linear_fwd(snerf_trainer* t, const LayerP& L, const float* In, int64_t ld_in, int64_t M, float* Z, int64_t ldz,
+                             float alpha, float* colsum, hipStream_t st) {
+    GemmArgs g{};
+    g.A = In; g.B = t->params + L.w; g.C = Z;
+    g.M = M; g.N = L.n_out; g.K = L.n_in;
+    g.sAm = ld_in; g.sAk = 1; g.sBk = 1; g.sBn = L.n_in; g.ldc = ldz;
+    g.alpha = alpha; g.bias = t->params + L.b; g.colsum = colsum; g.flags = 0; g.splitk = 1;
+    return launch_gemm(g, st);
+}
+// dIn[M, n_cols] (+)= alpha * dZ[M, n_out] W[:, :n_cols]
+static hipError_t linear_dgrad(snerf_trainer* t, const LayerP& L, const float* dZ, int64_t ldz, int64_t M, float* dIn, int64_t ld_in,
+                               int n_cols, float alpha, bool accumulate, hipStream_t st) {
+    GemmArgs g{};
+    g.A = dZ; g.B = t->params + L.w; g.C = dIn;
+    g.M = M; g.N = n_cols; g.K = L.n_out;
+    g.sAm = ldz; g.sAk = 1; g.sBk = L.n_in; g.sBn = 1; g.ldc = ld_in;
+    g.alpha = alpha; g.bias = nullptr; g.colsum = nullptr; g.flags = accumulate ? GEMM_ACCUM : 0; g.splitk = 1;
+    return launch_gemm(g, st);
+}
+// dW[n_out, n_in] += alpha * dZ^T In   (split over the point dimension, fp32 atomics)
+static hipError_t linear_wgrad(snerf_trainer* t, const LayerP& L, const float* dZ, int64_t ldz, const float* In, int64_t ld_in,
+                               int64_t M, float alpha, hipStream_t st) {
+    GemmArgs g{};
+    g.A = dZ; g.B = In; g.C = t->grads + L.w;
+    g.M = L.n_out; g.N = L.n_in; g.K = M;
+    g.sAm = 1; g.sAk = ldz; g.sBk = ld_in; g.sBn = 1; g.ldc = L.n_in;
+    g.alpha = alpha; g.bias = nullptr; g.colsum = nullptr; g.flags = GEMM_ATOMIC;
+    int64_t sk = (M + 2047) / 2048;
+    if (sk > 1024) sk = 1024;
+    if (sk < 1) sk = 1;
+    g.splitk = (int)sk;
+    return launch_gemm(g, st);
+}
+
+// SineLayer forward in train mode: Z = 30(In W^T + b) [stashed], H = sin(BN_batch(Z)) or sin(Z)
+static int sine_fwd(snerf_trainer* t, const LayerP& L, const float* In, int64_t ld_in, int64_t M, Act Z, Act H, float* bnslot,
+                    bool train_bn, hipStream_t st) {
+    const int C = L.n_out;
+    if (L.bn) {
+        float *colsum = bnslot, *m2 = bnslot + t->W, *mean = bnslot + 2 * t->W, *istd = bnslot + 3 * t->W;
+        if (train_bn) {
+            HIPCK(hipMemsetAsync(bnslot, 0, 2 * t->W * sizeof(float), st));
+            HIPCK(linear_fwd(t, L, In, ld_in, M, Z.p, Z.ld, 30.f, colsum, st));
+            HIPCK(launch_bn_finalize(colsum, m2, M, C, mean, istd, nullptr, nullptr, 0, st));
+            ColArgs ca{};
+            ca.mode = 0; ca.M = M; ca.C = C; ca.ld = Z.ld; ca.Z = Z.p; ca.mu = mean; ca.out0 = m2; ca.alpha0 = 1.f;
+            HIPCK(launch_colreduce(ca, st));
+            HIPCK(launch_bn_finalize(colsum, m2, M, C, mean, istd, t->buffers + L.rm, t->buffers + L.rv, 1, st));
+        } else {      // eval-mode statistics (running estimates)
+            HIPCK(linear_fwd(t, L, In, ld_in, M, Z.p, Z.ld, 30.f, nullptr, st));
+            HIPCK(hipMemcpyAsync(mean, t->buffers + L.rm, C * sizeof(float), hipMemcpyDeviceToDevice, st));
+            // istd from running var: reuse finalize stage 1 arithmetic with M = 1 via a tiny dedicated path
+            HIPCK(launch_bn_finalize(nullptr, t->buffers + L.rv, 1, C, mean, istd, nullptr, nullptr, 2, st));
+        }
+        HIPCK(launch_sin_fwd(Z.p, H.p, M, C, Z.ld, H.ld, mean, istd, t->params + L.g, t->params + L.beta, st));
+    } else {
+        HIPCK(linear_fwd(t, L, In, ld_in, M, Z.p, Z.ld, 30.f, nullptr, st));
+        HIPCK(launch_sin_fwd(Z.p, H.p, M, C, Z.ld, H.ld, nullptr, nullptr, nullptr, nullptr, st));
+    }
+    return SNERF_OK;
+}
+
+// SineLayer backward.  D holds dL/dH on entry ([M, n_out], ld = D.ld) and dL/dZ on exit (in place).
+// Accumulates weight/bias (and BN affine) gradients; if dIn.p != null writes dL/dIn[:, :n_in_cols].
+static int sine_bwd(snerf_trainer* t, const LayerP& L, Act D, Act Z, const float* In, int64_t ld_in, int64_t M, float* bnslot,
+                    Act dIn, int n_in_cols, bool accumulate_in, hipStream_t st) {
+    const int C = L.n_out;
+    if (L.bn) {
+        float *mean = bnslot + 2 * t->W, *istd = bnslot + 3 * t->W;
+        float *sdy = t->bn_bwd, *sdyx = t->bn_bwd + t->W;
+        HIPCK(hipMemsetAsync(t->bn_bwd, 0, 2 * t->W * sizeof(float), st));
+        ColArgs ca{};
+        ca.mode = 1; ca.M = M; ca.C = C; ca.ld = Z.ld; ca.Z = Z.p; ca.D = D.p; ca.mu = mean; ca.istd = istd;
+        ca.gamma = t->params + L.g; ca.beta = t->params + L.beta; ca.out0 = sdy; ca.out1 = sdyx; ca.alpha0 = 1.f;
+        if (D.ld != Z.ld) return snerf_set_error(SNERF_E_INVALID, "sine_bwd: gradient and activation strides differ");
+        HIPCK(launch_colreduce(ca, st));
+        // d beta = sum dY, d gamma = sum dY*xhat
+        HIPCK(launch_copy_cols(sdy, C, t->grads + L.beta, C, 1, C, true, st));
+        HIPCK(launch_copy_cols(sdyx, C, t->grads + L.g, C, 1, C, true, st));
+        HIPCK(launch_bn_bwd2(Z.p, D.p, M, C, Z.ld, mean, istd, t->params + L.g, sdy, sdyx, t->grads + L.b, 30.f, st));
+    } else {
+        ColArgs ca{};
+        ca.mode = 2; ca.M = M; ca.C = C; ca.ld = Z.ld; ca.Z = Z.p; ca.D = D.p; ca.out0 = t->grads + L.b; ca.alpha0 = 30.f;
+        if (D.ld != Z.ld) return snerf_set_error(SNERF_E_INVALID, "sine_bwd: gradient and activation strides differ");
+        HIPCK(launch_colreduce(ca, st));
+    }
+    HIPCK(linear_wgrad(t, L, D.p, D.ld, In, ld_in, M, 30.f, st));
+    if (dIn.p) HIPCK(linear_dgrad(t, L, D.p, D.ld, M, dIn.p, dIn.ld, n_in_cols, 30.f, accumulate_in, st));
+    return SNERF_OK;
+}
+
+// plain Linear (heads): Out[M, n_out] = In W^T + b
+static int plain_fwd(snerf_trainer* t, const LayerP& L, const float* In, int64_t ld_in, int64_t M, float* Out, int64_t ldo, hipStream_t st) {
+    HIPCK(linear_fwd(t, L, In, ld_in, M, Out, ldo, 1.f, nullptr, st));
+    return SNERF_OK;
+}
+static int plain_bwd(snerf_trainer* t, const LayerP& L, const float* dOut, int64_t ldo, const float* In, int64_t ld_in, int64_t M,
+                     float* dIn, int64_t ld_din, bool accumulate, hipStream_t st) {
+    HIPCK(linear_wgrad(t, L, dOut, ldo, In, ld_in, M, 1.f, st));
+    HIPCK(launch_colsum(dOut, M, L.n_out, ldo, 1.f, t->grads + L.b, st));
+    if (dIn) HIPCK(linear_dgrad(t, L, dOut, ldo, M, dIn, ld_din, L.n_in, 1.f, accumulate, st));
+    return SNERF_OK;
+}
+
+#define RC(x)                 \
+    do {                      \
+        int _rc = (x);        \
+        if (_rc) return _rc;  \
+    } while (0)
+
+static int forward_pass(snerf_trainer* t, snerf_trainer::Pass& P, bool solar, int64_t R, int S, const float* top, const float* bot,
+                        const float* tvals, const float* sun, const float* time, bool train_bn, hipStream_t st) {
+    const int W = t->W, W2 = t->W2, W4 = t->W4, C = t->C;
+    const int64_t N = R * S;
+    HIPCK(hipMemcpyAsync(P.top, top, R * 3 * sizeof(float), hipMemcpyDeviceToDevice, st));
+    HIPCK(hipMemcpyAsync(P.bot, bot, R * 3 * sizeof(float), hipMemcpyDeviceToDevice, st));
+    HIPCK(hipMemcpyAsync(P.tvals, tvals, S * sizeof(float), hipMemcpyDeviceToDevice, st));
+    auto& Ls = t->layers;
+    PeArgs pa{};
+    pa.n = N; pa.n_samples = S; pa.top = top; pa.bot = bot; pa.tvals = tvals; pa.pe = P.E.p; pa.pts = P.pts;
+    HIPCK(launch_pe_points(pa, st));
+    HIPCK(launch_copy_cols(P.E.p, 64, P.In5.p + W, W + 64, N, 64, false, st));
+    // trunk (G_NeRF.py:80-91)
+    RC(sine_fwd(t, Ls[L_FC1], P.E.p, 64, N, P.Z[0], P.H[0], nullptr, train_bn, st));
+    for (int l = 1; l < 9; ++l) {
+        const float* In = l == 4 ? P.In5.p : P.H[l - 1].p;
+        const int64_t ld = l == 4 ? W + 64 : P.H[l - 1].ld;
+        RC(sine_fwd(t, Ls[L_FC1 + l], In, ld, N, P.Z[l], P.H[l], P.bn + (l - 1) * 4 * W, train_bn, st));
+    }
+    const float* X1 = P.H[8].p;
+    RC(plain_fwd(t, Ls[L_COL], X1, W2, N, P.head.p, 4, st));
+    RC(plain_fwd(t, Ls[L_SIG], X1, W2, N, P.head.p + 3, 4, st));
+    // solar visibility branch (G_NeRF.py:100-108)
+    HIPCK(launch_pe_small(sun, 3, 3, 4, R, P.pe_sun, 28, st));
+    HIPCK(launch_copy_cols(X1, W2, P.In_s1.p, W2 + 28, N, W2, false, st));
+    HIPCK(launch_bcast_rows(P.pe_sun, 28, P.In_s1.p, W2 + 28, W2, N, S, st));
+    RC(sine_fwd(t, Ls[L_S1], P.In_s1.p, W2 + 28, N, P.Zs[0], P.Hs[0], nullptr, train_bn, st));
+    RC(sine_fwd(t, Ls[L_S2], P.Hs[0].p, W2, N, P.Zs[1], P.Hs[1], nullptr, train_bn, st));
+    RC(sine_fwd(t, Ls[L_S3], P.Hs[1].p, W2, N, P.Zs[2], P.Hs[2], nullptr, train_bn, st));
+    RC(plain_fwd(t, Ls[L_S4], P.Hs[2].p, W2, N, P.sv_raw.p, 1, st));
+    // sky colour head (G_NeRF.py:110-111), per ray
+    RC(sine_fwd(t, Ls[L_K1], P.pe_sun, 28, R, Act{P.Zk1, W4}, Act{P.Hk1, W4}, nullptr, train_bn, st));
+    RC(plain_fwd(t, Ls[L_K2], P.Hk1, W4, R, P.sky_raw, 3, st));
+    HIPCK(launch_sigmoid(P.sky_raw, P.sky, R * 3, st));
+    PointOutArgs po{};
+    po.n = N; po.n_samples = S; po.C = C; po.head = P.head.p; po.sv_raw = P.sv_raw.p; po.rho = P.rho; po.sv = P.sv;
+    if (!solar) {
+        // seasonal colour-adjust branch (T_NeRF_net_v2.py:83-88) and time -> class softmax (:77-78, per ray)
+        RC(sine_fwd(t, Ls[L_A1], X1, W2, N, P.Za[0], P.Ha[0], nullptr, train_bn, st));
+        RC(sine_fwd(t, Ls[L_A2], P.Ha[0].p, W, N, P.Za[1], P.Ha[1], nullptr, train_bn, st));
+        RC(sine_fwd(t, Ls[L_A3], P.Ha[1].p, W, N, P.Za[2], P.Ha[2], nullptr, train_bn, st));
+        RC(plain_fwd(t, Ls[L_AC], P.Ha[2].p, W, N, P.adj.p, 3 * C, st));
+        HIPCK(launch_pe_small(time, 4, 2, 2, R, P.pe_time, 12, st));
+        RC(sine_fwd(t, Ls[L_T1], P.pe_time, 12, R, Act{P.Zt1, W}, Act{P.Ht1, W}, nullptr, train_bn, st));
+        RC(sine_fwd(t, Ls[L_T2], P.Ht1, W, R, Act{P.Zt2, W}, Act{P.Ht2, W}, nullptr, train_bn, st));
+        RC(plain_fwd(t, Ls[L_CL], P.Ht2, W, R, P.logits, C, st));
+        HIPCK(launch_softmax(P.logits, P.cls, R, C, st));
+        po.adj = P.adj.p; po.cls = P.cls; po.col = P.col;
+    }
+    HIPCK(launch_point_out(po, false, st));
+    return SNERF_OK;
+}
+
+extern "C" {
+
+snerf_trainer* snerf_trainer_create(int layer_width, int n_classes) {
+    if (layer_width < 16 || layer_width % 4 != 0 || n_classes < 1 || n_classes > 5) {
+        snerf_set_error(SNERF_E_INVALID, "snerf_trainer_create: width must be a multiple of 4 (>=16), classes in [1,5]");
+        return nullptr;
+    }
+    snerf_trainer* t = new snerf_trainer();
+    t->W = layer_width; t->C = n_classes; t->W2 = layer_width / 2; t->W4 = layer_width / 4;
+    build_layers(t);
+    return t;
+}
+void snerf_trainer_destroy(snerf_trainer* t) { delete t; }
+int64_t snerf_trainer_param_floats(const snerf_trainer* t) { return t ? t->n_params : 0; }
+int64_t snerf_trainer_buffer_floats(const snerf_trainer* t) { return t ? t->n_buffers : 0; }
+int snerf_trainer_tensor_count(const snerf_trainer* t) {
+    if (!t) return 0;
+    int n = 0;
+    for (const LayerP& l : t->layers) n += 2 + (l.bn ? 4 : 0);
+    return n;
+}
+int snerf_trainer_tensor_info(const snerf_trainer* t, int index, char* key, int key_cap, int* is_buffer, int64_t* offset,
+                              int64_t* numel, int* rows, int* cols) {
+    if (!t || !key) return snerf_set_error(SNERF_E_INVALID, "snerf_trainer_tensor_info: bad argument");
+    int i = 0;
+    for (const LayerP& l : t->layers) {
+        const std::string lin = l.sine ? l.name + ".linear" : l.name;
+        struct Ent { std::string k; int buf; int64_t off, n; int r, c; };
+        std::vector<Ent> ents = {{lin + ".weight", 0, l.w, (int64_t)l.n_out * l.n_in, l.n_out, l.n_in}, {lin + ".bias", 0, l.b, l.n_out, l.n_out, 1}};
+        if (l.bn) {
+            ents.push_back({l.name + ".norm.weight", 0, l.g, l.n_out, l.n_out, 1});
+            ents.push_back({l.name + ".norm.bias", 0, l.beta, l.n_out, l.n_out, 1});
+            ents.push_back({l.name + ".norm.running_mean", 1, l.rm, l.n_out, l.n_out, 1});
+            ents.push_back({l.name + ".norm.running_var", 1, l.rv, l.n_out, l.n_out, 1});
+        }
+        for (const Ent& e : ents) {
+            if (i == index) {
+                std::strncpy(key, e.k.c_str(), key_cap - 1);
+                key[key_cap - 1] = 0;
+                if (is_buffer) *is_buffer = e.buf;
+                if (offset) *offset = e.off;
+                if (numel) *numel = e.n;
+                if (rows) *rows = e.r;
+                if (cols) *cols = e.c;
+                return SNERF_OK;
+            }
+            ++i;
+        }
+    }
+    return snerf_set_error(SNERF_E_INVALID, "snerf_trainer_tensor_info: index out of range");
+}
+
+size_t snerf_trainer_workspace_bytes(snerf_trainer* t, int64_t n_rays, int64_t n_solar_rays, int n_samples) {
+    if (!t) return 0;
+    snerf_trainer tmp = *t;
+    return carve(&tmp, nullptr, n_rays, n_solar_rays, n_samples);
+}
+
+int snerf_trainer_bind(snerf_trainer* t, float* d_params, float* d_grads, float* d_adam_m, float* d_adam_v, float* d_buffers,
+                       void* d_workspace, size_t workspace_bytes, int64_t n_rays, int64_t n_solar_rays, int n_samples) {
+    if (!t || !d_params || !d_grads || !d_buffers || !d_workspace || n_rays < 0 || n_solar_rays < 0 || n_samples < 1)
+        return snerf_set_error(SNERF_E_INVALID, "snerf_trainer_bind: bad argument");
+    const size_t need = snerf_trainer_workspace_bytes(t, n_rays, n_solar_rays, n_samples);
+    if (workspace_bytes < need) return snerf_set_error(SNERF_E_INVALID, "snerf_trainer_bind: workspace too small");
+    t->params = d_params; t->grads = d_grads; t->adam_m = d_adam_m; t->adam_v = d_adam_v; t->buffers = d_buffers;
+    t->ws = (char*)d_workspace; t->ws_bytes = workspace_bytes;
+    t->R = n_rays; t->Rs = n_solar_rays; t->S = n_samples;
+    carve(t, t->ws, n_rays, n_solar_rays, n_samples);
+    return SNERF_OK;
+}
+
+static int check_bound(const snerf_trainer* t, int64_t R, int S, bool solar) {
+    if (!t || !t->ws) return snerf_set_error(SNERF_E_STATE, "trainer not bound (call snerf_trainer_bind)");
+    if (S != t->S || R != (solar ? t->Rs : t->R)) return snerf_set_error(SNERF_E_INVALID, "ray/sample counts differ from the bound sizes");
+    return SNERF_OK;
+}
+
+int snerf_trainer_forward_image(snerf_trainer* t, int64_t n_rays, int n_samples, const float* d_top, const float* d_bot,
+                                const float* d_tvals, const float* d_sun, const float* d_time, int train_bn, int flags,
+                                const snerf_composite_out* out, float* d_sky, float* d_classes, const snerf_field_out* per_sample,
+                                void* stream) {
+    RC(check_bound(t, n_rays, n_samples, false));
+    if (!d_top || !d_bot || !d_tvals || !d_sun || !d_time || !out) return snerf_set_error(SNERF_E_INVALID, "snerf_trainer_forward_image: bad argument");
+    if (flags & 1) return snerf_set_error(SNERF_E_INVALID, "training with the classic solar model (Solar_Type_2) is not implemented");
+    hipStream_t st = (hipStream_t)stream;
+    RC(forward_pass(t, t->img, false, n_rays, n_samples, d_top, d_bot, d_tvals, d_sun, d_time, train_bn != 0, st));
+    snerf_trainer::Pass& P = t->img;
+    RC(snerf_composite_rays(n_rays, n_samples, d_top, d_bot, d_tvals, P.rho, P.col, P.sv, P.sky, flags, nullptr, 1.f, out, stream));
+    const int64_t N = n_rays * n_samples;
+    if (d_sky) HIPCK(hipMemcpyAsync(d_sky, P.sky, n_rays * 3 * sizeof(float), hipMemcpyDeviceToDevice, st));
+    if (d_classes) HIPCK(hipMemcpyAsync(d_classes, P.cls, n_rays * t->C * sizeof(float), hipMemcpyDeviceToDevice, st));
+    if (per_sample) {
+        if (per_sample->d_rho) HIPCK(hipMemcpyAsync(per_sample->d_rho, P.rho, N * 4, hipMemcpyDeviceToDevice, st));
+        if (per_sample->d_solar_vis) HIPCK(hipMemcpyAsync(per_sample->d_solar_vis, P.sv, N * 4, hipMemcpyDeviceToDevice, st));
+        if (per_sample->d_col) HIPCK(hipMemcpyAsync(per_sample->d_col, P.col, N * 12, hipMemcpyDeviceToDevice, st));
+        if (per_sample->d_points) HIPCK(hipMemcpyAsync(per_sample->d_points, P.pts, N * 12, hipMemcpyDeviceToDevice, st));
+    }
+    return SNERF_OK;
+}
+
+int snerf_trainer_backward_image(snerf_trainer* t, const float* d_g_rgb, const float* d_g_albedo, const float* d_g_sky,
+                                 const float* d_g_pe, void* stream) {
+    if (!t || !t->ws) return snerf_set_error(SNERF_E_STATE, "trainer not bound");
+    hipStream_t st = (hipStream_t)stream;
+    snerf_trainer::Pass& P = t->img;
+    const int W = t->W, W2 = t->W2, W4 = t->W4, C = t->C, S = t->S;
+    const int64_t R = P.R, N = P.N;
+    auto& Ls = t->layers;
+    CompBwdArgs cb{};
+    cb.n_rays = R; cb.n_samples = S; cb.top = P.top; cb.bot = P.bot; cb.rho = P.rho; cb.col = P.col; cb.sv = P.sv; cb.sky = P.sky;
+    cb.g_rgb = d_g_rgb; cb.g_albedo = d_g_albedo; cb.g_pe = d_g_pe; cb.d_rho = t->d_rho; cb.d_col = t->d_col; cb.d_sky = t->d_sky;
+    HIPCK(launch_composite_bwd(cb, st));
+    if (d_g_sky) HIPCK(launch_copy_cols(d_g_sky, 3, t->d_sky, 3, R, 3, true, st));
+    HIPCK(hipMemsetAsync(t->d_cls, 0, R * C * sizeof(float), st));
+    PointOutArgs po{};
+    po.n = N; po.n_samples = S; po.C = C; po.head = P.head.p; po.adj = P.adj.p; po.cls = P.cls; po.col = P.col; po.sv = P.sv;
+    po.d_rho = t->d_rho; po.d_col = t->d_col; po.d_head = t->d_head; po.d_adj = t->d_adj; po.d_cls = t->d_cls;
+    HIPCK(launch_point_out(po, true, st));
+    const float* X1 = P.H[8].p;
+    // adjust branch
+    RC(plain_bwd(t, Ls[L_AC], t->d_adj, 3 * C, P.Ha[2].p, W, N, t->dA.p, W, false, st));
+    RC(sine_bwd(t, Ls[L_A3], Act{t->dA.p, W}, P.Za[2], P.Ha[1].p, W, N, nullptr, Act{t->dB.p, W}, W, false, st));
+    RC(sine_bwd(t, Ls[L_A2], Act{t->dB.p, W}, P.Za[1], P.Ha[0].p, W, N, nullptr, Act{t->dA.p, W}, W, false, st));
+    RC(sine_bwd(t, Ls[L_A1], Act{t->dA.p, W}, P.Za[0], X1, W2, N, nullptr, Act{t->dX1.p, W2}, W2, false, st));
+    // sigma / colour heads
+    RC(plain_bwd(t, Ls[L_COL], t->d_head, 4, X1, W2, N, t->dX1.p, W2, true, st));
+    RC(plain_bwd(t, Ls[L_SIG], t->d_head + 3, 4, X1, W2, N, t->dX1.p, W2, true, st));
+    // trunk
+    float* cur = t->dA.p;
+    float* nxt = t->dB.p;
+    RC(sine_bwd(t, Ls[L_FC9], Act{t->dX1.p, W2}, P.Z[8], P.H[7].p, P.H[7].ld, N, P.bn + 7 * 4 * W, Act{cur, W}, W, false, st));
+    for (int l = 7; l >= 1; --l) {
+        const float* In = l == 4 ? P.In5.p : P.H[l - 1].p;
+        const int64_t ld = l == 4 ? W + 64 : P.H[l - 1].ld;
+        RC(sine_bwd(t, Ls[L_FC1 + l], Act{cur, W}, P.Z[l], In, ld, N, P.bn + (l - 1) * 4 * W, Act{nxt, W}, W, false, st));
+        float* tmp = cur; cur = nxt; nxt = tmp;
+    }
+    RC(sine_bwd(t, Ls[L_FC1], Act{cur, W}, P.Z[0], P.E.p, 64, N, nullptr, Act{nullptr, 0}, 0, false, st));
+    // time -> class branch (per ray)
+    HIPCK(launch_softmax_bwd(P.cls, t->d_cls, t->rayA, R, C, st));
+    RC(plain_bwd(t, Ls[L_CL], t->rayA, C, P.Ht2, W, R, t->rayB, W, false, st));
+    RC(sine_bwd(t, Ls[L_T2], Act{t->rayB, W}, Act{P.Zt2, W}, P.Ht1, W, R, nullptr, Act{t->rayA, W}, W, false, st));
+    RC(sine_bwd(t, Ls[L_T1], Act{t->rayA, W}, Act{P.Zt1, W}, P.pe_time, 12, R, nullptr, Act{nullptr, 0}, 0, false, st));
+    // sky colour head (per ray)
+    HIPCK(launch_sigmoid_bwd(P.sky, t->d_sky, t->rayB, R * 3, st));
+    RC(plain_bwd(t, Ls[L_K2], t->rayB, 3, P.Hk1, W4, R, t->rayA, W4, false, st));
+    RC(sine_bwd(t, Ls[L_K1], Act{t->rayA, W4}, Act{P.Zk1, W4}, P.pe_sun, 28, R, nullptr, Act{nullptr, 0}, 0, false, st));
+    return SNERF_OK;
+}
+
+int snerf_trainer_forward_solar(snerf_trainer* t, int64_t n_rays, int n_samples, const float* d_top, const float* d_bot,
+                                const float* d_tvals, const float* d_sun, int train_bn, float* d_solar_vis, float* d_pv,
+                                float* d_pe, float* d_sky_raw, void* stream) {
+    RC(check_bound(t, n_rays, n_samples, true));
+    if (!d_top || !d_bot || !d_tvals || !d_sun) return snerf_set_error(SNERF_E_INVALID, "snerf_trainer_forward_solar: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    snerf_trainer::Pass& P = t->sol;
+    RC(forward_pass(t, P, true, n_rays, n_samples, d_top, d_bot, d_tvals, d_sun, nullptr, train_bn != 0, st));
+    snerf_composite_out co{};
+    co.d_pv = d_pv; co.d_pe = d_pe;
+    // col is not produced by the sun-ray pass: composite only needs rho (col/sv operands are dummies of the right size)
+    RC(snerf_composite_rays(n_rays, n_samples, d_top, d_bot, d_tvals, P.rho, t->d_col, P.sv, P.sky, 0, nullptr, 1.f, &co, stream));
+    const int64_t N = n_rays * n_samples;
+    if (d_solar_vis) HIPCK(hipMemcpyAsync(d_solar_vis, P.sv, N * 4, hipMemcpyDeviceToDevice, st));
+    if (d_sky_raw) HIPCK(hipMemcpyAsync(d_sky_raw, P.sky_raw, n_rays * 12, hipMemcpyDeviceToDevice, st));
+    return SNERF_OK;
+}
+
+int snerf_trainer_backward_solar(snerf_trainer* t, const float* d_g_solar_vis, void* stream) {
+    if (!t || !t->ws || !d_g_solar_vis) return snerf_set_error(SNERF_E_STATE, "trainer not bound / NULL gradient");
+    hipStream_t st = (hipStream_t)stream;
+    snerf_trainer::Pass& P = t->sol;
+    const int W2 = t->W2;
+    const int64_t N = P.N;
+    auto& Ls = t->layers;
+    PointOutArgs po{};
+    po.n = N; po.n_samples = t->S; po.C = t->C; po.head = P.head.p; po.sv = P.sv; po.d_sv = d_g_solar_vis; po.d_sv_raw = t->d_sv_raw;
+    HIPCK(launch_point_out(po, true, st));
+    RC(plain_bwd(t, Ls[L_S4], t->d_sv_raw, 1, P.Hs[2].p, W2, N, t->dA.p, W2, false, st));
+    RC(sine_bwd(t, Ls[L_S3], Act{t->dA.p, W2}, P.Zs[2], P.Hs[1].p, W2, N, nullptr, Act{t->dB.p, W2}, W2, false, st));
+    RC(sine_bwd(t, Ls[L_S2], Act{t->dB.p, W2}, P.Zs[1], P.Hs[0].p, W2, N, nullptr, Act{t->dA.p, W2}, W2, false, st));
+    RC(sine_bwd(t, Ls[L_S1], Act{t->dA.p, W2}, P.Zs[0], P.In_s1.p, W2 + 28, N, nullptr, Act{nullptr, 0}, 0, false, st));
+    return SNERF_OK;
+}
+
+// Introspection for tests: copy an internal buffer of the last image-pass backward to the host (synchronous).
+int snerf_trainer_debug_read(snerf_trainer* t, const char* name, float* host_out, int64_t n_floats) {
+    if (!t || !t->ws || !name || !host_out) return snerf_set_error(SNERF_E_INVALID, "snerf_trainer_debug_read: bad argument");
+    const std::string k = name;
+    const float* src = k == "d_rho" ? t->d_rho : k == "d_col" ? t->d_col : k == "d_head" ? t->d_head : k == "d_adj" ? t->d_adj
+                     : k == "d_sky" ? t->d_sky : k == "d_cls" ? t->d_cls : k == "rho" ? t->img.rho : k == "col" ? t->img.col
+                     : k == "sv" ? t->img.sv : k == "sky" ? t->img.sky : k == "head" ? t->img.head.p : nullptr;
+    if (!src) return snerf_set_error(SNERF_E_INVALID, "snerf_trainer_debug_read: unknown buffer " + k);
+    HIPCK(hipDeviceSynchronize());
+    HIPCK(hipMemcpy(host_out, src, n_floats * sizeof(float), hipMemcpyDeviceToHost));
+    return SNERF_OK;
+}
+
+int snerf_trainer_zero_grad(snerf_trainer* t, void* stream) {
+    if (!t || !t->grads) return snerf_set_error(SNERF_E_STATE, "trainer not bound");
+    HIPCK(hipMemsetAsync(t->grads, 0, t->n_params * sizeof(float), (hipStream_t)stream));
+    return SNERF_OK;
+}
+
+int snerf_trainer_adam_step(snerf_trainer* t, float lr, float beta1, float beta2, float eps, int step, void* stream) {
+    if (!t || !t->params || !t->adam_m || !t->adam_v) return snerf_set_error(SNERF_E_STATE, "trainer not bound (Adam state)");
+    if (step < 1) return snerf_set_error(SNERF_E_INVALID, "Adam step counts from 1");
+    HIPCK(launch_adam(t->params, t->grads, t->adam_m, t->adam_v, t->n_params, lr, beta1, beta2, eps, step, (hipStream_t)stream));
+    return SNERF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,100 @@
+// Layer-wise training engine (internal header): kernels' argument blocks and launchers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace snerf {
+
+enum GemmFlags : int { GEMM_ACCUM = 1, GEMM_ATOMIC = 2 };
+
+struct GemmArgs {
+    const float* A;
+    const float* B;
+    float* C;
+    int64_t M, N, K;
+    int64_t sAm, sAk, sBk, sBn, ldc;
+    float alpha;
+    const float* bias;    // [N] added before alpha (only by split 0)
+    float* colsum;        // [N] += column sums of the written values (BatchNorm mean)
+    int flags;
+    int splitk;           // >1: K split over blockIdx.z, results combined with fp32 atomics (C must be zeroed)
+};
+hipError_t launch_gemm(const GemmArgs& g, hipStream_t st);
+
+// ---- elementwise / reduction kernels of the training path (train_kernels.hip)
+struct PeArgs {            // positions (from rays or explicit) -> PE(pos) [N,64] (63 features + zero pad) and points [N,3]
+    int64_t n;
+    int n_samples;
+    const float *points, *top, *bot, *tvals;
+    float* pe;             // [N,64]
+    float* pts;            // [N,3] or NULL
+};
+hipError_t launch_pe_points(const PeArgs& a, hipStream_t st);
+// per-row encodings of small vectors: sun [G,3] -> [G,28] (27 + pad), time[:,0:2] [G,4] -> [G,12] (10 + pad)
+hipError_t launch_pe_small(const float* in, int in_stride, int n_dims, int n_freq, int64_t rows, float* out, int out_stride, hipStream_t st);
+
+// column reductions over rows of X [M, ld] for C columns.  mode 0: sum (x - mu_c)^2 -> out0
+// mode 1: dY = dH*cos(Y) with Y = g_c*(z - mu_c)*istd_c + b_c (written in place over dH), out0 += sum dY, out1 += sum dY*xhat
+// mode 2: dZ = dH*cos(Z) in place, out0 += sum dZ            (layers without BatchNorm)
+struct ColArgs {
+    int mode;
+    int64_t M;
+    int C;
+    int64_t ld;
+    const float* Z;        // pre-activation [M, ld]
+    float* D;              // gradient buffer [M, ld] (in place)
+    const float *mu, *istd, *gamma, *beta;
+    float *out0, *out1;
+    float alpha0;          // scale of the out0 accumulation (mode 2: 30 = d bias of the Linear)
+};
+hipError_t launch_colreduce(const ColArgs& a, hipStream_t st);
+
+// BatchNorm finalize: mean = sum/M, var = m2/M, istd; EMA of running stats (momentum 0.01, unbiased var)
+hipError_t launch_bn_finalize(const float* colsum, const float* m2, int64_t M, int C, float* mean, float* istd,
+                              float* running_mean, float* running_var, int stage, hipStream_t st);
+// H = sin(gamma*(Z-mu)*istd + beta) (bn) or sin(Z)
+hipError_t launch_sin_fwd(const float* Z, float* H, int64_t M, int C, int64_t ldz, int64_t ldh, const float* mu, const float* istd,
+                          const float* gamma, const float* beta, hipStream_t st);
+// BN backward second pass: dZ = gamma*istd*(dY - sdy/M - xhat*sdyx/M) in place; colsum(dZ) -> out (bias grad)
+hipError_t launch_bn_bwd2(const float* Z, float* D, int64_t M, int C, int64_t ld, const float* mu, const float* istd,
+                          const float* gamma, const float* sdy, const float* sdyx, float* dbias_sum, float alpha, hipStream_t st);
+
+// point outputs: rho = softplus(head[:,3]), col = sigmoid(head[:,0:3] + sum_c cls[g,c]*adj[:,c,:]), sv = sigmoid(sv_raw)
+struct PointOutArgs {
+    int64_t n;
+    int n_samples, C;
+    const float *head, *adj, *sv_raw, *cls;     // [N,4], [N,3C], [N], [R,C]
+    float *rho, *col, *sv;                      // [N], [N,3], [N]
+    // backward (all optional): d_rho [N], d_col [N,3] -> d_head [N,4], d_adj [N,3C], d_cls [R,C] (atomic), d_sv -> d_sv_raw
+    const float *d_rho, *d_col, *d_sv;
+    float *d_head, *d_adj, *d_cls, *d_sv_raw;
+};
+hipError_t launch_point_out(const PointOutArgs& a, bool backward, hipStream_t st);
+
+// compositing backward (one wave per ray): from dL/dRendered_Col, dL/dAlbedo, dL/dPE (optional) -> d_rho, d_col, d_sky
+struct CompBwdArgs {
+    int64_t n_rays;
+    int n_samples;
+    const float *top, *bot;
+    const float *rho, *col, *sv, *sky;          // forward inputs ([N], [N,3], [N], [R,3])
+    const float *g_rgb, *g_albedo, *g_pe;       // [R,3], [R,3] or NULL, [N] or NULL
+    float *d_rho, *d_col, *d_sky;               // [N], [N,3], [R,3] (d_sky is overwritten)
+};
+hipError_t launch_composite_bwd(const CompBwdArgs& a, hipStream_t st);
+
+// softmax rows [R,C] forward / backward; sigmoid forward/backward on small tensors
+hipError_t launch_softmax(const float* logits, float* p, int64_t rows, int C, hipStream_t st);
+hipError_t launch_softmax_bwd(const float* p, const float* dp, float* dlogits, int64_t rows, int C, hipStream_t st);
+hipError_t launch_sigmoid(const float* x, float* y, int64_t n, hipStream_t st);
+hipError_t launch_sigmoid_bwd(const float* y, const float* dy, float* dx, int64_t n, hipStream_t st);
+// column sum of a small-N matrix [M,C] (bias gradients of head layers): out[c] += alpha * sum_m X[m,c]
+hipError_t launch_colsum(const float* X, int64_t M, int C, int64_t ld, float alpha, float* out, hipStream_t st);
+// concat-free helpers
+hipError_t launch_copy_cols(const float* src, int64_t ld_src, float* dst, int64_t ld_dst, int64_t M, int C, bool accumulate, hipStream_t st);
+// broadcast per-group rows [G,C] to per-point rows [G*S, C] and the transposed reduction
+hipError_t launch_bcast_rows(const float* src, int C, float* dst, int64_t ld_dst, int col0, int64_t n, int n_samples, hipStream_t st);
+hipError_t launch_reduce_rows(const float* src, int64_t ld_src, int col0, int C, float* dst, int64_t n_groups, int n_samples, hipStream_t st);
+// Adam on a flat arena (torch.optim.Adam semantics, no weight decay)
+hipError_t launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps, int step, hipStream_t st);
+
+}  // namespace snerf

@@ -1,0 +1,479 @@
+// Elementwise / reduction kernels of the layer-wise training path (see train.h).  All HBM-bound: rows of
+// [points x features] fp32 matrices are read with consecutive lanes on consecutive features (coalesced), per-column
+// reductions go block-partial -> one fp32 atomic per column per block.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "train.h"
+
+namespace snerf {
+
+#define LAUNCH_1D(kernel, n, st, ...)                                                    \
+    do {                                                                                 \
+        const int64_t _n = (n);                                                          \
+        if (_n > 0) {                                                                    \
+            int64_t _b = (_n + 255) / 256;                                               \
+            if (_b > 65536 * 16) _b = 65536 * 16;                                        \
+            hipLaunchKernelGGL(kernel, dim3((unsigned)_b), dim3(256), 0, st, __VA_ARGS__); \
+        }                                                                                \
+    } while (0)
+
+__device__ __forceinline__ float sigmoid_t(float x) { return 1.f / (1.f + expf(-x)); }
+__device__ __forceinline__ float softplus_t(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+
+// sin/cos of 2^j * fl32(fl32(pi/2)*x), reduced in fp64 (same construction as the inference kernel, misc.py:109-131)
+__device__ __forceinline__ void pe_sc(float x, int j, float& c, float& s) {
+    const float a0 = __fmul_rn(x, 1.57079637050628662109375f);
+    const double r = (double)a0 * 0.15915494309189533576888 * (double)(1 << j);
+    const double f = r - floor(r);
+    const double ang = f * 6.283185307179586476925287;
+    c = (float)cos(ang);
+    s = (float)sin(ang);
+}
+
+__global__ void pe_points_kernel(const PeArgs A) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < A.n; i += (int64_t)gridDim.x * blockDim.x) {
+        float x[3];
+        if (A.points) {
+            x[0] = A.points[i * 3]; x[1] = A.points[i * 3 + 1]; x[2] = A.points[i * 3 + 2];
+        } else {
+            const int64_t r = i / A.n_samples;
+            const int s = (int)(i - r * A.n_samples);
+            const float t = A.tvals[s], omt = __fsub_rn(1.f, t);
+#pragma unroll
+            for (int d = 0; d < 3; ++d) x[d] = __fadd_rn(__fmul_rn(A.top[r * 3 + d], omt), __fmul_rn(A.bot[r * 3 + d], t));
+        }
+        if (A.pts) { A.pts[i * 3] = x[0]; A.pts[i * 3 + 1] = x[1]; A.pts[i * 3 + 2] = x[2]; }
+        float* o = A.pe + i * 64;
+        o[0] = x[0]; o[1] = x[1]; o[2] = x[2];
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+            for (int j = 0; j < 10; ++j) {
+                float c, s;
+                pe_sc(x[d], j, c, s);
+                o[3 + 20 * d + j] = c;
+                o[3 + 20 * d + 10 + j] = s;
+            }
+        o[63] = 0.f;
+    }
+}
+hipError_t launch_pe_points(const PeArgs& a, hipStream_t st) {
+    LAUNCH_1D(pe_points_kernel, a.n, st, a);
+    return hipGetLastError();
+}
+
+__global__ void pe_small_kernel(const float* in, int in_stride, int D, int F, int64_t rows, float* out, int out_stride) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < rows; i += (int64_t)gridDim.x * blockDim.x) {
+        float* o = out + i * out_stride;
+        for (int d = 0; d < D; ++d) {
+            const float x = in[i * in_stride + d];
+            o[d] = x;
+            for (int j = 0; j < F; ++j) {
+                float c, s;
+                pe_sc(x, j, c, s);
+                o[D + 2 * F * d + j] = c;
+                o[D + 2 * F * d + F + j] = s;
+            }
+        }
+        for (int k = D * (2 * F + 1); k < out_stride; ++k) o[k] = 0.f;
+    }
+}
+hipError_t launch_pe_small(const float* in, int in_stride, int n_dims, int n_freq, int64_t rows, float* out, int out_stride, hipStream_t st) {
+    LAUNCH_1D(pe_small_kernel, rows, st, in, in_stride, n_dims, n_freq, rows, out, out_stride);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// column reductions: block = 256 threads, thread t owns column (t % CP) and row phase (t / CP), CP = min(C, 256) rounded
+constexpr int ROWS_PER_BLOCK = 512;
+__global__ __launch_bounds__(256) void colreduce_kernel(const ColArgs A) {
+    __shared__ float red0[256], red1[256];
+    const int C = A.C;
+    const int cp = C >= 256 ? 256 : (C >= 128 ? 128 : (C >= 64 ? 64 : 32));   // columns handled per pass
+    const int phases = 256 / cp;
+    const int tc = threadIdx.x % cp, tp = threadIdx.x / cp;
+    const int64_t r0 = (int64_t)blockIdx.x * ROWS_PER_BLOCK;
+    const int64_t r1 = r0 + ROWS_PER_BLOCK < A.M ? r0 + ROWS_PER_BLOCK : A.M;
+    for (int c0 = 0; c0 < C; c0 += cp) {
+        const int c = c0 + tc;
+        float s0 = 0.f, s1 = 0.f;
+        if (c < C) {
+            const float mu = A.mu ? A.mu[c] : 0.f, istd = A.istd ? A.istd[c] : 1.f;
+            const float gm = A.gamma ? A.gamma[c] : 1.f, bt = A.beta ? A.beta[c] : 0.f;
+            for (int64_t r = r0 + tp; r < r1; r += phases) {
+                const float z = A.Z[r * A.ld + c];
+                if (A.mode == 0) {
+                    const float d = z - mu;
+                    s0 += d * d;
+                } else if (A.mode == 1) {
+                    const float xh = (z - mu) * istd;
+                    const float dy = A.D[r * A.ld + c] * cosf(gm * xh + bt);
+                    A.D[r * A.ld + c] = dy;
+                    s0 += dy;
+                    s1 += dy * xh;
+                } else {
+                    const float dz = A.D[r * A.ld + c] * cosf(z);
+                    A.D[r * A.ld + c] = dz;
+                    s0 += dz;
+                }
+            }
+        }
+        red0[threadIdx.x] = s0;
+        red1[threadIdx.x] = s1;
+        __syncthreads();
+        if (tp == 0 && c < C) {
+            for (int p = 1; p < phases; ++p) { s0 += red0[p * cp + tc]; s1 += red1[p * cp + tc]; }
+            atomicAdd(A.out0 + c, (A.mode == 2 ? A.alpha0 : 1.f) * s0);
+            if (A.mode == 1) atomicAdd(A.out1 + c, s1);
+        }
+        __syncthreads();
+    }
+}
+hipError_t launch_colreduce(const ColArgs& a, hipStream_t st) {
+    if (a.M <= 0) return hipSuccess;
+    const int64_t blocks = (a.M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+    hipLaunchKernelGGL(colreduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+__global__ void bn_finalize_kernel(const float* colsum, const float* m2, int64_t M, int C, float* mean, float* istd,
+                                   float* running_mean, float* running_var, int stage) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    if (stage == 0) {
+        mean[c] = colsum[c] / (float)M;
+    } else if (stage == 2) {                                        // eval mode: m2 points at the running variance
+        istd[c] = 1.f / sqrtf(m2[c] + 1e-5f);
+    } else {
+        const float var_b = m2[c] / (float)M;                       // biased: normalisation (torch BatchNorm1d)
+        istd[c] = 1.f / sqrtf(var_b + 1e-5f);
+        const float var_u = M > 1 ? m2[c] / (float)(M - 1) : var_b; // unbiased: running estimate
+        running_mean[c] = 0.99f * running_mean[c] + 0.01f * mean[c];
+        running_var[c] = 0.99f * running_var[c] + 0.01f * var_u;
+    }
+}
+hipError_t launch_bn_finalize(const float* colsum, const float* m2, int64_t M, int C, float* mean, float* istd,
+                              float* running_mean, float* running_var, int stage, hipStream_t st) {
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, colsum, m2, M, C, mean, istd,
+                       running_mean, running_var, stage);
+    return hipGetLastError();
+}
+
+__global__ void sin_fwd_kernel(const float* Z, float* H, int64_t M, int C, int64_t ldz, int64_t ldh, const float* mu,
+                               const float* istd, const float* gamma, const float* beta) {
+    const int64_t total = M * C;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / C;
+        const int c = (int)(i - r * C);
+        float z = Z[r * ldz + c];
+        if (mu) z = gamma[c] * ((z - mu[c]) * istd[c]) + beta[c];
+        H[r * ldh + c] = sinf(z);
+    }
+}
+hipError_t launch_sin_fwd(const float* Z, float* H, int64_t M, int C, int64_t ldz, int64_t ldh, const float* mu, const float* istd,
+                          const float* gamma, const float* beta, hipStream_t st) {
+    LAUNCH_1D(sin_fwd_kernel, M * C, st, Z, H, M, C, ldz, ldh, mu, istd, gamma, beta);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void bn_bwd2_kernel(const float* Z, float* D, int64_t M, int C, int64_t ld, const float* mu,
+                                                      const float* istd, const float* gamma, const float* sdy, const float* sdyx,
+                                                      float* dbias_sum, float alpha) {
+    __shared__ float red0[256];
+    const int cp = C >= 256 ? 256 : (C >= 128 ? 128 : (C >= 64 ? 64 : 32));
+    const int phases = 256 / cp;
+    const int tc = threadIdx.x % cp, tp = threadIdx.x / cp;
+    const int64_t r0 = (int64_t)blockIdx.x * ROWS_PER_BLOCK;
+    const int64_t r1 = r0 + ROWS_PER_BLOCK < M ? r0 + ROWS_PER_BLOCK : M;
+    const float invM = 1.f / (float)M;
+    for (int c0 = 0; c0 < C; c0 += cp) {
+        const int c = c0 + tc;
+        float s0 = 0.f;
+        if (c < C) {
+            const float m = mu[c], is = istd[c], k = gamma[c] * is, a = sdy[c] * invM, b = sdyx[c] * invM;
+            for (int64_t r = r0 + tp; r < r1; r += phases) {
+                const float xh = (Z[r * ld + c] - m) * is;
+                const float dz = k * (D[r * ld + c] - a - xh * b);
+                D[r * ld + c] = dz;
+                s0 += dz;
+            }
+        }
+        red0[threadIdx.x] = s0;
+        __syncthreads();
+        if (tp == 0 && c < C && dbias_sum) {
+            for (int p = 1; p < phases; ++p) s0 += red0[p * cp + tc];
+            atomicAdd(dbias_sum + c, alpha * s0);
+        }
+        __syncthreads();
+    }
+}
+hipError_t launch_bn_bwd2(const float* Z, float* D, int64_t M, int C, int64_t ld, const float* mu, const float* istd,
+                          const float* gamma, const float* sdy, const float* sdyx, float* dbias_sum, float alpha, hipStream_t st) {
+    if (M <= 0) return hipSuccess;
+    const int64_t blocks = (M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+    hipLaunchKernelGGL(bn_bwd2_kernel, dim3((unsigned)blocks), dim3(256), 0, st, Z, D, M, C, ld, mu, istd, gamma, sdy, sdyx, dbias_sum, alpha);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+__global__ void point_out_fwd_kernel(const PointOutArgs A) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < A.n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t g = i / A.n_samples;
+        if (A.rho) A.rho[i] = softplus_t(A.head[i * 4 + 3]);
+        if (A.sv && A.sv_raw) A.sv[i] = sigmoid_t(A.sv_raw[i]);
+        if (A.col) {
+            float ac[3] = {0.f, 0.f, 0.f};
+            for (int c = 0; c < A.C; ++c) {
+                const float p = A.cls[g * A.C + c];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) ac[k] = __fadd_rn(ac[k], __fmul_rn(A.adj[i * 3 * A.C + 3 * c + k], p));
+            }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) A.col[i * 3 + k] = sigmoid_t(A.head[i * 4 + k] + ac[k]);
+        }
+    }
+}
+__global__ void point_out_bwd_kernel(const PointOutArgs A) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < A.n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t g = i / A.n_samples;
+        if (A.d_head) {
+            const float raw = A.head[i * 4 + 3];
+            A.d_head[i * 4 + 3] = A.d_rho ? A.d_rho[i] * (raw > 20.f ? 1.f : sigmoid_t(raw)) : 0.f;
+            float dpre[3] = {0.f, 0.f, 0.f};
+            if (A.d_col) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { const float y = A.col[i * 3 + k]; dpre[k] = A.d_col[i * 3 + k] * y * (1.f - y); }
+            }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) A.d_head[i * 4 + k] = dpre[k];
+            for (int c = 0; c < A.C; ++c) {
+                const float p = A.cls[g * A.C + c];
+                float dc = 0.f;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    if (A.d_adj) A.d_adj[i * 3 * A.C + 3 * c + k] = dpre[k] * p;
+                    dc += dpre[k] * A.adj[i * 3 * A.C + 3 * c + k];
+                }
+                if (A.d_cls) atomicAdd(A.d_cls + g * A.C + c, dc);
+            }
+        }
+        if (A.d_sv_raw && A.d_sv) { const float y = A.sv[i]; A.d_sv_raw[i] = A.d_sv[i] * y * (1.f - y); }
+    }
+}
+hipError_t launch_point_out(const PointOutArgs& a, bool backward, hipStream_t st) {
+    if (backward) LAUNCH_1D(point_out_bwd_kernel, a.n, st, a);
+    else LAUNCH_1D(point_out_fwd_kernel, a.n, st, a);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// compositing backward, one wavefront per ray (forward: Eval_Tools_2.py:187-215, default solar model):
+//   y = rho*delta, PV_s = exp(-sum_{j<s} y_j), PE_s = 1 - exp(-y_s), PS = PV*PE
+//   Albedo = sum PS*col ; u = sum PS*sv (sv detached) ; SV3 = sigmoid(30(u-.2)) ; F = SV3 + (1-SV3)*sky ; RGB = Albedo*F
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wscan_incl(float v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float t = __shfl_up(v, o, 64);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+__global__ __launch_bounds__(256) void composite_bwd_kernel(const CompBwdArgs A) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= A.n_rays) return;
+    const int S = A.n_samples;
+    const float dx = A.top[r * 3] - A.bot[r * 3], dy = A.top[r * 3 + 1] - A.bot[r * 3 + 1], dz = A.top[r * 3 + 2] - A.bot[r * 3 + 2];
+    const float delta = __fdiv_rn(__fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz))), (float)S);
+    const float sky[3] = {A.sky[r * 3], A.sky[r * 3 + 1], A.sky[r * 3 + 2]};
+    // ---- pass 1: forward sums (albedo, u)
+    float alb[3] = {0.f, 0.f, 0.f}, u = 0.f, carry = 0.f;
+    for (int base = 0; base < S; base += 64) {
+        const int s = base + lane;
+        const bool in = s < S;
+        const int64_t idx = r * S + (in ? s : S - 1);
+        const float y = in ? A.rho[idx] * delta : 0.f;
+        const float incl = wscan_incl(y, lane);
+        const float pv = expf(-(carry + incl - y));
+        carry += __shfl(incl, 63, 64);
+        const float ps = in ? pv * (1.f - expf(-y)) : 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) alb[k] += ps * A.col[idx * 3 + k];
+        u += ps * A.sv[idx];
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) alb[k] = wsum(alb[k]);
+    u = wsum(u);
+    const float sv3 = sigmoid_t((u - 0.2f) * 30.f);
+    float dalb[3], dsky[3], dsv3 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float F = sv3 + (1.f - sv3) * sky[k];
+        const float g = A.g_rgb ? A.g_rgb[r * 3 + k] : 0.f;
+        dalb[k] = g * F + (A.g_albedo ? A.g_albedo[r * 3 + k] : 0.f);
+        const float dF = g * alb[k];
+        dsv3 += dF * (1.f - sky[k]);
+        dsky[k] = dF * (1.f - sv3);
+    }
+    const float du = dsv3 * sv3 * (1.f - sv3) * 30.f;
+    if (lane == 0) { A.d_sky[r * 3] = dsky[0]; A.d_sky[r * 3 + 1] = dsky[1]; A.d_sky[r * 3 + 2] = dsky[2]; }
+    // ---- pass 2: dPS, then dy_s = dPE_s*exp(-y_s) - sum_{k>s} dPV_k*PV_k  (suffix sums, chunks walked backwards)
+    float suffix = 0.f;           // sum over later chunks of dPV_k*PV_k
+    const int nchunk = (S + 63) / 64;
+    // total prefix of y up to each chunk start: recompute forward carries
+    for (int ch = nchunk - 1; ch >= 0; --ch) {
+        // prefix sum of y before this chunk
+        float pre = 0.f;
+        for (int b2 = 0; b2 < ch; ++b2) {
+            const int s2 = b2 * 64 + lane;
+            pre += (s2 < S) ? A.rho[r * S + s2] * delta : 0.f;
+        }
+        pre = wsum(pre);
+        const int s = ch * 64 + lane;
+        const bool in = s < S;
+        const int64_t idx = r * S + (in ? s : S - 1);
+        const float y = in ? A.rho[idx] * delta : 0.f;
+        const float incl = wscan_incl(y, lane);
+        const float pv = expf(-(pre + incl - y));
+        const float ey = expf(-y);
+        const float pe = 1.f - ey;
+        float dps = 0.f;
+        if (in) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) dps += dalb[k] * A.col[idx * 3 + k];
+            dps += du * A.sv[idx];
+        }
+        const float dpv_pv = in ? dps * pe * pv : 0.f;          // dPV_s * PV_s
+        float dpe = in ? dps * pv : 0.f;
+        if (in && A.g_pe) dpe += A.g_pe[idx];
+        // exclusive suffix sum within the chunk: sum_{k>s} = total - inclusive prefix
+        const float incl2 = wscan_incl(dpv_pv, lane);
+        const float tot = __shfl(incl2, 63, 64);
+        const float later = suffix + (tot - incl2);
+        if (in) {
+            A.d_rho[idx] = (dpe * ey - later) * delta;
+            const float ps = pv * pe;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) A.d_col[idx * 3 + k] = dalb[k] * ps;
+        }
+        suffix += tot;
+    }
+}
+hipError_t launch_composite_bwd(const CompBwdArgs& a, hipStream_t st) {
+    if (a.n_rays <= 0) return hipSuccess;
+    hipLaunchKernelGGL(composite_bwd_kernel, dim3((unsigned)((a.n_rays + 3) / 4)), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+__global__ void softmax_kernel(const float* x, float* p, int64_t rows, int C) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < rows; i += (int64_t)gridDim.x * blockDim.x) {
+        float m = -3.0e38f;
+        for (int c = 0; c < C; ++c) m = fmaxf(m, x[i * C + c]);
+        float s = 0.f;
+        for (int c = 0; c < C; ++c) { const float e = expf(x[i * C + c] - m); p[i * C + c] = e; s += e; }
+        for (int c = 0; c < C; ++c) p[i * C + c] /= s;
+    }
+}
+__global__ void softmax_bwd_kernel(const float* p, const float* dp, float* dx, int64_t rows, int C) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < rows; i += (int64_t)gridDim.x * blockDim.x) {
+        float dot = 0.f;
+        for (int c = 0; c < C; ++c) dot += p[i * C + c] * dp[i * C + c];
+        for (int c = 0; c < C; ++c) dx[i * C + c] = p[i * C + c] * (dp[i * C + c] - dot);
+    }
+}
+__global__ void sigmoid_kernel(const float* x, float* y, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) y[i] = sigmoid_t(x[i]);
+}
+__global__ void sigmoid_bwd_kernel(const float* y, const float* dy, float* dx, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dx[i] = dy[i] * y[i] * (1.f - y[i]);
+}
+hipError_t launch_softmax(const float* x, float* p, int64_t rows, int C, hipStream_t st) { LAUNCH_1D(softmax_kernel, rows, st, x, p, rows, C); return hipGetLastError(); }
+hipError_t launch_softmax_bwd(const float* p, const float* dp, float* dx, int64_t rows, int C, hipStream_t st) { LAUNCH_1D(softmax_bwd_kernel, rows, st, p, dp, dx, rows, C); return hipGetLastError(); }
+hipError_t launch_sigmoid(const float* x, float* y, int64_t n, hipStream_t st) { LAUNCH_1D(sigmoid_kernel, n, st, x, y, n); return hipGetLastError(); }
+hipError_t launch_sigmoid_bwd(const float* y, const float* dy, float* dx, int64_t n, hipStream_t st) { LAUNCH_1D(sigmoid_bwd_kernel, n, st, y, dy, dx, n); return hipGetLastError(); }
+
+__global__ __launch_bounds__(256) void colsum_kernel(const float* X, int64_t M, int C, int64_t ld, float alpha, float* out) {
+    // small C (<= 16): thread per row slab, wave reduction
+    const int lane = threadIdx.x & 63;
+    for (int c = 0; c < C; ++c) {
+        float s = 0.f;
+        for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < M; r += (int64_t)gridDim.x * blockDim.x) s += X[r * ld + c];
+        s = wsum(s);
+        if (lane == 0) atomicAdd(out + c, alpha * s);
+    }
+}
+hipError_t launch_colsum(const float* X, int64_t M, int C, int64_t ld, float alpha, float* out, hipStream_t st) {
+    if (M <= 0) return hipSuccess;
+    int64_t b = (M + 255) / 256;
+    if (b > 1024) b = 1024;
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)b), dim3(256), 0, st, X, M, C, ld, alpha, out);
+    return hipGetLastError();
+}
+
+__global__ void copy_cols_kernel(const float* src, int64_t ld_src, float* dst, int64_t ld_dst, int64_t M, int C, int acc) {
+    const int64_t total = M * C;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / C;
+        const int c = (int)(i - r * C);
+        const float v = src[r * ld_src + c];
+        if (acc) dst[r * ld_dst + c] += v; else dst[r * ld_dst + c] = v;
+    }
+}
+hipError_t launch_copy_cols(const float* src, int64_t ld_src, float* dst, int64_t ld_dst, int64_t M, int C, bool accumulate, hipStream_t st) {
+    LAUNCH_1D(copy_cols_kernel, M * C, st, src, ld_src, dst, ld_dst, M, C, accumulate ? 1 : 0);
+    return hipGetLastError();
+}
+
+__global__ void bcast_rows_kernel(const float* src, int C, float* dst, int64_t ld_dst, int col0, int64_t n, int S) {
+    const int64_t total = n * C;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / C;
+        const int c = (int)(i - r * C);
+        dst[r * ld_dst + col0 + c] = src[(r / S) * C + c];
+    }
+}
+hipError_t launch_bcast_rows(const float* src, int C, float* dst, int64_t ld_dst, int col0, int64_t n, int n_samples, hipStream_t st) {
+    LAUNCH_1D(bcast_rows_kernel, n * C, st, src, C, dst, ld_dst, col0, n, n_samples);
+    return hipGetLastError();
+}
+
+__global__ void reduce_rows_kernel(const float* src, int64_t ld_src, int col0, int C, float* dst, int64_t G, int S) {
+    const int64_t total = G * C;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t g = i / C;
+        const int c = (int)(i - g * C);
+        float s = 0.f;
+        for (int k = 0; k < S; ++k) s += src[(g * S + k) * ld_src + col0 + c];
+        dst[g * C + c] = s;
+    }
+}
+hipError_t launch_reduce_rows(const float* src, int64_t ld_src, int col0, int C, float* dst, int64_t n_groups, int n_samples, hipStream_t st) {
+    LAUNCH_1D(reduce_rows_kernel, n_groups * C, st, src, ld_src, col0, C, dst, n_groups, n_samples);
+    return hipGetLastError();
+}
+
+__global__ void adam_kernel(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
+                            float bc1, float bc2) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float gi = g[i];
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        // torch.optim.Adam: step_size = lr / bias_correction1; denom = sqrt(v)/sqrt(bias_correction2) + eps
+        p[i] = p[i] - (lr / bc1) * (mi / (sqrtf(vi) / sqrtf(bc2) + eps));
+    }
+}
+hipError_t launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps, int step, hipStream_t st) {
+    const float bc1 = 1.f - powf(b1, (float)step), bc2 = 1.f - powf(b2, (float)step);
+    LAUNCH_1D(adam_kernel, n, st, p, g, m, v, n, lr, b1, b2, eps, bc1, bc2);
+    return hipGetLastError();
+}
+
+}  // namespace snerf

@@ -37,6 +37,8 @@ class All_in_One_Eval:
         self.use_MSE_loss = args.Use_MSE_loss
         self.ada_loss = ada_loss
         self.H, self.WC = H, WC
+        from .training import create_solor_rays_uniform
+        self.solar_creation_tool = create_solor_rays_uniform(H, WC, base_solar_vecs)
 
     # -------------------------------------------------------------------------------------------------
     def _check(self, Network):
@@ -54,6 +56,11 @@ class All_in_One_Eval:
         """Eval_Tools_2.py:165-252.  Keys: Rendered_Col, PE, PV, PS, Solar_Vis, Sky_Col, Classes, Adjust, Rho, Col,
         Col_Adj, deltas, sample_pts, Albedo_Color (+ the *_Supervised / *_Merged family with use_prior)."""
         self._check(Network)
+        if Network.training:                       # batch-statistics BatchNorm + autograd: layer-wise training engine
+            if self.use_prior:
+                raise NotImplementedError("season_nerf_amd: train-mode eval with the DSM prior is not implemented yet")
+            from . import training
+            return training.eval_train(self, data_dict, Network, train_mode)
         (top, bot, sun, tim) = Network._prep(*self._inputs(data_dict, Network))
         dev = top.device
         R, S, Cn = top.shape[0], self.args.n_samples, Network.n_classes
@@ -122,6 +129,9 @@ class All_in_One_Eval:
         self._check(Network)
         if self.use_prior:
             raise NotImplementedError("eval_Rho_Only with use_prior is not implemented by the HIP path yet")
+        if Network.training:
+            from . import training
+            return training.eval_rho_only_train(self, data_dict, Network, train_mode)
         dev = self.device
         top, bot, sun = Network._prep(*[data_dict[k].to(dev) for k in ("Top", "Bot", "Sun_Angle")])
         R, S = top.shape[0], self.args.n_samples
@@ -143,6 +153,9 @@ class All_in_One_Eval:
                    "composite_rays")
         return {"PE": pe, "PV_Exact": pv, "Solar_Vis": sv, "Sky_Col": sky_raw.unsqueeze(1).expand(R, S, 3)}
 
-    def get_loss(self, *a, **k):
-        raise NotImplementedError("season_nerf_amd: the training step (get_loss/backward) is not implemented on the "
-                                  "HIP path yet - SURVEY 8 row a9, next round")
+    def get_loss(self, data_dict, Network, current_step, train_mode):
+        """Eval_Tools_2.py:340-459 -> {name: [value, weight]} (values are torch scalars; `sum(v*w).backward()` runs the
+        HIP backward of both passes).  DSM-prior phase not implemented yet."""
+        self._check(Network)
+        from . import training
+        return training.get_loss(self, data_dict, Network, current_step, train_mode)

@@ -1,0 +1,298 @@
+"""Training step on the HIP path: host-side mirror of `All_in_One_Eval.get_loss` (Eval_Tools_2.py:340-459) and of the
+optimiser part of `Net_tool.train_step` (mg_run_NeRF.py:288-326).
+
+The heavy work (train-mode forward of both passes, backward, Adam) runs in the C-ABI training engine
+(`snerf_trainer_*`, csrc/train.cpp).  This module only
+  * owns the memory: one flat fp32 parameter arena (the module's Parameters become views into it, so `state_dict`,
+    `load_state_dict` and any torch optimiser keep working), the BatchNorm running-stat arena, the workspace;
+  * plugs the engine into autograd with two `torch.autograd.Function`s (image rays, sun rays), so the reference's
+    `optim.zero_grad(); loss = get_loss(); total.backward(); optim.step()` sequence works unchanged;
+  * restates the scalar loss terms on the small per-ray tensors with torch ops (R x 3 numbers).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .evaluator import sample_parameters
+
+
+def _ptr(t):
+    return t.data_ptr() if t is not None else None
+
+
+class TrainEngine:
+    """Binds a `season_nerf_amd.T_NeRF` to a `snerf_trainer` for fixed (rays, solar rays, samples)."""
+
+    def __init__(self, net, n_rays, n_solar_rays, n_samples):
+        L = _lib.lib()
+        self.L, self.net = L, net
+        self.dev = net.get_class_layer.weight.device
+        if self.dev.type != "cuda":
+            raise RuntimeError("season_nerf_amd training runs on an MI355X only: move the module with .to('cuda')")
+        self.h = L.snerf_trainer_create(net.layer_width, net.n_classes)
+        if not self.h:
+            raise RuntimeError("season_nerf_amd: " + L.snerf_last_error().decode())
+        self.R, self.Rs, self.S = n_rays, n_solar_rays, n_samples
+        self.n_params, self.n_buffers = L.snerf_trainer_param_floats(self.h), L.snerf_trainer_buffer_floats(self.h)
+        dev = self.dev
+        self.params = torch.empty(self.n_params, device=dev)
+        self.grads = torch.zeros(self.n_params, device=dev)
+        self.adam_m = torch.zeros(self.n_params, device=dev)
+        self.adam_v = torch.zeros(self.n_params, device=dev)
+        self.buffers = torch.empty(max(self.n_buffers, 1), device=dev)
+        self.ws = torch.empty(L.snerf_trainer_workspace_bytes(self.h, n_rays, n_solar_rays, n_samples), dtype=torch.uint8, device=dev)
+        # layout: state_dict key -> (is_buffer, offset, numel)
+        self.layout = {}
+        key = C.create_string_buffer(128)
+        isb, off, num, rows, cols = C.c_int(), C.c_int64(), C.c_int64(), C.c_int(), C.c_int()
+        for i in range(L.snerf_trainer_tensor_count(self.h)):
+            _lib.check(L.snerf_trainer_tensor_info(self.h, i, key, 128, C.byref(isb), C.byref(off), C.byref(num), C.byref(rows),
+                                                   C.byref(cols)), "trainer_tensor_info")
+            self.layout[key.value.decode()] = (bool(isb.value), off.value, num.value)
+        self._adopt()
+        _lib.check(L.snerf_trainer_bind(self.h, self.params.data_ptr(), self.grads.data_ptr(), self.adam_m.data_ptr(),
+                                        self.adam_v.data_ptr(), self.buffers.data_ptr(), self.ws.data_ptr(), self.ws.numel(),
+                                        n_rays, n_solar_rays, n_samples), "trainer_bind")
+        self.adam_steps = 0
+
+    def _adopt(self):
+        """Move every parameter / BatchNorm statistic of the module into the arenas (values preserved)."""
+        named = dict(self.net.named_parameters())
+        named.update(dict(self.net.named_buffers()))
+        self.param_keys, self.param_list = [], []
+        for k, (isb, off, num) in self.layout.items():
+            t = named[k]
+            arena = self.buffers if isb else self.params
+            view = arena[off:off + num].view(t.shape)
+            view.copy_(t.detach().to(self.dev, torch.float32))
+            t.data = view
+            if not isb:
+                self.param_keys.append(k)
+                self.param_list.append(t)
+        self._ptrs = [p.data_ptr() for p in self.param_list]
+
+    def adopted(self):
+        return all(p.data_ptr() == q for p, q in zip(self.param_list, self._ptrs))
+
+    def grad_copies(self):
+        out = []
+        for k, p in zip(self.param_keys, self.param_list):
+            _, off, num = self.layout[k]
+            out.append(self.grads[off:off + num].view(p.shape).clone())
+        return out
+
+    def stream(self):
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def zero_grad(self):
+        _lib.check(self.L.snerf_trainer_zero_grad(self.h, self.stream()), "trainer_zero_grad")
+
+    def adam_step(self, lr, betas=(0.9, 0.999), eps=1e-8):
+        self.adam_steps += 1
+        _lib.check(self.L.snerf_trainer_adam_step(self.h, float(lr), betas[0], betas[1], eps, self.adam_steps, self.stream()),
+                   "trainer_adam_step")
+
+    def __del__(self):
+        try:
+            self.L.snerf_trainer_destroy(self.h)
+        except Exception:
+            pass
+
+
+class _ImagePass(torch.autograd.Function):
+    """T_NeRF.forward (train mode) + compositing on R rays; differentiable outputs: Rendered_Col, Albedo_Color,
+    Sky_Col (per ray), PE."""
+
+    @staticmethod
+    def forward(ctx, eng, top, bot, tv, sun, tim, train_bn, *params):
+        R, S, dev = eng.R, eng.S, eng.dev
+        e = lambda *s: torch.empty(*s, device=dev)
+        o = {"rgb": e(R, 3), "albedo": e(R, 3), "pv": e(R, S, 1), "pe": e(R, S, 1), "ps": e(R, S, 1), "delta": e(R, S, 1),
+             "sky": e(R, 3), "cls": e(R, eng.net.n_classes), "rho": e(R, S, 1), "sv": e(R, S, 1), "col": e(R, S, 3), "pts": e(R, S, 3)}
+        co = _lib.CompositeOut(d_rgb=o["rgb"].data_ptr(), d_albedo=o["albedo"].data_ptr(), d_pv=o["pv"].data_ptr(),
+                               d_pe=o["pe"].data_ptr(), d_ps=o["ps"].data_ptr(), d_delta=o["delta"].data_ptr())
+        fo = _lib.FieldOut(d_rho=o["rho"].data_ptr(), d_solar_vis=o["sv"].data_ptr(), d_col=o["col"].data_ptr(), d_points=o["pts"].data_ptr())
+        _lib.check(eng.L.snerf_trainer_forward_image(eng.h, R, S, top.data_ptr(), bot.data_ptr(), tv.data_ptr(), sun.data_ptr(),
+                                                     tim.data_ptr(), 1 if train_bn else 0, 0, C.byref(co), o["sky"].data_ptr(),
+                                                     o["cls"].data_ptr(), C.byref(fo), eng.stream()), "trainer_forward_image")
+        ctx.eng = eng
+        outs = (o["rgb"], o["albedo"], o["sky"], o["pe"], o["pv"], o["ps"], o["delta"], o["cls"], o["rho"], o["sv"], o["col"], o["pts"])
+        ctx.mark_non_differentiable(*outs[4:])
+        return outs
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_albedo, g_sky, g_pe, *_):
+        eng = ctx.eng
+        c = lambda g: g.contiguous() if g is not None else None
+        g_rgb, g_albedo, g_sky, g_pe = c(g_rgb), c(g_albedo), c(g_sky), c(g_pe)
+        if g_rgb is None:
+            g_rgb = torch.zeros(eng.R, 3, device=eng.dev)
+        eng.zero_grad()
+        _lib.check(eng.L.snerf_trainer_backward_image(eng.h, _ptr(g_rgb), _ptr(g_albedo), _ptr(g_sky), _ptr(g_pe), eng.stream()),
+                   "trainer_backward_image")
+        return (None,) * 7 + tuple(eng.grad_copies())
+
+
+class _SolarPass(torch.autograd.Function):
+    """T_NeRF.forward_Solar (train mode) along sun rays; differentiable output: Solar_Vis (the trunk carries no gradient,
+    G_NeRF.py:141-145)."""
+
+    @staticmethod
+    def forward(ctx, eng, top, bot, tv, sun, train_bn, *params):
+        R, S, dev = eng.Rs, eng.S, eng.dev
+        e = lambda *s: torch.empty(*s, device=dev)
+        sv, pv, pe, sky_raw = e(R, S, 1), e(R, S, 1), e(R, S, 1), e(R, 3)
+        _lib.check(eng.L.snerf_trainer_forward_solar(eng.h, R, S, top.data_ptr(), bot.data_ptr(), tv.data_ptr(), sun.data_ptr(),
+                                                     1 if train_bn else 0, sv.data_ptr(), pv.data_ptr(), pe.data_ptr(),
+                                                     sky_raw.data_ptr(), eng.stream()), "trainer_forward_solar")
+        ctx.eng = eng
+        ctx.mark_non_differentiable(pv, pe, sky_raw)
+        return sv, pv, pe, sky_raw
+
+    @staticmethod
+    def backward(ctx, g_sv, *_):
+        eng = ctx.eng
+        eng.zero_grad()
+        if g_sv is not None:
+            g = g_sv.contiguous()
+            _lib.check(eng.L.snerf_trainer_backward_solar(eng.h, g.data_ptr(), eng.stream()), "trainer_backward_solar")
+        return (None,) * 6 + tuple(eng.grad_copies())
+
+
+class create_solor_rays_uniform:
+    """Random sun rays for the solar-correction loss (Eval_Tools_2.py:42-108, `__call__`): az ~ U[-180,180), el ~ U[1,90)
+    -> cube direction; random xy start at z = 1, end = start - 2 v / v_z.  Host numpy/torch RNG, as the reference."""
+
+    def __init__(self, W2L_H, WCW, base_vecs=None):
+        self.W2L, self.WC = W2L_H, WCW
+
+    def __call__(self, n, include_times=False):
+        from .render import world_angle_2_local_vec
+        az_el = np.random.random(n * 2).reshape([n, 2]) * np.array([[360, 89]]) + np.array([[-180, 1]])
+        vec = np.array([world_angle_2_local_vec(az_el[i][1], az_el[i][0], self.WC, self.W2L) for i in range(n)])
+        delta = 2 * (vec / vec[:, 2::])
+        starts = torch.ones([n, 3])
+        starts[:, 0] = torch.tensor(2.0) * torch.rand(n) + torch.tensor(-1.0)
+        starts[:, 1] = torch.tensor(2.0) * torch.rand(n) + torch.tensor(-1.0)
+        ends = (starts - delta).float()
+        vec_t = torch.tensor(vec).float()
+        if not include_times:
+            return starts, ends, vec_t
+        fr = torch.rand([n, 2]) * 2 * np.pi
+        times = torch.stack([torch.cos(fr[:, 0]), torch.sin(fr[:, 0]), torch.cos(fr[:, 1]), torch.sin(fr[:, 1])], 1)
+        return starts, ends, vec_t, times, az_el
+
+
+def _after_train_forward(net):
+    """Bookkeeping torch would do: BatchNorm1d.num_batches_tracked += 1 per train-mode forward; the running statistics
+    were updated by the engine outside torch's version counters, so the packed inference weights are stale."""
+    if net.training:
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.num_batches_tracked += 1
+        net._sig = None
+
+
+def _engine_for(net, R, Rs, S):
+    eng = getattr(net, "_train_engine", None)
+    if eng is None or (eng.R, eng.Rs, eng.S) != (R, Rs, S) or not eng.adopted():
+        eng = TrainEngine(net, R, Rs, S)
+        net._train_engine = eng
+    return eng
+
+
+def eval_train(ev, data_dict, net, train_mode):
+    """`All_in_One_Eval.eval` with a network in .train() mode (batch-statistics BatchNorm), differentiable."""
+    dev = ev.device
+    f = lambda k: data_dict[k].to(device=dev, dtype=torch.float32).contiguous()
+    top, bot, sun, tim = f("Top"), f("Bot"), f("Sun_Angle"), f("Time_Encoded")
+    R, S = top.shape[0], ev.args.n_samples
+    n_solar = R if ev.args.Use_Solar else 0
+    eng = _engine_for(net, R, n_solar, S)
+    tv = sample_parameters(S, eval_mode=not train_mode).to(dev)
+    rgb, alb, sky, pe, pv, ps, dl, cls, rho, sv, col, pts = _ImagePass.apply(eng, top, bot, tv, sun, tim, net.training, *eng.param_list)
+    _after_train_forward(net)
+    Cn = net.n_classes
+    return {"Rendered_Col": rgb, "PE": pe, "PV": pv, "PS": ps, "Solar_Vis": sv, "Sky_Col": sky.unsqueeze(1).expand(R, S, 3),
+            "Classes": cls.unsqueeze(1).expand(R, S, Cn), "Adjust": None, "Rho": rho, "Col": col, "Col_Adj": -1, "deltas": dl,
+            "sample_pts": pts, "Albedo_Color": alb}
+
+
+def eval_rho_only_train(ev, data_dict, net, train_mode):
+    dev = ev.device
+    f = lambda k: data_dict[k].to(device=dev, dtype=torch.float32).contiguous()
+    top, bot, sun = f("Top"), f("Bot"), f("Sun_Angle")
+    R, S = top.shape[0], ev.args.n_samples
+    eng = net._train_engine
+    if eng is None or eng.Rs != R:
+        raise RuntimeError("season_nerf_amd: the sun-ray pass must follow an image pass of the same step with as many rays")
+    tv = sample_parameters(S, eval_mode=not train_mode, include_end_pt=True).to(dev)
+    sv, pv, pe, sky_raw = _SolarPass.apply(eng, top, bot, tv, sun, net.training, *eng.param_list)
+    _after_train_forward(net)
+    return {"PE": pe, "PV_Exact": pv, "Solar_Vis": sv, "Sky_Col": sky_raw.unsqueeze(1).expand(R, S, 3)}
+
+
+def get_loss(ev, data_dict, net, current_step, train_mode):
+    """Eval_Tools_2.py:340-459 without the DSM prior: {name: [value, weight]}; total = sum value*weight."""
+    if ev.use_prior:
+        raise NotImplementedError("season_nerf_amd: get_loss with the DSM prior (use_prior=True) is not implemented yet")
+    args, dev = ev.args, ev.device
+    n_rays = data_dict["Top"].shape[0]
+    Loss = {}
+    weight = {"Color": 1.0, "Solar_Correction": args.sc_lambda, "Alpha_Adjust": 1.}
+    out = ev.eval(data_dict, net, current_step, train_mode)
+    if args.Use_Solar:
+        starts, ends, vec, stime, _ = ev.solar_creation_tool(n_rays, include_times=True)
+        so = ev.eval_Rho_Only({"Top": starts, "Bot": ends, "Sun_Angle": vec, "Time_Encoded": stime}, net, train_mode, current_step)
+        Loss["Solar_Correction"] = [torch.mean(torch.sum((so["Solar_Vis"] - so["PV_Exact"].detach()) ** 2, 1)), weight["Solar_Correction"]]
+        absorb = torch.mean(1 - torch.sum(so["PE"].detach() * so["PV_Exact"].detach() * so["Solar_Vis"], 1))
+        Loss["Solar_Correction_2"] = [absorb.detach() if not args.Solar_Type_2 else absorb, weight["Solar_Correction"]]
+        if not args.Solar_Type_2:
+            alb_min, _ = torch.min(out["Albedo_Color"], 0)
+            sel = alb_min[alb_min < .2]
+            alb_loss = torch.sum((1. - sel / .2) ** 2) / out["Albedo_Color"].shape[0] if sel.shape[0] > 0 else torch.tensor(0.0, device=dev)
+            x = (out["Sky_Col"] - .5) / .5
+            pos = x[x > 0]
+            sk = torch.sum(pos ** 2) / x.numel() if pos.shape[0] > 0 else torch.tensor(0., device=dev)
+            Loss["Sky_Color_Var"] = [sk, weight["Solar_Correction"]]
+            Loss["Albedo_Color"] = [alb_loss, weight["Solar_Correction"]]
+    gt = data_dict["GT_Color"].to(dev)
+    if ev.use_MSE_loss:
+        Loss["Color"] = [torch.mean((out["Rendered_Col"] - gt) ** 2), weight["Color"]]
+    else:
+        diff = out["Rendered_Col"] - gt
+        Loss["Color_ada"] = [torch.mean(ev.ada_loss.lossfun(diff)), weight["Color"]]
+        Loss["Color_alpha"] = [torch.mean(ev.ada_loss.alpha().detach()), 1.]
+        Loss["Color_width"] = [torch.mean(ev.ada_loss.scale().detach()), 1.]
+        scale = torch.mean(ev.ada_loss.scale().detach()) ** 2
+        Loss["Solar_Correction"][1] = Loss["Solar_Correction"][1] / scale
+        Loss["Solar_Correction_2"][1] = Loss["Solar_Correction_2"][1] / scale
+        with torch.no_grad():
+            Loss["Color"] = [torch.mean((out["Rendered_Col"] - gt) ** 2).detach(), weight["Color"]]
+    return Loss
+
+
+class FusedAdam(torch.optim.Optimizer):
+    """torch.optim.Adam semantics (betas, eps, no weight decay) as ONE kernel over the flat parameter arena of the
+    network's training engine (K12 of SURVEY 2.3).  `params` must be the parameters of one season_nerf_amd.T_NeRF."""
+
+    def __init__(self, net, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        self.net = net
+        super().__init__(list(net.parameters()), dict(lr=lr, betas=betas, eps=eps))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        eng = getattr(self.net, "_train_engine", None)
+        if eng is None:
+            raise RuntimeError("FusedAdam.step before any training forward/backward")
+        g = self.param_groups[0]
+        # gather the autograd-accumulated gradients into the arena (parameters without a gradient keep a zero slot)
+        eng.grads.zero_()
+        for k, p in zip(eng.param_keys, eng.param_list):
+            if p.grad is not None:
+                _, off, num = eng.layout[k]
+                eng.grads[off:off + num].copy_(p.grad.reshape(-1))
+        eng.adam_step(g["lr"], g["betas"], g["eps"])
+        self.net._sig = None          # parameters changed outside torch's version counters: re-pack before inference
