@@ -63,13 +63,82 @@ def cpu_baseline():
                       f"median of {reps} after warm-up"}
 
 
+def bench_train(a):
+    """BASELINE configs[2]: training step = zero_grad, get_loss (image rays + R random sun rays, train-mode BatchNorm),
+    backward, fused Adam; MSE colour loss (Barron's loss is an unpinned third-party dependency)."""
+    from types import SimpleNamespace
+    import season_nerf_amd as sn
+    from oracle import season_nerf_oracle as orc
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    torch.cuda.set_device(dev)
+    steps, warm = min(a.steps, 20), min(a.warmup, 3)
+    net = sn.T_NeRF(W, NC)
+    net.load_state_dict(orc.init_weights(W, NC, 0, bn_stats="identity"))
+    net = net.to(dev).train()
+    args = SimpleNamespace(n_samples=S, Use_Reg=True, Solar_Type_2=False, Use_MSE_loss=True, Use_Solar=True, sc_lambda=0.03,
+                           number_low_frequency_cases=NC)
+    WC, H4 = np.array([41.29, -95.9, 300.0]), np.array([[310.0, 12.0, 0.0, -11650.0], [-9.0, 240.0, 0.0, 23390.0], [0.0, 0.0, 0.01, -3.0], [0, 0, 0, 1.0]])
+    ev = sn.All_in_One_Eval(args, dev, 10, False, None, H4, WC)
+    d = synth(0, dev)
+    d["GT_Color"] = torch.rand(R, 3, device=dev)
+    opt = sn.FusedAdam(net, lr=10 ** -4.86)
+    np.random.seed(0)
+    torch.manual_seed(0)
+
+    def step():
+        opt.zero_grad()
+        loss = ev.get_loss(d, net, 0, True)
+        total = sum(v * w for v, w in loss.values())
+        total.backward()
+        opt.step()
+        return total
+
+    for _ in range(warm):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tot = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    # algorithmic FLOPs (SURVEY 8d): image rays 3 x forward; sun rays: trunk+heads+solar forward + 3 x solar/sky heads
+    flop = R * S * (3 * FLOP_PER_SAMPLE + 2 * (524800 + 3 * 54656))
+    out = {"metric": "training image-ray-samples/s (4096 rays x 96 samples + 4096 sun rays, MSE loss, fused Adam)",
+           "value": R * S / dt, "unit": "ray-samples/s", "n_gpus": 1, "steps": steps, "warmup": warm, "ms_per_step": dt * 1e3,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 (exact-fp32 MFMA)", "data": "synthetic",
+           "config": {"workload": "BASELINE configs[2]: training step 4096x96, T_NeRF(256,4) train-mode BatchNorm, solar branch on, MSE loss"},
+           "final_loss": float(tot),
+           "roofline": {"bound": "mfma", "achieved": flop / dt / 1e12, "peak": 157.3, "unit": "TFLOP/s", "frac": flop / dt / 157.3e12,
+                        "traffic": None, "note": "layer-wise fp32 path; peak = fp32 matrix (MI355X_MICROARCH.md); whole step, not one kernel"}}
+    if not a.no_cpu_baseline:
+        torch.set_num_threads(min(os.cpu_count() or 1, 32))
+        sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in orc.init_weights(W, NC, 0, bn_stats="identity").items()}
+        n = 256
+        dc = {k: v[:n].cpu() for k, v in d.items()}
+        rng = np.random.Generator(np.random.PCG64(1))
+        st = torch.tensor(np.concatenate([rng.uniform(-1, 1, (n, 2)), np.ones((n, 1))], 1), dtype=torch.float32)
+        vv = dc["Sun_Angle"]
+        solar = {"Top": st, "Bot": st - 2 * vv / vv[:, 2:], "Sun_Angle": vv}
+        t0 = time.perf_counter()
+        loss, _ = orc.get_loss_mse(sd, dc, solar, S, 0.03, True, True)
+        orc.total_loss(loss).backward()
+        tc = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": n * S / tc, "unit": "ray-samples/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": f"one MSE training step (forward both passes + backward) on {n} rays x {S} samples, torch-CPU oracle"}
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="render", choices=["render", "train"],
+                    help="render = headline (BASELINE configs[1]); train = configs[2]: one MSE training step, 4096x96 + 4096 sun rays")
     a = ap.parse_args()
+    if a.workload == "train":
+        return bench_train(a)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
