@@ -279,7 +279,8 @@ static int plain_bwd(snerf_trainer* t, const LayerP& L, const float* dOut, int64
     } while (0)
 
 static int forward_pass(snerf_trainer* t, snerf_trainer::Pass& P, bool solar, int64_t R, int S, const float* top, const float* bot,
-                        const float* tvals, const float* sun, const float* time, bool train_bn, hipStream_t st) {
+                        const float* tvals, const float* sun, const float* time, bool train_bn, hipStream_t st,
+                        float* adjust_col_out = nullptr) {
     const int W = t->W, W2 = t->W2, W4 = t->W4, C = t->C;
     const int64_t N = R * S;
     HIPCK(hipMemcpyAsync(P.top, top, R * 3 * sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -325,7 +326,7 @@ static int forward_pass(snerf_trainer* t, snerf_trainer::Pass& P, bool solar, in
         RC(sine_fwd(t, Ls[L_T2], P.Ht1, W, R, Act{P.Zt2, W}, Act{P.Ht2, W}, nullptr, train_bn, st));
         RC(plain_fwd(t, Ls[L_CL], P.Ht2, W, R, P.logits, C, st));
         HIPCK(launch_softmax(P.logits, P.cls, R, C, st));
-        po.adj = P.adj.p; po.cls = P.cls; po.col = P.col;
+        po.adj = P.adj.p; po.cls = P.cls; po.col = P.col; po.adjust_col = adjust_col_out;
     }
     HIPCK(launch_point_out(po, false, st));
     return SNERF_OK;
@@ -416,7 +417,8 @@ int snerf_trainer_forward_image(snerf_trainer* t, int64_t n_rays, int n_samples,
     if (!d_top || !d_bot || !d_tvals || !d_sun || !d_time || !out) return snerf_set_error(SNERF_E_INVALID, "snerf_trainer_forward_image: bad argument");
     if (flags & 1) return snerf_set_error(SNERF_E_INVALID, "training with the classic solar model (Solar_Type_2) is not implemented");
     hipStream_t st = (hipStream_t)stream;
-    RC(forward_pass(t, t->img, false, n_rays, n_samples, d_top, d_bot, d_tvals, d_sun, d_time, train_bn != 0, st));
+    RC(forward_pass(t, t->img, false, n_rays, n_samples, d_top, d_bot, d_tvals, d_sun, d_time, train_bn != 0, st,
+                    per_sample ? per_sample->d_adjust_col : nullptr));
     snerf_trainer::Pass& P = t->img;
     RC(snerf_composite_rays(n_rays, n_samples, d_top, d_bot, d_tvals, P.rho, P.col, P.sv, P.sky, flags, nullptr, 1.f, out, stream));
     const int64_t N = n_rays * n_samples;
@@ -427,6 +429,8 @@ int snerf_trainer_forward_image(snerf_trainer* t, int64_t n_rays, int n_samples,
         if (per_sample->d_solar_vis) HIPCK(hipMemcpyAsync(per_sample->d_solar_vis, P.sv, N * 4, hipMemcpyDeviceToDevice, st));
         if (per_sample->d_col) HIPCK(hipMemcpyAsync(per_sample->d_col, P.col, N * 12, hipMemcpyDeviceToDevice, st));
         if (per_sample->d_points) HIPCK(hipMemcpyAsync(per_sample->d_points, P.pts, N * 12, hipMemcpyDeviceToDevice, st));
+        if (per_sample->d_col_raw) HIPCK(launch_copy_cols(P.head.p, 4, per_sample->d_col_raw, 3, N, 3, false, st));
+        if (per_sample->d_adjust) HIPCK(hipMemcpyAsync(per_sample->d_adjust, P.adj.p, N * 3 * t->C * 4, hipMemcpyDeviceToDevice, st));
     }
     return SNERF_OK;
 }

@@ -65,6 +65,7 @@ struct PointOutArgs {
     int n_samples, C;
     const float *head, *adj, *sv_raw, *cls;     // [N,4], [N,3C], [N], [R,C]
     float *rho, *col, *sv;                      // [N], [N,3], [N]
+    float* adjust_col;                          // [N,3] optional: sum_c cls*adj
     // backward (all optional): d_rho [N], d_col [N,3] -> d_head [N,4], d_adj [N,3C], d_cls [R,C] (atomic), d_sv -> d_sv_raw
     const float *d_rho, *d_col, *d_sv;
     float *d_head, *d_adj, *d_cls, *d_sv_raw;

@@ -230,6 +230,7 @@ __global__ void point_out_fwd_kernel(const PointOutArgs A) {
             }
 #pragma unroll
             for (int k = 0; k < 3; ++k) A.col[i * 3 + k] = sigmoid_t(A.head[i * 4 + k] + ac[k]);
+            if (A.adjust_col) { A.adjust_col[i * 3] = ac[0]; A.adjust_col[i * 3 + 1] = ac[1]; A.adjust_col[i * 3 + 2] = ac[2]; }
         }
     }
 }

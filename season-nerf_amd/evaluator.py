@@ -56,7 +56,9 @@ class All_in_One_Eval:
         """Eval_Tools_2.py:165-252.  Keys: Rendered_Col, PE, PV, PS, Solar_Vis, Sky_Col, Classes, Adjust, Rho, Col,
         Col_Adj, deltas, sample_pts, Albedo_Color (+ the *_Supervised / *_Merged family with use_prior)."""
         self._check(Network)
-        if Network.training:                       # batch-statistics BatchNorm + autograd: layer-wise training engine
+        from .network import FUSED_WIDTHS
+        if Network.training or Network.layer_width not in FUSED_WIDTHS:
+            # batch-statistics BatchNorm + autograd, or a width without a fused kernel: layer-wise fp32 engine
             if self.use_prior:
                 raise NotImplementedError("season_nerf_amd: train-mode eval with the DSM prior is not implemented yet")
             from . import training
@@ -129,7 +131,8 @@ class All_in_One_Eval:
         self._check(Network)
         if self.use_prior:
             raise NotImplementedError("eval_Rho_Only with use_prior is not implemented by the HIP path yet")
-        if Network.training:
+        from .network import FUSED_WIDTHS
+        if Network.training or Network.layer_width not in FUSED_WIDTHS:
             from . import training
             return training.eval_rho_only_train(self, data_dict, Network, train_mode)
         dev = self.device

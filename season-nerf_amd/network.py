@@ -15,6 +15,7 @@ from torch import nn
 from . import _lib
 
 OMEGA0 = 30.0
+FUSED_WIDTHS = (64, 256)      # widths with a compiled fused MFMA kernel; others run on the layer-wise fp32 engine
 
 
 class SineLayer(nn.Module):
@@ -141,6 +142,24 @@ class T_NeRF(nn.Module):
                                                   sky_raw.data_ptr(), sky.data_ptr(), self._stream()), "group_forward")
         return cls, sky_raw, sky
 
+    def _generic_points(self, X, sun, tim):
+        """Any width: the layer-wise fp32 engine in eval mode, one 'ray' of one sample per point (still all HIP)."""
+        from . import training
+        N = X.shape[0]
+        eng = training._engine_for(self, N, 0, 1)
+        dev = X.device
+        e = lambda *s: torch.empty(*s, device=dev)
+        o = {"rho": e(N, 1), "sv": e(N, 1), "col": e(N, 3), "col_raw": e(N, 3), "adj": e(N, self.n_classes, 3),
+             "adjc": e(N, 3), "sky": e(N, 3), "cls": e(N, self.n_classes), "rgb": e(N, 3)}
+        tv = torch.zeros(1, device=dev)
+        co = _lib.CompositeOut(d_rgb=o["rgb"].data_ptr())
+        fo = _lib.FieldOut(d_rho=o["rho"].data_ptr(), d_solar_vis=o["sv"].data_ptr(), d_col=o["col"].data_ptr(),
+                           d_col_raw=o["col_raw"].data_ptr(), d_adjust=o["adj"].data_ptr(), d_adjust_col=o["adjc"].data_ptr())
+        _lib.check(eng.L.snerf_trainer_forward_image(eng.h, N, 1, X.data_ptr(), X.data_ptr(), tv.data_ptr(), sun.data_ptr(),
+                                                     tim.data_ptr(), 0, 0, C.byref(co), o["sky"].data_ptr(), o["cls"].data_ptr(),
+                                                     C.byref(fo), eng.stream()), "trainer_forward_image")
+        return o
+
     def _field_points(self, variant, X, sun, cls, want):
         N = X.shape[0]
         dev = X.device
@@ -160,6 +179,9 @@ class T_NeRF(nn.Module):
     def forward(self, X, Solar_Angle, Time):
         """-> Rho[N,1], Col[N,3], Solar_Vis[N,1], Sky_Col[N,3], output_class[N,C], Adjust_col[N,3]  (:75-105)"""
         X, sun, tim = self._prep(X, Solar_Angle, Time)
+        if self.layer_width not in FUSED_WIDTHS:
+            o = self._generic_points(X, sun, tim)
+            return o["rho"], o["col"], o["sv"], o["sky"], o["cls"], o["adjc"]
         cls, _, sky = self._groups(tim, sun)
         o = self._field_points(0, X, sun, cls, ["d_rho", "d_col", "d_solar_vis", "d_adjust_col"])
         return o["d_rho"], o["d_col"], o["d_solar_vis"], sky, cls, o["d_adjust_col"]
@@ -167,6 +189,9 @@ class T_NeRF(nn.Module):
     def forward_seperate(self, X, Solar_Angle, Time):
         """Col raw and Adjust[N,C,3] unmixed (:131-151)."""
         X, sun, tim = self._prep(X, Solar_Angle, Time)
+        if self.layer_width not in FUSED_WIDTHS:
+            o = self._generic_points(X, sun, tim)
+            return o["rho"], o["col_raw"], o["sv"], o["sky"], o["cls"], o["adj"]
         cls, _, sky = self._groups(tim, sun)
         o = self._field_points(0, X, sun, cls, ["d_rho", "d_col_raw", "d_solar_vis", "d_adjust"])
         return o["d_rho"], o["d_col_raw"], o["d_solar_vis"], sky, cls, o["d_adjust"]
@@ -176,17 +201,26 @@ class T_NeRF(nn.Module):
     def forward_Solar(self, X, Solar_Angle, Time):
         """-> softplus(Rho), sigmoid(Solar_Vis), Sky raw (:154-157)."""
         X, sun, tim = self._prep(X, Solar_Angle, Time)
+        if self.layer_width not in FUSED_WIDTHS:
+            o = self._generic_points(X, sun, tim)
+            sky = o["sky"].clamp(1e-7, 1 - 1e-7)
+            return o["rho"], o["sv"], torch.log(sky / (1 - sky))       # raw sky = logit of the sigmoided head output
         _, sky_raw, _ = self._groups(tim, sun)
         o = self._field_points(1, X, sun, None, ["d_rho", "d_solar_vis"])
         return o["d_rho"], o["d_solar_vis"], sky_raw
 
     def forward_Classic_Sigma_Only(self, X):
         (X,) = self._prep(X)
+        if self.layer_width not in FUSED_WIDTHS:
+            z = torch.zeros(X.shape[0], 4, device=X.device)
+            return self._generic_points(X, torch.ones(X.shape[0], 3, device=X.device), z)["rho"]
         return self._field_points(2, X, None, None, ["d_rho"])["d_rho"]
 
     def get_class_only(self, Time):
         (tim,) = self._prep(Time)
         sun = torch.zeros(tim.shape[0], 3, device=tim.device)
+        if self.layer_width not in FUSED_WIDTHS:
+            return self._generic_points(torch.zeros(tim.shape[0], 3, device=tim.device), sun + 1.0, tim)["cls"]
         return self._groups(tim, sun)[0]
 
     def Supervised_Sample(self, world_pts, delta):

@@ -110,15 +110,17 @@ class _ImagePass(torch.autograd.Function):
         R, S, dev = eng.R, eng.S, eng.dev
         e = lambda *s: torch.empty(*s, device=dev)
         o = {"rgb": e(R, 3), "albedo": e(R, 3), "pv": e(R, S, 1), "pe": e(R, S, 1), "ps": e(R, S, 1), "delta": e(R, S, 1),
-             "sky": e(R, 3), "cls": e(R, eng.net.n_classes), "rho": e(R, S, 1), "sv": e(R, S, 1), "col": e(R, S, 3), "pts": e(R, S, 3)}
+             "sky": e(R, 3), "cls": e(R, eng.net.n_classes), "rho": e(R, S, 1), "sv": e(R, S, 1), "col": e(R, S, 3), "pts": e(R, S, 3),
+             "adjc": e(R, S, 3)}
         co = _lib.CompositeOut(d_rgb=o["rgb"].data_ptr(), d_albedo=o["albedo"].data_ptr(), d_pv=o["pv"].data_ptr(),
                                d_pe=o["pe"].data_ptr(), d_ps=o["ps"].data_ptr(), d_delta=o["delta"].data_ptr())
-        fo = _lib.FieldOut(d_rho=o["rho"].data_ptr(), d_solar_vis=o["sv"].data_ptr(), d_col=o["col"].data_ptr(), d_points=o["pts"].data_ptr())
+        fo = _lib.FieldOut(d_rho=o["rho"].data_ptr(), d_solar_vis=o["sv"].data_ptr(), d_col=o["col"].data_ptr(), d_points=o["pts"].data_ptr(),
+                           d_adjust_col=o["adjc"].data_ptr())
         _lib.check(eng.L.snerf_trainer_forward_image(eng.h, R, S, top.data_ptr(), bot.data_ptr(), tv.data_ptr(), sun.data_ptr(),
                                                      tim.data_ptr(), 1 if train_bn else 0, 0, C.byref(co), o["sky"].data_ptr(),
                                                      o["cls"].data_ptr(), C.byref(fo), eng.stream()), "trainer_forward_image")
         ctx.eng = eng
-        outs = (o["rgb"], o["albedo"], o["sky"], o["pe"], o["pv"], o["ps"], o["delta"], o["cls"], o["rho"], o["sv"], o["col"], o["pts"])
+        outs = (o["rgb"], o["albedo"], o["sky"], o["pe"], o["pv"], o["ps"], o["delta"], o["cls"], o["rho"], o["sv"], o["col"], o["pts"], o["adjc"])
         ctx.mark_non_differentiable(*outs[4:])
         return outs
 
@@ -227,11 +229,11 @@ def eval_train(ev, data_dict, net, train_mode):
     n_solar = R if ev.args.Use_Solar else 0
     eng = _engine_for(net, R, n_solar, S)
     tv = sample_parameters(S, eval_mode=not train_mode).to(dev)
-    rgb, alb, sky, pe, pv, ps, dl, cls, rho, sv, col, pts = _ImagePass.apply(eng, top, bot, tv, sun, tim, net.training, *eng.param_list)
+    rgb, alb, sky, pe, pv, ps, dl, cls, rho, sv, col, pts, adjc = _ImagePass.apply(eng, top, bot, tv, sun, tim, net.training, *eng.param_list)
     _after_train_forward(net)
     Cn = net.n_classes
     return {"Rendered_Col": rgb, "PE": pe, "PV": pv, "PS": ps, "Solar_Vis": sv, "Sky_Col": sky.unsqueeze(1).expand(R, S, 3),
-            "Classes": cls.unsqueeze(1).expand(R, S, Cn), "Adjust": None, "Rho": rho, "Col": col, "Col_Adj": -1, "deltas": dl,
+            "Classes": cls.unsqueeze(1).expand(R, S, Cn), "Adjust": adjc, "Rho": rho, "Col": col, "Col_Adj": -1, "deltas": dl,
             "sample_pts": pts, "Albedo_Color": alb}
 
 
@@ -240,9 +242,11 @@ def eval_rho_only_train(ev, data_dict, net, train_mode):
     f = lambda k: data_dict[k].to(device=dev, dtype=torch.float32).contiguous()
     top, bot, sun = f("Top"), f("Bot"), f("Sun_Angle")
     R, S = top.shape[0], ev.args.n_samples
-    eng = net._train_engine
-    if eng is None or eng.Rs != R:
-        raise RuntimeError("season_nerf_amd: the sun-ray pass must follow an image pass of the same step with as many rays")
+    eng = getattr(net, "_train_engine", None)
+    if eng is None or eng.Rs != R or eng.S != S or not eng.adopted():
+        if torch.is_grad_enabled() and net.training:
+            raise RuntimeError("season_nerf_amd: the sun-ray pass must follow an image pass of the same step with as many rays")
+        eng = _engine_for(net, R, R, S)
     tv = sample_parameters(S, eval_mode=not train_mode, include_end_pt=True).to(dev)
     sv, pv, pe, sky_raw = _SolarPass.apply(eng, top, bot, tv, sun, net.training, *eng.param_list)
     _after_train_forward(net)

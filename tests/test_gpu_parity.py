@@ -148,5 +148,37 @@ def test_fails_loudly():
     net.train()
     with pytest.raises(NotImplementedError):
         net.forward(torch.zeros(4, 3).cuda(), torch.ones(4, 3).cuda(), torch.ones(4, 4).cuda())
-    with pytest.raises(RuntimeError):
-        sn().T_NeRF(96, 4).to("cuda").eval().forward_Classic_Sigma_Only(torch.zeros(4, 3).cuda())
+    with pytest.raises(RuntimeError):        # no kernel at all for a width that is not a multiple of 4
+        sn().T_NeRF(90, 4).to("cuda").eval().forward_Classic_Sigma_Only(torch.zeros(4, 3).cuda())
+
+
+def test_generic_width_runs_on_layerwise_engine():
+    """Widths without a fused kernel (the reference default is 512) run on the layer-wise fp32 HIP engine."""
+    W, C = 128, 4
+    net, sd = make_net(W, C, 9)
+    rng = np.random.Generator(np.random.PCG64(4))
+    N = 300
+    X = T(rng.uniform(-1, 1, (N, 3)))
+    sun = rng.uniform(0.05, 1, (N, 3)); sun = T(sun / np.linalg.norm(sun, axis=1, keepdims=True))
+    tim = T(rng.uniform(-1, 1, (N, 4)))
+    with torch.no_grad():
+        ref = orc.forward(sd, X, sun, tim)
+        ref_s = orc.forward_separate(sd, X, sun, tim)
+    got = net.forward(X.cuda(), sun.cuda(), tim.cuda())
+    for k, a, b in zip(["Rho", "Col", "Solar_Vis", "Sky_Col", "Class", "Adjust_col"], got, ref):
+        close("g128_" + k, a, b.numpy(), rtol=2e-4, atol=1e-4 if k == "Adjust_col" else 2e-5)
+    got = net.forward_seperate(X.cuda(), sun.cuda(), tim.cuda())
+    close("g128_sep_Col_raw", got[1], ref_s[1].numpy(), rtol=1e-4, atol=1e-4)
+    close("g128_sep_Adjust", got[5], ref_s[5].numpy(), rtol=1e-4, atol=1e-4)
+    close("g128_sigma", net.forward_Classic_Sigma_Only(X.cuda()), orc.forward_sigma_only(sd, X).detach().numpy(), rtol=2e-4, atol=2e-5)
+    R, S = 9, 40
+    top = np.concatenate([rng.uniform(-1, 1, (R, 2)), np.ones((R, 1))], 1)
+    bot = np.concatenate([rng.uniform(-1, 1, (R, 2)), -np.ones((R, 1))], 1)
+    data = {"Top": T(top), "Bot": T(bot), "Sun_Angle": sun[:R], "Time_Encoded": tim[:R]}
+    ev = sn().All_in_One_Eval(args_ns(S), torch.device("cuda"), 10, False, None, np.eye(4), np.zeros(3))
+    with torch.no_grad():
+        out = ev.eval(data, net, 0, False)
+        refo = orc.eval_rays(sd, data, S, train_mode=False)
+    close("g128_Rendered_Col", out["Rendered_Col"], refo["Rendered_Col"].numpy())
+    close("g128_PS", out["PS"], refo["PS"].numpy(), rtol=1e-4, atol=2e-5)
+    close("g128_Adjust", out["Adjust"], refo["Adjust"].numpy(), rtol=1e-4, atol=1e-4)
