@@ -165,14 +165,16 @@ int snerf_trainer_forward_image(snerf_trainer* t, int64_t n_rays, int n_samples,
                                 const float* d_tvals, const float* d_sun, const float* d_time, int train_bn, int flags,
                                 const snerf_composite_out* out, float* d_sky, float* d_classes,
                                 const snerf_field_out* per_sample, void* stream);
-/* gradients of the image pass: dL/dRendered_Col [R,3], dL/dAlbedo_Color [R,3] (opt), dL/dSky_Col per ray [R,3] (opt),
- * dL/dPE [R*S] (opt); ACCUMULATES into the gradient arena. */
+/* gradients of the image pass: dL/dRendered_Col [R,3] (opt), dL/dAlbedo_Color [R,3] (opt), dL/dSky_Col per ray [R,3] (opt),
+ * dL/dPE [R*S] (opt); DSM-prior phase (Eval_Tools_2.py:218-248): d_rho_prior [R*S] + trust and the gradients of
+ * Rendered_Col_Merged / the merged Albedo_Color (opt).  ACCUMULATES into the gradient arena. */
 int snerf_trainer_backward_image(snerf_trainer* t, const float* d_g_rgb, const float* d_g_albedo, const float* d_g_sky,
-                                 const float* d_g_pe, void* stream);
+                                 const float* d_g_pe, const float* d_rho_prior, float trust, const float* d_g_rgb_merged,
+                                 const float* d_g_albedo_merged, void* stream);
 /* sun-ray pass: T_NeRF.forward_Solar + PV_Exact / PE (end-point sampling is the caller's d_tvals). */
 int snerf_trainer_forward_solar(snerf_trainer* t, int64_t n_rays, int n_samples, const float* d_top, const float* d_bot,
                                 const float* d_tvals, const float* d_sun, int train_bn, float* d_solar_vis, float* d_pv,
-                                float* d_pe, float* d_sky_raw, void* stream);
+                                float* d_pe, float* d_sky_raw, float* d_rho, float* d_points, float* d_delta, void* stream);
 int snerf_trainer_backward_solar(snerf_trainer* t, const float* d_g_solar_vis, void* stream);
 int snerf_trainer_zero_grad(snerf_trainer* t, void* stream);
 /* test introspection: synchronous copy of an internal buffer ("d_rho", "d_col", "d_head", "d_sky", ...) to the host */

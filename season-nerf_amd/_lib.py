@@ -74,8 +74,8 @@ def lib():
     L.snerf_trainer_bind.argtypes = [vp, f32p, f32p, f32p, f32p, f32p, vp, C.c_size_t, i64, i64, i32]
     L.snerf_trainer_forward_image.argtypes = [vp, i64, i32, vp, vp, vp, vp, vp, i32, i32, C.POINTER(CompositeOut), vp, vp,
                                               C.POINTER(FieldOut), vp]
-    L.snerf_trainer_backward_image.argtypes = [vp, vp, vp, vp, vp, vp]
-    L.snerf_trainer_forward_solar.argtypes = [vp, i64, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp]
+    L.snerf_trainer_backward_image.argtypes = [vp, vp, vp, vp, vp, vp, C.c_float, vp, vp, vp]
+    L.snerf_trainer_forward_solar.argtypes = [vp, i64, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp]
     L.snerf_trainer_backward_solar.argtypes = [vp, vp, vp]
     L.snerf_trainer_zero_grad.argtypes = [vp, vp]
     L.snerf_trainer_debug_read.argtypes = [vp, C.c_char_p, vp, i64]

@@ -436,7 +436,8 @@ int snerf_trainer_forward_image(snerf_trainer* t, int64_t n_rays, int n_samples,
 }
 
 int snerf_trainer_backward_image(snerf_trainer* t, const float* d_g_rgb, const float* d_g_albedo, const float* d_g_sky,
-                                 const float* d_g_pe, void* stream) {
+                                 const float* d_g_pe, const float* d_rho_prior, float trust, const float* d_g_rgb_merged,
+                                 const float* d_g_albedo_merged, void* stream) {
     if (!t || !t->ws) return snerf_set_error(SNERF_E_STATE, "trainer not bound");
     hipStream_t st = (hipStream_t)stream;
     snerf_trainer::Pass& P = t->img;
@@ -446,6 +447,7 @@ int snerf_trainer_backward_image(snerf_trainer* t, const float* d_g_rgb, const f
     CompBwdArgs cb{};
     cb.n_rays = R; cb.n_samples = S; cb.top = P.top; cb.bot = P.bot; cb.rho = P.rho; cb.col = P.col; cb.sv = P.sv; cb.sky = P.sky;
     cb.g_rgb = d_g_rgb; cb.g_albedo = d_g_albedo; cb.g_pe = d_g_pe; cb.d_rho = t->d_rho; cb.d_col = t->d_col; cb.d_sky = t->d_sky;
+    cb.rho_prior = d_rho_prior; cb.trust = trust; cb.g_rgb_m = d_g_rgb_merged; cb.g_albedo_m = d_g_albedo_merged;
     HIPCK(launch_composite_bwd(cb, st));
     if (d_g_sky) HIPCK(launch_copy_cols(d_g_sky, 3, t->d_sky, 3, R, 3, true, st));
     HIPCK(hipMemsetAsync(t->d_cls, 0, R * C * sizeof(float), st));
@@ -487,19 +489,21 @@ int snerf_trainer_backward_image(snerf_trainer* t, const float* d_g_rgb, const f
 
 int snerf_trainer_forward_solar(snerf_trainer* t, int64_t n_rays, int n_samples, const float* d_top, const float* d_bot,
                                 const float* d_tvals, const float* d_sun, int train_bn, float* d_solar_vis, float* d_pv,
-                                float* d_pe, float* d_sky_raw, void* stream) {
+                                float* d_pe, float* d_sky_raw, float* d_rho, float* d_points, float* d_delta, void* stream) {
     RC(check_bound(t, n_rays, n_samples, true));
     if (!d_top || !d_bot || !d_tvals || !d_sun) return snerf_set_error(SNERF_E_INVALID, "snerf_trainer_forward_solar: bad argument");
     hipStream_t st = (hipStream_t)stream;
     snerf_trainer::Pass& P = t->sol;
     RC(forward_pass(t, P, true, n_rays, n_samples, d_top, d_bot, d_tvals, d_sun, nullptr, train_bn != 0, st));
     snerf_composite_out co{};
-    co.d_pv = d_pv; co.d_pe = d_pe;
+    co.d_pv = d_pv; co.d_pe = d_pe; co.d_delta = d_delta;
     // col is not produced by the sun-ray pass: composite only needs rho (col/sv operands are dummies of the right size)
     RC(snerf_composite_rays(n_rays, n_samples, d_top, d_bot, d_tvals, P.rho, t->d_col, P.sv, P.sky, 0, nullptr, 1.f, &co, stream));
     const int64_t N = n_rays * n_samples;
     if (d_solar_vis) HIPCK(hipMemcpyAsync(d_solar_vis, P.sv, N * 4, hipMemcpyDeviceToDevice, st));
     if (d_sky_raw) HIPCK(hipMemcpyAsync(d_sky_raw, P.sky_raw, n_rays * 12, hipMemcpyDeviceToDevice, st));
+    if (d_rho) HIPCK(hipMemcpyAsync(d_rho, P.rho, N * 4, hipMemcpyDeviceToDevice, st));
+    if (d_points) HIPCK(hipMemcpyAsync(d_points, P.pts, N * 12, hipMemcpyDeviceToDevice, st));
     return SNERF_OK;
 }
 

@@ -78,7 +78,12 @@ struct CompBwdArgs {
     int n_samples;
     const float *top, *bot;
     const float *rho, *col, *sv, *sky;          // forward inputs ([N], [N,3], [N], [R,3])
-    const float *g_rgb, *g_albedo, *g_pe;       // [R,3], [R,3] or NULL, [N] or NULL
+    const float *g_rgb, *g_albedo, *g_pe;       // [R,3] or NULL, [R,3] or NULL, [N] or NULL
+    // DSM-prior phase (Eval_Tools_2.py:218-248): merged density rho*trust + rho_prior*(1-trust); gradients of
+    // Rendered_Col_Merged / merged Albedo_Color.  The solar factor always comes from the un-merged PS.
+    const float* rho_prior;                     // [N] or NULL
+    float trust;
+    const float *g_rgb_m, *g_albedo_m;          // [R,3] or NULL
     float *d_rho, *d_col, *d_sky;               // [N], [N,3], [R,3] (d_sky is overwritten)
 };
 hipError_t launch_composite_bwd(const CompBwdArgs& a, hipStream_t st);

@@ -292,13 +292,16 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const CompBwdArgs A)
     const float dx = A.top[r * 3] - A.bot[r * 3], dy = A.top[r * 3 + 1] - A.bot[r * 3 + 1], dz = A.top[r * 3 + 2] - A.bot[r * 3 + 2];
     const float delta = __fdiv_rn(__fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz))), (float)S);
     const float sky[3] = {A.sky[r * 3], A.sky[r * 3 + 1], A.sky[r * 3 + 2]};
-    // ---- pass 1: forward sums (albedo, u)
-    float alb[3] = {0.f, 0.f, 0.f}, u = 0.f, carry = 0.f;
+    const bool prior = A.rho_prior != nullptr;
+    const float tr = A.trust;
+    // ---- pass 1: forward sums (albedo, merged albedo, u)
+    float alb[3] = {0.f, 0.f, 0.f}, albm[3] = {0.f, 0.f, 0.f}, u = 0.f, carry = 0.f, carry_m = 0.f;
     for (int base = 0; base < S; base += 64) {
         const int s = base + lane;
         const bool in = s < S;
         const int64_t idx = r * S + (in ? s : S - 1);
-        const float y = in ? A.rho[idx] * delta : 0.f;
+        const float rho = A.rho[idx];
+        const float y = in ? rho * delta : 0.f;
         const float incl = wscan_incl(y, lane);
         const float pv = expf(-(carry + incl - y));
         carry += __shfl(incl, 63, 64);
@@ -306,39 +309,54 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const CompBwdArgs A)
 #pragma unroll
         for (int k = 0; k < 3; ++k) alb[k] += ps * A.col[idx * 3 + k];
         u += ps * A.sv[idx];
+        if (prior) {
+            const float ym = in ? (rho * tr + A.rho_prior[idx] * (1.f - tr)) * delta : 0.f;
+            const float inclm = wscan_incl(ym, lane);
+            const float pvm = expf(-(carry_m + inclm - ym));
+            carry_m += __shfl(inclm, 63, 64);
+            const float psm = in ? pvm * (1.f - expf(-ym)) : 0.f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) albm[k] += psm * A.col[idx * 3 + k];
+        }
     }
 #pragma unroll
-    for (int k = 0; k < 3; ++k) alb[k] = wsum(alb[k]);
+    for (int k = 0; k < 3; ++k) { alb[k] = wsum(alb[k]); albm[k] = wsum(albm[k]); }
     u = wsum(u);
     const float sv3 = sigmoid_t((u - 0.2f) * 30.f);
-    float dalb[3], dsky[3], dsv3 = 0.f;
+    float dalb[3], dalbm[3], dsky[3], dsv3 = 0.f;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const float F = sv3 + (1.f - sv3) * sky[k];
         const float g = A.g_rgb ? A.g_rgb[r * 3 + k] : 0.f;
+        const float gm = (prior && A.g_rgb_m) ? A.g_rgb_m[r * 3 + k] : 0.f;
         dalb[k] = g * F + (A.g_albedo ? A.g_albedo[r * 3 + k] : 0.f);
-        const float dF = g * alb[k];
+        dalbm[k] = gm * F + ((prior && A.g_albedo_m) ? A.g_albedo_m[r * 3 + k] : 0.f);
+        const float dF = g * alb[k] + gm * albm[k];
         dsv3 += dF * (1.f - sky[k]);
         dsky[k] = dF * (1.f - sv3);
     }
     const float du = dsv3 * sv3 * (1.f - sv3) * 30.f;
     if (lane == 0) { A.d_sky[r * 3] = dsky[0]; A.d_sky[r * 3 + 1] = dsky[1]; A.d_sky[r * 3 + 2] = dsky[2]; }
     // ---- pass 2: dPS, then dy_s = dPE_s*exp(-y_s) - sum_{k>s} dPV_k*PV_k  (suffix sums, chunks walked backwards)
-    float suffix = 0.f;           // sum over later chunks of dPV_k*PV_k
+    float suffix = 0.f, suffix_m = 0.f;
     const int nchunk = (S + 63) / 64;
-    // total prefix of y up to each chunk start: recompute forward carries
     for (int ch = nchunk - 1; ch >= 0; --ch) {
-        // prefix sum of y before this chunk
-        float pre = 0.f;
+        float pre = 0.f, pre_m = 0.f;          // prefix of y (and merged y) before this chunk
         for (int b2 = 0; b2 < ch; ++b2) {
             const int s2 = b2 * 64 + lane;
-            pre += (s2 < S) ? A.rho[r * S + s2] * delta : 0.f;
+            if (s2 < S) {
+                const float rr = A.rho[r * S + s2];
+                pre += rr * delta;
+                if (prior) pre_m += (rr * tr + A.rho_prior[r * S + s2] * (1.f - tr)) * delta;
+            }
         }
         pre = wsum(pre);
+        pre_m = wsum(pre_m);
         const int s = ch * 64 + lane;
         const bool in = s < S;
         const int64_t idx = r * S + (in ? s : S - 1);
-        const float y = in ? A.rho[idx] * delta : 0.f;
+        const float rho = A.rho[idx];
+        const float y = in ? rho * delta : 0.f;
         const float incl = wscan_incl(y, lane);
         const float pv = expf(-(pre + incl - y));
         const float ey = expf(-y);
@@ -352,17 +370,41 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const CompBwdArgs A)
         const float dpv_pv = in ? dps * pe * pv : 0.f;          // dPV_s * PV_s
         float dpe = in ? dps * pv : 0.f;
         if (in && A.g_pe) dpe += A.g_pe[idx];
-        // exclusive suffix sum within the chunk: sum_{k>s} = total - inclusive prefix
         const float incl2 = wscan_incl(dpv_pv, lane);
         const float tot = __shfl(incl2, 63, 64);
         const float later = suffix + (tot - incl2);
-        if (in) {
-            A.d_rho[idx] = (dpe * ey - later) * delta;
-            const float ps = pv * pe;
+        float d_rho = (dpe * ey - later) * delta;
+        float dc[3];
+        const float ps = pv * pe;
 #pragma unroll
-            for (int k = 0; k < 3; ++k) A.d_col[idx * 3 + k] = dalb[k] * ps;
-        }
+        for (int k = 0; k < 3; ++k) dc[k] = dalb[k] * ps;
         suffix += tot;
+        if (prior) {
+            const float ym = in ? (rho * tr + A.rho_prior[idx] * (1.f - tr)) * delta : 0.f;
+            const float inclm = wscan_incl(ym, lane);
+            const float pvm = expf(-(pre_m + inclm - ym));
+            const float eym = expf(-ym);
+            const float pem = 1.f - eym;
+            float dpsm = 0.f;
+            if (in) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) dpsm += dalbm[k] * A.col[idx * 3 + k];
+            }
+            const float dpvm_pvm = in ? dpsm * pem * pvm : 0.f;
+            const float incl3 = wscan_incl(dpvm_pvm, lane);
+            const float totm = __shfl(incl3, 63, 64);
+            const float later_m = suffix_m + (totm - incl3);
+            d_rho += tr * (dpsm * pvm * eym - later_m) * delta;
+            const float psm = pvm * pem;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) dc[k] += dalbm[k] * psm;
+            suffix_m += totm;
+        }
+        if (in) {
+            A.d_rho[idx] = d_rho;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) A.d_col[idx * 3 + k] = dc[k];
+        }
     }
 }
 hipError_t launch_composite_bwd(const CompBwdArgs& a, hipStream_t st) {

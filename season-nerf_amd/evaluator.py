@@ -59,10 +59,8 @@ class All_in_One_Eval:
         from .network import FUSED_WIDTHS
         if Network.training or Network.layer_width not in FUSED_WIDTHS:
             # batch-statistics BatchNorm + autograd, or a width without a fused kernel: layer-wise fp32 engine
-            if self.use_prior:
-                raise NotImplementedError("season_nerf_amd: train-mode eval with the DSM prior is not implemented yet")
             from . import training
-            return training.eval_train(self, data_dict, Network, train_mode)
+            return training.eval_train(self, data_dict, Network, train_mode, current_step)
         (top, bot, sun, tim) = Network._prep(*self._inputs(data_dict, Network))
         dev = top.device
         R, S, Cn = top.shape[0], self.args.n_samples, Network.n_classes
@@ -129,12 +127,10 @@ class All_in_One_Eval:
         """Eval_Tools_2.py:297-337 (no-prior branch): density + solar visibility along sun rays, end-point sampling.
         Keys: PE, PV_Exact, Solar_Vis, Sky_Col (raw, not sigmoided - T_NeRF_net_v2.py:154-157)."""
         self._check(Network)
-        if self.use_prior:
-            raise NotImplementedError("eval_Rho_Only with use_prior is not implemented by the HIP path yet")
         from .network import FUSED_WIDTHS
-        if Network.training or Network.layer_width not in FUSED_WIDTHS:
+        if Network.training or Network.layer_width not in FUSED_WIDTHS or self.use_prior:
             from . import training
-            return training.eval_rho_only_train(self, data_dict, Network, train_mode)
+            return training.eval_rho_only_train(self, data_dict, Network, train_mode, current_step)
         dev = self.device
         top, bot, sun = Network._prep(*[data_dict[k].to(dev) for k in ("Top", "Bot", "Sun_Angle")])
         R, S = top.shape[0], self.args.n_samples

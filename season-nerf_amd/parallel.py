@@ -52,3 +52,27 @@ class ShardedEval:
         n = data_dict["Top"].shape[0]
         out = self.eval_tool.eval(shard_dict(data_dict, rank, world), self.network, current_step, train_mode)
         return {k: gather_rows(out[k].contiguous(), n, self.group) for k in self.keys}
+
+
+def allreduce_gradients(module_or_params, group=None, average=True):
+    """Data-parallel training: sum (average) the gradients of all ranks in ONE flat bucket (3.3 MB at W=256, 12.8 MB at
+    W=512 - a single RCCL all-reduce over xGMI).  Works with any optimiser; parameters without a gradient on
+    this rank contribute zeros.  Each rank's loss is a mean over its own rays, so `average=True` reproduces the
+    global-batch mean when shards are equal.  Note: train-mode BatchNorm statistics stay per rank."""
+    params = list(module_or_params.parameters()) if hasattr(module_or_params, "parameters") else list(module_or_params)
+    params = [p for p in params if p.requires_grad]
+    if not params or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    if average:
+        flat /= dist.get_world_size(group)
+    off = 0
+    for p in params:
+        n = p.numel()
+        g = flat[off:off + n].view_as(p)
+        if p.grad is None:
+            p.grad = g.clone()
+        else:
+            p.grad.copy_(g)
+        off += n

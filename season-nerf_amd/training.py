@@ -101,12 +101,25 @@ class TrainEngine:
             pass
 
 
+def _composite(eng, top, bot, tv, rho, col, sv, sky, prior=None, trust=1.0, want=("pv", "pe", "ps")):
+    """snerf_composite_rays on [R,S,*] tensors; returns dict of requested outputs."""
+    R, S, dev = rho.shape[0], rho.shape[1], rho.device
+    e = lambda *s: torch.empty(*s, device=dev)
+    shapes = {"rgb": (R, 3), "albedo": (R, 3), "pv": (R, S, 1), "pe": (R, S, 1), "ps": (R, S, 1), "delta": (R, S, 1)}
+    o = {k: e(*shapes[k]) for k in want}
+    co = _lib.CompositeOut(**{"d_" + k: v.data_ptr() for k, v in o.items()})
+    _lib.check(eng.L.snerf_composite_rays(R, S, top.data_ptr(), bot.data_ptr(), tv.data_ptr(), rho.data_ptr(), col.data_ptr(),
+                                          sv.data_ptr(), sky.data_ptr(), 0, _ptr(prior), float(trust), C.byref(co), eng.stream()),
+               "composite_rays")
+    return o
+
+
 class _ImagePass(torch.autograd.Function):
     """T_NeRF.forward (train mode) + compositing on R rays; differentiable outputs: Rendered_Col, Albedo_Color,
-    Sky_Col (per ray), PE."""
+    Sky_Col (per ray), PE and - in the DSM-prior phase - Rendered_Col_Merged and the merged Albedo_Color."""
 
     @staticmethod
-    def forward(ctx, eng, top, bot, tv, sun, tim, train_bn, *params):
+    def forward(ctx, eng, top, bot, tv, sun, tim, train_bn, prior, *params):
         R, S, dev = eng.R, eng.S, eng.dev
         e = lambda *s: torch.empty(*s, device=dev)
         o = {"rgb": e(R, 3), "albedo": e(R, 3), "pv": e(R, S, 1), "pe": e(R, S, 1), "ps": e(R, S, 1), "delta": e(R, S, 1),
@@ -119,22 +132,38 @@ class _ImagePass(torch.autograd.Function):
         _lib.check(eng.L.snerf_trainer_forward_image(eng.h, R, S, top.data_ptr(), bot.data_ptr(), tv.data_ptr(), sun.data_ptr(),
                                                      tim.data_ptr(), 1 if train_bn else 0, 0, C.byref(co), o["sky"].data_ptr(),
                                                      o["cls"].data_ptr(), C.byref(fo), eng.stream()), "trainer_forward_image")
-        ctx.eng = eng
-        outs = (o["rgb"], o["albedo"], o["sky"], o["pe"], o["pv"], o["ps"], o["delta"], o["cls"], o["rho"], o["sv"], o["col"], o["pts"], o["adjc"])
-        ctx.mark_non_differentiable(*outs[4:])
+        ctx.eng, ctx.prior = eng, None
+        extra = {}
+        rgb_m, alb_m = e(0), e(0)
+        if prior is not None:                                    # Eval_Tools_2.py:218-248
+            net, trust = prior
+            rs = net.Supervised_Sample(o["pts"].reshape(-1, 3), o["delta"].reshape(-1, 1)).reshape(R, S, 1).float().contiguous()
+            sup = _composite(eng, top, bot, tv, rs, o["col"], o["sv"], o["sky"])
+            mer = _composite(eng, top, bot, tv, o["rho"], o["col"], o["sv"], o["sky"], prior=rs, trust=trust, want=("rgb", "albedo"))
+            rgb_m, alb_m = mer["rgb"], mer["albedo"]
+            rho_m = o["rho"] * trust + rs * (1 - trust)
+            mm = _composite(eng, top, bot, tv, rho_m, o["col"], o["sv"], o["sky"])
+            extra = {"PV_Supervised": sup["pv"], "PE_Supervised": sup["pe"], "PS_Supervised": sup["ps"], "PV_Merged": mm["pv"],
+                     "PE_Merged": mm["pe"], "PS_Merged": mm["ps"], "Rho_Merged": rho_m}
+            ctx.prior = (rs, float(trust))
+        ctx.extra_keys = list(extra.keys())
+        outs = (o["rgb"], o["albedo"], o["sky"], o["pe"], rgb_m, alb_m, o["pv"], o["ps"], o["delta"], o["cls"], o["rho"], o["sv"],
+                o["col"], o["pts"], o["adjc"]) + tuple(extra.values())
+        ctx.mark_non_differentiable(*outs[6:])
         return outs
 
     @staticmethod
-    def backward(ctx, g_rgb, g_albedo, g_sky, g_pe, *_):
+    def backward(ctx, g_rgb, g_albedo, g_sky, g_pe, g_rgb_m, g_alb_m, *_):
         eng = ctx.eng
         c = lambda g: g.contiguous() if g is not None else None
-        g_rgb, g_albedo, g_sky, g_pe = c(g_rgb), c(g_albedo), c(g_sky), c(g_pe)
-        if g_rgb is None:
-            g_rgb = torch.zeros(eng.R, 3, device=eng.dev)
+        g_rgb, g_albedo, g_sky, g_pe, g_rgb_m, g_alb_m = c(g_rgb), c(g_albedo), c(g_sky), c(g_pe), c(g_rgb_m), c(g_alb_m)
+        rs, trust = ctx.prior if ctx.prior is not None else (None, 1.0)
+        if rs is None:
+            g_rgb_m = g_alb_m = None
         eng.zero_grad()
-        _lib.check(eng.L.snerf_trainer_backward_image(eng.h, _ptr(g_rgb), _ptr(g_albedo), _ptr(g_sky), _ptr(g_pe), eng.stream()),
-                   "trainer_backward_image")
-        return (None,) * 7 + tuple(eng.grad_copies())
+        _lib.check(eng.L.snerf_trainer_backward_image(eng.h, _ptr(g_rgb), _ptr(g_albedo), _ptr(g_sky), _ptr(g_pe), _ptr(rs), trust,
+                                                      _ptr(g_rgb_m), _ptr(g_alb_m), eng.stream()), "trainer_backward_image")
+        return (None,) * 8 + tuple(eng.grad_copies())
 
 
 class _SolarPass(torch.autograd.Function):
@@ -145,13 +174,14 @@ class _SolarPass(torch.autograd.Function):
     def forward(ctx, eng, top, bot, tv, sun, train_bn, *params):
         R, S, dev = eng.Rs, eng.S, eng.dev
         e = lambda *s: torch.empty(*s, device=dev)
-        sv, pv, pe, sky_raw = e(R, S, 1), e(R, S, 1), e(R, S, 1), e(R, 3)
+        sv, pv, pe, sky_raw, rho, pts, dl = e(R, S, 1), e(R, S, 1), e(R, S, 1), e(R, 3), e(R, S, 1), e(R, S, 3), e(R, S, 1)
         _lib.check(eng.L.snerf_trainer_forward_solar(eng.h, R, S, top.data_ptr(), bot.data_ptr(), tv.data_ptr(), sun.data_ptr(),
                                                      1 if train_bn else 0, sv.data_ptr(), pv.data_ptr(), pe.data_ptr(),
-                                                     sky_raw.data_ptr(), eng.stream()), "trainer_forward_solar")
+                                                     sky_raw.data_ptr(), rho.data_ptr(), pts.data_ptr(), dl.data_ptr(), eng.stream()),
+                   "trainer_forward_solar")
         ctx.eng = eng
-        ctx.mark_non_differentiable(pv, pe, sky_raw)
-        return sv, pv, pe, sky_raw
+        ctx.mark_non_differentiable(pv, pe, sky_raw, rho, pts, dl)
+        return sv, pv, pe, sky_raw, rho, pts, dl
 
     @staticmethod
     def backward(ctx, g_sv, *_):
@@ -220,8 +250,9 @@ def _engine_for(net, R, Rs, S):
     return eng
 
 
-def eval_train(ev, data_dict, net, train_mode):
-    """`All_in_One_Eval.eval` with a network in .train() mode (batch-statistics BatchNorm), differentiable."""
+def eval_train(ev, data_dict, net, train_mode, current_step=0):
+    """`All_in_One_Eval.eval` on the layer-wise engine: a network in .train() mode (batch-statistics BatchNorm,
+    differentiable) or a width without a fused kernel (eval mode)."""
     dev = ev.device
     f = lambda k: data_dict[k].to(device=dev, dtype=torch.float32).contiguous()
     top, bot, sun, tim = f("Top"), f("Bot"), f("Sun_Angle"), f("Time_Encoded")
@@ -229,15 +260,26 @@ def eval_train(ev, data_dict, net, train_mode):
     n_solar = R if ev.args.Use_Solar else 0
     eng = _engine_for(net, R, n_solar, S)
     tv = sample_parameters(S, eval_mode=not train_mode).to(dev)
-    rgb, alb, sky, pe, pv, ps, dl, cls, rho, sv, col, pts, adjc = _ImagePass.apply(eng, top, bot, tv, sun, tim, net.training, *eng.param_list)
+    prior = (net, current_step / ev.n_steps) if ev.use_prior else None
+    res = _ImagePass.apply(eng, top, bot, tv, sun, tim, net.training, prior, *eng.param_list)
+    rgb, alb, sky, pe, rgb_m, alb_m, pv, ps, dl, cls, rho, sv, col, pts, adjc = res[:15]
     _after_train_forward(net)
     Cn = net.n_classes
-    return {"Rendered_Col": rgb, "PE": pe, "PV": pv, "PS": ps, "Solar_Vis": sv, "Sky_Col": sky.unsqueeze(1).expand(R, S, 3),
-            "Classes": cls.unsqueeze(1).expand(R, S, Cn), "Adjust": adjc, "Rho": rho, "Col": col, "Col_Adj": -1, "deltas": dl,
-            "sample_pts": pts, "Albedo_Color": alb}
+    sky_e = sky.unsqueeze(1).expand(R, S, 3)
+    out = {"Rendered_Col": rgb, "PE": pe, "PV": pv, "PS": ps, "Solar_Vis": sv, "Sky_Col": sky_e,
+           "Classes": cls.unsqueeze(1).expand(R, S, Cn), "Adjust": adjc, "Rho": rho, "Col": col, "Col_Adj": -1, "deltas": dl,
+           "sample_pts": pts, "Albedo_Color": alb}
+    if ev.use_prior:
+        keys = ["PV_Supervised", "PE_Supervised", "PS_Supervised", "PV_Merged", "PE_Merged", "PS_Merged", "Rho_Merged"]
+        out.update(dict(zip(keys, res[15:])))
+        sv3 = torch.sigmoid(((sv * ps).sum(1) - .2) * 30)
+        out["Rendered_Col_Supervised"] = ((out["PS_Supervised"] * col).sum(1) * (sv3 + (1 - sv3) * sky)).detach()
+        out["Rendered_Col_Merged"] = rgb_m
+        out["Albedo_Color"] = alb_m                               # the reference overwrites it with the merged one (:243)
+    return out
 
 
-def eval_rho_only_train(ev, data_dict, net, train_mode):
+def eval_rho_only_train(ev, data_dict, net, train_mode, current_step=0):
     dev = ev.device
     f = lambda k: data_dict[k].to(device=dev, dtype=torch.float32).contiguous()
     top, bot, sun = f("Top"), f("Bot"), f("Sun_Angle")
@@ -248,19 +290,28 @@ def eval_rho_only_train(ev, data_dict, net, train_mode):
             raise RuntimeError("season_nerf_amd: the sun-ray pass must follow an image pass of the same step with as many rays")
         eng = _engine_for(net, R, R, S)
     tv = sample_parameters(S, eval_mode=not train_mode, include_end_pt=True).to(dev)
-    sv, pv, pe, sky_raw = _SolarPass.apply(eng, top, bot, tv, sun, net.training, *eng.param_list)
+    sv, pv, pe, sky_raw, rho, pts, dl = _SolarPass.apply(eng, top, bot, tv, sun, net.training, *eng.param_list)
     _after_train_forward(net)
+    if ev.use_prior:                                              # Eval_Tools_2.py:319-334
+        trust = current_step / ev.n_steps
+        p2, d2 = pts.reshape(-1, 3), dl.reshape(-1, 1)
+        good = torch.all((p2 <= 1.) & (p2 >= -1.), 1)
+        rs = rho.reshape(-1, 1).clone()
+        rs[good] = net.Supervised_Sample(p2[good], d2[good]).float()
+        rho_m = (rho * trust + rs.reshape(R, S, 1) * (1 - trust)).contiguous()
+        z3 = torch.zeros(R, S, 3, device=dev)
+        m = _composite(eng, top, bot, tv, rho_m, z3, sv.detach().contiguous(), torch.zeros(R, 3, device=dev), want=("pv", "pe"))
+        pv, pe = m["pv"], m["pe"]
     return {"PE": pe, "PV_Exact": pv, "Solar_Vis": sv, "Sky_Col": sky_raw.unsqueeze(1).expand(R, S, 3)}
 
 
 def get_loss(ev, data_dict, net, current_step, train_mode):
-    """Eval_Tools_2.py:340-459 without the DSM prior: {name: [value, weight]}; total = sum value*weight."""
-    if ev.use_prior:
-        raise NotImplementedError("season_nerf_amd: get_loss with the DSM prior (use_prior=True) is not implemented yet")
+    """Eval_Tools_2.py:340-459: {name: [value, weight]}; total = sum value*weight (mg_run_NeRF.py:305)."""
     args, dev = ev.args, ev.device
     n_rays = data_dict["Top"].shape[0]
     Loss = {}
     weight = {"Color": 1.0, "Solar_Correction": args.sc_lambda, "Alpha_Adjust": 1.}
+    mse = lambda a, b: torch.mean((a - b) ** 2)
     out = ev.eval(data_dict, net, current_step, train_mode)
     if args.Use_Solar:
         starts, ends, vec, stime, _ = ev.solar_creation_tool(n_rays, include_times=True)
@@ -275,21 +326,35 @@ def get_loss(ev, data_dict, net, current_step, train_mode):
             x = (out["Sky_Col"] - .5) / .5
             pos = x[x > 0]
             sk = torch.sum(pos ** 2) / x.numel() if pos.shape[0] > 0 else torch.tensor(0., device=dev)
+            if ev.use_prior:
+                sk = sk.detach()
             Loss["Sky_Color_Var"] = [sk, weight["Solar_Correction"]]
             Loss["Albedo_Color"] = [alb_loss, weight["Solar_Correction"]]
     gt = data_dict["GT_Color"].to(dev)
+    col_key = "Rendered_Col_Merged" if (ev.use_prior and train_mode) else "Rendered_Col"
     if ev.use_MSE_loss:
-        Loss["Color"] = [torch.mean((out["Rendered_Col"] - gt) ** 2), weight["Color"]]
+        Loss["Color"] = [mse(out[col_key], gt), weight["Color"]]
+        if ev.use_prior:
+            Loss["Alpha_Adjust"] = [mse(out["PE"], out["PE_Supervised"].detach()), weight["Alpha_Adjust"]]
     else:
-        diff = out["Rendered_Col"] - gt
-        Loss["Color_ada"] = [torch.mean(ev.ada_loss.lossfun(diff)), weight["Color"]]
-        Loss["Color_alpha"] = [torch.mean(ev.ada_loss.alpha().detach()), 1.]
-        Loss["Color_width"] = [torch.mean(ev.ada_loss.scale().detach()), 1.]
-        scale = torch.mean(ev.ada_loss.scale().detach()) ** 2
+        diff = out["Rendered_Col"] - gt                           # the adaptive loss sees the un-merged colour (:422)
+        ada = ev.ada_loss[0] if ev.use_prior else ev.ada_loss
+        if ev.use_prior:
+            adiff = (out["PE"] - out["PE_Supervised"].detach()).reshape([-1, 1])
+            Loss["Alpha_Adjust_ada"] = [torch.mean(ev.ada_loss[1].lossfun(adiff)), weight["Alpha_Adjust"]]
+        Loss["Color_ada"] = [torch.mean(ada.lossfun(diff)), weight["Color"]]
+        Loss["Color_alpha"] = [torch.mean(ada.alpha().detach()), 1.]
+        Loss["Color_width"] = [torch.mean(ada.scale().detach()), 1.]
+        if ev.use_prior:
+            Loss["Alpha_Adjust"] = [mse(out["PE"], out["PE_Supervised"].detach()), weight["Alpha_Adjust"]]
+        scale = torch.mean(ada.scale().detach()) ** 2
         Loss["Solar_Correction"][1] = Loss["Solar_Correction"][1] / scale
         Loss["Solar_Correction_2"][1] = Loss["Solar_Correction_2"][1] / scale
+        if ev.use_prior:
+            Loss["Alpha_alpha"] = [torch.mean(ev.ada_loss[1].alpha().detach()), 1.]
+            Loss["Alpha_width"] = [torch.mean(ev.ada_loss[1].scale().detach()), 1.]
         with torch.no_grad():
-            Loss["Color"] = [torch.mean((out["Rendered_Col"] - gt) ** 2).detach(), weight["Color"]]
+            Loss["Color"] = [mse(out[col_key], gt).detach(), weight["Color"]]
     return Loss
 
 
@@ -313,5 +378,9 @@ class FusedAdam(torch.optim.Optimizer):
             if p.grad is not None:
                 _, off, num = eng.layout[k]
                 eng.grads[off:off + num].copy_(p.grad.reshape(-1))
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            # data parallel: ONE all-reduce of the flat gradient arena over RCCL/xGMI, then identical Adam on every rank
+            torch.distributed.all_reduce(eng.grads)
+            eng.grads /= torch.distributed.get_world_size()
         eng.adam_step(g["lr"], g["betas"], g["eps"])
         self.net._sig = None          # parameters changed outside torch's version counters: re-pack before inference

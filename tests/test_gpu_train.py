@@ -16,15 +16,16 @@ def T(a):
     return torch.tensor(np.asarray(a), dtype=torch.float32)
 
 
-def setup(golden_dir):
+def setup(golden_dir, name="train_W64_R32_S32.npz"):
     import season_nerf_amd as sn
-    g = dict(np.load(os.path.join(golden_dir, "train_W64_R32_S32.npz"), allow_pickle=False))
-    net = sn.T_NeRF(int(g["W"]), int(g["C"]))
+    g = dict(np.load(os.path.join(golden_dir, name), allow_pickle=False))
+    prior = "hm" in g
+    net = sn.T_NeRF(int(g["W"]), int(g["C"]), HM=g["hm"]) if prior else sn.T_NeRF(int(g["W"]), int(g["C"]))
     net.load_state_dict(orc.init_weights(int(g["W"]), int(g["C"]), int(g["seed"])))
     net = net.to("cuda").train()
     args = SimpleNamespace(n_samples=int(g["S"]), Use_Reg=True, Solar_Type_2=False, Use_MSE_loss=True, Use_Solar=True,
                            sc_lambda=float(g["sc_lambda"]), number_low_frequency_cases=4)
-    ev = sn.All_in_One_Eval(args, torch.device("cuda"), 10, False, None, np.eye(4), np.zeros(3))
+    ev = sn.All_in_One_Eval(args, torch.device("cuda"), int(g["n_steps"]), prior, None, np.eye(4), np.zeros(3))
     R = g["in_Top"].shape[0]
     solar = (T(g["solar_Top"]), T(g["solar_Bot"]), T(g["solar_Sun_Angle"]), torch.zeros(R, 4), None)
     ev.solar_creation_tool = lambda n, include_times=True: solar
@@ -34,15 +35,17 @@ def setup(golden_dir):
 
 def run_step(g, net, ev, data):
     torch.manual_seed(77 + int(g["seed"]))              # the reference's two t.rand(S) jitter draws
-    loss = ev.get_loss(data, net, 0, True)
+    loss = ev.get_loss(data, net, int(g["step"]), True)
     total = 0
     for k in loss:
         total = total + loss[k][0] * loss[k][1]
     return loss, total
 
 
-def test_train_step_vs_reference(golden_dir):
-    sn, g, net, ev, data = setup(golden_dir)
+@pytest.mark.parametrize("name", ["train_W64_R32_S32.npz", "train_prior_W64_R24_S40.npz"])
+def test_train_step_vs_reference(golden_dir, name):
+    """name 2: the DSM-prior phase (use_prior=True: supervised + merged composites, Alpha_Adjust loss)."""
+    sn, g, net, ev, data = setup(golden_dir, name)
     opt = torch.optim.Adam(net.parameters(), lr=float(g["lr"]))
     opt.zero_grad()
     loss, total = run_step(g, net, ev, data)

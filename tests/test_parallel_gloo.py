@@ -56,3 +56,30 @@ def test_shard_bounds():
             assert b[0][0] == 0 and b[-1][1] == n and all(b[i][1] == b[i + 1][0] for i in range(w - 1))
             sizes = [hi - lo for lo, hi in b]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _grad_worker(rank, world, port):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    par = _load_parallel()
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Linear(7, 3))
+    net[1].bias.requires_grad_(True)
+    x = torch.arange(20, dtype=torch.float32).reshape(4, 5) * (rank + 1)
+    net(x).sum().backward()
+    if rank == 1:
+        net[1].bias.grad = None                      # a parameter without gradient on one rank
+    local = [None if p.grad is None else p.grad.clone() for p in net.parameters()]
+    par.allreduce_gradients(net)
+    # expected: average of the two ranks' gradients (rank r input is (r+1) * x0 -> gradients known analytically)
+    gathered = [torch.zeros_like(p) if g is None else g for p, g in zip(net.parameters(), local)]
+    for p, g in zip(net.parameters(), gathered):
+        both = [torch.zeros_like(g) for _ in range(world)]
+        dist.all_gather(both, g)
+        assert torch.allclose(p.grad, sum(both) / world, rtol=1e-6, atol=1e-6)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_allreduce_gradients_two_ranks():
+    mp.spawn(_grad_worker, args=(2, 29500 + (os.getpid() + 777) % 2000), nprocs=2, join=True)

@@ -149,8 +149,11 @@ def gen_eval(W, seed, R, S, tag, with_prior):
     np.savez_compressed(os.path.join(OUT, f"eval_{tag}.npz"), **out)
 
 
-def gen_train(W, seed, R, S, tag):
-    net, sd0 = make_net(W, 4, seed, train=True)
+def gen_train(W, seed, R, S, tag, prior=False):
+    hm = None
+    if prior:
+        hm = np.random.Generator(np.random.PCG64(9)).uniform(-0.8, 0.6, (48, 48))
+    net, sd0 = make_net(W, 4, seed, hm=hm, train=True)
     data = synth_rays(R, 300 + seed)
     rng = np.random.Generator(np.random.PCG64(400 + seed))
     # explicit solar rays following the a11 law (Eval_Tools_2.py:72-108), drawn by OUR generator
@@ -163,20 +166,23 @@ def gen_train(W, seed, R, S, tag):
     solar = {"Top": tt(starts), "Bot": tt(ends), "Sun_Angle": tt(vec)}
     solar_time = tt(np.tile(encode_time(0.3, 0.1), (R, 1)))
 
-    ev = All_in_One_Eval(args_ns(S), torch.device("cpu"), 10, False, None, H4, WC)
+    ev = All_in_One_Eval(args_ns(S), torch.device("cpu"), 10, prior, None, H4, WC)
+    step = 3 if prior else 0
     ev.solar_creation_tool = lambda n, include_times=True: (solar["Top"], solar["Bot"], solar["Sun_Angle"], solar_time, az_el)
     torch.manual_seed(77 + seed)
     j1, j2 = torch.rand(S), torch.rand(S)
     torch.manual_seed(77 + seed)
     opt = torch.optim.Adam(net.parameters(), lr=10 ** -4.86)
     opt.zero_grad()
-    loss = ev.get_loss(data, net, 0, True)
+    loss = ev.get_loss(data, net, step, True)
     total = 0
     for k in loss:
         total = total + loss[k][0] * loss[k][1]
     total.backward()
     out = {"W": W, "C": 4, "seed": seed, "S": S, "lr": 10 ** -4.86, "sc_lambda": 0.03,
-           "jitter": f32(j1), "jitter_solar": f32(j2), "total": f32(total)}
+           "jitter": f32(j1), "jitter_solar": f32(j2), "total": f32(total), "step": step, "n_steps": 10}
+    if prior:
+        out["hm"] = hm
     for k, v in data.items():
         out["in_" + k] = f32(v)
     for k, v in solar.items():
@@ -267,6 +273,7 @@ if __name__ == "__main__":
     gen_eval(256, 0, 64, 96, "W256_R64_S96", with_prior=False)
     gen_eval(64, 1, 48, 64, "W64_R48_S64", with_prior=True)
     gen_train(64, 0, 32, 32, "W64_R32_S32")
+    gen_train(64, 1, 24, 40, "prior_W64_R24_S40", prior=True)
     gen_render(64, 2, "W64_s2")
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
