@@ -34,7 +34,11 @@ typedef const __attribute__((address_space(3))) u32x4 lds_cu32x4;
 typedef const __attribute__((address_space(3))) f32x4 lds_cf32x4;
 typedef const __attribute__((address_space(1))) void glb_void;
 
-constexpr int RING_D = 6;                       // ring slots (16 KiB each)
+#ifndef SNERF_RING_D
+#define SNERF_RING_D 7
+#endif
+constexpr int RING_D = SNERF_RING_D;            // ring slots (one chunk each)
+constexpr int DMA_PER_WAVE = kChunkBytes / kFragBytes / 4;   // 1 KiB pieces each wave moves per chunk
 constexpr int RING_BYTES = RING_D * kChunkBytes;
 constexpr int TILE_PTS = 128;                   // points per workgroup tile (4 waves x 32)
 
@@ -47,9 +51,6 @@ struct Ring {
     uint32_t wr;       // LDS offset of the slot the next DMA fills
     uint32_t cur;      // LDS offset of the chunk being consumed
     uint32_t goff;     // byte offset in the (cyclic) global stream of the next chunk to fetch
-#ifdef SNERF_ABLATE
-    uint32_t debug;
-#endif
 };
 
 __device__ __forceinline__ float sin2pi(float r) { return __builtin_amdgcn_sinf(r); }   // v_sin_f32: revolutions,
@@ -100,24 +101,28 @@ __device__ __forceinline__ void dma_chunk(const uint8_t* stream, uint32_t goff, 
     const uint32_t dst = (uint32_t)(uintptr_t)(lds + wr + wave * kFragBytes); // wave-uniform LDS byte address
     const uint32_t voff = lane * 16;
     uint32_t keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %2\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %3\n\t"
-        "s_add_u32 m0, m0, 0x1000\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %4\n\t"
-        "s_add_u32 m0, m0, 0x1000\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %5\n\t"
-        "s_add_u32 m0, m0, 0x1000\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %6\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(voff), "s"(dst), "s"(b0), "s"(b0 + 4 * kFragBytes), "s"(b0 + 8 * kFragBytes), "s"(b0 + 12 * kFragBytes)
-        : "memory", "scc");
+#pragma unroll
+    for (int part = 0; part < DMA_PER_WAVE / 4; ++part) {
+        const uint8_t* bp = b0 + part * 16 * kFragBytes;
+        asm volatile(
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %2\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %1, %3\n\t"
+            "s_add_u32 m0, m0, 0x1000\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %1, %4\n\t"
+            "s_add_u32 m0, m0, 0x1000\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %1, %5\n\t"
+            "s_add_u32 m0, m0, 0x1000\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %1, %6\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(voff), "s"(dst + part * 16 * kFragBytes), "s"(bp), "s"(bp + 4 * kFragBytes), "s"(bp + 8 * kFragBytes), "s"(bp + 12 * kFragBytes)
+            : "memory", "scc");
+    }
 }
 
 __device__ __forceinline__ uint32_t ring_next(uint32_t off) {
@@ -125,21 +130,17 @@ __device__ __forceinline__ uint32_t ring_next(uint32_t off) {
     return off == RING_BYTES ? 0u : off;
 }
 
-// Hand the next chunk to the consumers and refill the slot that was just released.
-//  - vmcnt((D-2)*4): all but the (D-2) youngest chunks this wave fetched have landed  => chunk `rd` is complete
-//    (the count is in DMA instructions of THIS wave; extra older loads/stores only make the wait stricter);
-//  - lgkmcnt(0) + s_barrier: every wave's pieces have landed and every wave has finished reading slot `wr`.
+// Hand the next chunk to the consumers and refill the slot released TWO chunks ago.
+//  - vmcnt((D-3)*DMA_PER_WAVE): all but the (D-3) youngest chunks this wave fetched have landed => chunk `rd` is complete
+//    (counted in DMA instructions of THIS wave; extra older loads/stores only make the wait stricter);
+//  - s_barrier: every wave's pieces of chunk `rd` have landed, and every wave has issued the MFMAs that consumed the
+//    chunk two steps back (its LDS reads are therefore complete) - so the refill needs no lgkmcnt drain, and the
+//    software-pipelined fragment reads of the previous chunk stay in flight across the barrier.
 __device__ __forceinline__ void ring_step(Ring& rg, const uint8_t* stream, uint32_t stream_bytes, lds_char* lds, int wave, int lane) {
 #if defined(SNERF_ABLATE) && (ABL & 4)     // timing-only: no ring at all
     return;
 #endif
-#ifdef SNERF_ABLATE      // timing-only ablation builds (tools/ablate.sh); results are garbage by construction
-    if (!(rg.debug & 2)) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((RING_D - 2) * 4) : "memory");
-    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (!(rg.debug & 1))
-#else
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((RING_D - 2) * 4) : "memory");
-#endif
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((RING_D - 3) * DMA_PER_WAVE) : "memory");
     dma_chunk(stream, rg.goff, lds, rg.wr, wave, lane);
     rg.goff += kChunkBytes;
     if (rg.goff >= stream_bytes) rg.goff = 0;
@@ -169,15 +170,26 @@ constexpr int PF = SNERF_PF;
 struct EpiTmp {
     float v0, v1, ha, hb;
 };
-__device__ __forceinline__ void epi_A(const f32x16& acc, const f32x4* biasq, int e, EpiTmp& t) {
+__device__ __forceinline__ void epi_A(const f32x16& acc, int e, EpiTmp& t) {
     const int i0 = 2 * e, i1 = 2 * e + 1;
 #if defined(SNERF_ABLATE) && (ABL & 8)      // timing-only: no transcendental
-    t.v0 = (acc[i0] + biasq[i0 >> 2][i0 & 3]) * 0.5f;
-    t.v1 = (acc[i1] + biasq[i1 >> 2][i1 & 3]) * 0.5f;
+    t.v0 = acc[i0] * 0.5f;
+    t.v1 = acc[i1] * 0.5f;
 #else
-    t.v0 = sin2pi(acc[i0] + biasq[i0 >> 2][i0 & 3]);
-    t.v1 = sin2pi(acc[i1] + biasq[i1 >> 2][i1 & 3]);
+    t.v0 = sin2pi(acc[i0]);                 // the bias is already in the accumulator (it was its initial value)
+    t.v1 = sin2pi(acc[i1]);
 #endif
+}
+// accumulator initialised with the layer bias: 4 ds_read_b128 straight into the accumulator registers, no VALU
+__device__ __forceinline__ f32x16 load_bias(lds_cfloat* bias_l, int b, int h) {
+    lds_cf32x4* bp = (lds_cf32x4*)(bias_l + b * 32 + h * 16);
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 t = bp[q];
+        acc[4 * q] = t[0]; acc[4 * q + 1] = t[1]; acc[4 * q + 2] = t[2]; acc[4 * q + 3] = t[3];
+    }
+    return acc;
 }
 __device__ __forceinline__ void epi_B(int e, EpiTmp& t, Frag* out2) {
     // compiler-generated VALU only: an inline-asm v_cvt_pk/v_sub here read stale v_sin results (wrong low parts,
@@ -221,16 +233,11 @@ __device__ __forceinline__ void run_layer(Ring& rg, const uint8_t* stream, uint3
         }
     }
     f32x16 accs[2];
-    f32x4 biasq[2][4];
     EpiTmp et[8];
+    f32x16 next_init = load_bias(bias_l, 0, h);
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
-        lds_cf32x4* bp = (lds_cf32x4*)(bias_l + b * 32 + h * 16);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) biasq[b & 1][i] = bp[i];
-        f32x16 acc;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        f32x16 acc = next_init;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             const int q = b * KS + s;
@@ -247,17 +254,20 @@ __device__ __forceinline__ void run_layer(Ring& rg, const uint8_t* stream, uint3
 #endif
             }
             acc = mfma3(a_hi, a_lo, s < KS0 ? in0[s] : in1[s - KS0], acc);
+            // next block's bias -> its accumulator, issued a few k-steps early (after the previous epilogue released
+            // the other accumulator buffer), so the LDS latency hides behind this block's last MFMAs
+            if (b + 1 < NB && s == (KS >= 4 ? KS - 1 : 0)) next_init = load_bias(bias_l, b + 1, h);
             if (SIN && b > 0) {
-                // previous block's epilogue: pair e runs phase A at step sA(e) = e*(KS-2)/8, B at sA+1, C at sA+2
+                // previous block's epilogue: pair e runs phase A at step sA(e) = e*(KS-3)/8, B at sA+1, C at sA+2
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     if (PIPE) {
-                        const int sA = (e * (KS - 2)) / 8;
+                        const int sA = 1 + (e * (KS - 4)) / 8;   // starts one k-step late: the block's last MFMA has retired
                         if (s == sA + 2) epi_C(e, et[e], out + 2 * (b - 1));
                         if (s == sA + 1) epi_B(e, et[e], out + 2 * (b - 1));
-                        if (s == sA) epi_A(accs[(b - 1) & 1], biasq[(b - 1) & 1], e, et[e]);
+                        if (s == sA) epi_A(accs[(b - 1) & 1], e, et[e]);
                     } else if (s == 0) {
-                        epi_A(accs[(b - 1) & 1], biasq[(b - 1) & 1], e, et[e]);
+                        epi_A(accs[(b - 1) & 1], e, et[e]);
                         epi_B(e, et[e], out + 2 * (b - 1));
                         epi_C(e, et[e], out + 2 * (b - 1));
                     }
@@ -280,18 +290,13 @@ __device__ __forceinline__ void run_layer(Ring& rg, const uint8_t* stream, uint3
     }
     if (SIN) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) epi_A(accs[(NB - 1) & 1], biasq[(NB - 1) & 1], e, et[e]);
+        for (int e = 0; e < 8; ++e) epi_A(accs[(NB - 1) & 1], e, et[e]);
 #pragma unroll
         for (int e = 0; e < 8; ++e) epi_B(e, et[e], out + 2 * (NB - 1));
 #pragma unroll
         for (int e = 0; e < 8; ++e) epi_C(e, et[e], out + 2 * (NB - 1));
     } else {
-        f32x16 acc = accs[0];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            acc[i] += biasq[0][0][i]; acc[4 + i] += biasq[0][1][i]; acc[8 + i] += biasq[0][2][i]; acc[12 + i] += biasq[0][3][i];
-        }
-        *raw = acc;
+        *raw = accs[0];
     }
 }
 
@@ -387,24 +392,21 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpArgs A) {
     // bias table -> LDS (once per workgroup)
     for (int i = threadIdx.x; i < A.bias_floats; i += 256) bias_lds[i] = A.bias[i];
 
-    // prologue: RING_D-1 chunks in flight
+    // prologue: RING_D-2 chunks in flight (the refill target trails the consumer by two slots)
     Ring rg;
     rg.rd = 0;
     rg.cur = 0;
     rg.goff = 0;
-#ifdef SNERF_ABLATE
-    rg.debug = A.debug;
-#endif
     {
         uint32_t wr = 0;
 #pragma unroll
-        for (int c = 0; c < RING_D - 1; ++c) {
+        for (int c = 0; c < RING_D - 2; ++c) {
             dma_chunk(A.stream, rg.goff, lds, wr, wave, lane);
             rg.goff += kChunkBytes;
             if (rg.goff >= A.stream_bytes) rg.goff = 0;
             wr += kChunkBytes;
         }
-        rg.wr = wr;   // = (RING_D-1)*chunk, the slot "before" slot 0
+        rg.wr = wr;   // = (RING_D-2)*chunk: at the step that publishes chunk k this is the slot of chunk k-2
     }
     __syncthreads();   // bias table visible (drains the prologue DMAs once; harmless)
 

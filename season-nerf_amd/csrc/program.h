@@ -22,8 +22,11 @@ namespace snerf {
 
 constexpr int kFragBytes = 1024;
 constexpr int kPairBytes = 2 * kFragBytes;
-constexpr int kChunkPairs = 8;
-constexpr int kChunkBytes = kChunkPairs * kPairBytes;   // 16 KiB
+#ifndef SNERF_CHUNK_PAIRS
+#define SNERF_CHUNK_PAIRS 8
+#endif
+constexpr int kChunkPairs = SNERF_CHUNK_PAIRS;
+constexpr int kChunkBytes = kChunkPairs * kPairBytes;   // 16 KiB (8 pairs) or 32 KiB (16 pairs)
 constexpr int kMaxClasses = 5;                           // 3*C adjust rows must fit the 16 rows one lane owns
 
 constexpr int PE_POS_N = 10, PE_SUN_N = 4, PE_TIME_N = 2;     // G_NeRF.py:7, T_NeRF_net_v2.py:36
