@@ -22,40 +22,56 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 constexpr int GBM = 128, GBN = 128, GBK = 16, GPAD = 4;
 
-// load a [rows x GBK] (K_CONTIG) or [GBK x rows] tile into k-major LDS: dst[k][r]
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+// A [rows x GBK] (K_CONTIG) or [GBK x rows] tile is moved in two phases (register staging, T14): `fetch` issues the
+// global loads of the NEXT tile before the MFMA block, `stash` writes them to the k-major LDS image dst[k][r] after it,
+// so HBM/L2 latency hides behind the matrix work.  8 elements per thread; 16-byte loads when the layout allows.
 template <bool K_CONTIG>
-__device__ __forceinline__ void load_tile(const float* __restrict__ P, int64_t sR, int64_t sK, int64_t r0, int64_t rows_total,
-                                          int64_t k0, int64_t k_total, float (*dst)[GBM + GPAD], int tid) {
-    // 128 x 16 elements, 256 threads, 8 per thread
+__device__ __forceinline__ void fetch_tile(const float* __restrict__ P, int64_t sR, int64_t sK, int64_t r0, int64_t rows_total,
+                                           int64_t k0, int64_t k_total, bool vec_ok, float (&v)[8], int tid) {
     if (K_CONTIG) {
-        // thread -> (row = tid/2, 8 consecutive k)
-        const int r = tid >> 1, kb = (tid & 1) * 8;
-        const int64_t gr = r0 + r;
+        const int r = tid >> 1, kb = (tid & 1) * 8;           // thread -> (row, 8 consecutive k)
+        const int64_t gr = r0 + r, gk = k0 + kb;
+        if (vec_ok && gr < rows_total && gk + 8 <= k_total) {
+            const f32x4* p = (const f32x4*)(P + gr * sR + gk);
+            const f32x4 a = p[0], b = p[1];
+            v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+        } else {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int64_t gk = k0 + kb + i;
-            float v = 0.f;
-            if (gr < rows_total && gk < k_total) v = P[gr * sR + gk * sK];
-            dst[kb + i][r] = v;
+            for (int i = 0; i < 8; ++i) v[i] = (gr < rows_total && gk + i < k_total) ? P[gr * sR + (gk + i) * sK] : 0.f;
         }
     } else {
-        // rows contiguous in memory: thread -> (k = tid/16, 8 consecutive rows)
-        const int k = tid >> 4, rb = (tid & 15) * 8;
-        const int64_t gk = k0 + k;
+        const int k = tid >> 4, rb = (tid & 15) * 8;          // thread -> (k, 8 consecutive rows)
+        const int64_t gk = k0 + k, gr = r0 + rb;
+        if (vec_ok && gk < k_total && gr + 8 <= rows_total) {
+            const f32x4* p = (const f32x4*)(P + gk * sK + gr);
+            const f32x4 a = p[0], b = p[1];
+            v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+        } else {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int64_t gr = r0 + rb + i;
-            float v = 0.f;
-            if (gr < rows_total && gk < k_total) v = P[gr * sR + gk * sK];
-            dst[k][rb + i] = v;
+            for (int i = 0; i < 8; ++i) v[i] = (gk < k_total && gr + i < rows_total) ? P[(gr + i) * sR + gk * sK] : 0.f;
         }
+    }
+}
+template <bool K_CONTIG>
+__device__ __forceinline__ void stash_tile(const float (&v)[8], float (*dst)[GBM + GPAD], int tid) {
+    if (K_CONTIG) {
+        const int r = tid >> 1, kb = (tid & 1) * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dst[kb + i][r] = v[i];
+    } else {
+        const int k = tid >> 4, rb = (tid & 15) * 8;
+        f32x4* d = (f32x4*)&dst[k][rb];                       // (GBM+GPAD)*4 and rb*4 are multiples of 16 bytes
+        d[0] = f32x4{v[0], v[1], v[2], v[3]};
+        d[1] = f32x4{v[4], v[5], v[6], v[7]};
     }
 }
 
 template <bool A_K_CONTIG, bool B_K_CONTIG>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
-    __shared__ float As[2][GBK][GBM + GPAD];
-    __shared__ float Bs[2][GBK][GBN + GPAD];
+    __shared__ __attribute__((aligned(16))) float As[2][GBK][GBM + GPAD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][GBK][GBN + GPAD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int r = lane & 31, h = lane >> 5;
@@ -64,6 +80,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
     const int64_t kchunk = (g.K + gridDim.z - 1) / gridDim.z;
     const int64_t kbeg = (int64_t)blockIdx.z * kchunk;
     const int64_t kend = kbeg + kchunk < g.K ? kbeg + kchunk : g.K;
+    // 16-byte loads need: unit stride along the vectorised axis (by construction), the other stride a multiple of 4,
+    // a 16-byte aligned base and a 4-aligned first index of this block
+    const bool a_vec = ((uintptr_t)g.A % 16 == 0) && ((A_K_CONTIG ? g.sAm : g.sAk) % 4 == 0) && ((A_K_CONTIG ? kbeg : m0) % 4 == 0);
+    const bool b_vec = ((uintptr_t)g.B % 16 == 0) && ((B_K_CONTIG ? g.sBn : g.sBk) % 4 == 0) && ((B_K_CONTIG ? kbeg : n0) % 4 == 0);
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -73,13 +93,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
     if (kbeg < kend) {
         int buf = 0;
-        load_tile<A_K_CONTIG>(g.A, g.sAm, g.sAk, m0, g.M, kbeg, kend, As[0], tid);
-        load_tile<B_K_CONTIG>(g.B, g.sBn, g.sBk, n0, g.N, kbeg, kend, Bs[0], tid);
+        float va[8], vb[8];
+        fetch_tile<A_K_CONTIG>(g.A, g.sAm, g.sAk, m0, g.M, kbeg, kend, a_vec, va, tid);
+        fetch_tile<B_K_CONTIG>(g.B, g.sBn, g.sBk, n0, g.N, kbeg, kend, b_vec, vb, tid);
+        stash_tile<A_K_CONTIG>(va, As[0], tid);
+        stash_tile<B_K_CONTIG>(vb, Bs[0], tid);
         __syncthreads();
         for (int64_t k0 = kbeg; k0 < kend; k0 += GBK) {
-            if (k0 + GBK < kend) {
-                load_tile<A_K_CONTIG>(g.A, g.sAm, g.sAk, m0, g.M, k0 + GBK, kend, As[buf ^ 1], tid);
-                load_tile<B_K_CONTIG>(g.B, g.sBn, g.sBk, n0, g.N, k0 + GBK, kend, Bs[buf ^ 1], tid);
+            const bool more = k0 + GBK < kend;
+            if (more) {
+                fetch_tile<A_K_CONTIG>(g.A, g.sAm, g.sAk, m0, g.M, k0 + GBK, kend, a_vec, va, tid);
+                fetch_tile<B_K_CONTIG>(g.B, g.sBn, g.sBk, n0, g.N, k0 + GBK, kend, b_vec, vb, tid);
             }
 #pragma unroll
             for (int kk = 0; kk < GBK; kk += 2) {
@@ -89,6 +113,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
                 acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
                 acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
                 acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            }
+            if (more) {
+                stash_tile<A_K_CONTIG>(va, As[buf ^ 1], tid);
+                stash_tile<B_K_CONTIG>(vb, Bs[buf ^ 1], tid);
             }
             __syncthreads();
             buf ^= 1;
