@@ -179,11 +179,15 @@ class ImgDict(dict):
     dev = None
 
 
-def _render_by_dir_device(net, view_el_az, sun_el_az, time_frac, out_img_size, W2C, W2L_H, device, include_exact_solar):
+def _render_by_dir_device(net, view_el_az, sun_el_az, time_frac, out_img_size, W2C, W2L_H, device, include_exact_solar,
+                          ray_range=None):
+    """ray_range=(lo, hi): render only rays lo..hi-1 of the row-major H*W grid (a rank's tile in a sharded render)."""
     Hh, Ww, S = out_img_size
     dev = torch.device(device)
     g = np.stack(np.meshgrid(np.linspace(1, -1, Hh), np.linspace(-1, 1, Ww), indexing="ij"), -1).reshape([-1, 2])
     g = np.concatenate([g, np.zeros([g.shape[0], 1])], 1)
+    if ray_range is not None:
+        g = g[ray_range[0]:ray_range[1]]
     v = world_angle_2_local_vec(view_el_az[0], view_el_az[1], W2C, W2L_H)
     sunv = world_angle_2_local_vec(sun_el_az[0], sun_el_az[1], W2C, W2L_H)
     top, bot = _f32(g + np.expand_dims(v / v[2], 0), dev), _f32(g - np.expand_dims(v / v[2], 0), dev)
@@ -310,14 +314,27 @@ def get_imgs_from_Img_Dict_t_step(Img_Dict, out_img_size: tuple, class_vecs_arra
 
 
 def render_season_sweep(the_network, view_el_az, sun_el_az, time_fracs, out_img_size: tuple, W2C, W2L_H, device,
-                        include_exact_solar=False, render_time_frac=None):
+                        include_exact_solar=False, render_time_frac=None, group=None, sharded=False):
     """BASELINE config 5 in one GPU pipeline: one component render + class vectors of all `time_fracs` + sweep kernel
     (what mg_merge_seasons.merge_season_walk does through the float64 host dict, mg_merge_seasons.py:270-273).
-    Returns a [T, H, W, 3] float32 tensor on the GPU."""
+    Returns a [T, H, W, 3] float32 tensor on the GPU.
+    sharded=True (one process per GPU, torch.distributed initialised): every rank renders a contiguous block of the
+    H*W rays and the [rays, T, 3] tiles are all-gathered over RCCL (BASELINE configs[4]); every rank gets the full sweep."""
     with torch.no_grad():
         tf0 = time_fracs[0] if render_time_frac is None else render_time_frac
-        d = _render_by_dir_device(the_network, view_el_az, sun_el_az, tf0, out_img_size, W2C, W2L_H, device, include_exact_solar)
+        n_total = out_img_size[0] * out_img_size[1]
+        rr = None
+        if sharded:
+            import torch.distributed as dist
+            from .parallel import shard_bounds
+            rr = shard_bounds(n_total, dist.get_world_size(group))[dist.get_rank(group)]
+        d = _render_by_dir_device(the_network, view_el_az, sun_el_az, tf0, out_img_size, W2C, W2L_H, device, include_exact_solar,
+                                  ray_range=rr)
         times = _f32(np.stack([encode_time(t) for t in time_fracs]), d["Rho"].device)
         cls = the_network.get_class_only(times)
         o = _sweep(d, cls.cpu().numpy(), "Exact_Solar" if include_exact_solar else "Est_Solar_Vis")
-        return o["shaded"].reshape(len(time_fracs), out_img_size[0], out_img_size[1], 3)
+        shaded = o["shaded"]                                                  # [T, rays(local), 3]
+        if sharded:
+            from .parallel import gather_rows
+            shaded = gather_rows(shaded.permute(1, 0, 2).contiguous(), n_total, group).permute(1, 0, 2).contiguous()
+        return shaded.reshape(len(time_fracs), out_img_size[0], out_img_size[1], 3)

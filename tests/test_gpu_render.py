@@ -91,3 +91,17 @@ def test_exact_solar_by_dir(setup):
     close("Exact_Solar", d["Exact_Solar"], g["exact_Exact_Solar"], rtol=1e-4, atol=2e-5)
     im = sn.get_imgs_from_Img_Dict(d, (4, 4, 24), False)
     assert "Shadow_Mask_Exact" in im
+
+
+def test_sharded_sweep_tiles_equal_full_render(setup):
+    """The per-rank tile of a sharded sweep (ray_range) is bit-identical to the same rays of the full render."""
+    sn, g, net, args = setup
+    from season_nerf_amd import render as R_
+    size = (12, 12, 48)
+    full = R_._render_by_dir_device(net, (80, 0), (30, 90), 0.25, size, g["WC"], g["H"], torch.device("cuda"), False)
+    parts = []
+    for lo, hi in sn.parallel.shard_bounds(144, 3):
+        d = R_._render_by_dir_device(net, (80, 0), (30, 90), 0.25, size, g["WC"], g["H"], torch.device("cuda"), False, ray_range=(lo, hi))
+        parts.append(R_._sweep(d, g["sweep_classes"], "Est_Solar_Vis")["shaded"])
+    whole = R_._sweep(full, g["sweep_classes"], "Est_Solar_Vis")["shaded"]
+    assert torch.equal(torch.cat(parts, 1), whole)
