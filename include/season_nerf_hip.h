@@ -182,6 +182,14 @@ int snerf_trainer_debug_read(snerf_trainer* t, const char* name, float* host_out
 /* torch.optim.Adam semantics (no weight decay) over the whole parameter arena in one launch; step counts from 1. */
 int snerf_trainer_adam_step(snerf_trainer* t, float lr, float beta1, float beta2, float eps, int step, void* stream);
 
+/* ---- ray table on the GPU: P_img_Pinhole.invert_P (pre_NeRF/P_Img.py:133-147) over the pixel grid of
+ * mg_Pt_holder.setup_quick_loader (mg_Pt_holder.py:178-194).  P_3x4: HOST pointer to the row-major 3x4 projective
+ * camera (12 doubles).  Pixel (i, j) of the rows x cols grid is image pixel (i*downscale, j*downscale).  Writes
+ * d_rows [rows*cols, 11] = Img_Pt(2) | Top(3, z=+1) | Bot(3, z=-1) | View(3) - the first 11 of the 22 training-row
+ * columns (mg_run_NeRF.py:122-133; sun, time, weight, colour are per-image constants / image data) - and
+ * d_valid [rows*cols] = 1 where Top and Bot lie inside [-1,1]^2 (the reference drops the others). */
+int snerf_rays_from_camera(const double* P_3x4, int rows, int cols, int downscale, float* d_rows, uint8_t* d_valid, void* stream);
+
 /* Name and launch geometry of the dominant kernel (for profiling scripts): fills grid/block/lds bytes. */
 int snerf_field_kernel_info(const snerf_model* m, int64_t n_points, int* grid, int* block, int* lds_bytes);
 

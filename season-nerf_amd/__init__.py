@@ -3,6 +3,7 @@ call boundary: `T_NeRF` (network), `All_in_One_Eval` (ray evaluator).  All arith
 `csrc/` through the C ABI of `include/season_nerf_hip.h`; importing this package never falls back to a CPU path."""
 from . import _lib
 from . import parallel
+from . import raytable
 from .training import FusedAdam, TrainEngine, create_solor_rays_uniform
 from .network import T_NeRF, SineLayer
 from .evaluator import All_in_One_Eval, sample_parameters
@@ -11,4 +12,4 @@ from .render import (Quick_Run_Net, component_render_by_dir, get_imgs_from_Img_D
 
 __all__ = ["T_NeRF", "SineLayer", "All_in_One_Eval", "sample_parameters", "Quick_Run_Net", "component_render_by_dir",
            "get_imgs_from_Img_Dict", "get_imgs_from_Img_Dict_t_step", "render_season_sweep", "world_angle_2_local_vec",
-           "encode_time", "parallel", "FusedAdam", "TrainEngine", "create_solor_rays_uniform", "_lib"]
+           "encode_time", "parallel", "raytable", "FusedAdam", "TrainEngine", "create_solor_rays_uniform", "_lib"]

@@ -292,6 +292,15 @@ int snerf_composite_sweep(int64_t n_rays, int n_samples, int n_classes, int n_ti
     return e == hipSuccess ? SNERF_OK : fail_hip(e, "sweep kernel launch");
 }
 
+int snerf_rays_from_camera(const double* P_3x4, int rows, int cols, int downscale, float* d_rows, uint8_t* d_valid, void* stream) {
+    if (!P_3x4 || rows < 0 || cols < 0 || downscale < 1 || !d_rows) return fail(SNERF_E_INVALID, "snerf_rays_from_camera: bad argument");
+    RayGenArgs a{};
+    for (int i = 0; i < 12; ++i) a.P[i] = P_3x4[i];
+    a.rows = rows; a.cols = cols; a.ds = downscale; a.rows_out = d_rows; a.valid = d_valid;
+    hipError_t e = launch_rays_from_camera(a, (hipStream_t)stream);
+    return e == hipSuccess ? SNERF_OK : fail_hip(e, "ray generation kernel launch");
+}
+
 int snerf_field_kernel_info(const snerf_model* m, int64_t n_points, int* grid, int* block, int* lds_bytes) {
     if (!m) return fail(SNERF_E_INVALID, "NULL model");
     int rc = pack_both(const_cast<snerf_model*>(m));

@@ -55,6 +55,14 @@ struct CompArgs {
     CompOutDev out;
 };
 
+struct RayGenArgs {
+    double P[12];          // row-major 3x4, normalised so that P[11] = 1 is NOT assumed
+    int rows, cols, ds;
+    float* rows_out;       // [rows*cols, 11]: img_pt 2 | top 3 | bot 3 | view 3
+    uint8_t* valid;        // [rows*cols] or NULL
+};
+hipError_t launch_rays_from_camera(const RayGenArgs& a, hipStream_t st);
+
 struct SweepArgs {
     int64_t n_rays;
     int n_samples, n_classes, n_times, flags;

@@ -766,6 +766,48 @@ hipError_t launch_sweep(const SweepArgs& a, hipStream_t st) {
 }
 
 // =====================================================================================================
+// ray table from a 3x4 projective camera (pre_NeRF/P_Img.py:133-147 `invert_P`, mg_Pt_holder.py:178-194): for every
+// pixel (i*DS, j*DS) of the down-scaled grid, the cube xy where its ray crosses z = +1 (Top) and z = -1 (Bot): a 2x2
+// solve in fp64 (as the reference), results rounded to fp32 rows [Img_Pt 2 | Top 3 | Bot 3 | View 3] + validity.
+__global__ void rays_from_camera_kernel(const RayGenArgs A) {
+    const int64_t n = (int64_t)A.rows * A.cols;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int pi = (int)(i / A.cols), pj = (int)(i - (int64_t)pi * A.cols);
+        const double row = (double)pi * A.ds, col = (double)pj * A.ds;
+        const double* P = A.P;
+        const double a11 = P[0] - P[8] * row, a12 = P[1] - P[9] * row, a21 = P[4] - P[8] * col, a22 = P[5] - P[9] * col;
+        const double den = a11 * a22 - a12 * a21;
+        double xy[2][2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const double hgt = k == 0 ? 1.0 : -1.0;
+            const double c2 = P[6] * hgt + P[7] - P[10] * hgt * col - P[11] * col;     // P23 h + P24 - P33 h y - P34 y
+            const double c1 = P[2] * hgt + P[3] - P[10] * hgt * row - P[11] * row;     // P13 h + P14 - P33 h x - P34 x
+            xy[k][0] = (a12 * c2 - a22 * c1) / den;
+            xy[k][1] = (-a11 * c2 + a21 * c1) / den;
+        }
+        const bool good = xy[0][0] <= 1.0 && xy[0][0] >= -1.0 && xy[0][1] <= 1.0 && xy[0][1] >= -1.0 &&
+                          xy[1][0] <= 1.0 && xy[1][0] >= -1.0 && xy[1][1] <= 1.0 && xy[1][1] >= -1.0;
+        if (A.valid) A.valid[i] = good ? 1 : 0;
+        float* o = A.rows_out + i * 11;
+        o[0] = (float)pi; o[1] = (float)pj;
+        o[2] = (float)xy[0][0]; o[3] = (float)xy[0][1]; o[4] = 1.f;
+        o[5] = (float)xy[1][0]; o[6] = (float)xy[1][1]; o[7] = -1.f;
+        const double vx = xy[1][0] - xy[0][0], vy = xy[1][1] - xy[0][1], vz = -2.0;       // view = (bot - top) / |bot - top|
+        const double vn = sqrt(vx * vx + vy * vy + vz * vz);
+        o[8] = (float)(vx / vn); o[9] = (float)(vy / vn); o[10] = (float)(vz / vn);
+    }
+}
+hipError_t launch_rays_from_camera(const RayGenArgs& a, hipStream_t st) {
+    const int64_t n = (int64_t)a.rows * a.cols;
+    if (n <= 0) return hipSuccess;
+    int64_t b = (n + 255) / 256;
+    if (b > 65536) b = 65536;
+    hipLaunchKernelGGL(rays_from_camera_kernel, dim3((unsigned)b), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+// =====================================================================================================
 // launchers
 template <int PROG, int W, int VARIANT>
 static hipError_t launch_mlp_t(const MlpArgs& a, int n_cu, hipStream_t st) {

@@ -105,3 +105,35 @@ def test_sharded_sweep_tiles_equal_full_render(setup):
         parts.append(R_._sweep(d, g["sweep_classes"], "Est_Solar_Vis")["shaded"])
     whole = R_._sweep(full, g["sweep_classes"], "Est_Solar_Vis")["shaded"]
     assert torch.equal(torch.cat(parts, 1), whole)
+
+
+def test_ray_table_from_camera(golden_dir):
+    """On-GPU invert_P / ray-table rows vs the reference's invert_P golden and the oracle's restatement."""
+    import season_nerf_amd as sn
+    g = dict(np.load(os.path.join(golden_dir, "micro.npz"), allow_pickle=False))
+    P = g["P"]
+    rows, valid = sn.raytable.rays_from_camera(P, 2000, 1501, downscale=1)
+    rows = rows.cpu().numpy().reshape(2000, 1501, 11)
+    for r, c, x, y in zip(g["invP_row"], g["invP_col"], g["invP_x"], g["invP_y"]):
+        # golden: invert_P(row, col, h=0.4); a point at height 0.4 lies on the segment Top(z=1)..Bot(z=-1) at t=0.3
+        top, bot = rows[int(r), int(c), 2:5], rows[int(r), int(c), 5:8]
+        p = top * 0.7 + bot * 0.3
+        np.testing.assert_allclose(p[:2], [x, y], rtol=2e-6, atol=2e-6)
+    # a camera whose rays stay in the cube: full table vs the oracle, validity mask, view vectors, 22-column rows
+    P2 = np.array([[47., 1.0, -6.0, 48.], [-0.8, 39., 5.5, 40.], [0.002, -0.001, 0.01, 1.0]])
+    H, W, DS = 96, 80, 2
+    img = np.random.default_rng(0).uniform(0, 1, (H, W, 3)).astype(np.float32)
+    tab = sn.raytable.ray_table(P2, img, [0.1, 0.2, 0.97], [1, 0, 0.5, 0.5], downscale=DS, weight=0.7)
+    ii, jj = np.meshgrid(np.arange(H // DS), np.arange(W // DS), indexing="ij")
+    xt, yt, _ = orc.invert_P(P2, ii.ravel() * DS, jj.ravel() * DS, 1.0)
+    xb, yb, _ = orc.invert_P(P2, ii.ravel() * DS, jj.ravel() * DS, -1.0)
+    good = (np.abs(xt) <= 1) & (np.abs(yt) <= 1) & (np.abs(xb) <= 1) & (np.abs(yb) <= 1)
+    assert 0 < good.sum() and tab.shape == (good.sum(), 22)
+    d = sn.raytable.data_to_dict(tab)
+    np.testing.assert_allclose(d["Top"].cpu().numpy(), np.stack([xt, yt, np.ones_like(xt)], 1)[good].astype(np.float32), rtol=0, atol=0)
+    np.testing.assert_allclose(d["Bot"].cpu().numpy(), np.stack([xb, yb, -np.ones_like(xb)], 1)[good].astype(np.float32), rtol=0, atol=0)
+    v = np.stack([xb - xt, yb - yt, -2 * np.ones_like(xt)], 1)[good]
+    np.testing.assert_allclose(d["View_Angle"].cpu().numpy(), v / np.linalg.norm(v, axis=1, keepdims=True), rtol=1e-6, atol=1e-7)
+    ij = d["Img_Pt"].cpu().numpy().astype(int)
+    np.testing.assert_array_equal(d["GT_Color"].cpu().numpy(), img[ij[:, 0] * DS, ij[:, 1] * DS])
+    assert float(d["Sample_Weight"][0]) == pytest.approx(0.7) and d["Time_Encoded"].shape[1] == 4
