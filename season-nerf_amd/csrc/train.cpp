@@ -6,6 +6,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -59,6 +60,8 @@ struct snerf_trainer {
     } img, sol;
     Act dA, dB, dX1;
     float *d_head, *d_adj, *d_rho, *d_col, *d_sky, *d_cls, *d_sv_raw, *rayA, *rayB, *bn_bwd;   // bn_bwd: [2][W]
+    uint16_t *w_hi = nullptr, *w_lo = nullptr;      // scratch for the bf16 hi/lo split of one weight matrix
+    int gemm_mode = 1;                              // 1 = bf16x3 MFMA for forward/dgrad (default), 0 = exact fp32 MFMA everywhere
 };
 
 static int64_t align64(int64_t x) { return (x + 63) / 64 * 64; }
@@ -157,6 +160,9 @@ static size_t carve(snerf_trainer* t, char* base, int64_t R, int64_t Rs, int S) 
     t->d_sky = c.take(Rmax * 3); t->d_cls = c.take(Rmax * C); t->d_sv_raw = c.take(Nmax);
     t->rayA = c.take(Rmax * W); t->rayB = c.take(Rmax * W);
     t->bn_bwd = c.take(2 * W);
+    const int64_t wmax = (int64_t)(W + 64) * (W + 96);      // [rows <= W+63][kp <= W+96] bf16 = half as many floats
+    t->w_hi = (uint16_t*)c.take((wmax + 1) / 2);
+    t->w_lo = (uint16_t*)c.take((wmax + 1) / 2);
     return c.off;
 }
 
@@ -170,6 +176,15 @@ static size_t carve(snerf_trainer* t, char* base, int64_t R, int64_t Rs, int S) 
 // Z[M, n_out] = alpha * (In[M, K] W^T + b);  colsum optional
 static hipError_t linear_fwd(snerf_trainer* t, const LayerP& L, const float* In, int64_t ld_in, int64_t M, float* Z, int64_t ldz,
                              float alpha, float* colsum, hipStream_t st) {
+    if (t->gemm_mode == 1 && M >= 1024 && L.n_in >= 16 && L.n_out >= 16) {
+        const int kp = (L.n_in + 31) / 32 * 32;
+        hipError_t e = launch_split_weights(t->params + L.w, L.n_out, L.n_in, false, t->w_hi, t->w_lo, L.n_out, kp, st);
+        if (e != hipSuccess) return e;
+        GemmX x{};
+        x.A = In; x.Bh = t->w_hi; x.Bl = t->w_lo; x.C = Z; x.M = M; x.N = L.n_out; x.K = L.n_in; x.lda = ld_in; x.ldc = ldz;
+        x.kp = kp; x.alpha = alpha; x.bias = t->params + L.b; x.colsum = colsum; x.accumulate = 0;
+        return launch_gemm_bf16x3(x, st);
+    }
     GemmArgs g{};
     g.A = In; g.B = t->params + L.w; g.C = Z;
     g.M = M; g.N = L.n_out; g.K = L.n_in;
@@ -180,6 +195,16 @@ static hipError_t linear_fwd(snerf_trainer* t, const LayerP& L, const float* In,
 // dIn[M, n_cols] (+)= alpha * dZ[M, n_out] W[:, :n_cols]
 static hipError_t linear_dgrad(snerf_trainer* t, const LayerP& L, const float* dZ, int64_t ldz, int64_t M, float* dIn, int64_t ld_in,
                                int n_cols, float alpha, bool accumulate, hipStream_t st) {
+    if (t->gemm_mode == 1 && M >= 1024 && L.n_out >= 16 && n_cols >= 16) {
+        const int kp = (L.n_out + 31) / 32 * 32;
+        // Bt[n = input feature][k = output feature] = W[k][n]: transposed split
+        hipError_t e = launch_split_weights(t->params + L.w, L.n_out, L.n_in, true, t->w_hi, t->w_lo, n_cols, kp, st);
+        if (e != hipSuccess) return e;
+        GemmX x{};
+        x.A = dZ; x.Bh = t->w_hi; x.Bl = t->w_lo; x.C = dIn; x.M = M; x.N = n_cols; x.K = L.n_out; x.lda = ldz; x.ldc = ld_in;
+        x.kp = kp; x.alpha = alpha; x.bias = nullptr; x.colsum = nullptr; x.accumulate = accumulate ? 1 : 0;
+        return launch_gemm_bf16x3(x, st);
+    }
     GemmArgs g{};
     g.A = dZ; g.B = t->params + L.w; g.C = dIn;
     g.M = M; g.N = n_cols; g.K = L.n_out;
@@ -341,6 +366,7 @@ snerf_trainer* snerf_trainer_create(int layer_width, int n_classes) {
     }
     snerf_trainer* t = new snerf_trainer();
     t->W = layer_width; t->C = n_classes; t->W2 = layer_width / 2; t->W4 = layer_width / 4;
+    if (const char* e = getenv("SNERF_TRAIN_GEMM")) t->gemm_mode = std::strcmp(e, "fp32") == 0 ? 0 : 1;
     build_layers(t);
     return t;
 }

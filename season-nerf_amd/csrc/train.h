@@ -21,6 +21,21 @@ struct GemmArgs {
 };
 hipError_t launch_gemm(const GemmArgs& g, hipStream_t st);
 
+// bf16x3 NT GEMM (forward and dgrad of the training engine): C (+)= alpha*(A Bt^T + bias), Bt pre-split by launch_split_weights
+struct GemmX {
+    const float* A;            // [M, lda] fp32, k contiguous
+    const uint16_t *Bh, *Bl;   // [>= N rows, kp] bf16 hi / lo, zero padded
+    float* C;
+    int64_t M, N, K, lda, ldc;
+    int kp;
+    float alpha;
+    const float* bias;
+    float* colsum;
+    int accumulate;
+};
+hipError_t launch_split_weights(const float* W, int rows, int cols, bool transpose, uint16_t* hi, uint16_t* lo, int out_rows, int kp, hipStream_t st);
+hipError_t launch_gemm_bf16x3(const GemmX& g, hipStream_t st);
+
 // ---- elementwise / reduction kernels of the training path (train_kernels.hip)
 struct PeArgs {            // positions (from rays or explicit) -> PE(pos) [N,64] (63 features + zero pad) and points [N,3]
     int64_t n;

@@ -84,7 +84,11 @@ def test_train_step_vs_reference(golden_dir, name):
         if np.abs(g["grad_" + n]).max() < 1e-3 * gmax:
             continue
         got = params[n].detach().cpu().numpy() - before[n]
-        np.testing.assert_allclose(got, g["adam_" + n] - before[n], atol=0.05 * float(g["lr"]) + 1e-9, err_msg=n)
+        # the first Adam step is -lr*g/(|g|+eps) ~ -lr*sign(g): an element whose gradient is below the gradient tolerance
+        # may land anywhere in [-lr, lr], so the update is compared where the sign is determined
+        sure = np.abs(g["grad_" + n]) > 2e-3 * max(np.abs(g["grad_" + n]).max(), 1e-3 * gmax)
+        np.testing.assert_allclose(got[sure], (g["adam_" + n] - before[n])[sure], atol=0.05 * float(g["lr"]) + 1e-9, err_msg=n)
+        assert np.abs(got).max() <= 1.01 * float(g["lr"])
 
 
 def test_fused_adam_matches_torch_adam(golden_dir):
