@@ -64,68 +64,107 @@ def cpu_baseline():
 
 
 def bench_train(a):
-    """BASELINE configs[2]: training step = zero_grad, get_loss (image rays + R random sun rays, train-mode BatchNorm),
-    backward, fused Adam; MSE colour loss (Barron's loss is an unpinned third-party dependency)."""
+    """BASELINE configs[2]: training step = zero_grad, get_loss (image rays + R random sun rays, train-mode BatchNorm,
+    Barron adaptive colour loss by default - `--loss mse` selects the reference's other colour loss, the one whose gradients
+    are pinned against the reference), backward, gradient all-reduce over RCCL when N > 1, fused Adam."""
     from types import SimpleNamespace
     import season_nerf_amd as sn
     from oracle import season_nerf_oracle as orc
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
     dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    if a.gpus > 1 and world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} needs torch.distributed.run with {a.gpus} ranks (WORLD_SIZE={world})")
     torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
     steps, warm = min(a.steps, 20), min(a.warmup, 3)
     net = sn.T_NeRF(W, NC)
     net.load_state_dict(orc.init_weights(W, NC, 0, bn_stats="identity"))
     net = net.to(dev).train()
-    args = SimpleNamespace(n_samples=S, Use_Reg=True, Solar_Type_2=False, Use_MSE_loss=True, Use_Solar=True, sc_lambda=0.03,
+    barron = a.loss == "barron"
+    args = SimpleNamespace(n_samples=S, Use_Reg=True, Solar_Type_2=False, Use_MSE_loss=not barron, Use_Solar=True, sc_lambda=0.03,
                            number_low_frequency_cases=NC)
     WC, H4 = np.array([41.29, -95.9, 300.0]), np.array([[310.0, 12.0, 0.0, -11650.0], [-9.0, 240.0, 0.0, 23390.0], [0.0, 0.0, 0.01, -3.0], [0, 0, 0, 1.0]])
-    ev = sn.All_in_One_Eval(args, dev, 10, False, None, H4, WC)
-    d = synth(0, dev)
+    # Net_Tool_2.py:69: the colour loss object of the un-guided phase
+    ada = sn.AdaptiveLossFunction(3, torch.float32, dev, alpha_hi=2.99, alpha_init=2.0, scale_init=0.03, scale_lo=0.01) if barron else None
+    ev = sn.All_in_One_Eval(args, dev, 10, False, ada, H4, WC)
+    d = synth(rank, dev)
     d["GT_Color"] = torch.rand(R, 3, device=dev)
     opt = sn.FusedAdam(net, lr=10 ** -4.86)
-    np.random.seed(0)
-    torch.manual_seed(0)
+    opt_ada = torch.optim.Adam(ada.parameters(), lr=10 ** -4.86) if barron else None      # Net_Tool_2.py:115 (second Adam)
+    np.random.seed(rank)
+    torch.manual_seed(rank)
 
     def step():
         opt.zero_grad()
+        if opt_ada is not None:
+            opt_ada.zero_grad()
         loss = ev.get_loss(d, net, 0, True)
         total = sum(v * w for v, w in loss.values())
         total.backward()
-        opt.step()
+        opt.step()                       # all-reduces the flat gradient arena when torch.distributed is initialised
+        if opt_ada is not None:
+            if world > 1:
+                for p_ in ada.parameters():
+                    dist.all_reduce(p_.grad)
+                    p_.grad /= world
+            opt_ada.step()
         return total
 
     for _ in range(warm):
         step()
+    if world > 1:
+        dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
         tot = step()
+    if world > 1:
+        dist.barrier()
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    dt /= steps
     # algorithmic FLOPs (SURVEY 8d): image rays 3 x forward; sun rays: trunk+heads+solar forward + 3 x solar/sky heads
     flop = R * S * (3 * FLOP_PER_SAMPLE + 2 * (524800 + 3 * 54656))
-    out = {"metric": "training image-ray-samples/s (4096 rays x 96 samples + 4096 sun rays, MSE loss, fused Adam)",
-           "value": R * S / dt, "unit": "ray-samples/s", "n_gpus": 1, "steps": steps, "warmup": warm, "ms_per_step": dt * 1e3,
-           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 (exact-fp32 MFMA)", "data": "synthetic",
-           "config": {"workload": "BASELINE configs[2]: training step 4096x96, T_NeRF(256,4) train-mode BatchNorm, solar branch on, MSE loss"},
-           "final_loss": float(tot),
-           "roofline": {"bound": "mfma", "achieved": flop / dt / 1e12, "peak": 157.3, "unit": "TFLOP/s", "frac": flop / dt / 157.3e12,
-                        "traffic": None, "note": "layer-wise fp32 path; peak = fp32 matrix (MI355X_MICROARCH.md); whole step, not one kernel"}}
-    if not a.no_cpu_baseline:
-        torch.set_num_threads(min(os.cpu_count() or 1, 32))
-        sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in orc.init_weights(W, NC, 0, bn_stats="identity").items()}
-        n = 256
-        dc = {k: v[:n].cpu() for k, v in d.items()}
-        rng = np.random.Generator(np.random.PCG64(1))
-        st = torch.tensor(np.concatenate([rng.uniform(-1, 1, (n, 2)), np.ones((n, 1))], 1), dtype=torch.float32)
-        vv = dc["Sun_Angle"]
-        solar = {"Top": st, "Bot": st - 2 * vv / vv[:, 2:], "Sun_Angle": vv}
-        t0 = time.perf_counter()
-        loss, _ = orc.get_loss_mse(sd, dc, solar, S, 0.03, True, True)
-        orc.total_loss(loss).backward()
-        tc = time.perf_counter() - t0
-        out["cpu_baseline"] = {"value": n * S / tc, "unit": "ray-samples/s", "cores": torch.get_num_threads(), "kind": "port",
-                               "sample": f"one MSE training step (forward both passes + backward) on {n} rays x {S} samples, torch-CPU oracle"}
-    print(json.dumps(out))
+    lname = "Barron adaptive loss" if barron else "MSE loss"
+    gemm = os.environ.get("SNERF_TRAIN_GEMM", "bf16x3")
+    if rank == 0:
+        out = {"metric": f"training image-ray-samples/s (4096 rays x 96 samples + 4096 sun rays per GPU, {lname}, fused Adam)",
+               "value": world * R * S / dt, "unit": "ray-samples/s", "n_gpus": world, "steps": steps, "warmup": warm, "ms_per_step": dt * 1e3,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f32 storage; forward/dgrad GEMMs " + ("bf16x3 split MFMA" if gemm != "fp32" else "fp32 MFMA") + ", wgrad fp32 MFMA",
+               "data": "synthetic",
+               "config": {"workload": f"BASELINE configs[2]: training step 4096x96, T_NeRF(256,4) train-mode BatchNorm, solar branch on, {lname}",
+                          "parallelism": f"rays sharded over {world} GPU(s), one all-reduce of the flat gradient arena, BatchNorm statistics per rank"},
+               "final_loss": float(tot),
+               "roofline": {"bound": "mfma", "achieved": flop / dt / 1e12, "peak": 157.3, "unit": "TFLOP/s", "frac": flop / dt / 157.3e12,
+                            "traffic": None, "note": "layer-wise path, whole step (not one kernel) priced against the fp32 matrix peak "
+                                                     "(MI355X_MICROARCH.md); per-kernel times in profiles/r1"}}
+        if not a.no_cpu_baseline:
+            torch.set_num_threads(min(os.cpu_count() or 1, 32))
+            sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in orc.init_weights(W, NC, 0, bn_stats="identity").items()}
+            n = 256
+            dc = {k: v[:n].cpu() for k, v in d.items()}
+            rng = np.random.Generator(np.random.PCG64(1))
+            st = torch.tensor(np.concatenate([rng.uniform(-1, 1, (n, 2)), np.ones((n, 1))], 1), dtype=torch.float32)
+            vv = dc["Sun_Angle"]
+            solar = {"Top": st, "Bot": st - 2 * vv / vv[:, 2:], "Sun_Angle": vv}
+            t0 = time.perf_counter()
+            loss, _ = orc.get_loss_mse(sd, dc, solar, S, 0.03, True, True)
+            orc.total_loss(loss).backward()
+            tc = time.perf_counter() - t0
+            out["cpu_baseline"] = {"value": n * S / tc, "unit": "ray-samples/s", "cores": torch.get_num_threads(), "kind": "port",
+                                   "sample": f"one MSE training step (forward both passes + backward) on {n} rays x {S} samples, torch-CPU oracle"}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def main():
@@ -135,7 +174,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", default="render", choices=["render", "train"],
-                    help="render = headline (BASELINE configs[1]); train = configs[2]: one MSE training step, 4096x96 + 4096 sun rays")
+                    help="render = headline (BASELINE configs[1]); train = configs[2]: one training step, 4096x96 + 4096 sun rays")
+    ap.add_argument("--loss", default="barron", choices=["barron", "mse"], help="colour loss of --workload train")
     a = ap.parse_args()
     if a.workload == "train":
         return bench_train(a)

@@ -190,6 +190,23 @@ int snerf_trainer_adam_step(snerf_trainer* t, float lr, float beta1, float beta2
  * d_valid [rows*cols] = 1 where Top and Bot lie inside [-1,1]^2 (the reference drops the others). */
 int snerf_rays_from_camera(const double* P_3x4, int rows, int cols, int downscale, float* d_rows, uint8_t* d_valid, void* stream);
 
+/* ---- DSM prior and validation helpers: the gathers the reference runs on the CPU between passes.
+ * snerf_prior_density = T_NeRF.Supervised_Sample (T_NeRF_net_v2.py:175-181): rho = -log(1 - min(HM[ix,iy] >= z, .99)) / delta
+ *   with (ix,iy) = trunc((xy+1)/2 * (shape-1)); d_height_map is the float64 [rows,cols] array the module is built with.
+ *   d_outside (optional, [n]) supplies the value for points outside [-1,1]^3 (eval_Rho_Only keeps the network's own
+ *   density there, Eval_Tools_2.py:321-326); with NULL every point must lie inside the cube.
+ * snerf_surface_distance = Net_tool.get_Dist for one DSM (mg_run_NeRF.py:106-120): the expected distance along each ray
+ *   to the first cell of the dense occupancy volume (DSM >= linspace(-1,1,S)[k], NaN cells kept: mg_run_NeRF.py:55-61);
+ *   d_levels is that linspace in float64, d_tvals the eval-mode sample parameters; float64 [R] out (NaN = no surface).
+ * snerf_image_error = the colour error sums of eval_img (mg_run_NeRF.py:204-208), accumulated into d_sums[3]:
+ *   sum log(1/2 (gt-img)^2 + 1), sum (gt-img)^2, 3 * #pixels with any(gt != 0).  The caller zeroes d_sums. */
+int snerf_prior_density(int64_t n_points, const float* d_points, const float* d_delta, const double* d_height_map,
+                        int hm_rows, int hm_cols, const float* d_outside, float* d_rho_prior, void* stream);
+int snerf_surface_distance(int64_t n_rays, int n_samples, const float* d_top, const float* d_bot, const float* d_tvals,
+                           const double* d_dsm, int dsm_rows, int dsm_cols, const double* d_levels, double* d_dist,
+                           void* stream);
+int snerf_image_error(int64_t n_pixels, const float* d_image, const float* d_gt, double* d_sums, void* stream);
+
 /* Name and launch geometry of the dominant kernel (for profiling scripts): fills grid/block/lds bytes. */
 int snerf_field_kernel_info(const snerf_model* m, int64_t n_points, int* grid, int* block, int* lds_bytes);
 

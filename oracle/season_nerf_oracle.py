@@ -388,6 +388,32 @@ def surface_depth(PS, pts, deltas):
     return loc, dist
 
 
+def dense_from_dsm(dsm: np.ndarray, n: int) -> Tensor:
+    """Dense occupancy volume of Net_tool.__init__, mg_run_NeRF.py:55-68: [X, Y, n] float64, NaN cells stay NaN."""
+    dsm = np.asarray(dsm, dtype=np.float64)
+    out = np.zeros([dsm.shape[0], dsm.shape[1], n])
+    for i, h in enumerate(np.linspace(-1, 1, n)):
+        out[:, :, i] = (dsm >= h) + dsm * 0
+    return torch.tensor(out)
+
+
+def get_dist(top: Tensor, bot: Tensor, dsm: np.ndarray, n: int) -> Tensor:
+    """Net_tool.get_Dist for one DSM, mg_run_NeRF.py:106-111 (+ _scale_to_DSM :98-104): float64 [R,1]."""
+    pts, delta = sample_pt_coarse(top, bot, n, eval_mode=True)
+    dense = dense_from_dsm(dsm, n)
+    K = torch.tensor([dense.shape[0] - 1, dense.shape[1] - 1, n - 1]).reshape(1, 1, 3)
+    idx = ((pts + 1) / 2 * K).type(torch.long).reshape(-1, 3)
+    pe = dense[idx[:, 0], idx[:, 1], idx[:, 2]].reshape(-1, n, 1)
+    prob = pe * torch.cumprod(torch.cat([torch.ones(pe.shape[0], 1, 1), 1 - pe], 1), 1)[:, 0:-1]
+    return torch.sum(prob * torch.cumsum(delta, 1), 1) / torch.sum(prob, 1)
+
+
+def cauchy_color_error(gt: np.ndarray, img: np.ndarray) -> float:
+    """One image's term of eval_img's Overall_Cauchy_Color_Error, mg_run_NeRF.py:206-208."""
+    n = np.sum(np.any(gt != 0, 2)) * 3
+    return float(np.sum(np.log(1 / 2 * (gt - img) ** 2 + 1)) / n)
+
+
 # --------------------------------------------------------------------------------------
 # losses (MSE path pinned; Barron path parity-unpinned)
 # --------------------------------------------------------------------------------------

@@ -13,3 +13,6 @@ from .render import (Quick_Run_Net, component_render_by_dir, get_imgs_from_Img_D
 __all__ = ["T_NeRF", "SineLayer", "All_in_One_Eval", "sample_parameters", "Quick_Run_Net", "component_render_by_dir",
            "get_imgs_from_Img_Dict", "get_imgs_from_Img_Dict_t_step", "render_season_sweep", "world_angle_2_local_vec",
            "encode_time", "parallel", "raytable", "FusedAdam", "TrainEngine", "create_solor_rays_uniform", "_lib"]
+from .adaptive_loss import AdaptiveLossFunction  # noqa: E402,F401
+from . import validation  # noqa: E402,F401
+from .validation import DSM_Distance, eval_img, image_error  # noqa: E402,F401

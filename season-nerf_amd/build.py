@@ -8,7 +8,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libseason_nerf_hip.so")
-SOURCES = ["kernels.hip", "api.cpp", "pack.cpp", "gemm.hip", "train_kernels.hip", "train.cpp"]
+SOURCES = ["kernels.hip", "api.cpp", "pack.cpp", "gemm.hip", "train_kernels.hip", "train.cpp", "dsm.hip"]
 DEPS = SOURCES + ["kernels.h", "pack.h", "program.h", "train.h", os.path.join("..", "..", "include", "season_nerf_hip.h")]
 
 

@@ -5,6 +5,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <string>
 
@@ -299,6 +300,37 @@ int snerf_rays_from_camera(const double* P_3x4, int rows, int cols, int downscal
     a.rows = rows; a.cols = cols; a.ds = downscale; a.rows_out = d_rows; a.valid = d_valid;
     hipError_t e = launch_rays_from_camera(a, (hipStream_t)stream);
     return e == hipSuccess ? SNERF_OK : fail_hip(e, "ray generation kernel launch");
+}
+
+int snerf_prior_density(int64_t n_points, const float* d_points, const float* d_delta, const double* d_height_map, int hm_rows, int hm_cols,
+                        const float* d_outside, float* d_rho_prior, void* stream) {
+    if (n_points < 0) return fail(SNERF_E_INVALID, "snerf_prior_density: negative point count");
+    if (n_points == 0) return SNERF_OK;
+    if (!d_points || !d_delta || !d_height_map || !d_rho_prior || hm_rows < 1 || hm_cols < 1)
+        return fail(SNERF_E_INVALID, "snerf_prior_density: bad argument");
+    const float term = -logf(1.0f - 0.99f);          // Prob_exist clamped to .99 (T_NeRF_net_v2.py:178-179)
+    hipError_t e = launch_prior_density(n_points, d_points, d_delta, d_height_map, hm_rows, hm_cols, d_outside, term, d_rho_prior,
+                                        (hipStream_t)stream);
+    return e == hipSuccess ? SNERF_OK : fail_hip(e, "prior density kernel launch");
+}
+
+int snerf_surface_distance(int64_t n_rays, int n_samples, const float* d_top, const float* d_bot, const float* d_tvals,
+                           const double* d_dsm, int dsm_rows, int dsm_cols, const double* d_levels, double* d_dist, void* stream) {
+    if (n_rays < 0 || n_samples < 1) return fail(SNERF_E_INVALID, "snerf_surface_distance: bad ray/sample count");
+    if (n_rays == 0) return SNERF_OK;
+    if (!d_top || !d_bot || !d_tvals || !d_dsm || !d_levels || !d_dist || dsm_rows < 1 || dsm_cols < 1)
+        return fail(SNERF_E_INVALID, "snerf_surface_distance: bad argument");
+    hipError_t e = launch_surface_distance(n_rays, n_samples, d_top, d_bot, d_tvals, d_dsm, dsm_rows, dsm_cols, d_levels, d_dist,
+                                           (hipStream_t)stream);
+    return e == hipSuccess ? SNERF_OK : fail_hip(e, "surface distance kernel launch");
+}
+
+int snerf_image_error(int64_t n_pixels, const float* d_image, const float* d_gt, double* d_sums, void* stream) {
+    if (n_pixels < 0) return fail(SNERF_E_INVALID, "snerf_image_error: negative pixel count");
+    if (n_pixels == 0) return SNERF_OK;
+    if (!d_image || !d_gt || !d_sums) return fail(SNERF_E_INVALID, "snerf_image_error: bad argument");
+    hipError_t e = launch_image_error(n_pixels, d_image, d_gt, d_sums, (hipStream_t)stream);
+    return e == hipSuccess ? SNERF_OK : fail_hip(e, "image error kernel launch");
 }
 
 int snerf_field_kernel_info(const snerf_model* m, int64_t n_points, int* grid, int* block, int* lds_bytes) {

@@ -76,6 +76,12 @@ struct SweepArgs {
 hipError_t launch_sweep(const SweepArgs& a, hipStream_t st);
 hipError_t launch_mlp(int prog, int W, int variant, const MlpArgs& a, int n_cu, hipStream_t st);
 hipError_t launch_composite(const CompArgs& a, hipStream_t st);
+// dsm.hip
+hipError_t launch_prior_density(int64_t n, const float* pts, const float* delta, const double* hm, int hx, int hy, const float* outside,
+                                float neg_log_term, float* rho, hipStream_t st);
+hipError_t launch_surface_distance(int64_t n_rays, int S, const float* top, const float* bot, const float* tvals, const double* dsm, int dx,
+                                   int dy, const double* levels, double* dist, hipStream_t st);
+hipError_t launch_image_error(int64_t n_pix, const float* img, const float* gt, double* sums, hipStream_t st);
 int mlp_lds_bytes(int bias_floats);
 int mlp_tile_points();
 int field_variant_chunks(int W, int C, int variant);

@@ -112,6 +112,34 @@ class All_in_One_Eval:
                         "Rendered_Col_Merged": rgb_m, "Rho_Merged": rho_m, "Albedo_Color": alb_m})
         return res
 
+    def render_summary(self, data_dict, Network):
+        """Per-ray results only, for validation renders (Net_tool.eval_img, mg_run_NeRF.py:181-190): eval-mode
+        `Rendered_Col` [R,3], expected surface location sum(PS*pts)/(sum PS + 1e-8) [R,3] and expected surface distance
+        sum(cumsum(delta)*PS)/sum(PS) [R,1], reduced inside the compositing kernel - no [R,S] tensor is written."""
+        self._check(Network)
+        from .network import FUSED_WIDTHS
+        if Network.layer_width not in FUSED_WIDTHS or Network.training:
+            res = self.eval(data_dict, Network, self.n_steps, False)
+            ps, dl, pts = res["PS"], res["deltas"], res["sample_pts"].to(self.device)
+            return (res["Rendered_Col"], (ps * pts).sum(1) / (ps.sum(1) + 1e-8), (torch.cumsum(dl, 1) * ps).sum(1) / ps.sum(1))
+        (top, bot, sun, tim) = Network._prep(*self._inputs(data_dict, Network))
+        dev = top.device
+        R, S = top.shape[0], self.args.n_samples
+        L, st = _lib.lib(), Network._stream()
+        tv = sample_parameters(S, eval_mode=True).to(dev)
+        cls, _, sky = Network._groups(tim, sun)
+        e = lambda *s: torch.empty(*s, device=dev)
+        rho, sv, col = e(R, S, 1), e(R, S, 1), e(R, S, 3)
+        fo = _lib.FieldOut(d_rho=rho.data_ptr(), d_solar_vis=sv.data_ptr(), d_col=col.data_ptr())
+        _lib.check(L.snerf_field_forward_rays(Network.device_model(), 0, R, S, top.data_ptr(), bot.data_ptr(), tv.data_ptr(), 1,
+                                              sun.data_ptr(), cls.data_ptr(), C.byref(fo), st), "field_forward_rays")
+        rgb, loc, dist = e(R, 3), e(R, 3), e(R, 1)
+        co = _lib.CompositeOut(d_rgb=rgb.data_ptr(), d_surf_loc=loc.data_ptr(), d_surf_dist=dist.data_ptr())
+        _lib.check(L.snerf_composite_rays(R, S, top.data_ptr(), bot.data_ptr(), tv.data_ptr(), rho.data_ptr(), col.data_ptr(),
+                                          sv.data_ptr(), sky.data_ptr(), 1 if self.use_classic_solar else 0, None, 1.0,
+                                          C.byref(co), st), "composite_rays")
+        return rgb, loc, dist
+
     def full_eval(self, data_dict, Network, current_step):
         """Eval_Tools_2.py:127-163: eval-mode sampling, no prior; same keys minus Albedo/Col_Adj."""
         saved = self.use_prior

@@ -60,6 +60,7 @@ class T_NeRF(nn.Module):
         self.n_classes = n_classes
         self.hm = torch.tensor(HM, requires_grad=False)
         self._hm_const = torch.tensor(self.hm.shape).reshape([1, 2]) - 1
+        self._hm_dev = None
         self.G_NeRF_net = _GNeRF(W)
         self.time_layer_1 = SineLayer(10, W, is_first=True)
         self.time_layer_2 = SineLayer(W, W)
@@ -223,9 +224,30 @@ class T_NeRF(nn.Module):
             return self._generic_points(torch.zeros(tim.shape[0], 3, device=tim.device), sun + 1.0, tim)["cls"]
         return self._groups(tim, sun)[0]
 
-    def Supervised_Sample(self, world_pts, delta):
-        """DSM prior density (:175-181); tiny gather, done with torch ops on whatever device the points live on."""
-        hm = self.hm.to(world_pts.device)
-        xy = ((world_pts[:, 0:2] + 1) / 2 * self._hm_const.to(world_pts.device)).long()
-        p = (hm[xy[:, 0], xy[:, 1]] >= world_pts[:, 2]).float().clamp(max=0.99)
-        return -torch.log(1 - p.unsqueeze(1)) / delta
+    def Supervised_Sample(self, world_pts, delta, outside=None):
+        """DSM prior density (:175-181) as one gather kernel (snerf_prior_density).  The reference moves the points to
+        the CPU for this (Eval_Tools_2.py:220-221); here they stay where the field network left them.
+        `outside` (optional [N]) = value for points outside the cube, the masked assignment of Eval_Tools_2.py:321-326."""
+        dev = self.device
+        if dev.type != "cuda":
+            raise RuntimeError("season_nerf_amd.T_NeRF runs on an MI355X only: move the module with .to('cuda')")
+        f = lambda t: t.detach().to(device=dev, dtype=torch.float32).contiguous()
+        pts, dl = f(world_pts), f(delta).reshape(-1)
+        n = pts.shape[0]
+        if pts.dim() != 2 or pts.shape[1] != 3 or dl.shape[0] != n:
+            raise ValueError(f"Supervised_Sample: points {tuple(world_pts.shape)} / deltas {tuple(delta.shape)}")
+        if self._hm_dev is None or self._hm_dev.device != dev:
+            self._hm_dev = self.hm.to(device=dev, dtype=torch.float64).contiguous()
+        if self._hm_dev.dim() != 2:
+            raise ValueError("Supervised_Sample needs the 2-D height map the module was built with (HM=...)")
+        # without `outside` every point must lie in the cube, as in the reference (which indexes out of range otherwise);
+        # the kernel clamps the index for memory safety instead of synchronising to check
+        if outside is not None:
+            outside = f(outside).reshape(-1)
+            if outside.shape[0] != n:
+                raise ValueError("Supervised_Sample: `outside` must hold one value per point")
+        out = torch.empty(n, 1, device=pts.device)
+        _lib.check(_lib.lib().snerf_prior_density(n, pts.data_ptr(), dl.data_ptr(), self._hm_dev.data_ptr(), self._hm_dev.shape[0],
+                                                  self._hm_dev.shape[1], outside.data_ptr() if outside is not None else None,
+                                                  out.data_ptr(), self._stream()), "snerf_prior_density")
+        return out

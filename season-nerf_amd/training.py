@@ -295,9 +295,7 @@ def eval_rho_only_train(ev, data_dict, net, train_mode, current_step=0):
     if ev.use_prior:                                              # Eval_Tools_2.py:319-334
         trust = current_step / ev.n_steps
         p2, d2 = pts.reshape(-1, 3), dl.reshape(-1, 1)
-        good = torch.all((p2 <= 1.) & (p2 >= -1.), 1)
-        rs = rho.reshape(-1, 1).clone()
-        rs[good] = net.Supervised_Sample(p2[good], d2[good]).float()
+        rs = net.Supervised_Sample(p2, d2, outside=rho.detach().reshape(-1))      # outside the cube: the network's own density
         rho_m = (rho * trust + rs.reshape(R, S, 1) * (1 - trust)).contiguous()
         z3 = torch.zeros(R, S, 3, device=dev)
         m = _composite(eng, top, bot, tv, rho_m, z3, sv.detach().contiguous(), torch.zeros(R, 3, device=dev), want=("pv", "pe"))

@@ -51,7 +51,7 @@ def test_train_step_vs_reference(golden_dir, name):
     loss, total = run_step(g, net, ev, data)
     for k in loss:
         ref = float(g["loss_" + k])
-        print(f"  loss {k:20s} {float(loss[k][0]):.8f} ref {ref:.8f}")
+        print(f"  loss {k:20s} {float(loss[k][0].detach()):.8f} ref {ref:.8f}")
         assert abs(float(loss[k][0]) - ref) <= 2e-5 * max(1.0, abs(ref)) + 1e-6, k
         assert abs(float(loss[k][1]) - float(g["weight_" + k])) < 1e-9
     assert abs(float(total) - float(g["total"])) <= 1e-4 * abs(float(g["total"]))

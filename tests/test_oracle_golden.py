@@ -175,3 +175,16 @@ def test_renderers(golden_dir):
     close(cls, g["sweep_classes"])
     sw = orc.images_t_step(d, size, g["sweep_classes"].astype(np.float64))
     np.testing.assert_allclose(sw, g["sweep_imgs"], rtol=1e-4, atol=2e-5)
+
+
+def test_dsm_distance_and_prior_density(golden_dir):
+    """oracle.get_dist / supervised_sample against the reference's Net_tool.get_Dist / T_NeRF.Supervised_Sample."""
+    g = np.load(os.path.join(golden_dir, "dsm_R48_S32.npz"))
+    top, bot, n = torch.tensor(g["Top"]), torch.tensor(g["Bot"]), int(g["n_samples"])
+    for key, dsm in (("Dist_GT", g["GT_DSM"]), ("Dist_Prior", g["training_DSM"])):
+        got = orc.get_dist(top, bot, dsm, n).numpy()
+        np.testing.assert_array_equal(np.isnan(got), np.isnan(g[key]))
+        np.testing.assert_allclose(got, g[key], rtol=1e-12, atol=0, equal_nan=True)
+    assert np.isnan(g["Dist_GT"]).sum() >= 2                     # NaN cells and never-hit rays are exercised
+    rho = orc.supervised_sample(g["HM"], torch.tensor(g["prior_pts"]), torch.tensor(g["prior_delta"])).numpy()
+    np.testing.assert_array_equal(rho, g["prior_rho"])

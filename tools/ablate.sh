@@ -5,7 +5,7 @@ cd $GRAFT_REPO_ROOT
 D="season-nerf_amd"
 for abl in 0 1 2 4 3 7; do
   hipcc -std=c++17 -O3 --offload-arch=gfx950 -fPIC -shared -ffp-contract=off -DSNERF_ABLATE -DABL=$abl -Wno-unused-command-line-argument \
-     -o /tmp/abl_$abl.so $D/csrc/kernels.hip $D/csrc/api.cpp $D/csrc/pack.cpp $D/csrc/gemm.hip $D/csrc/train_kernels.hip $D/csrc/train.cpp &
+     -o /tmp/abl_$abl.so $D/csrc/kernels.hip $D/csrc/api.cpp $D/csrc/pack.cpp $D/csrc/gemm.hip $D/csrc/train_kernels.hip $D/csrc/train.cpp $D/csrc/dsm.hip &
 done
 wait
 for abl in 0 1 2 4 3 7; do

@@ -264,6 +264,34 @@ def gen_micro():
     np.savez_compressed(os.path.join(OUT, "micro.npz"), **out)
 
 
+def gen_dsm():
+    """Net_tool.get_Dist (mg_run_NeRF.py:106-120) and T_NeRF.Supervised_Sample (T_NeRF_net_v2.py:175-181) of the reference.
+    Net_tool's constructor needs the data loaders, so get_Dist/_scale_to_DSM run as unbound methods on a stand-in object whose
+    dense volumes are built by the constructor's own recipe (:55-68, restated in oracle.dense_from_dsm)."""
+    import mg_run_NeRF
+    rng = np.random.Generator(np.random.PCG64(7))
+    nS, R = 32, 48
+    gt = rng.uniform(-0.8, 0.6, (24, 20))
+    prior = np.clip(gt + rng.normal(0, 0.08, gt.shape), -1, 1)
+    gt[3:5, 4:7] = np.nan
+    gt[10:14, 10:15] = -1.5                     # cells below the cube floor: rays there never meet the surface -> NaN distance
+    fake = SimpleNamespace(GT_DSM=gt, training_DSM=prior, n_DSM_samples=nS,
+                           GT_DSM_Dense=orc.dense_from_dsm(gt, nS), training_DSM_Dense=orc.dense_from_dsm(prior, nS))
+    fake._scale_to_DSM = lambda pts, use_GT: mg_run_NeRF.Net_tool._scale_to_DSM(fake, pts, use_GT)
+    top = torch.tensor(np.concatenate([rng.uniform(-1, 1, (R, 2)), np.ones((R, 1))], 1), dtype=torch.float32)
+    bot = torch.tensor(np.concatenate([rng.uniform(-1, 1, (R, 2)), -np.ones((R, 1))], 1), dtype=torch.float32)
+    d_gt, d_prior = mg_run_NeRF.Net_tool.get_Dist(fake, top, bot)
+    out = {"n_samples": nS, "GT_DSM": gt, "training_DSM": prior, "Top": f32(top), "Bot": f32(bot),
+           "Dist_GT": d_gt.numpy(), "Dist_Prior": d_prior.numpy()}
+    hm = rng.uniform(-0.7, 0.7, (17, 23))
+    net = T_NeRF(64, 4, HM=hm)
+    pts = torch.tensor(rng.uniform(-1, 1, (500, 3)), dtype=torch.float32)
+    pts[:4] = torch.tensor([[1.0, 1.0, 1.0], [-1.0, -1.0, -1.0], [1.0, -1.0, 0.0], [0.0, 0.0, 0.0]])
+    delta = torch.tensor(rng.uniform(0.01, 0.05, (500, 1)), dtype=torch.float32)
+    out.update({"HM": hm, "prior_pts": f32(pts), "prior_delta": f32(delta), "prior_rho": f32(net.Supervised_Sample(pts, delta))})
+    np.savez_compressed(os.path.join(OUT, "dsm_R48_S32.npz"), **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -275,5 +303,6 @@ if __name__ == "__main__":
     gen_train(64, 0, 32, 32, "W64_R32_S32")
     gen_train(64, 1, 24, 40, "prior_W64_R24_S40", prior=True)
     gen_render(64, 2, "W64_s2")
+    gen_dsm()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -6,7 +6,7 @@ i=0
 for flags in "$@"; do
   i=$((i+1))
   hipcc -std=c++17 -O3 --offload-arch=gfx950 -fPIC -shared -ffp-contract=off $flags -Wno-unused-command-line-argument \
-     -o /tmp/pvar_$i.so $D/csrc/kernels.hip $D/csrc/api.cpp $D/csrc/pack.cpp $D/csrc/gemm.hip $D/csrc/train_kernels.hip $D/csrc/train.cpp &
+     -o /tmp/pvar_$i.so $D/csrc/kernels.hip $D/csrc/api.cpp $D/csrc/pack.cpp $D/csrc/gemm.hip $D/csrc/train_kernels.hip $D/csrc/train.cpp $D/csrc/dsm.hip &
 done
 wait
 i=0
