@@ -168,18 +168,25 @@ hipError_t launch_gemm(const GemmArgs& g, hipStream_t st) {
 }  // namespace snerf
 
 // =====================================================================================================
-// bf16x3 "NT" GEMM:  C[m,n] (+)= alpha * (sum_k A[m,k] * Bt[n,k] + bias[n])
-//   A  : fp32 activations / gradients [M, lda], k contiguous - split into bf16 hi/lo while staging into LDS
-//   Bt : weights already split (split_weights_kernel) into bf16 hi / lo [N, Kp], Kp = K rounded up to 32, zero padded
-// 3-term error-compensated product on v_mfma_f32_32x32x16_bf16 (hi*hi + lo*hi + hi*lo, fp32 accumulate): ~1e-5 relative,
-// 16/3 x the fp32-MFMA rate - with 403 MB in and out per layer these GEMMs become HBM-bound.
+// bf16x3 "row-owner" GEMM (forward and dgrad of the training engine):
+//     C[m,n] (+)= alpha * (sum_k A[m,k] * Bt[n,k] + bias[n])          [+ per-column shifted sums for train-mode BatchNorm]
+//   A  : fp32 activations / gradients [M, lda], k contiguous - read straight from HBM into MFMA operand registers
+//        (lane (r,h) of a 32x32x16 MFMA holds 8 consecutive k of row r: two 16-byte loads), split into bf16 hi/lo in registers
+//   Bt : weights, pre-split by split_weights_kernel into MFMA fragment order, resident in LDS for the whole kernel
+// Every wave owns its 64 rows: no barrier in the main loop, activations never touch LDS, the compiler is free to keep
+// three k-steps of loads in flight.  Persistent: 1 workgroup (8 waves) per CU loops over 512-row tiles; the n-groups of
+// one row tile sit on the same XCD so the second reader of a tile hits that XCD's L2.
+// 3-term error-compensated product (hi*hi + lo*hi + hi*lo, fp32 accumulate): ~1e-5 relative, 16/3 x the fp32-MFMA rate,
+// which makes these GEMMs HBM-bound (403 MB in + 403 MB out per layer at 4096 x 96).
 namespace snerf {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 
-constexpr int XBM = 128, XBN = 128, XBK = 32, XLD = 40;      // LDS row stride in bf16 elements (80 B: conflict-free b128 reads)
+constexpr int RO_WAVES = 8, RO_MT = 2;                       // 8 waves x (2 x 32) rows = 512 rows per workgroup tile
+constexpr int RO_ROWS = RO_WAVES * RO_MT * 32;
+constexpr int RO_PF = 2;                                     // k-steps of A loads in flight ahead of the MFMAs
 
 __device__ __forceinline__ void split2_bf16(float a, float b, uint32_t& hi, uint32_t& lo) {
     bf16x2_t hv;
@@ -194,142 +201,367 @@ __device__ __forceinline__ void split2_bf16(float a, float b, uint32_t& hi, uint
     lo = __builtin_bit_cast(uint32_t, lv);
 }
 
-__global__ void split_weights_kernel(const float* W, int rows, int cols, int transpose, uint16_t* hi, uint16_t* lo, int out_rows, int kp) {
-    // out[r][k] = W[r][k] (transpose = 0, rows x cols) or W[k][r] (transpose = 1); zero padded to [out_rows, kp]
-    const int64_t total = (int64_t)out_rows * kp;
+// Fragment-order split: tile T (32 output columns), k-step ks (16 k): 1 KiB hi then 1 KiB lo; inside, lane (r,h) owns 16 bytes =
+// bf16 of Bt[T*32 + r][ks*16 + h*8 + 0..7].  Bt[n][k] = W[n][k] (transpose = 0, W is [rows x cols]) or W[k][n] (transpose = 1).
+__global__ void split_weights_kernel(const float* W, int rows, int cols, int transpose, uint16_t* frag, int n_tiles, int ksteps) {
+    const int64_t total = (int64_t)n_tiles * ksteps * 512;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int r = (int)(i / kp), k = (int)(i - (int64_t)r * kp);
+        const int e = (int)(i & 7), lane = (int)((i >> 3) & 63);
+        const int64_t tk = i >> 9;
+        const int ks = (int)(tk % ksteps), T = (int)(tk / ksteps);
+        const int n = T * 32 + (lane & 31), k = ks * 16 + (lane >> 5) * 8 + e;
         float v = 0.f;
-        if (!transpose) { if (r < rows && k < cols) v = W[(int64_t)r * cols + k]; }
-        else { if (k < rows && r < cols) v = W[(int64_t)k * cols + r]; }
+        if (!transpose) { if (n < rows && k < cols) v = W[(int64_t)n * cols + k]; }
+        else { if (k < rows && n < cols) v = W[(int64_t)k * cols + n]; }
         const __bf16 h = (__bf16)v;
-        const float hf = (float)h;
-        const __bf16 l = (__bf16)(v - hf);
-        hi[i] = __builtin_bit_cast(uint16_t, h);
-        lo[i] = __builtin_bit_cast(uint16_t, l);
+        const __bf16 l = (__bf16)(v - (float)h);
+        uint16_t* dst = frag + tk * 1024 + lane * 8 + e;
+        dst[0] = __builtin_bit_cast(uint16_t, h);
+        dst[512] = __builtin_bit_cast(uint16_t, l);
     }
 }
 
-__global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const GemmX g) {
-    __shared__ __attribute__((aligned(16))) uint16_t Ah[XBM][XLD], Al[XBM][XLD], Bh[XBN][XLD], Bl[XBN][XLD];
+template <int NT>
+__global__ __launch_bounds__(512) void gemm_rows_kernel(const GemmX g) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_w[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
     const int r = lane & 31, h = lane >> 5;
-    const int64_t m0 = (int64_t)blockIdx.x * XBM, n0 = (int64_t)blockIdx.y * XBN;
-    const int srow = tid >> 1, skh = (tid & 1) * 16;          // staging: thread -> (row, 16 consecutive k)
+    const int KS = g.ksteps;
+    const int n_groups = (g.n_tiles + NT - 1) / NT;
+    // block -> (XCD, slot on the XCD) -> (n-group, worker): all n-groups of a worker share an XCD (and its L2)
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
+    const int workers_per_xcd = slots / n_groups;
+    if (slot >= workers_per_xcd * n_groups) return;
+    const int grp = slot % n_groups, worker = (slot / n_groups) * 8 + xcd, n_workers = workers_per_xcd * 8;
+    const int tiles_here = (g.n_tiles - grp * NT) < NT ? (g.n_tiles - grp * NT) : NT;
+
+    {   // weights of this n-group -> LDS (fragment order, straight copy)
+        const u32x4* src = (const u32x4*)(g.frag + (int64_t)grp * NT * KS * 1024);
+        u32x4* dst = (u32x4*)lds_w;
+        const int n16 = tiles_here * KS * 128;
+        for (int i = tid; i < n16; i += 512) dst[i] = src[i];
+    }
+    __syncthreads();
+
     const bool a_vec = ((uintptr_t)g.A % 16 == 0) && (g.lda % 4 == 0);
-    f32x16 acc[2][2];
+    const int64_t n_row_tiles = (g.M + RO_ROWS - 1) / RO_ROWS;
+    float st1[NT], st2[NT];                                          // shifted column sums over this block's rows
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < NT; ++j) st1[j] = st2[j] = 0.f;
+
+    for (int64_t rt = worker; rt < n_row_tiles; rt += n_workers) {
+        const int64_t row0 = rt * RO_ROWS + wave * (RO_MT * 32);
+        const float* arow[RO_MT];
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    float va[16];
-    u32x4 vbh[2], vbl[2];
-    auto fetch = [&](int64_t k0) {
-        const int64_t gr = m0 + srow, gk = k0 + skh;
-        if (gr < g.M && a_vec && gk + 16 <= g.K) {
-            const f32x4* p = (const f32x4*)(g.A + gr * g.lda + gk);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { const f32x4 t = p[q]; va[4 * q] = t[0]; va[4 * q + 1] = t[1]; va[4 * q + 2] = t[2]; va[4 * q + 3] = t[3]; }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) va[i] = (gr < g.M && gk + i < g.K) ? g.A[gr * g.lda + gk + i] : 0.f;
+        for (int i = 0; i < RO_MT; ++i) {
+            int64_t m = row0 + i * 32 + r;
+            if (m > g.M - 1) m = g.M - 1;                            // loads stay in bounds, stores are masked
+            arow[i] = g.A + m * g.lda + h * 8;
         }
-        const int64_t gn = n0 + srow;
-        if (gn < g.N) {
-            const u32x4* ph = (const u32x4*)(g.Bh + gn * g.kp + gk);
-            const u32x4* pl = (const u32x4*)(g.Bl + gn * g.kp + gk);
-            vbh[0] = ph[0]; vbh[1] = ph[1]; vbl[0] = pl[0]; vbl[1] = pl[1];
-        } else {
-            vbh[0] = vbh[1] = vbl[0] = vbl[1] = u32x4{0, 0, 0, 0};
-        }
-    };
-    auto stash = [&]() {
-        u32x4 hq[2], lq[2];
+        auto load_a = [&](int ks, float (&v)[RO_MT][8]) {
+            const int k0 = ks * 16 + h * 8;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            uint32_t hh, ll;
-            split2_bf16(va[2 * q], va[2 * q + 1], hh, ll);
-            hq[q >> 2][q & 3] = hh;
-            lq[q >> 2][q & 3] = ll;
-        }
-        u32x4* dh = (u32x4*)&Ah[srow][skh];
-        u32x4* dl = (u32x4*)&Al[srow][skh];
-        dh[0] = hq[0]; dh[1] = hq[1]; dl[0] = lq[0]; dl[1] = lq[1];
-        u32x4* eh = (u32x4*)&Bh[srow][skh];
-        u32x4* el = (u32x4*)&Bl[srow][skh];
-        eh[0] = vbh[0]; eh[1] = vbh[1]; el[0] = vbl[0]; el[1] = vbl[1];
-    };
-    const int64_t ksteps = (g.K + XBK - 1) / XBK;
-    fetch(0);
-    for (int64_t ks = 0; ks < ksteps; ++ks) {
-        __syncthreads();                 // previous step's fragment reads are done
-        stash();
-        __syncthreads();
-        if (ks + 1 < ksteps) fetch((ks + 1) * XBK);          // next tile's global loads fly during the MFMAs
+            for (int i = 0; i < RO_MT; ++i) {
+                const float* p = arow[i] + ks * 16;
+                if (a_vec && k0 + 8 <= g.K) {
+                    const f32x4 x = *(const f32x4*)p, y = *(const f32x4*)(p + 4);
+                    v[i][0] = x[0]; v[i][1] = x[1]; v[i][2] = x[2]; v[i][3] = x[3];
+                    v[i][4] = y[0]; v[i][5] = y[1]; v[i][6] = y[2]; v[i][7] = y[3];
+                } else {
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            u32x4 ah[2], al[2], bh[2], bl[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                ah[i] = *(const u32x4*)&Ah[wm * 64 + i * 32 + r][kk * 16 + h * 8];
-                al[i] = *(const u32x4*)&Al[wm * 64 + i * 32 + r][kk * 16 + h * 8];
-                bh[i] = *(const u32x4*)&Bh[wn * 64 + i * 32 + r][kk * 16 + h * 8];
-                bl[i] = *(const u32x4*)&Bl[wn * 64 + i * 32 + r][kk * 16 + h * 8];
+                    for (int e = 0; e < 8; ++e) v[i][e] = (k0 + e < g.K) ? p[e] : 0.f;
+                }
             }
+        };
+        f32x16 acc[RO_MT][NT];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < RO_MT; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const bf16x8 Ahi = __builtin_bit_cast(bf16x8, ah[i]), Alo = __builtin_bit_cast(bf16x8, al[i]);
-                    const bf16x8 Bhi = __builtin_bit_cast(bf16x8, bh[j]), Blo = __builtin_bit_cast(bf16x8, bl[j]);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Alo, Bhi, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ahi, Blo, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ahi, Bhi, acc[i][j], 0, 0, 0);
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        float pf[RO_PF][RO_MT][8];
+#pragma unroll
+        for (int d = 0; d < RO_PF; ++d)
+            if (d < KS) load_a(d, pf[d]);
+        for (int ks0 = 0; ks0 < KS; ks0 += RO_PF) {
+#pragma unroll
+            for (int d = 0; d < RO_PF; ++d) {
+                const int ks = ks0 + d;
+                if (ks < KS) {
+                    u32x4 ahi[RO_MT], alo[RO_MT];
+#pragma unroll
+                    for (int i = 0; i < RO_MT; ++i)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            uint32_t hh, ll;
+                            split2_bf16(pf[d][i][2 * q], pf[d][i][2 * q + 1], hh, ll);
+                            ahi[i][q] = hh;
+                            alo[i][q] = ll;
+                        }
+                    if (ks + RO_PF < KS) load_a(ks + RO_PF, pf[d]);          // refill the slot just consumed
+                    const uint32_t base = (uint32_t)ks * 2048u + (uint32_t)lane * 16u;
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        if (j < tiles_here) {
+                            const u32x4 bh = *(const u32x4*)(lds_w + base + (uint32_t)j * KS * 2048u);
+                            const u32x4 bl = *(const u32x4*)(lds_w + base + (uint32_t)j * KS * 2048u + 1024u);
+                            const bf16x8 Bhi = __builtin_bit_cast(bf16x8, bh), Blo = __builtin_bit_cast(bf16x8, bl);
+#pragma unroll
+                            for (int i = 0; i < RO_MT; ++i) {
+                                const bf16x8 Ahi = __builtin_bit_cast(bf16x8, ahi[i]), Alo = __builtin_bit_cast(bf16x8, alo[i]);
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Alo, Bhi, acc[i][j], 0, 0, 0);
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ahi, Blo, acc[i][j], 0, 0, 0);
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ahi, Bhi, acc[i][j], 0, 0, 0);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        // epilogue: D[row = (e&3) + 8(e>>2) + 4h, col = r]
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int64_t n = (int64_t)(grp * NT + j) * 32 + r;
+            const bool nok = j < tiles_here && n < g.N;
+            const float bias = (g.bias && nok) ? g.bias[n] : 0.f;
+            const float shift = (g.stats && nok) ? g.alpha * bias : 0.f;
+#pragma unroll
+            for (int i = 0; i < RO_MT; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int64_t m = row0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    if (nok && m < g.M) {
+                        float v = g.alpha * (acc[i][j][e] + bias);
+                        float* c = g.C + m * g.ldc + n;
+                        if (g.accumulate) v += *c;
+                        *c = v;
+                        const float d = v - shift;
+                        st1[j] += d;
+                        st2[j] += d * d;
+                    }
                 }
         }
     }
+    if (g.stats) {      // per-column sum(v - shift) and sum((v - shift)^2) over this block's rows -> double atomics
+        __syncthreads();                                   // weights no longer needed: reuse LDS for the cross-wave reduction
+        float* red = (float*)lds_w;                        // [8 waves][NT][2][32]
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int64_t n = n0 + wn * 64 + j * 32 + r;
-        const bool nok = n < g.N;
-        const float bias = (g.bias && nok) ? g.bias[n] : 0.f;
-        float colsum = 0.f;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int64_t m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (nok && m < g.M) {
-                    float v = g.alpha * (acc[i][j][e] + bias);
-                    float* c = g.C + m * g.ldc + n;
-                    if (g.accumulate) v += *c;
-                    *c = v;
-                    colsum += v;
-                }
+        for (int j = 0; j < NT; ++j) {
+            float a = st1[j] + __shfl_xor(st1[j], 32, 64), b = st2[j] + __shfl_xor(st2[j], 32, 64);
+            if (h == 0) {
+                red[((wave * NT + j) * 2 + 0) * 32 + r] = a;
+                red[((wave * NT + j) * 2 + 1) * 32 + r] = b;
             }
         }
-        if (g.colsum) {
-            colsum += __shfl_xor(colsum, 32, 64);
-            if (h == 0 && nok) atomicAdd(g.colsum + n, colsum);
+        __syncthreads();
+        if (tid < NT * 64) {
+            const int j = tid >> 6, which = (tid >> 5) & 1, c = tid & 31;
+            double s = 0.0;
+#pragma unroll
+            for (int w = 0; w < RO_WAVES; ++w) s += (double)red[((w * NT + j) * 2 + which) * 32 + c];
+            const int64_t n = (int64_t)(grp * NT + j) * 32 + c;
+            if (j < tiles_here && n < g.N) atomicAdd(g.stats + which * g.N + n, s);
         }
     }
 }
 
-hipError_t launch_split_weights(const float* W, int rows, int cols, bool transpose, uint16_t* hi, uint16_t* lo, int out_rows, int kp, hipStream_t st) {
-    const int64_t total = (int64_t)out_rows * kp;
+// =====================================================================================================
+// bf16x3 weight-gradient GEMM:   dW[o, i] += alpha * sum_m dZ[m, o] * In[m, i]           (K = #points, split over workgroups)
+// Both operands are point-major, so the 8 consecutive-k values an MFMA lane needs are 8 rows of one column: each lane gathers
+// them with 8 row-coalesced dword loads (32 lanes = 128 contiguous bytes of a row), splits them into bf16 hi/lo in registers
+// and publishes the finished 1 KiB fragments through LDS, where the 8 waves of the workgroup share them: the workgroup
+// holds the whole dW block (up to 256 x 256, 128 accumulator registers per lane), so dZ and In are read from HBM exactly once.
+// Stage = 32 points; double-buffered LDS (2 x 64 KiB), one barrier per stage; the loads of stage s+1 fly during the MFMAs of s.
+static int ro_grid_blocks() {
+    static int n = 0;
+    if (!n) {
+        hipDeviceProp_t p;
+        int dev = 0;
+        n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) ? p.multiProcessorCount : 256;
+        n = n / 8 * 8;
+        if (n < 8) n = 8;
+    }
+    return n;
+}
+
+struct WgradX {
+    const float *dZ, *In;
+    float* dW;
+    int64_t M, ldz, ldi, ldw;
+    int n_out, n_in;
+    float alpha;
+    int64_t rows_per_block;      // multiple of 32
+};
+
+constexpr int WG_STAGE = 32;
+
+__global__ __launch_bounds__(512) void wgrad_bf16x3_kernel(const WgradX g) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_f[];          // [2 buffers][2 operands][8 tiles][2 ksteps][hi,lo][1 KiB]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int o_base = blockIdx.y * 256, i_base = blockIdx.z * 256;
+    const int to_n = (g.n_out - o_base + 31) / 32 < 8 ? (g.n_out - o_base + 31) / 32 : 8;      // valid 32-column tiles of each operand
+    const int ti_n = (g.n_in - i_base + 31) / 32 < 8 ? (g.n_in - i_base + 31) / 32 : 8;
+    const int wo = wave >> 1, wi = wave & 1;                 // this wave's dW piece: n_out tiles {2wo, 2wo+1} x n_in tiles {4wi .. 4wi+3}
+    const int64_t m_begin = (int64_t)blockIdx.x * g.rows_per_block;
+    const int64_t m_end = m_begin + g.rows_per_block < g.M ? m_begin + g.rows_per_block : g.M;
+    if (m_begin >= m_end) return;
+    const int n_stages = (int)((m_end - m_begin + WG_STAGE - 1) / WG_STAGE);
+
+    // producer role: wave w gathers tile w of dZ and tile w of In (both k-steps of the stage)
+    const bool make_o = wave < to_n, make_i = wave < ti_n;
+    const int col_o = o_base + wave * 32 + r, col_i = i_base + wave * 32 + r;
+    const bool ok_o = make_o && col_o < g.n_out, ok_i = make_i && col_i < g.n_in;
+    float vo[2][8], vi[2][8];
+    auto gather = [&](int stage) {
+        const int64_t m0 = m_begin + (int64_t)stage * WG_STAGE + h * 8;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int64_t m = m0 + ks * 16 + e;
+                const bool mok = m < m_end;
+                vo[ks][e] = (ok_o && mok) ? g.dZ[m * g.ldz + col_o] : 0.f;
+                vi[ks][e] = (ok_i && mok) ? g.In[m * g.ldi + col_i] : 0.f;
+            }
+    };
+    auto publish = [&](int buf) {
+        uint8_t* base = lds_f + buf * 65536;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            u32x4 oh, ol, ih, il;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                uint32_t a, b;
+                split2_bf16(vo[ks][2 * q], vo[ks][2 * q + 1], a, b);
+                oh[q] = a; ol[q] = b;
+                split2_bf16(vi[ks][2 * q], vi[ks][2 * q + 1], a, b);
+                ih[q] = a; il[q] = b;
+            }
+            const uint32_t f = (uint32_t)((wave * 2 + ks) * 2048 + lane * 16);
+            if (make_o) { *(u32x4*)(base + f) = oh; *(u32x4*)(base + f + 1024) = ol; }
+            if (make_i) { *(u32x4*)(base + 32768 + f) = ih; *(u32x4*)(base + 32768 + f + 1024) = il; }
+        }
+    };
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+    gather(0);
+    publish(0);
+    __syncthreads();
+    for (int s = 0; s < n_stages; ++s) {
+        if (s + 1 < n_stages) gather(s + 1);                 // in flight during the MFMAs below
+        const uint8_t* base = lds_f + (s & 1) * 65536 + lane * 16;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            u32x4 ah[2], al[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const uint32_t f = (uint32_t)(((2 * wo + a) * 2 + ks) * 2048);
+                ah[a] = *(const u32x4*)(base + f);
+                al[a] = *(const u32x4*)(base + f + 1024);
+            }
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                if (4 * wi + b < ti_n) {
+                    const uint32_t f = (uint32_t)(32768 + ((4 * wi + b) * 2 + ks) * 2048);
+                    const bf16x8 Bhi = __builtin_bit_cast(bf16x8, *(const u32x4*)(base + f));
+                    const bf16x8 Blo = __builtin_bit_cast(bf16x8, *(const u32x4*)(base + f + 1024));
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) {
+                        if (2 * wo + a < to_n) {
+                            const bf16x8 Ahi = __builtin_bit_cast(bf16x8, ah[a]), Alo = __builtin_bit_cast(bf16x8, al[a]);
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Alo, Bhi, acc[a][b], 0, 0, 0);
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ahi, Blo, acc[a][b], 0, 0, 0);
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ahi, Bhi, acc[a][b], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+        if (s + 1 < n_stages) publish((s + 1) & 1);          // that buffer was last read in stage s-1, behind the previous barrier
+        __syncthreads();
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            if (2 * wo + a < to_n && 4 * wi + b < ti_n) {
+                const int i = i_base + (4 * wi + b) * 32 + r;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int o = o_base + (2 * wo + a) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    if (o < g.n_out && i < g.n_in) atomicAdd(g.dW + (int64_t)o * g.ldw + i, g.alpha * acc[a][b][e]);
+                }
+            }
+        }
+}
+
+hipError_t launch_wgrad_bf16x3(const float* dZ, int64_t ldz, const float* In, int64_t ldi, int64_t M, int n_out, int n_in, float alpha,
+                               float* dW, int64_t ldw, hipStream_t st) {
+    if (M <= 0 || n_out <= 0 || n_in <= 0) return hipSuccess;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)wgrad_bf16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    WgradX g{};
+    g.dZ = dZ; g.In = In; g.dW = dW; g.M = M; g.ldz = ldz; g.ldi = ldi; g.ldw = ldw; g.n_out = n_out; g.n_in = n_in; g.alpha = alpha;
+    const int by = (n_out + 255) / 256, bz = (n_in + 255) / 256;
+    int64_t bx = ro_grid_blocks() / (by * bz);
+    if (bx < 1) bx = 1;
+    int64_t rows = (M + bx - 1) / bx;
+    rows = (rows + WG_STAGE - 1) / WG_STAGE * WG_STAGE;
+    if (rows < 4 * WG_STAGE) rows = 4 * WG_STAGE;
+    bx = (M + rows - 1) / rows;
+    g.rows_per_block = rows;
+    hipLaunchKernelGGL(wgrad_bf16x3_kernel, dim3((unsigned)bx, by, bz), dim3(512), 131072, st, g);
+    return hipGetLastError();
+}
+
+hipError_t launch_split_weights(const float* W, int rows, int cols, bool transpose, uint16_t* frag, int n_tiles, int ksteps, hipStream_t st) {
+    const int64_t total = (int64_t)n_tiles * ksteps * 512;
     if (total <= 0) return hipSuccess;
     int64_t b = (total + 255) / 256;
     if (b > 4096) b = 4096;
-    hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)b), dim3(256), 0, st, W, rows, cols, transpose ? 1 : 0, hi, lo, out_rows, kp);
+    hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)b), dim3(256), 0, st, W, rows, cols, transpose ? 1 : 0, frag, n_tiles, ksteps);
     return hipGetLastError();
 }
+
+int gemm_rows_group_tiles(int ksteps) { return ksteps <= 16 ? 4 : (ksteps <= 32 ? 2 : 0); }     // n-tiles whose weights fit LDS
+
 hipError_t launch_gemm_bf16x3(const GemmX& g, hipStream_t st) {
     if (g.M <= 0 || g.N <= 0) return hipSuccess;
-    dim3 grid((unsigned)((g.M + XBM - 1) / XBM), (unsigned)((g.N + XBN - 1) / XBN));
-    hipLaunchKernelGGL(gemm_bf16x3_kernel, grid, dim3(256), 0, st, g);
+    const int nt = gemm_rows_group_tiles(g.ksteps);
+    if (!nt) return hipErrorInvalidValue;
+    const size_t lds = (size_t)nt * g.ksteps * 2048;
+    const int groups = (g.n_tiles + nt - 1) / nt;
+    int blocks = ro_grid_blocks();
+    if (blocks / 8 < groups) blocks = groups * 8;            // at least one worker per XCD
+    static bool attr_done[2] = {false, false};
+    if (nt == 4) {
+        if (!attr_done[0]) {
+            hipError_t e = hipFuncSetAttribute((const void*)gemm_rows_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 16 * 2048);
+            if (e != hipSuccess) return e;
+            attr_done[0] = true;
+        }
+        hipLaunchKernelGGL(gemm_rows_kernel<4>, dim3(blocks), dim3(512), lds, st, g);
+    } else {
+        if (!attr_done[1]) {
+            hipError_t e = hipFuncSetAttribute((const void*)gemm_rows_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 32 * 2048);
+            if (e != hipSuccess) return e;
+            attr_done[1] = true;
+        }
+        hipLaunchKernelGGL(gemm_rows_kernel<2>, dim3(blocks), dim3(512), lds, st, g);
+    }
     return hipGetLastError();
 }
 

@@ -60,7 +60,8 @@ struct snerf_trainer {
     } img, sol;
     Act dA, dB, dX1;
     float *d_head, *d_adj, *d_rho, *d_col, *d_sky, *d_cls, *d_sv_raw, *rayA, *rayB, *bn_bwd;   // bn_bwd: [2][W]
-    uint16_t *w_hi = nullptr, *w_lo = nullptr;      // scratch for the bf16 hi/lo split of one weight matrix
+    uint16_t* w_frag = nullptr;                     // scratch: one weight matrix split into bf16 hi/lo MFMA fragments
+    double* bn_stats = nullptr;                     // [2][W] shifted column sums from the GEMM epilogue
     int gemm_mode = 1;                              // 1 = bf16x3 MFMA for forward/dgrad (default), 0 = exact fp32 MFMA everywhere
 };
 
@@ -160,9 +161,9 @@ static size_t carve(snerf_trainer* t, char* base, int64_t R, int64_t Rs, int S) 
     t->d_sky = c.take(Rmax * 3); t->d_cls = c.take(Rmax * C); t->d_sv_raw = c.take(Nmax);
     t->rayA = c.take(Rmax * W); t->rayB = c.take(Rmax * W);
     t->bn_bwd = c.take(2 * W);
-    const int64_t wmax = (int64_t)(W + 64) * (W + 96);      // [rows <= W+63][kp <= W+96] bf16 = half as many floats
-    t->w_hi = (uint16_t*)c.take((wmax + 1) / 2);
-    t->w_lo = (uint16_t*)c.take((wmax + 1) / 2);
+    const int64_t frag_bytes = (int64_t)((W + 64 + 31) / 32) * ((W + 64 + 15) / 16) * 2048;
+    t->w_frag = (uint16_t*)c.take(frag_bytes / 4);
+    t->bn_stats = (double*)c.take(4 * W + 2);
     return c.off;
 }
 
@@ -173,16 +174,20 @@ static size_t carve(snerf_trainer* t, char* base, int64_t R, int64_t Rs, int S) 
         if (_e != hipSuccess) return snerf_set_error(SNERF_E_HIP, std::string(#x) + ": " + hipGetErrorString(_e)); \
     } while (0)
 
-// Z[M, n_out] = alpha * (In[M, K] W^T + b);  colsum optional
+// bf16x3 row-owner kernel usable for an [M x K] x [K x N] product?
+static bool rows_ok(const snerf_trainer* t, int64_t M, int K, int N) {
+    return t->gemm_mode == 1 && M >= 1024 && K >= 16 && N >= 16 && gemm_rows_group_tiles((K + 15) / 16) > 0;
+}
+// Z[M, n_out] = alpha * (In[M, K] W^T + b);  colsum (fp32 path) / stats (bf16x3 path) optional
 static hipError_t linear_fwd(snerf_trainer* t, const LayerP& L, const float* In, int64_t ld_in, int64_t M, float* Z, int64_t ldz,
-                             float alpha, float* colsum, hipStream_t st) {
-    if (t->gemm_mode == 1 && M >= 1024 && L.n_in >= 16 && L.n_out >= 16) {
-        const int kp = (L.n_in + 31) / 32 * 32;
-        hipError_t e = launch_split_weights(t->params + L.w, L.n_out, L.n_in, false, t->w_hi, t->w_lo, L.n_out, kp, st);
-        if (e != hipSuccess) return e;
+                             float alpha, float* colsum, hipStream_t st, double* stats = nullptr) {
+    if (rows_ok(t, M, L.n_in, L.n_out)) {
         GemmX x{};
-        x.A = In; x.Bh = t->w_hi; x.Bl = t->w_lo; x.C = Z; x.M = M; x.N = L.n_out; x.K = L.n_in; x.lda = ld_in; x.ldc = ldz;
-        x.kp = kp; x.alpha = alpha; x.bias = t->params + L.b; x.colsum = colsum; x.accumulate = 0;
+        x.n_tiles = (L.n_out + 31) / 32; x.ksteps = (L.n_in + 15) / 16;
+        hipError_t e = launch_split_weights(t->params + L.w, L.n_out, L.n_in, false, t->w_frag, x.n_tiles, x.ksteps, st);
+        if (e != hipSuccess) return e;
+        x.A = In; x.frag = t->w_frag; x.C = Z; x.M = M; x.N = L.n_out; x.K = L.n_in; x.lda = ld_in; x.ldc = ldz;
+        x.alpha = alpha; x.bias = t->params + L.b; x.stats = stats; x.accumulate = 0;
         return launch_gemm_bf16x3(x, st);
     }
     GemmArgs g{};
@@ -195,14 +200,14 @@ static hipError_t linear_fwd(snerf_trainer* t, const LayerP& L, const float* In,
 // dIn[M, n_cols] (+)= alpha * dZ[M, n_out] W[:, :n_cols]
 static hipError_t linear_dgrad(snerf_trainer* t, const LayerP& L, const float* dZ, int64_t ldz, int64_t M, float* dIn, int64_t ld_in,
                                int n_cols, float alpha, bool accumulate, hipStream_t st) {
-    if (t->gemm_mode == 1 && M >= 1024 && L.n_out >= 16 && n_cols >= 16) {
-        const int kp = (L.n_out + 31) / 32 * 32;
-        // Bt[n = input feature][k = output feature] = W[k][n]: transposed split
-        hipError_t e = launch_split_weights(t->params + L.w, L.n_out, L.n_in, true, t->w_hi, t->w_lo, n_cols, kp, st);
-        if (e != hipSuccess) return e;
+    if (rows_ok(t, M, L.n_out, n_cols)) {
         GemmX x{};
-        x.A = dZ; x.Bh = t->w_hi; x.Bl = t->w_lo; x.C = dIn; x.M = M; x.N = n_cols; x.K = L.n_out; x.lda = ldz; x.ldc = ld_in;
-        x.kp = kp; x.alpha = alpha; x.bias = nullptr; x.colsum = nullptr; x.accumulate = accumulate ? 1 : 0;
+        x.n_tiles = (n_cols + 31) / 32; x.ksteps = (L.n_out + 15) / 16;
+        // Bt[n = input feature][k = output feature] = W[k][n]: transposed split
+        hipError_t e = launch_split_weights(t->params + L.w, L.n_out, L.n_in, true, t->w_frag, x.n_tiles, x.ksteps, st);
+        if (e != hipSuccess) return e;
+        x.A = dZ; x.frag = t->w_frag; x.C = dIn; x.M = M; x.N = n_cols; x.K = L.n_out; x.lda = ldz; x.ldc = ld_in;
+        x.alpha = alpha; x.bias = nullptr; x.stats = nullptr; x.accumulate = accumulate ? 1 : 0;
         return launch_gemm_bf16x3(x, st);
     }
     GemmArgs g{};
@@ -215,6 +220,8 @@ static hipError_t linear_dgrad(snerf_trainer* t, const LayerP& L, const float* d
 // dW[n_out, n_in] += alpha * dZ^T In   (split over the point dimension, fp32 atomics)
 static hipError_t linear_wgrad(snerf_trainer* t, const LayerP& L, const float* dZ, int64_t ldz, const float* In, int64_t ld_in,
                                int64_t M, float alpha, hipStream_t st) {
+    if (t->gemm_mode == 1 && M >= 1024 && L.n_out >= 16 && L.n_in >= 16)
+        return launch_wgrad_bf16x3(dZ, ldz, In, ld_in, M, L.n_out, L.n_in, alpha, t->grads + L.w, L.n_in, st);
     GemmArgs g{};
     g.A = dZ; g.B = In; g.C = t->grads + L.w;
     g.M = L.n_out; g.N = L.n_in; g.K = M;
@@ -233,7 +240,12 @@ static int sine_fwd(snerf_trainer* t, const LayerP& L, const float* In, int64_t 
     const int C = L.n_out;
     if (L.bn) {
         float *colsum = bnslot, *m2 = bnslot + t->W, *mean = bnslot + 2 * t->W, *istd = bnslot + 3 * t->W;
-        if (train_bn) {
+        if (train_bn && rows_ok(t, M, L.n_in, L.n_out)) {
+            // batch statistics from the GEMM epilogue: shifted sums (shift = 30 b) in double, no extra pass over Z
+            HIPCK(hipMemsetAsync(t->bn_stats, 0, 2 * C * sizeof(double), st));
+            HIPCK(linear_fwd(t, L, In, ld_in, M, Z.p, Z.ld, 30.f, nullptr, st, t->bn_stats));
+            HIPCK(launch_bn_finalize_shifted(t->bn_stats, t->params + L.b, 30.f, M, C, mean, istd, t->buffers + L.rm, t->buffers + L.rv, st));
+        } else if (train_bn) {
             HIPCK(hipMemsetAsync(bnslot, 0, 2 * t->W * sizeof(float), st));
             HIPCK(linear_fwd(t, L, In, ld_in, M, Z.p, Z.ld, 30.f, colsum, st));
             HIPCK(launch_bn_finalize(colsum, m2, M, C, mean, istd, nullptr, nullptr, 0, st));

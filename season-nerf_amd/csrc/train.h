@@ -21,20 +21,25 @@ struct GemmArgs {
 };
 hipError_t launch_gemm(const GemmArgs& g, hipStream_t st);
 
-// bf16x3 NT GEMM (forward and dgrad of the training engine): C (+)= alpha*(A Bt^T + bias), Bt pre-split by launch_split_weights
+// bf16x3 row-owner GEMM (forward and dgrad of the training engine): C (+)= alpha*(A Bt^T + bias); Bt pre-split into MFMA
+// fragment order by launch_split_weights (n_tiles x ksteps fragments of 2 KiB: bf16 hi, bf16 lo)
 struct GemmX {
     const float* A;            // [M, lda] fp32, k contiguous
-    const uint16_t *Bh, *Bl;   // [>= N rows, kp] bf16 hi / lo, zero padded
+    const uint16_t* frag;      // [n_tiles][ksteps][2][512] bf16
     float* C;
     int64_t M, N, K, lda, ldc;
-    int kp;
+    int n_tiles, ksteps;       // ceil(N/32), ceil(K/16)
     float alpha;
     const float* bias;
-    float* colsum;
+    double* stats;             // optional [2][N]: += sum_m (v - alpha*bias), += sum_m (v - alpha*bias)^2   (train-mode BatchNorm)
     int accumulate;
 };
-hipError_t launch_split_weights(const float* W, int rows, int cols, bool transpose, uint16_t* hi, uint16_t* lo, int out_rows, int kp, hipStream_t st);
+hipError_t launch_split_weights(const float* W, int rows, int cols, bool transpose, uint16_t* frag, int n_tiles, int ksteps, hipStream_t st);
+int gemm_rows_group_tiles(int ksteps);      // 0 = K too large for the LDS-resident weight layout (caller falls back to fp32 MFMA)
 hipError_t launch_gemm_bf16x3(const GemmX& g, hipStream_t st);
+// bf16x3 weight gradient: dW[n_out, n_in] (ld ldw) += alpha * dZ[M, n_out]^T In[M, n_in]   (fp32 atomics over M-chunks)
+hipError_t launch_wgrad_bf16x3(const float* dZ, int64_t ldz, const float* In, int64_t ldi, int64_t M, int n_out, int n_in, float alpha,
+                               float* dW, int64_t ldw, hipStream_t st);
 
 // ---- elementwise / reduction kernels of the training path (train_kernels.hip)
 struct PeArgs {            // positions (from rays or explicit) -> PE(pos) [N,64] (63 features + zero pad) and points [N,3]
@@ -68,6 +73,8 @@ hipError_t launch_colreduce(const ColArgs& a, hipStream_t st);
 hipError_t launch_bn_finalize(const float* colsum, const float* m2, int64_t M, int C, float* mean, float* istd,
                               float* running_mean, float* running_var, int stage, hipStream_t st);
 // H = sin(gamma*(Z-mu)*istd + beta) (bn) or sin(Z)
+hipError_t launch_bn_finalize_shifted(const double* stats, const float* bias, float alpha, int64_t M, int C, float* mean, float* istd,
+                                      float* running_mean, float* running_var, hipStream_t st);
 hipError_t launch_sin_fwd(const float* Z, float* H, int64_t M, int C, int64_t ldz, int64_t ldh, const float* mu, const float* istd,
                           const float* gamma, const float* beta, hipStream_t st);
 // BN backward second pass: dZ = gamma*istd*(dY - sdy/M - xhat*sdyx/M) in place; colsum(dZ) -> out (bias grad)

@@ -8,6 +8,8 @@
 
 namespace snerf {
 
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
 #define LAUNCH_1D(kernel, n, st, ...)                                                    \
     do {                                                                                 \
         const int64_t _n = (n);                                                          \
@@ -159,6 +161,28 @@ hipError_t launch_bn_finalize(const float* colsum, const float* m2, int64_t M, i
     return hipGetLastError();
 }
 
+// train-mode statistics from the shifted sums of the GEMM epilogue: S1 = sum(z - s), S2 = sum((z - s)^2), s = alpha*bias
+__global__ void bn_finalize_shifted_kernel(const double* stats, const float* bias, float alpha, int64_t M, int C, float* mean, float* istd,
+                                           float* running_mean, float* running_var) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double m1 = stats[c] / (double)M, m2 = stats[C + c] / (double)M;
+    const double mu = (double)(alpha * bias[c]) + m1;
+    double var_b = m2 - m1 * m1;                                    // biased: normalisation (torch BatchNorm1d)
+    if (var_b < 0.0) var_b = 0.0;
+    mean[c] = (float)mu;
+    istd[c] = 1.f / sqrtf((float)var_b + 1e-5f);
+    const double var_u = M > 1 ? var_b * (double)M / (double)(M - 1) : var_b;    // unbiased: running estimate
+    running_mean[c] = 0.99f * running_mean[c] + 0.01f * (float)mu;
+    running_var[c] = 0.99f * running_var[c] + 0.01f * (float)var_u;
+}
+hipError_t launch_bn_finalize_shifted(const double* stats, const float* bias, float alpha, int64_t M, int C, float* mean, float* istd,
+                                      float* running_mean, float* running_var, hipStream_t st) {
+    hipLaunchKernelGGL(bn_finalize_shifted_kernel, dim3((C + 255) / 256), dim3(256), 0, st, stats, bias, alpha, M, C, mean, istd,
+                       running_mean, running_var);
+    return hipGetLastError();
+}
+
 __global__ void sin_fwd_kernel(const float* Z, float* H, int64_t M, int C, int64_t ldz, int64_t ldh, const float* mu,
                                const float* istd, const float* gamma, const float* beta) {
     const int64_t total = M * C;
@@ -170,8 +194,42 @@ __global__ void sin_fwd_kernel(const float* Z, float* H, int64_t M, int C, int64
         H[r * ldh + c] = sinf(z);
     }
 }
+// 16-byte variant (C, ldz, ldh multiples of 4, aligned bases): a thread keeps the BatchNorm constants of its 4 columns in
+// registers and walks down the rows - no index division, full-width loads and stores
+__global__ __launch_bounds__(256) void sin_fwd_vec_kernel(const float* Z, float* H, int64_t M, int C4, int cpt, int64_t ldz, int64_t ldh,
+                                                          const float* mu, const float* istd, const float* gamma, const float* beta) {
+    const int tc = threadIdx.x % cpt, tr = threadIdx.x / cpt, rows_pass = 256 / cpt;
+    if (tc >= C4) return;
+    float sc[4] = {1.f, 1.f, 1.f, 1.f}, m_[4] = {0.f, 0.f, 0.f, 0.f}, is_[4] = {1.f, 1.f, 1.f, 1.f}, be[4] = {0.f, 0.f, 0.f, 0.f};
+    if (mu) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { sc[q] = gamma[tc * 4 + q]; m_[q] = mu[tc * 4 + q]; is_[q] = istd[tc * 4 + q]; be[q] = beta[tc * 4 + q]; }
+    }
+    for (int64_t r = (int64_t)blockIdx.x * rows_pass + tr; r < M; r += (int64_t)gridDim.x * rows_pass) {
+        const f32x4_t z = *(const f32x4_t*)(Z + r * ldz + tc * 4);
+        f32x4_t o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float y = z[q];
+            if (mu) y = sc[q] * ((y - m_[q]) * is_[q]) + be[q];
+            o[q] = sinf(y);
+        }
+        *(f32x4_t*)(H + r * ldh + tc * 4) = o;
+    }
+}
 hipError_t launch_sin_fwd(const float* Z, float* H, int64_t M, int C, int64_t ldz, int64_t ldh, const float* mu, const float* istd,
                           const float* gamma, const float* beta, hipStream_t st) {
+    if (M <= 0 || C <= 0) return hipSuccess;
+    if (C % 4 == 0 && C <= 1024 && ldz % 4 == 0 && ldh % 4 == 0 && (uintptr_t)Z % 16 == 0 && (uintptr_t)H % 16 == 0) {
+        const int C4 = C / 4;
+        int cpt = 1;
+        while (cpt < C4) cpt <<= 1;                       // threads per row, power of two <= 256
+        const int rows_pass = 256 / cpt;
+        int64_t blocks = (M + rows_pass - 1) / rows_pass;
+        if (blocks > 8192) blocks = 8192;
+        hipLaunchKernelGGL(sin_fwd_vec_kernel, dim3((unsigned)blocks), dim3(256), 0, st, Z, H, M, C4, cpt, ldz, ldh, mu, istd, gamma, beta);
+        return hipGetLastError();
+    }
     LAUNCH_1D(sin_fwd_kernel, M * C, st, Z, H, M, C, ldz, ldh, mu, istd, gamma, beta);
     return hipGetLastError();
 }
