@@ -119,9 +119,12 @@ def bench_train(a):
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(steps):
+    for i in range(steps):
+        marks[i].record()
         tot = step()
+    marks[steps].record()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -131,6 +134,7 @@ def bench_train(a):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     dt /= steps
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))     # stream time of each step (diagnostic)
     # algorithmic FLOPs: image rays 3 x forward; sun rays: trunk+heads+solar forward + 3 x solar/sky heads
     flop = R * S * (3 * FLOP_PER_SAMPLE + 2 * (524800 + 3 * 54656))
     lname = "Barron adaptive loss" if barron else "MSE loss"
@@ -143,7 +147,7 @@ def bench_train(a):
                "data": "synthetic",
                "config": {"workload": f"BASELINE configs[2]: training step 4096x96, T_NeRF(256,4) train-mode BatchNorm, solar branch on, {lname}",
                           "parallelism": f"rays sharded over {world} GPU(s), one all-reduce of the flat gradient arena, BatchNorm statistics per rank"},
-               "final_loss": float(tot),
+               "final_loss": float(tot.detach()), "step_ms_median": per_step[len(per_step) // 2], "step_ms_min": per_step[0],
                "roofline": {"bound": "mfma", "achieved": flop / dt / 1e12, "peak": 157.3, "unit": "TFLOP/s", "frac": flop / dt / 157.3e12,
                             "traffic": None, "note": "layer-wise path, whole step (not one kernel) priced against the fp32 matrix peak "
                                                      "(MI355X_MICROARCH.md); per-kernel times in profiles/r1"}}

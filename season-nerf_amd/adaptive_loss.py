@@ -58,6 +58,7 @@ def _log_partition_table(a_max=4.0, n=513):
 
 
 _TABLE = None
+_TABLE_DEV = {}
 
 
 def _table():
@@ -75,8 +76,10 @@ def log_base_partition_function(alpha):
     """log Z(alpha) for alpha in [0, 4], differentiable in alpha (cubic Hermite interpolation of the table)."""
     a, v, s = _table()
     h = float(a[1] - a[0])
-    va = torch.as_tensor(v, dtype=alpha.dtype, device=alpha.device)
-    sa = torch.as_tensor(s, dtype=alpha.dtype, device=alpha.device)
+    key = (alpha.dtype, alpha.device)
+    if key not in _TABLE_DEV:            # uploaded once per device: a per-call host->device copy would stall the stream
+        _TABLE_DEV[key] = (torch.as_tensor(v, dtype=alpha.dtype, device=alpha.device), torch.as_tensor(s, dtype=alpha.dtype, device=alpha.device))
+    va, sa = _TABLE_DEV[key]
     u = torch.clamp(alpha, 0.0, float(a[-1])) / h
     i = torch.clamp(u.detach().floor().long(), 0, len(a) - 2)
     f = u - i

@@ -224,7 +224,7 @@ __global__ void split_weights_kernel(const float* W, int rows, int cols, int tra
 template <int NT>
 __global__ __launch_bounds__(512) void gemm_rows_kernel(const GemmX g) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_w[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     const int KS = g.ksteps;
     const int n_groups = (g.n_tiles + NT - 1) / NT;
@@ -396,13 +396,14 @@ struct WgradX {
 
 constexpr int WG_STAGE = 32;
 
+template <bool FULL>            // FULL: every 256 x 256 block of dW is complete (no tile or column masks in the hot loop)
 __global__ __launch_bounds__(512) void wgrad_bf16x3_kernel(const WgradX g) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_f[];          // [2 buffers][2 operands][8 tiles][2 ksteps][hi,lo][1 KiB]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     const int o_base = blockIdx.y * 256, i_base = blockIdx.z * 256;
-    const int to_n = (g.n_out - o_base + 31) / 32 < 8 ? (g.n_out - o_base + 31) / 32 : 8;      // valid 32-column tiles of each operand
-    const int ti_n = (g.n_in - i_base + 31) / 32 < 8 ? (g.n_in - i_base + 31) / 32 : 8;
+    const int to_n = FULL ? 8 : ((g.n_out - o_base + 31) / 32 < 8 ? (g.n_out - o_base + 31) / 32 : 8);      // valid 32-column tiles of each operand
+    const int ti_n = FULL ? 8 : ((g.n_in - i_base + 31) / 32 < 8 ? (g.n_in - i_base + 31) / 32 : 8);
     const int wo = wave >> 1, wi = wave & 1;                 // this wave's dW piece: n_out tiles {2wo, 2wo+1} x n_in tiles {4wi .. 4wi+3}
     const int64_t m_begin = (int64_t)blockIdx.x * g.rows_per_block;
     const int64_t m_end = m_begin + g.rows_per_block < g.M ? m_begin + g.rows_per_block : g.M;
@@ -410,21 +411,31 @@ __global__ __launch_bounds__(512) void wgrad_bf16x3_kernel(const WgradX g) {
     const int n_stages = (int)((m_end - m_begin + WG_STAGE - 1) / WG_STAGE);
 
     // producer role: wave w gathers tile w of dZ and tile w of In (both k-steps of the stage)
-    const bool make_o = wave < to_n, make_i = wave < ti_n;
+    const bool make_o = FULL || wave < to_n, make_i = FULL || wave < ti_n;
     const int col_o = o_base + wave * 32 + r, col_i = i_base + wave * 32 + r;
-    const bool ok_o = make_o && col_o < g.n_out, ok_i = make_i && col_i < g.n_in;
+    const bool ok_o = FULL || (make_o && col_o < g.n_out), ok_i = FULL || (make_i && col_i < g.n_in);
+    // branch-free gathers: a wave-uniform 64-bit stage base plus a 32-bit lane offset (row clamped to the last valid row of this
+    // workgroup's range); out-of-range values are zeroed at publish time so that nothing depends on the loads before then
+    const uint32_t ldz = (uint32_t)g.ldz, ldi = (uint32_t)g.ldi;
+    const uint32_t co = ok_o ? (uint32_t)col_o : 0u, ci = ok_i ? (uint32_t)col_i : 0u;
+    const int64_t m_last = m_end - 1;
     float vo[2][8], vi[2][8];
+    int gathered_last = 0;
     auto gather = [&](int stage) {
-        const int64_t m0 = m_begin + (int64_t)stage * WG_STAGE + h * 8;
+        const int64_t ms = m_begin + (int64_t)stage * WG_STAGE;                  // uniform
+        const int last_rel = (int)(m_last - ms < 63 ? m_last - ms : 63);         // >= 0: the stage exists
+        const float* bo = g.dZ + ms * g.ldz;
+        const float* bi = g.In + ms * g.ldi;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const int64_t m = m0 + ks * 16 + e;
-                const bool mok = m < m_end;
-                vo[ks][e] = (ok_o && mok) ? g.dZ[m * g.ldz + col_o] : 0.f;
-                vi[ks][e] = (ok_i && mok) ? g.In[m * g.ldi + col_i] : 0.f;
+                const int k = h * 8 + ks * 16 + e;
+                const uint32_t kr = (uint32_t)(k < last_rel ? k : last_rel);
+                vo[ks][e] = bo[kr * ldz + co];          // raw: masking waits for publish, so nothing here depends on the
+                vi[ks][e] = bi[kr * ldi + ci];          // loads and they stay in flight across the MFMA block
             }
+        gathered_last = last_rel;
     };
     auto publish = [&](int buf) {
         uint8_t* base = lds_f + buf * 65536;
@@ -434,9 +445,10 @@ __global__ __launch_bounds__(512) void wgrad_bf16x3_kernel(const WgradX g) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 uint32_t a, b;
-                split2_bf16(vo[ks][2 * q], vo[ks][2 * q + 1], a, b);
+                const bool k0 = h * 8 + ks * 16 + 2 * q <= gathered_last, k1 = h * 8 + ks * 16 + 2 * q + 1 <= gathered_last;
+                split2_bf16((ok_o && k0) ? vo[ks][2 * q] : 0.f, (ok_o && k1) ? vo[ks][2 * q + 1] : 0.f, a, b);
                 oh[q] = a; ol[q] = b;
-                split2_bf16(vi[ks][2 * q], vi[ks][2 * q + 1], a, b);
+                split2_bf16((ok_i && k0) ? vi[ks][2 * q] : 0.f, (ok_i && k1) ? vi[ks][2 * q + 1] : 0.f, a, b);
                 ih[q] = a; il[q] = b;
             }
             const uint32_t f = (uint32_t)((wave * 2 + ks) * 2048 + lane * 16);
@@ -470,13 +482,13 @@ __global__ __launch_bounds__(512) void wgrad_bf16x3_kernel(const WgradX g) {
             }
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
-                if (4 * wi + b < ti_n) {
+                if (FULL || 4 * wi + b < ti_n) {
                     const uint32_t f = (uint32_t)(32768 + ((4 * wi + b) * 2 + ks) * 2048);
                     const bf16x8 Bhi = __builtin_bit_cast(bf16x8, *(const u32x4*)(base + f));
                     const bf16x8 Blo = __builtin_bit_cast(bf16x8, *(const u32x4*)(base + f + 1024));
 #pragma unroll
                     for (int a = 0; a < 2; ++a) {
-                        if (2 * wo + a < to_n) {
+                        if (FULL || 2 * wo + a < to_n) {
                             const bf16x8 Ahi = __builtin_bit_cast(bf16x8, ah[a]), Alo = __builtin_bit_cast(bf16x8, al[a]);
                             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Alo, Bhi, acc[a][b], 0, 0, 0);
                             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ahi, Blo, acc[a][b], 0, 0, 0);
@@ -493,12 +505,12 @@ __global__ __launch_bounds__(512) void wgrad_bf16x3_kernel(const WgradX g) {
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-            if (2 * wo + a < to_n && 4 * wi + b < ti_n) {
+            if (FULL || (2 * wo + a < to_n && 4 * wi + b < ti_n)) {
                 const int i = i_base + (4 * wi + b) * 32 + r;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int o = o_base + (2 * wo + a) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                    if (o < g.n_out && i < g.n_in) atomicAdd(g.dW + (int64_t)o * g.ldw + i, g.alpha * acc[a][b][e]);
+                    if (FULL || (o < g.n_out && i < g.n_in)) atomicAdd(g.dW + (int64_t)o * g.ldw + i, g.alpha * acc[a][b][e]);
                 }
             }
         }
@@ -507,9 +519,11 @@ __global__ __launch_bounds__(512) void wgrad_bf16x3_kernel(const WgradX g) {
 hipError_t launch_wgrad_bf16x3(const float* dZ, int64_t ldz, const float* In, int64_t ldi, int64_t M, int n_out, int n_in, float alpha,
                                float* dW, int64_t ldw, hipStream_t st) {
     if (M <= 0 || n_out <= 0 || n_in <= 0) return hipSuccess;
+    if (ldz >= (1 << 24) || ldi >= (1 << 24)) return hipErrorInvalidValue;      // 32-bit lane offsets: 64 rows x ld
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)wgrad_bf16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        hipError_t e = hipFuncSetAttribute((const void*)wgrad_bf16x3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wgrad_bf16x3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
@@ -523,7 +537,10 @@ hipError_t launch_wgrad_bf16x3(const float* dZ, int64_t ldz, const float* In, in
     if (rows < 4 * WG_STAGE) rows = 4 * WG_STAGE;
     bx = (M + rows - 1) / rows;
     g.rows_per_block = rows;
-    hipLaunchKernelGGL(wgrad_bf16x3_kernel, dim3((unsigned)bx, by, bz), dim3(512), 131072, st, g);
+    if (n_out % 256 == 0 && n_in % 256 == 0)
+        hipLaunchKernelGGL(wgrad_bf16x3_kernel<true>, dim3((unsigned)bx, by, bz), dim3(512), 131072, st, g);
+    else
+        hipLaunchKernelGGL(wgrad_bf16x3_kernel<false>, dim3((unsigned)bx, by, bz), dim3(512), 131072, st, g);
     return hipGetLastError();
 }
 

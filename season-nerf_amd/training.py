@@ -18,6 +18,38 @@ from . import _lib
 from .evaluator import sample_parameters
 
 
+class _PinnedRing:
+    """Persistent pinned staging buffers for the few small host tensors a training step uploads (sample parameters, the
+    random sun rays).  A pageable H2D copy waits for all queued GPU work - a hidden sync per step - and a fresh pinned
+    allocation per upload (hipHostMalloc) is itself expensive; a ring of 16 reusable slots per shape is neither.  A slot is
+    rewritten 16 uploads later, by which time its copy has long left the queue (the stream runs at most ~2 steps ahead)."""
+    SLOTS = 16
+
+    def __init__(self):
+        self.rings = {}
+
+    def upload(self, t, dev):
+        key = (tuple(t.shape), torch.device(dev))
+        ring = self.rings.get(key)
+        if ring is None:
+            ring = self.rings[key] = [[torch.empty(t.shape, dtype=torch.float32).pin_memory() for _ in range(self.SLOTS)], 0]
+        slot = ring[0][ring[1] % self.SLOTS]
+        ring[1] += 1
+        slot.copy_(t)
+        return slot.to(dev, non_blocking=True)
+
+
+_RING = _PinnedRing()
+
+
+def _to_dev(t, dev):
+    """Host -> device without stalling the stream (see _PinnedRing); device tensors pass through."""
+    t = t.detach()
+    if t.device.type == "cpu" and torch.device(dev).type == "cuda":
+        return _RING.upload(t, dev)
+    return t.to(device=dev, dtype=torch.float32).contiguous()
+
+
 def _ptr(t):
     return t.data_ptr() if t is not None else None
 
@@ -72,16 +104,31 @@ class TrainEngine:
                 self.param_keys.append(k)
                 self.param_list.append(t)
         self._ptrs = [p.data_ptr() for p in self.param_list]
+        self._grad_views = None
 
     def adopted(self):
         return all(p.data_ptr() == q for p, q in zip(self.param_list, self._ptrs))
 
-    def grad_copies(self):
-        out = []
-        for k, p in zip(self.param_keys, self.param_list):
-            _, off, num = self.layout[k]
-            out.append(self.grads[off:off + num].view(p.shape).clone())
-        return out
+    def attach_grads(self):
+        """Make every parameter's .grad a view of the engine's flat gradient arena, which the backward kernels accumulate
+        into directly (no per-parameter copies through autograd).  A .grad that is None (optimizer.zero_grad(set_to_none=True))
+        gets a zeroed view; a foreign .grad tensor is copied into its slice first."""
+        views = self._grad_views
+        if views is None:
+            views = self._grad_views = [self.grads[off:off + num].view(p.shape)
+                                        for p, (_, off, num) in ((p, self.layout[k]) for k, p in zip(self.param_keys, self.param_list))]
+        state = [0 if p.grad is None else (1 if p.grad.data_ptr() == v.data_ptr() else 2) for p, v in zip(self.param_list, views)]
+        if all(s_ == 1 for s_ in state):
+            return
+        all_none = all(s_ == 0 for s_ in state)
+        if all_none:
+            self.grads.zero_()
+        for p, v, s_ in zip(self.param_list, views, state):
+            if s_ == 0 and not all_none:
+                v.zero_()
+            elif s_ == 2:
+                v.copy_(p.grad)
+            p.grad = v
 
     def stream(self):
         return C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -121,6 +168,8 @@ class _ImagePass(torch.autograd.Function):
     @staticmethod
     def forward(ctx, eng, top, bot, tv, sun, tim, train_bn, prior, *params):
         R, S, dev = eng.R, eng.S, eng.dev
+        if any(p.requires_grad for p in params):
+            eng.attach_grads()
         e = lambda *s: torch.empty(*s, device=dev)
         o = {"rgb": e(R, 3), "albedo": e(R, 3), "pv": e(R, S, 1), "pe": e(R, S, 1), "ps": e(R, S, 1), "delta": e(R, S, 1),
              "sky": e(R, 3), "cls": e(R, eng.net.n_classes), "rho": e(R, S, 1), "sv": e(R, S, 1), "col": e(R, S, 3), "pts": e(R, S, 3),
@@ -160,10 +209,11 @@ class _ImagePass(torch.autograd.Function):
         rs, trust = ctx.prior if ctx.prior is not None else (None, 1.0)
         if rs is None:
             g_rgb_m = g_alb_m = None
-        eng.zero_grad()
+        # parameter gradients accumulate straight into the arena behind every p.grad (attach_grads): autograd gets None
+        eng.attach_grads()
         _lib.check(eng.L.snerf_trainer_backward_image(eng.h, _ptr(g_rgb), _ptr(g_albedo), _ptr(g_sky), _ptr(g_pe), _ptr(rs), trust,
                                                       _ptr(g_rgb_m), _ptr(g_alb_m), eng.stream()), "trainer_backward_image")
-        return (None,) * 8 + tuple(eng.grad_copies())
+        return (None,) * (8 + len(eng.param_list))
 
 
 class _SolarPass(torch.autograd.Function):
@@ -186,11 +236,11 @@ class _SolarPass(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_sv, *_):
         eng = ctx.eng
-        eng.zero_grad()
         if g_sv is not None:
+            eng.attach_grads()
             g = g_sv.contiguous()
             _lib.check(eng.L.snerf_trainer_backward_solar(eng.h, g.data_ptr(), eng.stream()), "trainer_backward_solar")
-        return (None,) * 6 + tuple(eng.grad_copies())
+        return (None,) * (6 + len(eng.param_list))
 
 
 def _angles_to_local_vecs(el_deg, az_deg, world_center, W2L_H):
@@ -227,7 +277,7 @@ class create_solor_rays_uniform:
         vec_t = torch.tensor(vec).float()
         if not include_times:
             return starts, ends, vec_t
-        fr = torch.rand([n, 2]) * 2 * np.pi
+        fr = torch.rand([n, 2]) * (2 * float(np.pi))
         times = torch.stack([torch.cos(fr[:, 0]), torch.sin(fr[:, 0]), torch.cos(fr[:, 1]), torch.sin(fr[:, 1])], 1)
         return starts, ends, vec_t, times, az_el
 
@@ -236,9 +286,9 @@ def _after_train_forward(net):
     """Bookkeeping torch would do: BatchNorm1d.num_batches_tracked += 1 per train-mode forward; the running statistics
     were updated by the engine outside torch's version counters, so the packed inference weights are stale."""
     if net.training:
-        for m in net.modules():
-            if isinstance(m, torch.nn.BatchNorm1d):
-                m.num_batches_tracked += 1
+        nbt = [m.num_batches_tracked for m in net.modules() if isinstance(m, torch.nn.BatchNorm1d)]
+        if nbt:
+            torch._foreach_add_(nbt, 1)
         net._sig = None
 
 
@@ -254,12 +304,12 @@ def eval_train(ev, data_dict, net, train_mode, current_step=0):
     """`All_in_One_Eval.eval` on the layer-wise engine: a network in .train() mode (batch-statistics BatchNorm,
     differentiable) or a width without a fused kernel (eval mode)."""
     dev = ev.device
-    f = lambda k: data_dict[k].to(device=dev, dtype=torch.float32).contiguous()
+    f = lambda k: _to_dev(data_dict[k], dev)
     top, bot, sun, tim = f("Top"), f("Bot"), f("Sun_Angle"), f("Time_Encoded")
     R, S = top.shape[0], ev.args.n_samples
     n_solar = R if ev.args.Use_Solar else 0
     eng = _engine_for(net, R, n_solar, S)
-    tv = sample_parameters(S, eval_mode=not train_mode).to(dev)
+    tv = _to_dev(sample_parameters(S, eval_mode=not train_mode), dev)
     prior = (net, current_step / ev.n_steps) if ev.use_prior else None
     res = _ImagePass.apply(eng, top, bot, tv, sun, tim, net.training, prior, *eng.param_list)
     rgb, alb, sky, pe, rgb_m, alb_m, pv, ps, dl, cls, rho, sv, col, pts, adjc = res[:15]
@@ -281,7 +331,7 @@ def eval_train(ev, data_dict, net, train_mode, current_step=0):
 
 def eval_rho_only_train(ev, data_dict, net, train_mode, current_step=0):
     dev = ev.device
-    f = lambda k: data_dict[k].to(device=dev, dtype=torch.float32).contiguous()
+    f = lambda k: _to_dev(data_dict[k], dev)
     top, bot, sun = f("Top"), f("Bot"), f("Sun_Angle")
     R, S = top.shape[0], ev.args.n_samples
     eng = getattr(net, "_train_engine", None)
@@ -289,7 +339,7 @@ def eval_rho_only_train(ev, data_dict, net, train_mode, current_step=0):
         if torch.is_grad_enabled() and net.training:
             raise RuntimeError("season_nerf_amd: the sun-ray pass must follow an image pass of the same step with as many rays")
         eng = _engine_for(net, R, R, S)
-    tv = sample_parameters(S, eval_mode=not train_mode, include_end_pt=True).to(dev)
+    tv = _to_dev(sample_parameters(S, eval_mode=not train_mode, include_end_pt=True), dev)
     sv, pv, pe, sky_raw, rho, pts, dl = _SolarPass.apply(eng, top, bot, tv, sun, net.training, *eng.param_list)
     _after_train_forward(net)
     if ev.use_prior:                                              # Eval_Tools_2.py:319-334
@@ -318,12 +368,12 @@ def get_loss(ev, data_dict, net, current_step, train_mode):
         absorb = torch.mean(1 - torch.sum(so["PE"].detach() * so["PV_Exact"].detach() * so["Solar_Vis"], 1))
         Loss["Solar_Correction_2"] = [absorb.detach() if not args.Solar_Type_2 else absorb, weight["Solar_Correction"]]
         if not args.Solar_Type_2:
+            # the reference selects with boolean indexing (`SK_Albedo[SK_Albedo < .2]`, `SK_Sky[SK_Sky > 0]`, :374-388), a
+            # device->host sync per step; masked sums give the same values without leaving the stream
             alb_min, _ = torch.min(out["Albedo_Color"], 0)
-            sel = alb_min[alb_min < .2]
-            alb_loss = torch.sum((1. - sel / .2) ** 2) / out["Albedo_Color"].shape[0] if sel.shape[0] > 0 else torch.tensor(0.0, device=dev)
+            alb_loss = torch.sum(torch.where(alb_min < .2, (1. - alb_min / .2) ** 2, torch.zeros_like(alb_min))) / out["Albedo_Color"].shape[0]
             x = (out["Sky_Col"] - .5) / .5
-            pos = x[x > 0]
-            sk = torch.sum(pos ** 2) / x.numel() if pos.shape[0] > 0 else torch.tensor(0., device=dev)
+            sk = torch.sum(torch.where(x > 0, x ** 2, torch.zeros_like(x))) / x.numel()
             if ev.use_prior:
                 sk = sk.detach()
             Loss["Sky_Color_Var"] = [sk, weight["Solar_Correction"]]
@@ -364,18 +414,21 @@ class FusedAdam(torch.optim.Optimizer):
         self.net = net
         super().__init__(list(net.parameters()), dict(lr=lr, betas=betas, eps=eps))
 
+    def zero_grad(self, set_to_none=False):
+        """Zero the gradient arena in one kernel; the parameters keep their .grad views (set_to_none is accepted and ignored)."""
+        eng = getattr(self.net, "_train_engine", None)
+        if eng is None:
+            return super().zero_grad(set_to_none=True)
+        eng.attach_grads()
+        eng.zero_grad()
+
     @torch.no_grad()
     def step(self, closure=None):
         eng = getattr(self.net, "_train_engine", None)
         if eng is None:
             raise RuntimeError("FusedAdam.step before any training forward/backward")
         g = self.param_groups[0]
-        # gather the autograd-accumulated gradients into the arena (parameters without a gradient keep a zero slot)
-        eng.grads.zero_()
-        for k, p in zip(eng.param_keys, eng.param_list):
-            if p.grad is not None:
-                _, off, num = eng.layout[k]
-                eng.grads[off:off + num].copy_(p.grad.reshape(-1))
+        eng.attach_grads()            # every p.grad is a view of the flat arena the backward kernels accumulated into
         if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
             # data parallel: ONE all-reduce of the flat gradient arena over RCCL/xGMI, then identical Adam on every rank
             torch.distributed.all_reduce(eng.grads)
