@@ -177,6 +177,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the auxiliary 512x512 sweep measurement (counter passes)")
     ap.add_argument("--workload", default="render", choices=["render", "train"],
                     help="render = headline (BASELINE configs[1]); train = configs[2]: one training step, 4096x96 + 4096 sun rays")
     ap.add_argument("--loss", default="barron", choices=["barron", "mse"], help="colour loss of --workload train")
@@ -250,7 +251,7 @@ def main():
     field_ms = float(np.mean([ev0[i].elapsed_time(ev1[i]) for i in range(a.steps)]))
 
     extra = {}
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not a.no_sweep:
         # outside the timed region: a whole 512x512x96 novel-view image and the 12-step seasonal sweep (BASELINE configs[4],
         # single GPU), through the renderer seam (component render + sweep kernel); wall clock incl. host-side ray grid
         WC, H4 = np.array([41.29, -95.9, 300.0]), np.array([[310.0, 12.0, 0.0, -11650.0], [-9.0, 240.0, 0.0, 23390.0], [0.0, 0.0, 0.01, -3.0], [0, 0, 0, 1.0]])
@@ -271,7 +272,7 @@ def main():
         achieved = FLOP_PER_SAMPLE * R * S / (field_ms * 1e-3)
         traffic = None          # HBM bytes per launch from the committed PMC passes of this same command (profiles/)
         try:
-            traffic = json.load(open(os.path.join(REPO, "profiles", "r1", "c_traffic.json")))["bytes_per_launch"]
+            traffic = json.load(open(os.path.join(REPO, "profiles", "r1", "e_traffic.json")))["bytes_per_launch"]
         except Exception:
             pass
         out = {

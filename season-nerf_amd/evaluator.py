@@ -26,6 +26,20 @@ def sample_parameters(n_samples, eval_mode, include_end_pt=False):
     return ts.float().contiguous()
 
 
+_TV_CACHE = {}
+
+
+def sample_parameters_on(dev, n_samples, eval_mode, include_end_pt=False):
+    """sample_parameters on the device.  The eval-mode vector is deterministic and cached per device (a pageable host->device
+    copy per call would wait for all queued GPU work); the jittered train-mode vector is drawn on the host like the reference's."""
+    if not eval_mode:
+        return sample_parameters(n_samples, False, include_end_pt).to(dev)
+    key = (int(n_samples), bool(include_end_pt), torch.device(dev))
+    if key not in _TV_CACHE:
+        _TV_CACHE[key] = sample_parameters(n_samples, True, include_end_pt).to(dev)
+    return _TV_CACHE[key]
+
+
 class All_in_One_Eval:
     def __init__(self, args, device, n_steps, use_prior, ada_loss, H, WC, base_solar_vecs=None):
         self.device = torch.device(device)
@@ -67,7 +81,7 @@ class All_in_One_Eval:
         N = R * S
         L = _lib.lib()
         st = Network._stream()
-        tv = sample_parameters(S, eval_mode=not train_mode).to(dev)
+        tv = sample_parameters_on(dev, S, eval_mode=not train_mode)
         cls, _, sky = Network._groups(tim, sun)
         e = lambda *s: torch.empty(*s, device=dev)
         rho, sv, col, adjc, pts = e(R, S, 1), e(R, S, 1), e(R, S, 3), e(R, S, 3), e(R, S, 3)
@@ -126,7 +140,7 @@ class All_in_One_Eval:
         dev = top.device
         R, S = top.shape[0], self.args.n_samples
         L, st = _lib.lib(), Network._stream()
-        tv = sample_parameters(S, eval_mode=True).to(dev)
+        tv = sample_parameters_on(dev, S, eval_mode=True)
         cls, _, sky = Network._groups(tim, sun)
         e = lambda *s: torch.empty(*s, device=dev)
         rho, sv, col = e(R, S, 1), e(R, S, 1), e(R, S, 3)
@@ -164,7 +178,7 @@ class All_in_One_Eval:
         R, S = top.shape[0], self.args.n_samples
         L = _lib.lib()
         st = Network._stream()
-        tv = sample_parameters(S, eval_mode=not train_mode, include_end_pt=True).to(dev)
+        tv = sample_parameters_on(dev, S, eval_mode=not train_mode, include_end_pt=True)
         tim = torch.zeros(R, 4, device=dev)
         _, sky_raw, sky = Network._groups(tim, sun)
         e = lambda *s: torch.empty(*s, device=dev)

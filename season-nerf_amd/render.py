@@ -17,7 +17,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .evaluator import All_in_One_Eval, sample_parameters
+from .evaluator import All_in_One_Eval, sample_parameters, sample_parameters_on
 from .network import T_NeRF
 
 
@@ -56,7 +56,7 @@ def _exact_solar_visibility(net: T_NeRF, pts, sun_vec, S, zero_oob, chunk_rays=6
     L = _lib.lib()
     st = net._stream()
     M = pts.shape[0]
-    tv = sample_parameters(S, eval_mode=True, include_end_pt=True).to(dev)
+    tv = sample_parameters_on(dev, S, eval_mode=True, include_end_pt=True)
     sun = sun_vec if sun_vec.dim() == 2 else sun_vec.unsqueeze(0).expand(M, 3)
     K = (1.0 - pts[:, 2]) / sun[:, 2]
     if sun64 is None:
@@ -195,7 +195,7 @@ def _render_by_dir_device(net, view_el_az, sun_el_az, time_frac, out_img_size, W
     (top, bot) = net._prep(top, bot)
     L = _lib.lib()
     st = net._stream()
-    tv = sample_parameters(S, eval_mode=True, include_end_pt=True).to(dev)
+    tv = sample_parameters_on(dev, S, eval_mode=True, include_end_pt=True)
     sun1, tim1 = _f32(sunv.reshape(1, 3), dev), _f32(encode_time(time_frac).reshape(1, 4), dev)
     cls, _, sky = net._groups(tim1, sun1)                                  # one (time, sun) group for the whole image
     e = lambda *s: torch.empty(*s, device=dev)
