@@ -177,6 +177,24 @@ int snerf_trainer_forward_solar(snerf_trainer* t, int64_t n_rays, int n_samples,
                                 float* d_pe, float* d_sky_raw, float* d_rho, float* d_points, float* d_delta, void* stream);
 int snerf_trainer_backward_solar(snerf_trainer* t, const float* d_g_solar_vis, void* stream);
 int snerf_trainer_zero_grad(snerf_trainer* t, void* stream);
+/* ---- the three products of a Linear / SineLayer (`misc.SineLayer.forward`, misc.py:188-194, and its autograd backward) as
+ * stand-alone calls - the building blocks of the training engine, exposed for tests and for callers that schedule layers
+ * themselves.  Row-major fp32, leading dimensions in floats; weight is the [n_out, n_in] nn.Linear matrix.
+ * precision: 1 = error-compensated bf16x3 MFMA (~1e-5 relative, needs d_scratch of snerf_linear_scratch_bytes), 0 = exact
+ * fp32 MFMA.
+ *   forward: out[m, o] = alpha * (sum_i in[m, i] * weight[o, i] + bias[o]);  d_stats (optional, bf16x3 only, caller-zeroed
+ *            double[2][n_out]) += sum_m (out - alpha*bias), sum_m (out - alpha*bias)^2   (train-mode BatchNorm statistics)
+ *   dgrad:   grad_in[m, i] (+)= alpha * sum_o grad_out[m, o] * weight[o, i]   for i < n_cols
+ *   wgrad:   grad_weight[o, i] += alpha * sum_m grad_out[m, o] * in[m, i]     (always accumulates) */
+size_t snerf_linear_scratch_bytes(int n_out, int n_in);
+int snerf_linear_forward(int64_t n_points, int n_in, int n_out, const float* d_in, int64_t ld_in, const float* d_weight,
+                         const float* d_bias, float alpha, float* d_out, int64_t ld_out, double* d_stats, int precision,
+                         void* d_scratch, size_t scratch_bytes, void* stream);
+int snerf_linear_dgrad(int64_t n_points, int n_in, int n_out, const float* d_grad_out, int64_t ld_go, const float* d_weight,
+                       int n_cols, float alpha, int accumulate, float* d_grad_in, int64_t ld_gi, int precision,
+                       void* d_scratch, size_t scratch_bytes, void* stream);
+int snerf_linear_wgrad(int64_t n_points, int n_in, int n_out, const float* d_grad_out, int64_t ld_go, const float* d_in,
+                       int64_t ld_in, float alpha, float* d_grad_weight, int precision, void* stream);
 /* test introspection: synchronous copy of an internal buffer ("d_rho", "d_col", "d_head", "d_sky", ...) to the host */
 int snerf_trainer_debug_read(snerf_trainer* t, const char* name, float* host_out, int64_t n_floats);
 /* torch.optim.Adam semantics (no weight decay) over the whole parameter arena in one launch; step counts from 1. */

@@ -37,7 +37,7 @@ struct snerf_model {
 extern "C" {
 
 const char* snerf_last_error(void) { return g_err.c_str(); }
-int snerf_abi_version(void) { return 2; }
+int snerf_abi_version(void) { return 3; }
 
 snerf_model* snerf_model_create(int layer_width, int n_classes) {
     if (layer_width != 64 && layer_width != 256) {

@@ -575,6 +575,87 @@ int snerf_trainer_debug_read(snerf_trainer* t, const char* name, float* host_out
     return SNERF_OK;
 }
 
+// ---- the three products of a Linear layer as stand-alone calls (building blocks of the training engine; tests)
+size_t snerf_linear_scratch_bytes(int n_out, int n_in) {
+    const int64_t d = n_out > n_in ? n_out : n_in;
+    return (size_t)(((d + 31) / 32) * ((d + 15) / 16) * 2048 + 256);
+}
+
+static int linear_mode(int precision, int64_t M, int K, int N) {      // 1 = bf16x3 kernel applicable and requested
+    return (precision == 1 && M >= 1 && K >= 1 && N >= 1 && gemm_rows_group_tiles((K + 15) / 16) > 0) ? 1 : 0;
+}
+
+int snerf_linear_forward(int64_t n_points, int n_in, int n_out, const float* d_in, int64_t ld_in, const float* d_weight,
+                         const float* d_bias, float alpha, float* d_out, int64_t ld_out, double* d_stats, int precision,
+                         void* d_scratch, size_t scratch_bytes, void* stream) {
+    if (n_points < 0 || n_in < 1 || n_out < 1) return snerf_set_error(SNERF_E_INVALID, "snerf_linear_forward: bad shape");
+    if (n_points == 0) return SNERF_OK;
+    if (!d_in || !d_weight || !d_out || ld_in < n_in || ld_out < n_out) return snerf_set_error(SNERF_E_INVALID, "snerf_linear_forward: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    if (linear_mode(precision, n_points, n_in, n_out)) {
+        if (!d_scratch || scratch_bytes < snerf_linear_scratch_bytes(n_out, n_in)) return snerf_set_error(SNERF_E_INVALID, "snerf_linear_forward: scratch too small");
+        GemmX x{};
+        x.n_tiles = (n_out + 31) / 32; x.ksteps = (n_in + 15) / 16;
+        HIPCK(launch_split_weights(d_weight, n_out, n_in, false, (uint16_t*)d_scratch, x.n_tiles, x.ksteps, st));
+        x.A = d_in; x.frag = (const uint16_t*)d_scratch; x.C = d_out; x.M = n_points; x.N = n_out; x.K = n_in; x.lda = ld_in; x.ldc = ld_out;
+        x.alpha = alpha; x.bias = d_bias; x.stats = d_stats; x.accumulate = 0;
+        HIPCK(launch_gemm_bf16x3(x, st));
+        return SNERF_OK;
+    }
+    if (d_stats) return snerf_set_error(SNERF_E_INVALID, "snerf_linear_forward: column statistics need the bf16x3 path");
+    GemmArgs g{};
+    g.A = d_in; g.B = d_weight; g.C = d_out; g.M = n_points; g.N = n_out; g.K = n_in;
+    g.sAm = ld_in; g.sAk = 1; g.sBk = 1; g.sBn = n_in; g.ldc = ld_out;
+    g.alpha = alpha; g.bias = d_bias; g.colsum = nullptr; g.flags = 0; g.splitk = 1;
+    HIPCK(launch_gemm(g, st));
+    return SNERF_OK;
+}
+
+int snerf_linear_dgrad(int64_t n_points, int n_in, int n_out, const float* d_grad_out, int64_t ld_go, const float* d_weight,
+                       int n_cols, float alpha, int accumulate, float* d_grad_in, int64_t ld_gi, int precision, void* d_scratch,
+                       size_t scratch_bytes, void* stream) {
+    if (n_points < 0 || n_in < 1 || n_out < 1 || n_cols < 1 || n_cols > n_in) return snerf_set_error(SNERF_E_INVALID, "snerf_linear_dgrad: bad shape");
+    if (n_points == 0) return SNERF_OK;
+    if (!d_grad_out || !d_weight || !d_grad_in || ld_go < n_out || ld_gi < n_cols) return snerf_set_error(SNERF_E_INVALID, "snerf_linear_dgrad: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    if (linear_mode(precision, n_points, n_out, n_cols)) {
+        if (!d_scratch || scratch_bytes < snerf_linear_scratch_bytes(n_out, n_in)) return snerf_set_error(SNERF_E_INVALID, "snerf_linear_dgrad: scratch too small");
+        GemmX x{};
+        x.n_tiles = (n_cols + 31) / 32; x.ksteps = (n_out + 15) / 16;
+        HIPCK(launch_split_weights(d_weight, n_out, n_in, true, (uint16_t*)d_scratch, x.n_tiles, x.ksteps, st));
+        x.A = d_grad_out; x.frag = (const uint16_t*)d_scratch; x.C = d_grad_in; x.M = n_points; x.N = n_cols; x.K = n_out; x.lda = ld_go; x.ldc = ld_gi;
+        x.alpha = alpha; x.bias = nullptr; x.stats = nullptr; x.accumulate = accumulate ? 1 : 0;
+        HIPCK(launch_gemm_bf16x3(x, st));
+        return SNERF_OK;
+    }
+    GemmArgs g{};
+    g.A = d_grad_out; g.B = d_weight; g.C = d_grad_in; g.M = n_points; g.N = n_cols; g.K = n_out;
+    g.sAm = ld_go; g.sAk = 1; g.sBk = n_in; g.sBn = 1; g.ldc = ld_gi;
+    g.alpha = alpha; g.bias = nullptr; g.colsum = nullptr; g.flags = accumulate ? GEMM_ACCUM : 0; g.splitk = 1;
+    HIPCK(launch_gemm(g, st));
+    return SNERF_OK;
+}
+
+int snerf_linear_wgrad(int64_t n_points, int n_in, int n_out, const float* d_grad_out, int64_t ld_go, const float* d_in,
+                       int64_t ld_in, float alpha, float* d_grad_weight, int precision, void* stream) {
+    if (n_points < 0 || n_in < 1 || n_out < 1) return snerf_set_error(SNERF_E_INVALID, "snerf_linear_wgrad: bad shape");
+    if (n_points == 0) return SNERF_OK;
+    if (!d_grad_out || !d_in || !d_grad_weight || ld_go < n_out || ld_in < n_in) return snerf_set_error(SNERF_E_INVALID, "snerf_linear_wgrad: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    if (precision == 1) {
+        HIPCK(launch_wgrad_bf16x3(d_grad_out, ld_go, d_in, ld_in, n_points, n_out, n_in, alpha, d_grad_weight, n_in, st));
+        return SNERF_OK;
+    }
+    GemmArgs g{};
+    g.A = d_grad_out; g.B = d_in; g.C = d_grad_weight; g.M = n_out; g.N = n_in; g.K = n_points;
+    g.sAm = 1; g.sAk = ld_go; g.sBk = ld_in; g.sBn = 1; g.ldc = n_in;
+    g.alpha = alpha; g.bias = nullptr; g.colsum = nullptr; g.flags = GEMM_ATOMIC;
+    int64_t sk = (n_points + 2047) / 2048;
+    g.splitk = (int)(sk > 1024 ? 1024 : (sk < 1 ? 1 : sk));
+    HIPCK(launch_gemm(g, st));
+    return SNERF_OK;
+}
+
 int snerf_trainer_zero_grad(snerf_trainer* t, void* stream) {
     if (!t || !t->grads) return snerf_set_error(SNERF_E_STATE, "trainer not bound");
     HIPCK(hipMemsetAsync(t->grads, 0, t->n_params * sizeof(float), (hipStream_t)stream));

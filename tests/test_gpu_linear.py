@@ -1,0 +1,115 @@
+"""The three Linear-layer products of the training engine (snerf_linear_forward / dgrad / wgrad: the bf16x3 row-owner and
+weight-gradient kernels and the exact-fp32 MFMA kernel) against float64 torch matmuls at awkward shapes: row counts that are
+not tile multiples, K / N that are not multiples of 16 / 32, unaligned leading dimensions, the 64-column-group variant
+(K > 256), several column groups per row tile, partial 256 x 256 blocks of dW."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TOL = {1: 3e-5, 0: 2e-6}          # max |err| / max |ref|: bf16x3 (3 x 2^-17-ish per product, fp32 accumulate) / exact fp32
+
+
+def _env():
+    import season_nerf_amd as sn
+    L = sn._lib.lib()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return sn, L, st
+
+
+def _scratch(L, n_out, n_in):
+    return torch.empty(L.snerf_linear_scratch_bytes(n_out, n_in), dtype=torch.uint8, device="cuda")
+
+
+def _rel(got, ref):
+    return float((got.double() - ref).abs().max() / ref.abs().max())
+
+
+FWD = [  # M, K (n_in), N (n_out), lda, ldc
+    (1000, 64, 64, 64, 64), (1536, 319, 256, 320, 256), (777, 63, 256, 64, 260), (2048, 256, 256, 256, 256), (513, 128, 12, 128, 12),
+    (130, 283, 128, 284, 128), (4101, 256, 319, 256, 320), (600, 63, 100, 63, 101), (1100, 512, 512, 512, 512), (700, 528, 40, 528, 40),
+    (1, 16, 16, 16, 16), (65, 7, 5, 7, 5)]
+
+
+@pytest.mark.parametrize("precision", [1, 0])
+@pytest.mark.parametrize("shape", FWD)
+def test_linear_forward(shape, precision):
+    sn, L, st = _env()
+    M, K, N, lda, ldc = shape
+    g = torch.Generator(device="cpu").manual_seed(M + K)
+    A = torch.randn(M, lda, generator=g).cuda()
+    Wt = (torch.randn(N, K, generator=g) / np.sqrt(K)).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    out = torch.full((M, ldc), 7.0, device="cuda")
+    use_stats = precision == 1 and K <= 512
+    stats = torch.zeros(2, N, dtype=torch.float64, device="cuda")
+    sc = _scratch(L, N, K)
+    sn._lib.check(L.snerf_linear_forward(M, K, N, A.data_ptr(), lda, Wt.data_ptr(), b.data_ptr(), 30.0, out.data_ptr(), ldc,
+                                         stats.data_ptr() if use_stats else None, precision, sc.data_ptr(), sc.numel(), st), "linear_forward")
+    ref = 30.0 * (A[:, :K].double() @ Wt.double().T + b.double())
+    assert _rel(out[:, :N], ref) < TOL[precision]
+    assert bool((out[:, N:] == 7.0).all())                       # padding columns of the output untouched
+    if use_stats:
+        d = ref - 30.0 * b.double()
+        s = stats.cpu()
+        np.testing.assert_allclose(s[0].numpy(), d.sum(0).cpu().numpy(), rtol=0, atol=2e-4 * float(d.abs().sum(0).max()))
+        np.testing.assert_allclose(s[1].numpy(), (d * d).sum(0).cpu().numpy(), rtol=2e-4, atol=2e-4 * float((d * d).sum(0).max()))
+
+
+DG = [  # M, n_in, n_out, n_cols, ld_go, ld_gi
+    (1500, 319, 256, 256, 256, 256), (1500, 319, 256, 319, 256, 320), (900, 128, 128, 128, 128, 128), (2049, 256, 12, 256, 12, 256),
+    (640, 283, 128, 283, 132, 283), (1030, 63, 256, 63, 256, 64)]
+
+
+@pytest.mark.parametrize("precision", [1, 0])
+@pytest.mark.parametrize("shape", DG)
+@pytest.mark.parametrize("accumulate", [0, 1])
+def test_linear_dgrad(shape, precision, accumulate):
+    sn, L, st = _env()
+    M, n_in, n_out, n_cols, ld_go, ld_gi = shape
+    g = torch.Generator(device="cpu").manual_seed(M + n_in + accumulate)
+    dZ = torch.randn(M, ld_go, generator=g).cuda()
+    Wt = (torch.randn(n_out, n_in, generator=g) / np.sqrt(n_out)).cuda()
+    base = torch.randn(M, ld_gi, generator=g).cuda()
+    dIn = base.clone()
+    sc = _scratch(L, n_out, n_in)
+    sn._lib.check(L.snerf_linear_dgrad(M, n_in, n_out, dZ.data_ptr(), ld_go, Wt.data_ptr(), n_cols, 30.0, accumulate, dIn.data_ptr(), ld_gi,
+                                       precision, sc.data_ptr(), sc.numel(), st), "linear_dgrad")
+    ref = 30.0 * (dZ[:, :n_out].double() @ Wt.double()[:, :n_cols]) + (base[:, :n_cols].double() if accumulate else 0.0)
+    assert _rel(dIn[:, :n_cols], ref) < TOL[precision]
+    assert torch.equal(dIn[:, n_cols:], base[:, n_cols:])
+
+
+WG = [  # M, n_in, n_out, ld_go, ld_in
+    (5000, 256, 256, 256, 256), (3001, 319, 256, 256, 320), (1024, 283, 128, 128, 284), (100, 63, 64, 64, 64), (1234, 512, 512, 512, 512),
+    (257, 128, 12, 12, 128), (33, 16, 16, 20, 17)]
+
+
+@pytest.mark.parametrize("precision", [1, 0])
+@pytest.mark.parametrize("shape", WG)
+def test_linear_wgrad(shape, precision):
+    sn, L, st = _env()
+    M, n_in, n_out, ld_go, ld_in = shape
+    g = torch.Generator(device="cpu").manual_seed(M + n_in)
+    dZ = torch.randn(M, ld_go, generator=g).cuda()
+    X = torch.randn(M, ld_in, generator=g).cuda()
+    base = torch.randn(n_out, n_in, generator=g).cuda()
+    dW = base.clone()
+    sn._lib.check(L.snerf_linear_wgrad(M, n_in, n_out, dZ.data_ptr(), ld_go, X.data_ptr(), ld_in, 0.5, dW.data_ptr(), precision, st), "linear_wgrad")
+    ref = base.double() + 0.5 * (dZ[:, :n_out].double().T @ X[:, :n_in].double())
+    scale = float((0.5 * (dZ[:, :n_out].double().T @ X[:, :n_in].double())).abs().max())
+    assert float((dW.double() - ref).abs().max()) / scale < TOL[precision] * 3        # split-K fp32 atomics on top
+
+
+def test_linear_argument_errors():
+    sn, L, st = _env()
+    a = torch.zeros(8, 8, device="cuda")
+    assert L.snerf_linear_forward(8, 8, 8, a.data_ptr(), 4, a.data_ptr(), None, 1.0, a.data_ptr(), 8, None, 0, None, 0, st) != 0      # ld < n_in
+    assert b"bad argument" in L.snerf_last_error()
+    assert L.snerf_linear_forward(8, 8, 8, a.data_ptr(), 8, a.data_ptr(), None, 1.0, a.data_ptr(), 8, None, 1, None, 0, st) != 0      # no scratch
+    assert L.snerf_linear_forward(0, 8, 8, None, 8, None, None, 1.0, None, 8, None, 1, None, 0, st) == 0                                  # empty batch
+    assert L.snerf_linear_dgrad(8, 8, 8, a.data_ptr(), 8, a.data_ptr(), 9, 1.0, 0, a.data_ptr(), 8, 0, None, 0, st) != 0                 # n_cols > n_in
+    assert L.snerf_linear_wgrad(-1, 8, 8, a.data_ptr(), 8, a.data_ptr(), 8, 1.0, a.data_ptr(), 0, st) != 0

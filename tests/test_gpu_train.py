@@ -42,9 +42,18 @@ def run_step(g, net, ev, data):
     return loss, total
 
 
-@pytest.mark.parametrize("name", ["train_W64_R32_S32.npz", "train_prior_W64_R24_S40.npz"])
+def _ref_grads(g):
+    """name -> (reference gradient values, flat index step); the W=256 fixture stores every k-th element of big tensors."""
+    out = {k[5:]: (g[k].reshape(-1), 1) for k in g if k.startswith("grad_")}
+    out.update({k[5:]: (g[k], int(g["subsample"])) for k in g if k.startswith("gsub_")})
+    return out
+
+
+@pytest.mark.parametrize("name", ["train_W64_R32_S32.npz", "train_prior_W64_R24_S40.npz", "train_W256_R32_S40.npz"])
 def test_train_step_vs_reference(golden_dir, name):
-    """name 2: the DSM-prior phase (use_prior=True: supervised + merged composites, Alpha_Adjust loss)."""
+    """name 2: the DSM-prior phase (use_prior=True: supervised + merged composites, Alpha_Adjust loss); name 3: the benchmark
+    width (W=256: 64-column-group GEMM for fc5, several column groups per row tile, full 256x256 wgrad blocks, 1280 points =
+    not a multiple of the 512-row tile)."""
     sn, g, net, ev, data = setup(golden_dir, name)
     opt = torch.optim.Adam(net.parameters(), lr=float(g["lr"]))
     opt.zero_grad()
@@ -52,21 +61,23 @@ def test_train_step_vs_reference(golden_dir, name):
     for k in loss:
         ref = float(g["loss_" + k])
         print(f"  loss {k:20s} {float(loss[k][0].detach()):.8f} ref {ref:.8f}")
-        assert abs(float(loss[k][0]) - ref) <= 2e-5 * max(1.0, abs(ref)) + 1e-6, k
+        assert abs(float(loss[k][0].detach()) - ref) <= 2e-5 * max(1.0, abs(ref)) + 1e-6, k
         assert abs(float(loss[k][1]) - float(g["weight_" + k])) < 1e-9
-    assert abs(float(total) - float(g["total"])) <= 1e-4 * abs(float(g["total"]))
+    assert abs(float(total.detach()) - float(g["total"])) <= 1e-4 * abs(float(g["total"]))
     total.backward()
-    names = [k[5:] for k in g if k.startswith("grad_")]
+    refs = _ref_grads(g)
+    names = list(refs)
     params = dict(net.named_parameters())
-    gmax = max(np.abs(g["grad_" + n]).max() for n in names)
+    gmax = max(np.abs(v).max() for v, _ in refs.values())
     worst = 0
     for n in names:
-        ref = g["grad_" + n]
-        got = params[n].grad.cpu().numpy()
+        ref, step = refs[n]
+        got = params[n].grad.cpu().numpy().reshape(-1)[::step]
         scale = max(np.abs(ref).max(), 1e-3 * gmax)      # zero-gradient biases in front of BN: see test_oracle_golden
         err = np.abs(got - ref).max() / scale
         worst = max(worst, err)
-        print(f"  grad {n:44s} rel err {err:.2e}  (|ref| max {np.abs(ref).max():.2e})")
+        if "gnorm_" + n in g:
+            assert abs(float(params[n].grad.double().norm()) - float(g["gnorm_" + n])) <= 2e-3 * float(g["gnorm_" + n]), n
     print(f"  worst relative gradient error {worst:.2e}")
     assert worst < 2e-3
     for n in ("adjust_rho.weight", "adjust_solar_vis.bias", "adjust_sky_col.weight"):      # dead heads stay without gradient
@@ -81,7 +92,7 @@ def test_train_step_vs_reference(golden_dir, name):
     before = {n: params[n].detach().cpu().numpy().copy() for n in names}
     opt.step()
     for n in names:
-        if np.abs(g["grad_" + n]).max() < 1e-3 * gmax:
+        if "adam_" + n not in g or np.abs(refs[n][0]).max() < 1e-3 * gmax:
             continue
         got = params[n].detach().cpu().numpy() - before[n]
         # the first Adam step is -lr*g/(|g|+eps) ~ -lr*sign(g): an element whose gradient is below the gradient tolerance
@@ -114,4 +125,4 @@ def test_fused_adam_matches_torch_adam(golden_dir):
     _, total2 = run_step(g, net, ev, data)
     total2.backward()
     fa.step()
-    assert float(total2) != float(total)
+    assert float(total2.detach()) != float(total.detach())

@@ -149,7 +149,9 @@ def gen_eval(W, seed, R, S, tag, with_prior):
     np.savez_compressed(os.path.join(OUT, f"eval_{tag}.npz"), **out)
 
 
-def gen_train(W, seed, R, S, tag, prior=False):
+def gen_train(W, seed, R, S, tag, prior=False, subsample=0):
+    """subsample > 0: tensors above 4096 elements are stored as every `subsample`-th element (flat order) plus their L2 norm
+    (keeps the W=256 fixture small)."""
     hm = None
     if prior:
         hm = np.random.Generator(np.random.PCG64(9)).uniform(-0.8, 0.6, (48, 48))
@@ -190,16 +192,23 @@ def gen_train(W, seed, R, S, tag, prior=False):
     for k in loss:
         out["loss_" + k] = f32(loss[k][0])
         out["weight_" + k] = np.float32(loss[k][1])
+    big = lambda p: subsample and p.numel() > 4096
+    if subsample:
+        out["subsample"] = subsample
     for n, p in net.named_parameters():
         if p.grad is not None:
-            out["grad_" + n] = f32(p.grad)
+            if big(p):
+                out["gsub_" + n] = f32(p.grad).reshape(-1)[::subsample]
+                out["gnorm_" + n] = np.float64(p.grad.double().norm())
+            else:
+                out["grad_" + n] = f32(p.grad)
     opt.step()
     new_sd = net.state_dict()
     for n in new_sd:
         if n.endswith("running_mean") or n.endswith("running_var"):
             out["bn_" + n] = f32(new_sd[n])
     for n, p in net.named_parameters():
-        if p.grad is not None:
+        if p.grad is not None and not big(p):
             out["adam_" + n] = f32(p)
     np.savez_compressed(os.path.join(OUT, f"train_{tag}.npz"), **out)
 
@@ -302,6 +311,7 @@ if __name__ == "__main__":
     gen_eval(64, 1, 48, 64, "W64_R48_S64", with_prior=True)
     gen_train(64, 0, 32, 32, "W64_R32_S32")
     gen_train(64, 1, 24, 40, "prior_W64_R24_S40", prior=True)
+    gen_train(256, 2, 32, 40, "W256_R32_S40", subsample=37)
     gen_render(64, 2, "W64_s2")
     gen_dsm()
     for f in sorted(os.listdir(OUT)):
