@@ -284,7 +284,7 @@ static int sine_bwd(snerf_trainer* t, const LayerP& L, Act D, Act Z, const float
         // d beta = sum dY, d gamma = sum dY*xhat
         HIPCK(launch_copy_cols(sdy, C, t->grads + L.beta, C, 1, C, true, st));
         HIPCK(launch_copy_cols(sdyx, C, t->grads + L.g, C, 1, C, true, st));
-        HIPCK(launch_bn_bwd2(Z.p, D.p, M, C, Z.ld, mean, istd, t->params + L.g, sdy, sdyx, t->grads + L.b, 30.f, st));
+        HIPCK(launch_bn_bwd2(Z.p, D.p, M, C, Z.ld, mean, istd, t->params + L.g, t->params + L.beta, sdy, sdyx, t->grads + L.b, 30.f, st));
     } else {
         ColArgs ca{};
         ca.mode = 2; ca.M = M; ca.C = C; ca.ld = Z.ld; ca.Z = Z.p; ca.D = D.p; ca.out0 = t->grads + L.b; ca.alpha0 = 30.f;

@@ -79,7 +79,8 @@ hipError_t launch_sin_fwd(const float* Z, float* H, int64_t M, int C, int64_t ld
                           const float* gamma, const float* beta, hipStream_t st);
 // BN backward second pass: dZ = gamma*istd*(dY - sdy/M - xhat*sdyx/M) in place; colsum(dZ) -> out (bias grad)
 hipError_t launch_bn_bwd2(const float* Z, float* D, int64_t M, int C, int64_t ld, const float* mu, const float* istd,
-                          const float* gamma, const float* sdy, const float* sdyx, float* dbias_sum, float alpha, hipStream_t st);
+                          const float* gamma, const float* beta, const float* sdy, const float* sdyx, float* dbias_sum, float alpha,
+                          hipStream_t st);
 
 // point outputs: rho = softplus(head[:,3]), col = sigmoid(head[:,0:3] + sum_c cls[g,c]*adj[:,c,:]), sv = sigmoid(sv_raw)
 struct PointOutArgs {

@@ -109,8 +109,7 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const ColArgs A) {
                     s0 += d * d;
                 } else if (A.mode == 1) {
                     const float xh = (z - mu) * istd;
-                    const float dy = A.D[r * A.ld + c] * cosf(gm * xh + bt);
-                    A.D[r * A.ld + c] = dy;
+                    const float dy = A.D[r * A.ld + c] * cosf(gm * xh + bt);       // not stored: the dZ pass recomputes it
                     s0 += dy;
                     s1 += dy * xh;
                 } else {
@@ -131,8 +130,84 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const ColArgs A) {
         __syncthreads();
     }
 }
+// 16-byte variant of the column passes of a SineLayer backward (C, ld multiples of 4, aligned bases): a thread owns 4
+// columns (constants in registers) and walks down a 512-row chunk; partial sums meet in LDS, one atomic per column and block.
+//   MODE 1  BatchNorm reduction: sum dY, sum dY*xhat with dY = dH*cos(gamma*xhat+beta)   (reads Z, D; writes nothing)
+//   MODE 2  plain layer: D <- dH*cos(z), out0 += alpha0 * sum
+//   MODE 3  BatchNorm dZ: D <- gamma*istd*(dY - mean(dY) - xhat*mean(dY*xhat)), out0 += alpha0 * sum   (sdy/sdyx via mu2/istd2)
+template <int MODE>
+__global__ __launch_bounds__(256) void colpass_vec_kernel(const ColArgs A, int C4, int cpt, const float* sdy, const float* sdyx) {
+    __shared__ float red[2][256][4];
+    const int tc = threadIdx.x % cpt, tr = threadIdx.x / cpt, rows_pass = 256 / cpt;
+    const bool live = tc < C4;
+    float mu[4] = {0.f, 0.f, 0.f, 0.f}, is[4] = {1.f, 1.f, 1.f, 1.f}, gm[4] = {1.f, 1.f, 1.f, 1.f}, bt[4] = {0.f, 0.f, 0.f, 0.f};
+    float ma[4] = {0.f, 0.f, 0.f, 0.f}, mb[4] = {0.f, 0.f, 0.f, 0.f};
+    if (live && MODE != 2) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = tc * 4 + q;
+            mu[q] = A.mu[c]; is[q] = A.istd[c]; gm[q] = A.gamma[c]; bt[q] = A.beta[c];
+            if (MODE == 3) { const float invM = 1.f / (float)A.M; ma[q] = sdy[c] * invM; mb[q] = sdyx[c] * invM; }
+        }
+    }
+    float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
+    const int64_t r0 = (int64_t)blockIdx.x * ROWS_PER_BLOCK;
+    const int64_t r1 = r0 + ROWS_PER_BLOCK < A.M ? r0 + ROWS_PER_BLOCK : A.M;
+    if (live) {
+        for (int64_t r = r0 + tr; r < r1; r += rows_pass) {
+            const f32x4_t z = *(const f32x4_t*)(A.Z + r * A.ld + tc * 4);
+            f32x4_t d = *(const f32x4_t*)(A.D + r * A.ld + tc * 4);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (MODE == 2) {
+                    d[q] *= cosf(z[q]);
+                    s0[q] += d[q];
+                } else {
+                    const float xh = (z[q] - mu[q]) * is[q];
+                    const float dy = d[q] * cosf(gm[q] * xh + bt[q]);
+                    if (MODE == 1) {
+                        s0[q] += dy;
+                        s1[q] += dy * xh;
+                    } else {
+                        d[q] = (gm[q] * is[q]) * (dy - ma[q] - xh * mb[q]);
+                        s0[q] += d[q];
+                    }
+                }
+            }
+            if (MODE != 1) *(f32x4_t*)(A.D + r * A.ld + tc * 4) = d;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { red[0][threadIdx.x][q] = s0[q]; red[1][threadIdx.x][q] = s1[q]; }
+    __syncthreads();
+    if (tr == 0 && live) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float a = 0.f, b = 0.f;
+            for (int p = 0; p < rows_pass; ++p) { a += red[0][p * cpt + tc][q]; b += red[1][p * cpt + tc][q]; }
+            const int c = tc * 4 + q;
+            if (A.out0) atomicAdd(A.out0 + c, (MODE == 1 ? 1.f : A.alpha0) * a);
+            if (MODE == 1) atomicAdd(A.out1 + c, b);
+        }
+    }
+}
+static bool colpass_vec_ok(const ColArgs& a) {
+    return a.C % 4 == 0 && a.C <= 1024 && a.ld % 4 == 0 && (uintptr_t)a.Z % 16 == 0 && (uintptr_t)a.D % 16 == 0;
+}
+template <int MODE>
+static hipError_t launch_colpass_vec(const ColArgs& a, const float* sdy, const float* sdyx, hipStream_t st) {
+    const int C4 = a.C / 4;
+    int cpt = 1;
+    while (cpt < C4) cpt <<= 1;
+    const int64_t blocks = (a.M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+    hipLaunchKernelGGL(colpass_vec_kernel<MODE>, dim3((unsigned)blocks), dim3(256), 0, st, a, C4, cpt, sdy, sdyx);
+    return hipGetLastError();
+}
+
 hipError_t launch_colreduce(const ColArgs& a, hipStream_t st) {
     if (a.M <= 0) return hipSuccess;
+    if (colpass_vec_ok(a) && a.mode == 1) return launch_colpass_vec<1>(a, nullptr, nullptr, st);
+    if (colpass_vec_ok(a) && a.mode == 2) return launch_colpass_vec<2>(a, nullptr, nullptr, st);
     const int64_t blocks = (a.M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
     hipLaunchKernelGGL(colreduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
     return hipGetLastError();
@@ -235,8 +310,8 @@ hipError_t launch_sin_fwd(const float* Z, float* H, int64_t M, int C, int64_t ld
 }
 
 __global__ __launch_bounds__(256) void bn_bwd2_kernel(const float* Z, float* D, int64_t M, int C, int64_t ld, const float* mu,
-                                                      const float* istd, const float* gamma, const float* sdy, const float* sdyx,
-                                                      float* dbias_sum, float alpha) {
+                                                      const float* istd, const float* gamma, const float* beta, const float* sdy,
+                                                      const float* sdyx, float* dbias_sum, float alpha) {
     __shared__ float red0[256];
     const int cp = C >= 256 ? 256 : (C >= 128 ? 128 : (C >= 64 ? 64 : 32));
     const int phases = 256 / cp;
@@ -248,10 +323,11 @@ __global__ __launch_bounds__(256) void bn_bwd2_kernel(const float* Z, float* D, 
         const int c = c0 + tc;
         float s0 = 0.f;
         if (c < C) {
-            const float m = mu[c], is = istd[c], k = gamma[c] * is, a = sdy[c] * invM, b = sdyx[c] * invM;
+            const float m = mu[c], is = istd[c], gm = gamma[c], bt = beta[c], k = gm * is, a = sdy[c] * invM, b = sdyx[c] * invM;
             for (int64_t r = r0 + tp; r < r1; r += phases) {
                 const float xh = (Z[r * ld + c] - m) * is;
-                const float dz = k * (D[r * ld + c] - a - xh * b);
+                const float dy = D[r * ld + c] * cosf(gm * xh + bt);          // D holds dL/dH on entry
+                const float dz = k * (dy - a - xh * b);
                 D[r * ld + c] = dz;
                 s0 += dz;
             }
@@ -266,10 +342,15 @@ __global__ __launch_bounds__(256) void bn_bwd2_kernel(const float* Z, float* D, 
     }
 }
 hipError_t launch_bn_bwd2(const float* Z, float* D, int64_t M, int C, int64_t ld, const float* mu, const float* istd,
-                          const float* gamma, const float* sdy, const float* sdyx, float* dbias_sum, float alpha, hipStream_t st) {
+                          const float* gamma, const float* beta, const float* sdy, const float* sdyx, float* dbias_sum, float alpha,
+                          hipStream_t st) {
     if (M <= 0) return hipSuccess;
+    ColArgs a{};
+    a.mode = 3; a.M = M; a.C = C; a.ld = ld; a.Z = Z; a.D = D; a.mu = mu; a.istd = istd; a.gamma = gamma; a.beta = beta;
+    a.out0 = dbias_sum; a.alpha0 = alpha;
+    if (colpass_vec_ok(a)) return launch_colpass_vec<3>(a, sdy, sdyx, st);
     const int64_t blocks = (M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
-    hipLaunchKernelGGL(bn_bwd2_kernel, dim3((unsigned)blocks), dim3(256), 0, st, Z, D, M, C, ld, mu, istd, gamma, sdy, sdyx, dbias_sum, alpha);
+    hipLaunchKernelGGL(bn_bwd2_kernel, dim3((unsigned)blocks), dim3(256), 0, st, Z, D, M, C, ld, mu, istd, gamma, beta, sdy, sdyx, dbias_sum, alpha);
     return hipGetLastError();
 }
 
