@@ -553,7 +553,7 @@ hipError_t launch_split_weights(const float* W, int rows, int cols, bool transpo
     return hipGetLastError();
 }
 
-int gemm_rows_group_tiles(int ksteps) { return ksteps <= 16 ? 4 : (ksteps <= 32 ? 2 : 0); }     // n-tiles whose weights fit LDS
+int gemm_rows_group_tiles(int ksteps) { return ksteps <= 20 ? 4 : (ksteps <= 32 ? 2 : 0); }     // n-tiles whose weights fit the 160 KiB LDS
 
 hipError_t launch_gemm_bf16x3(const GemmX& g, hipStream_t st) {
     if (g.M <= 0 || g.N <= 0) return hipSuccess;
@@ -566,7 +566,7 @@ hipError_t launch_gemm_bf16x3(const GemmX& g, hipStream_t st) {
     static bool attr_done[2] = {false, false};
     if (nt == 4) {
         if (!attr_done[0]) {
-            hipError_t e = hipFuncSetAttribute((const void*)gemm_rows_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 16 * 2048);
+            hipError_t e = hipFuncSetAttribute((const void*)gemm_rows_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 20 * 2048);
             if (e != hipSuccess) return e;
             attr_done[0] = true;
         }
