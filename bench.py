@@ -77,7 +77,8 @@ def bench_train(a):
         raise SystemExit(f"--gpus {a.gpus} needs torch.distributed.run with {a.gpus} ranks (WORLD_SIZE={world})")
     torch.cuda.set_device(dev)
     dist = None
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ          # under torch.distributed.run the RCCL path runs even with one rank
+    if use_dist:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
     steps, warm = min(a.steps, 20), min(a.warmup, 3)
@@ -107,7 +108,7 @@ def bench_train(a):
         total.backward()
         opt.step()                       # all-reduces the flat gradient arena when torch.distributed is initialised
         if opt_ada is not None:
-            if world > 1:
+            if use_dist:
                 for p_ in ada.parameters():
                     dist.all_reduce(p_.grad)
                     p_.grad /= world
@@ -116,7 +117,7 @@ def bench_train(a):
 
     for _ in range(warm):
         step()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
@@ -125,11 +126,11 @@ def bench_train(a):
         marks[i].record()
         tot = step()
     marks[steps].record()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -167,7 +168,7 @@ def bench_train(a):
             out["cpu_baseline"] = {"value": n * S / tc, "unit": "ray-samples/s", "cores": torch.get_num_threads(), "kind": "port",
                                    "sample": f"one MSE training step (forward both passes + backward) on {n} rays x {S} samples, torch-CPU oracle"}
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
@@ -193,7 +194,8 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ          # under torch.distributed.run the RCCL path runs even with one rank
+    if use_dist:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
 
@@ -209,10 +211,14 @@ def main():
     tv = sn.sample_parameters(S, eval_mode=True).to(dev)
     e = lambda *s: torch.empty(*s, device=dev)
     cls, sky_raw, sky = e(R, NC), e(R, 3), e(R, 3)
-    rho, sv, col, rgb = e(R * S), e(R * S), e(R * S, 3), e(R, 3)
-    gathered = e(world * R, 3) if world > 1 else None
+    rho, sv, col = e(R * S), e(R * S), e(R * S, 3)
+    # RGB tiles are double-buffered so that the all-gather of step i (RCCL's own stream) overlaps the kernels of step i+1
+    rgbs = [e(R, 3), e(R, 3)]
+    gathered = [e(world * R, 3), e(world * R, 3)] if use_dist else None
+    pending = [None, None]
     fo = sn._lib.FieldOut(d_rho=rho.data_ptr(), d_solar_vis=sv.data_ptr(), d_col=col.data_ptr())
-    co = sn._lib.CompositeOut(d_rgb=rgb.data_ptr())
+    cos = [sn._lib.CompositeOut(d_rgb=t.data_ptr()) for t in rgbs]
+    counter = [0]
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps)]
@@ -226,25 +232,32 @@ def main():
                                                  1, sun.data_ptr(), cls.data_ptr(), C.byref(fo), st), "field")
         if i is not None:
             ev1[i].record()
+        b = counter[0] & 1
+        counter[0] += 1
+        if pending[b] is not None:
+            pending[b].wait()                  # the gather that last read this RGB buffer (two steps ago)
         sn._lib.check(L.snerf_composite_rays(R, S, top.data_ptr(), bot.data_ptr(), tv.data_ptr(), rho.data_ptr(),
-                                             col.data_ptr(), sv.data_ptr(), sky.data_ptr(), 0, None, 1.0, C.byref(co), st),
+                                             col.data_ptr(), sv.data_ptr(), sky.data_ptr(), 0, None, 1.0, C.byref(cos[b]), st),
                       "composite")
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, rgb)
+        if use_dist:
+            pending[b] = dist.all_gather_into_tensor(gathered[b], rgbs[b], async_op=True)
 
     for _ in range(a.warmup):
         step()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(a.steps):
         step(i)
-    if world > 1:
+    for w in pending:
+        if w is not None:
+            w.wait()
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -295,7 +308,7 @@ def main():
         if not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
