@@ -115,7 +115,10 @@ def bench_train(a):
             opt_ada.step()
         return total
 
-    for _ in range(warm):
+    step()                                   # builds the engine
+    if a.bn_sync == "global" and use_dist:
+        net._train_engine.sync_batchnorm(True)
+    for _ in range(max(warm - 1, 0)):
         step()
     if use_dist:
         dist.barrier()
@@ -144,10 +147,11 @@ def bench_train(a):
         out = {"metric": f"training image-ray-samples/s (4096 rays x 96 samples + 4096 sun rays per GPU, {lname}, fused Adam)",
                "value": world * R * S / dt, "unit": "ray-samples/s", "n_gpus": world, "steps": steps, "warmup": warm, "ms_per_step": dt * 1e3,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "f32 storage; forward/dgrad GEMMs " + ("bf16x3 split MFMA" if gemm != "fp32" else "fp32 MFMA") + ", wgrad fp32 MFMA",
+               "dtype": "f32 storage; " + ("bf16x3 split MFMA GEMMs (forward, dgrad, wgrad), thin layers fp32 MFMA" if gemm != "fp32" else "fp32 MFMA GEMMs"),
                "data": "synthetic",
                "config": {"workload": f"BASELINE configs[2]: training step 4096x96, T_NeRF(256,4) train-mode BatchNorm, solar branch on, {lname}",
-                          "parallelism": f"rays sharded over {world} GPU(s), one all-reduce of the flat gradient arena, BatchNorm statistics per rank"},
+                          "parallelism": f"rays sharded over {world} GPU(s), one all-reduce of the flat gradient arena, BatchNorm statistics "
+                                         + ("over the global batch (all-reduced)" if a.bn_sync == "global" and use_dist else "per rank")},
                "final_loss": float(tot.detach()), "step_ms_median": per_step[len(per_step) // 2], "step_ms_min": per_step[0],
                "roofline": {"bound": "mfma", "achieved": flop / dt / 1e12, "peak": 157.3, "unit": "TFLOP/s", "frac": flop / dt / 157.3e12,
                             "traffic": None, "note": "layer-wise path, whole step (not one kernel) priced against the fp32 matrix peak "
@@ -182,6 +186,9 @@ def main():
     ap.add_argument("--workload", default="render", choices=["render", "train"],
                     help="render = headline (BASELINE configs[1]); train = configs[2]: one training step, 4096x96 + 4096 sun rays")
     ap.add_argument("--loss", default="barron", choices=["barron", "mse"], help="colour loss of --workload train")
+    ap.add_argument("--bn_sync", default="local", choices=["local", "global"],
+                    help="--workload train, N > 1: BatchNorm statistics per rank, or over the global batch (RCCL all-reduces of the "
+                         "per-layer statistics: the single-process reference's semantics)")
     a = ap.parse_args()
     if a.workload == "train":
         return bench_train(a)

@@ -177,6 +177,13 @@ int snerf_trainer_forward_solar(snerf_trainer* t, int64_t n_rays, int n_samples,
                                 float* d_pe, float* d_sky_raw, float* d_rho, float* d_points, float* d_delta, void* stream);
 int snerf_trainer_backward_solar(snerf_trainer* t, const float* d_g_solar_vis, void* stream);
 int snerf_trainer_zero_grad(snerf_trainer* t, void* stream);
+/* Data-parallel training with BatchNorm statistics over the GLOBAL batch (what the single-process reference computes on the
+ * concatenated rays; `nn.BatchNorm1d` in misc.SineLayer, misc.py:169-170).  `fn` must sum `count` elements of the device
+ * buffer `d_buf` (float when is_double == 0, double otherwise) over all ranks, in stream order on `stream`, and return 0.
+ * The engine calls it for the per-layer statistics in forward (2 x n_out doubles) and the two BatchNorm backward sums
+ * (2 x W floats); every rank must run the same shapes (equal ray shards).  fn == NULL restores per-rank statistics. */
+typedef int (*snerf_allreduce_fn)(void* user, void* d_buf, int64_t count, int is_double, void* stream);
+int snerf_trainer_set_allreduce(snerf_trainer* t, snerf_allreduce_fn fn, void* user, int world_size);
 /* ---- the three products of a Linear / SineLayer (`misc.SineLayer.forward`, misc.py:188-194, and its autograd backward) as
  * stand-alone calls - the building blocks of the training engine, exposed for tests and for callers that schedule layers
  * themselves.  Row-major fp32, leading dimensions in floats; weight is the [n_out, n_in] nn.Linear matrix.

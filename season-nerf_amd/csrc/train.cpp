@@ -63,7 +63,19 @@ struct snerf_trainer {
     uint16_t* w_frag = nullptr;                     // scratch: one weight matrix split into bf16 hi/lo MFMA fragments
     double* bn_stats = nullptr;                     // [2][W] shifted column sums from the GEMM epilogue
     int gemm_mode = 1;                              // 1 = bf16x3 MFMA for forward/dgrad (default), 0 = exact fp32 MFMA everywhere
+    // data-parallel BatchNorm over the global batch: sum-all-reduce of the statistics buffers (snerf_trainer_set_allreduce)
+    snerf_allreduce_fn ar_fn = nullptr;
+    void* ar_user = nullptr;
+    int world = 1;
 };
+
+// sum the buffer over all ranks (no-op without a registered collective)
+static int all_reduce(snerf_trainer* t, void* buf, int64_t count, bool is_double, hipStream_t st) {
+    if (!t->ar_fn) return SNERF_OK;
+    if (t->ar_fn(t->ar_user, buf, count, is_double ? 1 : 0, (void*)st) != 0)
+        return snerf_set_error(SNERF_E_STATE, "the registered all-reduce callback failed");
+    return SNERF_OK;
+}
 
 static int64_t align64(int64_t x) { return (x + 63) / 64 * 64; }
 
@@ -178,6 +190,12 @@ static size_t carve(snerf_trainer* t, char* base, int64_t R, int64_t Rs, int S) 
 static bool rows_ok(const snerf_trainer* t, int64_t M, int K, int N) {
     return t->gemm_mode == 1 && M >= 1024 && K >= 16 && N >= 16 && gemm_rows_group_tiles((K + 15) / 16) > 0;
 }
+#define RCI(x)                 \
+    do {                      \
+        int _rci = (x);       \
+        if (_rci) return _rci; \
+    } while (0)
+
 // Z[M, n_out] = alpha * (In[M, K] W^T + b);  colsum (fp32 path) / stats (bf16x3 path) optional
 static hipError_t linear_fwd(snerf_trainer* t, const LayerP& L, const float* In, int64_t ld_in, int64_t M, float* Z, int64_t ldz,
                              float alpha, float* colsum, hipStream_t st, double* stats = nullptr) {
@@ -238,21 +256,25 @@ static hipError_t linear_wgrad(snerf_trainer* t, const LayerP& L, const float* d
 static int sine_fwd(snerf_trainer* t, const LayerP& L, const float* In, int64_t ld_in, int64_t M, Act Z, Act H, float* bnslot,
                     bool train_bn, hipStream_t st) {
     const int C = L.n_out;
+    const int64_t Mg = M * (t->ar_fn ? t->world : 1);      // rows of the global batch (equal shards per rank)
     if (L.bn) {
         float *colsum = bnslot, *m2 = bnslot + t->W, *mean = bnslot + 2 * t->W, *istd = bnslot + 3 * t->W;
         if (train_bn && rows_ok(t, M, L.n_in, L.n_out)) {
             // batch statistics from the GEMM epilogue: shifted sums (shift = 30 b) in double, no extra pass over Z
             HIPCK(hipMemsetAsync(t->bn_stats, 0, 2 * C * sizeof(double), st));
             HIPCK(linear_fwd(t, L, In, ld_in, M, Z.p, Z.ld, 30.f, nullptr, st, t->bn_stats));
-            HIPCK(launch_bn_finalize_shifted(t->bn_stats, t->params + L.b, 30.f, M, C, mean, istd, t->buffers + L.rm, t->buffers + L.rv, st));
+            RCI(all_reduce(t, t->bn_stats, 2 * C, true, st));          // the shift 30 b is the same on every rank: the sums add
+            HIPCK(launch_bn_finalize_shifted(t->bn_stats, t->params + L.b, 30.f, Mg, C, mean, istd, t->buffers + L.rm, t->buffers + L.rv, st));
         } else if (train_bn) {
             HIPCK(hipMemsetAsync(bnslot, 0, 2 * t->W * sizeof(float), st));
             HIPCK(linear_fwd(t, L, In, ld_in, M, Z.p, Z.ld, 30.f, colsum, st));
-            HIPCK(launch_bn_finalize(colsum, m2, M, C, mean, istd, nullptr, nullptr, 0, st));
+            RCI(all_reduce(t, colsum, C, false, st));
+            HIPCK(launch_bn_finalize(colsum, m2, Mg, C, mean, istd, nullptr, nullptr, 0, st));
             ColArgs ca{};
             ca.mode = 0; ca.M = M; ca.C = C; ca.ld = Z.ld; ca.Z = Z.p; ca.mu = mean; ca.out0 = m2; ca.alpha0 = 1.f;
             HIPCK(launch_colreduce(ca, st));
-            HIPCK(launch_bn_finalize(colsum, m2, M, C, mean, istd, t->buffers + L.rm, t->buffers + L.rv, 1, st));
+            RCI(all_reduce(t, m2, C, false, st));
+            HIPCK(launch_bn_finalize(colsum, m2, Mg, C, mean, istd, t->buffers + L.rm, t->buffers + L.rv, 1, st));
         } else {      // eval-mode statistics (running estimates)
             HIPCK(linear_fwd(t, L, In, ld_in, M, Z.p, Z.ld, 30.f, nullptr, st));
             HIPCK(hipMemcpyAsync(mean, t->buffers + L.rm, C * sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -282,9 +304,11 @@ static int sine_bwd(snerf_trainer* t, const LayerP& L, Act D, Act Z, const float
         if (D.ld != Z.ld) return snerf_set_error(SNERF_E_INVALID, "sine_bwd: gradient and activation strides differ");
         HIPCK(launch_colreduce(ca, st));
         // d beta = sum dY, d gamma = sum dY*xhat
-        HIPCK(launch_copy_cols(sdy, C, t->grads + L.beta, C, 1, C, true, st));
+        HIPCK(launch_copy_cols(sdy, C, t->grads + L.beta, C, 1, C, true, st));       // parameter gradients stay per-rank sums
         HIPCK(launch_copy_cols(sdyx, C, t->grads + L.g, C, 1, C, true, st));
-        HIPCK(launch_bn_bwd2(Z.p, D.p, M, C, Z.ld, mean, istd, t->params + L.g, t->params + L.beta, sdy, sdyx, t->grads + L.b, 30.f, st));
+        RCI(all_reduce(t, t->bn_bwd, 2 * t->W, false, st));                           // the BatchNorm backward means are global
+        HIPCK(launch_bn_bwd2(Z.p, D.p, M, C, Z.ld, mean, istd, t->params + L.g, t->params + L.beta, sdy, sdyx, t->grads + L.b, 30.f,
+                             M * (t->ar_fn ? t->world : 1), st));
     } else {
         ColArgs ca{};
         ca.mode = 2; ca.M = M; ca.C = C; ca.ld = Z.ld; ca.Z = Z.p; ca.D = D.p; ca.out0 = t->grads + L.b; ca.alpha0 = 30.f;
@@ -653,6 +677,13 @@ int snerf_linear_wgrad(int64_t n_points, int n_in, int n_out, const float* d_gra
     int64_t sk = (n_points + 2047) / 2048;
     g.splitk = (int)(sk > 1024 ? 1024 : (sk < 1 ? 1 : sk));
     HIPCK(launch_gemm(g, st));
+    return SNERF_OK;
+}
+
+int snerf_trainer_set_allreduce(snerf_trainer* t, snerf_allreduce_fn fn, void* user, int world_size) {
+    if (!t) return snerf_set_error(SNERF_E_INVALID, "NULL trainer");
+    if (fn && world_size < 1) return snerf_set_error(SNERF_E_INVALID, "snerf_trainer_set_allreduce: world_size must be >= 1");
+    t->ar_fn = fn; t->ar_user = user; t->world = fn ? world_size : 1;
     return SNERF_OK;
 }
 

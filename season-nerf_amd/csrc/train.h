@@ -66,6 +66,7 @@ struct ColArgs {
     const float *mu, *istd, *gamma, *beta;
     float *out0, *out1;
     float alpha0;          // scale of the out0 accumulation (mode 2: 30 = d bias of the Linear)
+    int64_t M_global;      // mode 3: rows of the global batch the BatchNorm means were taken over (>= M)
 };
 hipError_t launch_colreduce(const ColArgs& a, hipStream_t st);
 
@@ -80,7 +81,7 @@ hipError_t launch_sin_fwd(const float* Z, float* H, int64_t M, int C, int64_t ld
 // BN backward second pass: dZ = gamma*istd*(dY - sdy/M - xhat*sdyx/M) in place; colsum(dZ) -> out (bias grad)
 hipError_t launch_bn_bwd2(const float* Z, float* D, int64_t M, int C, int64_t ld, const float* mu, const float* istd,
                           const float* gamma, const float* beta, const float* sdy, const float* sdyx, float* dbias_sum, float alpha,
-                          hipStream_t st);
+                          int64_t M_global, hipStream_t st);
 
 // point outputs: rho = softplus(head[:,3]), col = sigmoid(head[:,0:3] + sum_c cls[g,c]*adj[:,c,:]), sv = sigmoid(sv_raw)
 struct PointOutArgs {

@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void colpass_vec_kernel(const ColArgs A, int C
         for (int q = 0; q < 4; ++q) {
             const int c = tc * 4 + q;
             mu[q] = A.mu[c]; is[q] = A.istd[c]; gm[q] = A.gamma[c]; bt[q] = A.beta[c];
-            if (MODE == 3) { const float invM = 1.f / (float)A.M; ma[q] = sdy[c] * invM; mb[q] = sdyx[c] * invM; }
+            if (MODE == 3) { const float invM = 1.f / (float)A.M_global; ma[q] = sdy[c] * invM; mb[q] = sdyx[c] * invM; }
         }
     }
     float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
@@ -311,14 +311,13 @@ hipError_t launch_sin_fwd(const float* Z, float* H, int64_t M, int C, int64_t ld
 
 __global__ __launch_bounds__(256) void bn_bwd2_kernel(const float* Z, float* D, int64_t M, int C, int64_t ld, const float* mu,
                                                       const float* istd, const float* gamma, const float* beta, const float* sdy,
-                                                      const float* sdyx, float* dbias_sum, float alpha) {
+                                                      const float* sdyx, float* dbias_sum, float alpha, float invM) {
     __shared__ float red0[256];
     const int cp = C >= 256 ? 256 : (C >= 128 ? 128 : (C >= 64 ? 64 : 32));
     const int phases = 256 / cp;
     const int tc = threadIdx.x % cp, tp = threadIdx.x / cp;
     const int64_t r0 = (int64_t)blockIdx.x * ROWS_PER_BLOCK;
     const int64_t r1 = r0 + ROWS_PER_BLOCK < M ? r0 + ROWS_PER_BLOCK : M;
-    const float invM = 1.f / (float)M;
     for (int c0 = 0; c0 < C; c0 += cp) {
         const int c = c0 + tc;
         float s0 = 0.f;
@@ -343,14 +342,15 @@ __global__ __launch_bounds__(256) void bn_bwd2_kernel(const float* Z, float* D, 
 }
 hipError_t launch_bn_bwd2(const float* Z, float* D, int64_t M, int C, int64_t ld, const float* mu, const float* istd,
                           const float* gamma, const float* beta, const float* sdy, const float* sdyx, float* dbias_sum, float alpha,
-                          hipStream_t st) {
+                          int64_t M_global, hipStream_t st) {
     if (M <= 0) return hipSuccess;
     ColArgs a{};
-    a.mode = 3; a.M = M; a.C = C; a.ld = ld; a.Z = Z; a.D = D; a.mu = mu; a.istd = istd; a.gamma = gamma; a.beta = beta;
+    a.mode = 3; a.M = M; a.M_global = M_global; a.C = C; a.ld = ld; a.Z = Z; a.D = D; a.mu = mu; a.istd = istd; a.gamma = gamma; a.beta = beta;
     a.out0 = dbias_sum; a.alpha0 = alpha;
     if (colpass_vec_ok(a)) return launch_colpass_vec<3>(a, sdy, sdyx, st);
     const int64_t blocks = (M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
-    hipLaunchKernelGGL(bn_bwd2_kernel, dim3((unsigned)blocks), dim3(256), 0, st, Z, D, M, C, ld, mu, istd, gamma, beta, sdy, sdyx, dbias_sum, alpha);
+    hipLaunchKernelGGL(bn_bwd2_kernel, dim3((unsigned)blocks), dim3(256), 0, st, Z, D, M, C, ld, mu, istd, gamma, beta, sdy, sdyx, dbias_sum, alpha,
+                       1.f / (float)M_global);
     return hipGetLastError();
 }
 

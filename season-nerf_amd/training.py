@@ -130,6 +130,37 @@ class TrainEngine:
                 v.copy_(p.grad)
             p.grad = v
 
+    def sync_batchnorm(self, enable=True, group=None):
+        """BatchNorm statistics over the global batch of all ranks (the reference's single-process semantics on the
+        concatenated rays) instead of per rank: registers a sum-all-reduce (RCCL through torch.distributed) that the engine
+        calls on its statistics buffers - 2 small collectives per BatchNorm layer in forward, 1 in backward, all in stream
+        order.  Every rank must use the same ray counts."""
+        import torch.distributed as dist
+        if not enable:
+            _lib.check(self.L.snerf_trainer_set_allreduce(self.h, None, None, 1), "trainer_set_allreduce")
+            self._ar_cb = None
+            return
+        if not (dist.is_available() and dist.is_initialized()):
+            raise RuntimeError("sync_batchnorm needs an initialised torch.distributed process group")
+        base, nbytes = self.ws.data_ptr(), self.ws.numel()
+
+        def allreduce(user, ptr, count, is_double, stream):
+            try:
+                off, size = ptr - base, count * (8 if is_double else 4)
+                if off < 0 or off + size > nbytes:
+                    return 1
+                view = self.ws[off:off + size].view(torch.float64 if is_double else torch.float32)
+                dist.all_reduce(view, op=dist.ReduceOp.SUM, group=group)      # stream-ordered: torch inserts the event waits
+                return 0
+            except Exception:                                                  # never unwind through the C frames
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        self._ar_cb = _lib.ALLREDUCE_FN(allreduce)                            # keep the trampoline alive with the engine
+        _lib.check(self.L.snerf_trainer_set_allreduce(self.h, C.cast(self._ar_cb, C.c_void_p), None, dist.get_world_size(group)),
+                   "trainer_set_allreduce")
+
     def stream(self):
         return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
