@@ -154,6 +154,43 @@ class All_in_One_Eval:
                                           C.byref(co), st), "composite_rays")
         return rgb, loc, dist
 
+    def _get_exact_solar(self, world_pts, sun_angle, Network):
+        """Eval_Tools_2.py:255-271 for the samples of one ray (or any [M,3] points with a [3] / [M,3] sun vector):
+        (exact_vis, est_vis) [M,1] - transmittance towards the sun along a secondary ray per point, and the network's own
+        solar-visibility estimate at the point."""
+        from .render import _exact_solar_visibility
+        (pts, sun) = Network._prep(world_pts.reshape(-1, 3), sun_angle)
+        M = pts.shape[0]
+        S = self.args.n_samples
+        exact = _exact_solar_visibility(Network, pts, sun, S, zero_oob=False).reshape(M, 1)
+        sun_m = sun if sun.dim() == 2 else sun.unsqueeze(0).expand(M, 3)
+        est = Network._field_points(1, pts, sun_m.contiguous(), None, ["d_solar_vis"])["d_solar_vis"].reshape(M, 1)
+        return exact, est
+
+    def eval_exact_solar(self, data_dict, Network, current_step, train_mode):
+        """Eval_Tools_2.py:273-295: `eval` with `Solar_Vis` replaced by the exact visibility from secondary sun rays (one per
+        sample, O(R S^2) density evaluations - all rays batched into sigma-only launches instead of the reference's per-ray
+        Python loop); adds `Est_Solar_Vis` and `Col_Adj`, recomputes `Rendered_Col`."""
+        from .render import _exact_solar_visibility
+        out = self.eval(data_dict, Network, current_step, train_mode)
+        R, S = out["PS"].shape[0], self.args.n_samples
+        out["Est_Solar_Vis"] = out["Solar_Vis"].clone()
+        if R == 0:
+            return out
+        (sun,) = Network._prep(data_dict["Sun_Angle"])
+        sun_e = sun.unsqueeze(1).expand(R, S, 3).reshape(-1, 3)
+        vis = _exact_solar_visibility(Network, out["sample_pts"].reshape(-1, 3).to(sun.device), sun_e, S, zero_oob=False)
+        sv = vis.reshape(R, S, 1)
+        out["Solar_Vis"] = sv
+        sky = out["Sky_Col"]
+        out["Col_Adj"] = (sv + (1 - sv) * sky) * out["Col"]
+        if self.use_classic_solar:
+            out["Rendered_Col"] = (out["PS"] * out["Col"] * (sv + (1 - sv) * sky)).sum(1)
+        else:
+            sv3 = torch.sigmoid(((sv * out["PS"]).sum(1) - .2) * 30)
+            out["Rendered_Col"] = (out["PS"] * out["Col"]).sum(1) * (sv3 + (1 - sv3) * sky.mean(1))
+        return out
+
     def full_eval(self, data_dict, Network, current_step):
         """Eval_Tools_2.py:127-163: eval-mode sampling, no prior; same keys minus Albedo/Col_Adj."""
         saved = self.use_prior

@@ -123,21 +123,9 @@ class Quick_Run_Net:
                 "Sun_Angle": _f32(np.tile(sun, (n, 1)), dev), "Time_Encoded": _f32(np.tile(encode_time(time_frac), (n, 1)), dev)}
 
     def _eval(self, d, exact):
-        out = self.eval_tool.eval(d, self.network, -1, False)
-        if exact and d["Top"].shape[0] > 0:                                   # eval_exact_solar, Eval_Tools_2.py:273-295
-            R, S = out["PS"].shape[0], self.n_samples
-            out["Est_Solar_Vis"] = out["Solar_Vis"].clone()
-            sun = d["Sun_Angle"].unsqueeze(1).expand(R, S, 3).reshape(-1, 3)
-            vis = _exact_solar_visibility(self.network, out["sample_pts"].reshape(-1, 3), sun, S, zero_oob=False)
-            sv = vis.reshape(R, S, 1)
-            out["Solar_Vis"] = sv
-            sky = out["Sky_Col"]
-            if self.eval_tool.use_classic_solar:
-                out["Rendered_Col"] = (out["PS"] * out["Col"] * (sv + (1 - sv) * sky)).sum(1)
-            else:
-                sv3 = torch.sigmoid(((sv * out["PS"]).sum(1) - .2) * 30)
-                out["Rendered_Col"] = (out["PS"] * out["Col"]).sum(1) * (sv3 + (1 - sv3) * sky.mean(1))
-        return out
+        if exact and d["Top"].shape[0] > 0:
+            return self.eval_tool.eval_exact_solar(d, self.network, -1, False)      # Quick_Run.py:184-186
+        return self.eval_tool.eval(d, self.network, -1, False)
 
     def render_img(self, camera_el_and_az, solar_el_and_az, time_frac, out_img_size, region=None):
         """-> ({"Col_Img", "Shadow_Mask"[, "Estimated_Shadow_Mask"]}, mask)   (Quick_Run.py:173-205, :14-35)"""

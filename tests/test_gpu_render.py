@@ -137,3 +137,32 @@ def test_ray_table_from_camera(golden_dir):
     ij = d["Img_Pt"].cpu().numpy().astype(int)
     np.testing.assert_array_equal(d["GT_Color"].cpu().numpy(), img[ij[:, 0] * DS, ij[:, 1] * DS])
     assert float(d["Sample_Weight"][0]) == pytest.approx(0.7) and d["Time_Encoded"].shape[1] == 4
+
+
+def test_evaluator_exact_solar_seam(setup):
+    """All_in_One_Eval.eval_exact_solar / _get_exact_solar (Eval_Tools_2.py:255-295) as the reference exposes them: the per-ray
+    helper reproduces row i of the batched result, the estimate equals the network's own Solar_Vis at the samples."""
+    sn, g, net, _ = setup
+    WC, H = g["WC"], g["H"]
+    S, R = 48, 12
+    args = SimpleNamespace(n_samples=S, Use_Reg=True, Solar_Type_2=False, Use_MSE_loss=True, Use_Solar=True, sc_lambda=0.03,
+                           number_low_frequency_cases=4)
+    ev = sn.All_in_One_Eval(args, torch.device("cuda"), 10, False, None, H, WC)
+    rng = np.random.Generator(np.random.PCG64(21))
+    t = lambda a: torch.tensor(a, dtype=torch.float32)
+    sun = rng.uniform(0.2, 1, (R, 3))
+    d = {"Top": t(np.concatenate([rng.uniform(-1, 1, (R, 2)), np.ones((R, 1))], 1)),
+         "Bot": t(np.concatenate([rng.uniform(-1, 1, (R, 2)), -np.ones((R, 1))], 1)),
+         "Sun_Angle": t(sun / np.linalg.norm(sun, axis=1, keepdims=True)), "Time_Encoded": t(np.tile(sn.encode_time(0.4), (R, 1)))}
+    plain = ev.eval(d, net, 0, False)
+    out = ev.eval_exact_solar(d, net, 0, False)
+    assert set(out) >= set(plain) | {"Est_Solar_Vis", "Col_Adj"}
+    np.testing.assert_array_equal(out["Est_Solar_Vis"].cpu().numpy(), plain["Solar_Vis"].cpu().numpy())
+    assert out["Solar_Vis"].shape == (R, S, 1) and float(out["Solar_Vis"].min()) >= 0 and float(out["Solar_Vis"].max()) <= 1
+    for i in (0, R - 1):
+        exact, est = ev._get_exact_solar(out["sample_pts"][i], d["Sun_Angle"][i], net)
+        np.testing.assert_allclose(exact.cpu().numpy(), out["Solar_Vis"][i].cpu().numpy(), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(est.cpu().numpy(), out["Est_Solar_Vis"][i].cpu().numpy(), rtol=1e-4, atol=2e-6)
+    sv, ps, col, sky = out["Solar_Vis"], out["PS"], out["Col"], out["Sky_Col"]
+    sv3 = torch.sigmoid(((sv * ps).sum(1) - .2) * 30)
+    np.testing.assert_allclose(out["Rendered_Col"].cpu().numpy(), ((ps * col).sum(1) * (sv3 + (1 - sv3) * sky.mean(1))).cpu().numpy(), rtol=1e-6)
