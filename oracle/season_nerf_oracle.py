@@ -542,6 +542,23 @@ def quick_run_dsm(sd, size, WC, H, S=96, region=None):
     return img
 
 
+def internal_render(sd, tops, bots, sunv, time_frac, S, mm=None):
+    """_internal_render without exact solar, mg_Img_Eval.py:17-72: float64 per-sample dict for rays tops/bots [R,3]."""
+    R = tops.shape[0]
+    pts, deltas = sample_pt_coarse(tops, bots, S, True, include_end_pt=True)
+    deltas = deltas.clone()
+    deltas[outside_cube(pts)] = 0.0
+    sun = torch.tensor(np.tile(sunv, (R * S, 1))).float()
+    tim = torch.tensor(np.tile(encode_time(time_frac), (R * S, 1))).float()
+    with torch.no_grad():
+        rho, col, sv, sky, cls, adj = forward_separate(sd, pts.reshape(-1, 3), sun, tim, mm=mm)
+    C = cls.shape[1]
+    f = lambda a, k: a.reshape(R, S, k).numpy().astype(np.float64)
+    return {"World_Points": pts.numpy().astype(np.float64), "Deltas": deltas.numpy().astype(np.float64),
+            "Rho": f(rho, 1), "Base_Col": f(col, 3), "Est_Solar_Vis": f(sv, 1), "Sky_Col": f(sky, 3),
+            "Output_class": f(cls, C), "Adjust_col": adj.reshape(R, S, C, 3).numpy().astype(np.float64)}
+
+
 def render_by_dir(sd, view_el_az, sun_el_az, time_frac, out_size, W2C, W2L_H, mm=None):
     """component_render_by_dir + _internal_render without exact solar, mg_Img_Eval.py:17-72,96-115.
     Returns the float64 per-sample dict."""
@@ -552,21 +569,26 @@ def render_by_dir(sd, view_el_az, sun_el_az, time_frac, out_size, W2C, W2L_H, mm
     sunv = world_angle_2_local_vec(sun_el_az[0], sun_el_az[1], W2C, W2L_H)
     tops = torch.tensor(g + (v / v[2])[None]).float()
     bots = torch.tensor(g - (v / v[2])[None]).float()
-    R = tops.shape[0]
-    pts, deltas = sample_pt_coarse(tops, bots, S, True, include_end_pt=True)
-    deltas = deltas.clone()
-    deltas[outside_cube(pts)] = 0.0
-    sun = torch.tensor(np.tile(sunv, (R * S, 1))).float()
-    tim = torch.tensor(np.tile(encode_time(time_frac), (R * S, 1))).float()
-    with torch.no_grad():
-        rho, col, sv, sky, cls, adj = forward_separate(sd, pts.reshape(-1, 3), sun, tim, mm=mm)
-    C = cls.shape[1]
-    XY = np.stack(np.meshgrid(np.arange(Hh), np.arange(Ww), indexing="ij"), -1).reshape(-1, 2)
-    f = lambda a, k: a.reshape(R, S, k).numpy().astype(np.float64)
-    return {"World_Points": pts.numpy().astype(np.float64), "Deltas": deltas.numpy().astype(np.float64),
-            "Rho": f(rho, 1), "Base_Col": f(col, 3), "Est_Solar_Vis": f(sv, 1), "Sky_Col": f(sky, 3),
-            "Output_class": f(cls, C), "Adjust_col": adj.reshape(R, S, C, 3).numpy().astype(np.float64),
-            "Image_Points": XY}
+    d = internal_render(sd, tops, bots, sunv, time_frac, S, mm=mm)
+    d["Image_Points"] = np.stack(np.meshgrid(np.arange(Hh), np.arange(Ww), indexing="ij"), -1).reshape(-1, 2)
+    return d
+
+
+def render_by_P(sd, P, img_shape, sun_vec, year_frac, out_size, mm=None):
+    """component_render_by_P without exact solar, mg_Img_Eval.py:74-94: output-pixel grid -> source pixels (rounded linspace)
+    -> rays by invert_P at h = +1 / -1, rays leaving the cube dropped."""
+    Hh, Ww, S = out_size
+    XY = np.stack(np.meshgrid(np.linspace(0, img_shape[0] - 1, Hh), np.linspace(0, img_shape[1] - 1, Ww), indexing="ij"), -1)
+    XY = np.round(XY).astype(int).reshape(-1, 2)
+    x, y, _ = invert_P(P, XY[:, 0], XY[:, 1], 1.0)
+    tops = np.stack([x, y, np.ones_like(x)], -1)
+    x, y, _ = invert_P(P, XY[:, 0], XY[:, 1], -1.0)
+    bots = np.stack([x, y, -np.ones_like(x)], -1)
+    good = np.all((tops[:, :2] >= -1) & (tops[:, :2] <= 1) & (bots[:, :2] >= -1) & (bots[:, :2] <= 1), 1)
+    d = internal_render(sd, torch.tensor(tops[good]).float(), torch.tensor(bots[good]).float(), np.asarray(sun_vec), year_frac, S, mm=mm)
+    d["Image_Points_in_GT_Img"] = XY[good]
+    d["Image_Points"] = np.stack(np.meshgrid(np.arange(Hh), np.arange(Ww), indexing="ij"), -1).reshape(-1, 2)[good]
+    return d
 
 
 def _sig(x):

@@ -167,6 +167,41 @@ class ImgDict(dict):
     dev = None
 
 
+def _internal_render_device(net, top, bot, sunv, time_frac, S, device, include_exact_solar):
+    """`_internal_render` (mg_Img_Eval.py:17-72) on device tensors: rays top/bot [R,3] (fp32, device), ONE sun vector
+    (float64 numpy [3]) and ONE time for the whole image; returns the per-sample device tensors of the reference's dict."""
+    dev = torch.device(device)
+    R, Cn = top.shape[0], net.n_classes
+    (top, bot) = net._prep(top, bot)
+    L = _lib.lib()
+    st = net._stream()
+    tv = sample_parameters_on(dev, S, eval_mode=True, include_end_pt=True)
+    sun1, tim1 = _f32(np.asarray(sunv, dtype=np.float64).reshape(1, 3), dev), _f32(encode_time(time_frac).reshape(1, 4), dev)
+    cls, _, sky = net._groups(tim1, sun1)                                  # one (time, sun) group for the whole image
+    e = lambda *s: torch.empty(*s, device=dev)
+    rho, sv, col_raw, adj, pts = e(R, S, 1), e(R, S, 1), e(R, S, 3), e(R, S, Cn, 3), e(R, S, 3)
+    dl = e(R, S, 1)
+    if R > 0:
+        fo = _lib.FieldOut(d_rho=rho.data_ptr(), d_solar_vis=sv.data_ptr(), d_col_raw=col_raw.data_ptr(),
+                           d_adjust=adj.data_ptr(), d_points=pts.data_ptr())
+        model = net.device_model()
+        # one (sun, time) group for all rays: rays_per_group = R
+        _lib.check(L.snerf_field_forward_rays(model, 0, R, S, top.data_ptr(), bot.data_ptr(), tv.data_ptr(), R, sun1.data_ptr(),
+                                              cls.data_ptr(), C.byref(fo), st), "field_forward_rays")
+        z3 = torch.zeros(R, S, 3, device=dev)
+        sky_r = sky.expand(R, 3).contiguous()
+        co = _lib.CompositeOut(d_delta=dl.data_ptr())
+        _lib.check(L.snerf_composite_rays(R, S, top.data_ptr(), bot.data_ptr(), tv.data_ptr(), rho.data_ptr(), z3.data_ptr(),
+                                          sv.data_ptr(), sky_r.data_ptr(), 2, None, 1.0, C.byref(co), st), "composite_rays")
+    devd = {"top": top, "bot": bot, "tv": tv, "World_Points": pts, "Deltas": dl, "Rho": rho, "Base_Col": col_raw,
+            "Est_Solar_Vis": sv, "Sky": sky[0].contiguous(), "Class": cls[0].contiguous(), "Adjust_col": adj}
+    if include_exact_solar:
+        sun_d = _f32(sunv, dev)
+        devd["Exact_Solar"] = (_exact_solar_visibility(net, pts.reshape(-1, 3), sun_d, S, zero_oob=True, sun64=sunv).reshape(R, S, 1)
+                               if R > 0 else e(0, S, 1))
+    return devd
+
+
 def _render_by_dir_device(net, view_el_az, sun_el_az, time_frac, out_img_size, W2C, W2L_H, device, include_exact_solar,
                           ray_range=None):
     """ray_range=(lo, hi): render only rays lo..hi-1 of the row-major H*W grid (a rank's tile in a sharded render)."""
@@ -179,34 +214,45 @@ def _render_by_dir_device(net, view_el_az, sun_el_az, time_frac, out_img_size, W
     v = world_angle_2_local_vec(view_el_az[0], view_el_az[1], W2C, W2L_H)
     sunv = world_angle_2_local_vec(sun_el_az[0], sun_el_az[1], W2C, W2L_H)
     top, bot = _f32(g + np.expand_dims(v / v[2], 0), dev), _f32(g - np.expand_dims(v / v[2], 0), dev)
-    R, Cn = top.shape[0], net.n_classes
-    (top, bot) = net._prep(top, bot)
-    L = _lib.lib()
-    st = net._stream()
-    tv = sample_parameters_on(dev, S, eval_mode=True, include_end_pt=True)
-    sun1, tim1 = _f32(sunv.reshape(1, 3), dev), _f32(encode_time(time_frac).reshape(1, 4), dev)
-    cls, _, sky = net._groups(tim1, sun1)                                  # one (time, sun) group for the whole image
-    e = lambda *s: torch.empty(*s, device=dev)
-    rho, sv, col_raw, adj, pts = e(R, S, 1), e(R, S, 1), e(R, S, 3), e(R, S, Cn, 3), e(R, S, 3)
-    fo = _lib.FieldOut(d_rho=rho.data_ptr(), d_solar_vis=sv.data_ptr(), d_col_raw=col_raw.data_ptr(),
-                       d_adjust=adj.data_ptr(), d_points=pts.data_ptr())
-    model = net.device_model()
-    # one (sun, time) group for all rays: rays_per_group = R
-    _lib.check(L.snerf_field_forward_rays(model, 0, R, S, top.data_ptr(), bot.data_ptr(), tv.data_ptr(), R, sun1.data_ptr(),
-                                          cls.data_ptr(), C.byref(fo), st), "field_forward_rays")
-    dl = e(R, S, 1)
-    z3 = torch.zeros(R, S, 3, device=dev)
-    sky_r = sky.expand(R, 3).contiguous()
-    co = _lib.CompositeOut(d_delta=dl.data_ptr())
-    _lib.check(L.snerf_composite_rays(R, S, top.data_ptr(), bot.data_ptr(), tv.data_ptr(), rho.data_ptr(), z3.data_ptr(),
-                                      sv.data_ptr(), sky_r.data_ptr(), 2, None, 1.0, C.byref(co), st), "composite_rays")
-    devd = {"top": top, "bot": bot, "tv": tv, "World_Points": pts, "Deltas": dl, "Rho": rho, "Base_Col": col_raw,
-            "Est_Solar_Vis": sv, "Sky": sky[0].contiguous(), "Class": cls[0].contiguous(), "Adjust_col": adj}
+    return _internal_render_device(net, top, bot, sunv, time_frac, S, device, include_exact_solar)
+
+
+def _to_img_dict(d, the_network, S, include_exact_solar):
+    R, Cn = d["Rho"].shape[0], the_network.n_classes
+    f = lambda t: t.cpu().numpy().astype(np.float64)
+    res = ImgDict()
+    for k in ["World_Points", "Deltas", "Rho", "Base_Col", "Est_Solar_Vis", "Adjust_col"]:
+        res[k] = f(d[k])
+    res["Sky_Col"] = np.broadcast_to(f(d["Sky"]).reshape(1, 1, 3), (R, S, 3)).copy()
+    res["Output_class"] = np.broadcast_to(f(d["Class"]).reshape(1, 1, Cn), (R, S, Cn)).copy()
     if include_exact_solar:
-        sun_d = _f32(sunv, dev)
-        devd["Exact_Solar"] = _exact_solar_visibility(net, pts.reshape(-1, 3), sun_d, S, zero_oob=True,
-                                                      sun64=sunv).reshape(R, S, 1)
-    return devd
+        res["Exact_Solar"] = f(d["Exact_Solar"])
+    res.dev = d
+    return res
+
+
+def component_render_by_P(the_network, a_P_img, out_img_size: tuple, device, max_batch_size=150000, include_exact_solar=True):
+    """mg_Img_Eval.py:74-94: render through a camera.  `a_P_img` is the reference's projective-image object (duck-typed:
+    `.img.shape`, `.invert_P(rows, cols, h)`, `.sun_el_and_az_vec`, `.get_year_frac()`): pixel grid -> rays by its own float64
+    `invert_P` (out_h x out_w solves on the host), rays leaving the cube dropped, then the same device render as by-direction.
+    Adds `Image_Points_in_GT_Img` and `Image_Points` (rows of the kept rays)."""
+    with torch.no_grad():
+        Hh, Ww, S = out_img_size
+        XY = np.stack(np.meshgrid(np.linspace(0, a_P_img.img.shape[0] - 1, Hh), np.linspace(0, a_P_img.img.shape[1] - 1, Ww), indexing="ij"), -1)
+        XY = np.round(XY).astype(int).reshape([-1, 2])
+        x, y, _ = a_P_img.invert_P(XY[:, 0], XY[:, 1], 1.)
+        tops = np.stack([x, y, np.ones_like(x)], -1)
+        x, y, _ = a_P_img.invert_P(XY[:, 0], XY[:, 1], -1.)
+        bots = np.stack([x, y, -np.ones_like(x)], -1)
+        good = (tops[:, 0] >= -1) * (tops[:, 1] <= 1) * (bots[:, 0] >= -1) * (bots[:, 1] <= 1) * \
+               (tops[:, 1] >= -1) * (tops[:, 0] <= 1) * (bots[:, 1] >= -1) * (bots[:, 0] <= 1)
+        dev = torch.device(device)
+        d = _internal_render_device(the_network, _f32(tops[good], dev), _f32(bots[good], dev), np.asarray(a_P_img.sun_el_and_az_vec, dtype=np.float64),
+                                    a_P_img.get_year_frac(), S, device, include_exact_solar)
+        res = _to_img_dict(d, the_network, S, include_exact_solar)
+        res["Image_Points_in_GT_Img"] = XY[good]
+        res["Image_Points"] = np.stack(np.meshgrid(np.arange(Hh), np.arange(Ww), indexing="ij"), -1).reshape([-1, 2])[good]
+    return res
 
 
 def component_render_by_dir(the_network, view_el_az, sun_el_az, time_frac, out_img_size: tuple, W2C, W2L_H, device,
@@ -217,17 +263,8 @@ def component_render_by_dir(the_network, view_el_az, sun_el_az, time_frac, out_i
         Hh, Ww, S = out_img_size
         d = _render_by_dir_device(the_network, view_el_az, sun_el_az, time_frac, out_img_size, W2C, W2L_H, device,
                                   include_exact_solar)
-        R, Cn = d["Rho"].shape[0], the_network.n_classes
-        f = lambda t: t.cpu().numpy().astype(np.float64)
-        res = ImgDict()
-        for k in ["World_Points", "Deltas", "Rho", "Base_Col", "Est_Solar_Vis", "Adjust_col"]:
-            res[k] = f(d[k])
-        res["Sky_Col"] = np.broadcast_to(f(d["Sky"]).reshape(1, 1, 3), (R, S, 3)).copy()
-        res["Output_class"] = np.broadcast_to(f(d["Class"]).reshape(1, 1, Cn), (R, S, Cn)).copy()
-        if include_exact_solar:
-            res["Exact_Solar"] = f(d["Exact_Solar"])
+        res = _to_img_dict(d, the_network, S, include_exact_solar)
         res["Image_Points"] = np.stack(np.meshgrid(np.arange(Hh), np.arange(Ww), indexing="ij"), -1).reshape([-1, 2])
-        res.dev = d
     return res
 
 

@@ -166,3 +166,37 @@ def test_evaluator_exact_solar_seam(setup):
     sv, ps, col, sky = out["Solar_Vis"], out["PS"], out["Col"], out["Sky_Col"]
     sv3 = torch.sigmoid(((sv * ps).sum(1) - .2) * 30)
     np.testing.assert_allclose(out["Rendered_Col"].cpu().numpy(), ((ps * col).sum(1) * (sv3 + (1 - sv3) * sky.mean(1))).cpu().numpy(), rtol=1e-6)
+
+
+def test_component_render_by_P(golden_dir):
+    """component_render_by_P (mg_Img_Eval.py:74-94) against the reference's own output through a hand-made camera
+    (tests/golden/renderP_W64_s2.npz); the camera object is duck-typed like the reference's P_img."""
+    import season_nerf_amd as sn
+    g = dict(np.load(os.path.join(golden_dir, "renderP_W64_s2.npz"), allow_pickle=False))
+    net = sn.T_NeRF(int(g["W"]), int(g["C"]))
+    net.load_state_dict(orc.init_weights(int(g["W"]), int(g["C"]), int(g["seed"])))
+    net = net.to("cuda").eval()
+
+    class Cam:
+        img = np.zeros(tuple(int(v) for v in g["img_shape"]))
+        sun_el_and_az_vec = g["sun_vec"]
+
+        def invert_P(self, row, col, h=0):
+            return orc.invert_P(g["P"], row, col, h)
+
+        def get_year_frac(self):
+            return float(g["year_frac"])
+
+    size = tuple(int(v) for v in g["size"])
+    d = sn.component_render_by_P(net, Cam(), size, "cuda", include_exact_solar=True)
+    assert (d["Image_Points"] == g["P_Image_Points"]).all() and (d["Image_Points_in_GT_Img"] == g["P_Image_Points_in_GT_Img"]).all()
+    tol = {"World_Points": dict(rtol=0, atol=0), "Deltas": dict(rtol=1e-6, atol=0), "Rho": dict(rtol=2e-4, atol=2e-5),
+           "Base_Col": dict(atol=1e-4), "Est_Solar_Vis": {}, "Adjust_col": dict(atol=1e-4)}       # as for the by-direction render
+    for k in tol:
+        assert d[k].dtype == np.float64
+        close("P_" + k, d[k], g["P_" + k], **tol[k])
+    close("P_Exact_Solar", d["Exact_Solar"], g["P_Exact_Solar"], rtol=1e-4, atol=2e-5)
+    close("P_class", d["Output_class"][0, 0], g["P_Output_class0"]); close("P_sky", d["Sky_Col"][0, 0], g["P_Sky_Col0"])
+    im = sn.get_imgs_from_Img_Dict(d, size)                          # the image assembly accepts the by-P dict as well
+    assert im["Base_Img"].shape == (size[0], size[1], 3) and np.isnan(im["Base_Img"]).any() and np.isfinite(im["Base_Img"]).any()
+

@@ -201,3 +201,16 @@ def test_dsm_distance_and_prior_density(golden_dir):
     assert np.isnan(g["Dist_GT"]).sum() >= 2                     # NaN cells and never-hit rays are exercised
     rho = orc.supervised_sample(g["HM"], torch.tensor(g["prior_pts"]), torch.tensor(g["prior_delta"])).numpy()
     np.testing.assert_array_equal(rho, g["prior_rho"])
+
+
+def test_render_by_P(golden_dir):
+    """oracle.render_by_P against the reference's component_render_by_P through a hand-made projective camera."""
+    g = load(golden_dir, "renderP_W64_s2.npz")
+    sd = orc.init_weights(int(g["W"]), int(g["C"]), int(g["seed"]))
+    d = orc.render_by_P(sd, g["P"], g["img_shape"], g["sun_vec"], float(g["year_frac"]), tuple(int(v) for v in g["size"]))
+    assert (d["Image_Points"] == g["P_Image_Points"]).all() and (d["Image_Points_in_GT_Img"] == g["P_Image_Points_in_GT_Img"]).all()
+    assert 0 < d["Rho"].shape[0] < int(g["size"][0]) * int(g["size"][1])          # the cube test drops rays
+    for k in ["World_Points", "Deltas", "Rho", "Base_Col", "Est_Solar_Vis", "Adjust_col"]:
+        close(d[k], g["P_" + k])
+    close(d["Output_class"][0, 0], g["P_Output_class0"]); close(d["Sky_Col"][0, 0], g["P_Sky_Col0"])
+

@@ -34,7 +34,7 @@ sys.path.insert(0, REPO)
 from T_NeRF_Full_2.T_NeRF_net_v2 import T_NeRF            # noqa: E402
 from T_NeRF_Full_2.Eval_Tools_2 import All_in_One_Eval    # noqa: E402
 from T_NeRF_Full_2.Quick_Run import Quick_Run_Net, encode_time  # noqa: E402
-from T_NeRF_Eval_Utils.mg_Img_Eval import (component_render_by_dir, get_imgs_from_Img_Dict,   # noqa: E402
+from T_NeRF_Eval_Utils.mg_Img_Eval import (component_render_by_dir, component_render_by_P, get_imgs_from_Img_Dict,   # noqa: E402
                                            get_imgs_from_Img_Dict_t_step)
 from all_NeRF.mg_unit_converter import world_angle_2_local_vec  # noqa: E402
 from pre_NeRF.P_Img import P_img_Pinhole                   # noqa: E402
@@ -248,6 +248,27 @@ def gen_render(W, seed, tag):
     np.savez_compressed(os.path.join(OUT, f"render_{tag}.npz"), **out)
 
 
+def gen_render_by_P(W, seed, tag):
+    """component_render_by_P (mg_Img_Eval.py:74-94) through a hand-made projective camera (the fitted cameras of the reference
+    need RPC files): pixel grid -> rays with the reference's own invert_P, cube test, per-sample dict."""
+    net, _ = make_net(W, 4, seed)
+    cam = P_img_Pinhole.__new__(P_img_Pinhole)
+    cam.P = np.array([[20.0, 2.0, 3.0, 32.0], [-1.5, 15.0, -2.0, 24.0], [0.001, -0.002, 0.003, 1.0]])
+    cam.img = np.zeros((64, 48, 3))
+    sun = np.array([0.35, -0.25, 0.9])
+    cam.sun_el_and_az_vec = sun / np.linalg.norm(sun)
+    cam.time_obj = SimpleNamespace(get_time_frac=lambda: (0, 0.37))
+    size = (10, 8, 48)
+    d = component_render_by_P(net, cam, size, "cpu", include_exact_solar=True)
+    out = {"W": W, "C": 4, "seed": seed, "P": cam.P, "img_shape": np.array(cam.img.shape), "sun_vec": cam.sun_el_and_az_vec,
+           "year_frac": 0.37, "size": np.array(size)}
+    for k in ["World_Points", "Deltas", "Rho", "Base_Col", "Est_Solar_Vis", "Exact_Solar", "Adjust_col"]:
+        out["P_" + k] = f32(d[k])
+    out["P_Output_class0"], out["P_Sky_Col0"] = f32(d["Output_class"][0, 0]), f32(d["Sky_Col"][0, 0])
+    out["P_Image_Points"], out["P_Image_Points_in_GT_Img"] = d["Image_Points"], d["Image_Points_in_GT_Img"]
+    np.savez_compressed(os.path.join(OUT, f"renderP_{tag}.npz"), **out)
+
+
 def gen_micro():
     out = {}
     pe = misc.PE_Encode(2, True)
@@ -313,6 +334,7 @@ if __name__ == "__main__":
     gen_train(64, 1, 24, 40, "prior_W64_R24_S40", prior=True)
     gen_train(256, 2, 32, 40, "W256_R32_S40", subsample=37)
     gen_render(64, 2, "W64_s2")
+    gen_render_by_P(64, 2, "W64_s2")
     gen_dsm()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
