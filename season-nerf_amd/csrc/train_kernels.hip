@@ -581,20 +581,31 @@ hipError_t launch_sigmoid(const float* x, float* y, int64_t n, hipStream_t st) {
 hipError_t launch_sigmoid_bwd(const float* y, const float* dy, float* dx, int64_t n, hipStream_t st) { LAUNCH_1D(sigmoid_bwd_kernel, n, st, y, dy, dx, n); return hipGetLastError(); }
 
 __global__ __launch_bounds__(256) void colsum_kernel(const float* X, int64_t M, int C, int64_t ld, float alpha, float* out) {
-    // small C (<= 16): thread per row slab, wave reduction
+    // small C (<= 16): every thread walks rows and keeps all C column sums in registers - one pass over X
     const int lane = threadIdx.x & 63;
-    for (int c = 0; c < C; ++c) {
-        float s = 0.f;
-        for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < M; r += (int64_t)gridDim.x * blockDim.x) s += X[r * ld + c];
-        s = wsum(s);
-        if (lane == 0) atomicAdd(out + c, alpha * s);
+    float s[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) s[c] = 0.f;
+    for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < M; r += (int64_t)gridDim.x * blockDim.x) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+            if (c < C) s[c] += X[r * ld + c];
     }
+    __shared__ float red[4][16];               // same-address atomics serialise: one per column and workgroup
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const float v = c < C ? wsum(s[c]) : 0.f;
+        if (lane == 0) red[threadIdx.x >> 6][c] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < C) atomicAdd(out + threadIdx.x, alpha * (red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]));
 }
 hipError_t launch_colsum(const float* X, int64_t M, int C, int64_t ld, float alpha, float* out, hipStream_t st) {
     if (M <= 0) return hipSuccess;
     int64_t b = (M + 255) / 256;
-    if (b > 1024) b = 1024;
-    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)b), dim3(256), 0, st, X, M, C, ld, alpha, out);
+    if (b > 512) b = 512;
+    for (int c0 = 0; c0 < C; c0 += 16)          // 16 columns per pass (heads have 1..12 outputs at the default 4 classes)
+        hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)b), dim3(256), 0, st, X + c0, M, C - c0 < 16 ? C - c0 : 16, ld, alpha, out + c0);
     return hipGetLastError();
 }
 
