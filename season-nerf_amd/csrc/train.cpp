@@ -188,7 +188,9 @@ static size_t carve(snerf_trainer* t, char* base, int64_t R, int64_t Rs, int S) 
 
 // bf16x3 row-owner kernel usable for an [M x K] x [K x N] product?
 static bool rows_ok(const snerf_trainer* t, int64_t M, int K, int N) {
-    return t->gemm_mode == 1 && M >= 1024 && K >= 16 && N >= 16 && gemm_rows_group_tiles((K + 15) / 16) > 0;
+    // thin layers included (heads with 1..12 outputs): the kernels mask partial tiles, and every such GEMM is a single pass
+    // over a [points x W] activation - HBM-bound either way
+    return t->gemm_mode == 1 && M >= 1024 && K >= 1 && N >= 1 && gemm_rows_group_tiles((K + 15) / 16) > 0;
 }
 #define RCI(x)                 \
     do {                      \
@@ -238,7 +240,7 @@ static hipError_t linear_dgrad(snerf_trainer* t, const LayerP& L, const float* d
 // dW[n_out, n_in] += alpha * dZ^T In   (split over the point dimension, fp32 atomics)
 static hipError_t linear_wgrad(snerf_trainer* t, const LayerP& L, const float* dZ, int64_t ldz, const float* In, int64_t ld_in,
                                int64_t M, float alpha, hipStream_t st) {
-    if (t->gemm_mode == 1 && M >= 1024 && L.n_out >= 16 && L.n_in >= 16)
+    if (t->gemm_mode == 1 && M >= 1024)
         return launch_wgrad_bf16x3(dZ, ldz, In, ld_in, M, L.n_out, L.n_in, alpha, t->grads + L.w, L.n_in, st);
     GemmArgs g{};
     g.A = dZ; g.B = In; g.C = t->grads + L.w;
