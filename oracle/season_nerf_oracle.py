@@ -418,28 +418,30 @@ def cauchy_color_error(gt: np.ndarray, img: np.ndarray) -> float:
 # losses (MSE path pinned; Barron path parity-unpinned)
 # --------------------------------------------------------------------------------------
 def get_loss_mse(sd, data, solar, S: int, sc_lambda: float, train_mode: bool, train_bn: bool,
-                 jitter=None, jitter_solar=None, bn_out=None, bn_out_solar=None, mm=None):
-    """All_in_One_Eval.get_loss with Use_MSE_loss, Use_Solar, Solar_Type_2=False, no prior
-    (Eval_Tools_2.py:340-420).  `solar` = dict Top, Bot, Sun_Angle of the random sun rays (a11).
+                 jitter=None, jitter_solar=None, bn_out=None, bn_out_solar=None, mm=None, classic=False):
+    """All_in_One_Eval.get_loss with Use_MSE_loss, Use_Solar, no prior (Eval_Tools_2.py:340-420).
+    `solar` = dict Top, Bot, Sun_Angle of the random sun rays (a11).  classic = args.Solar_Type_2: per-sample shading in
+    Rendered_Col (:211-212), Solar_Correction_2 keeps its gradient (:367-370), no sky / albedo regularisers (:373-389).
     Returns ({name: (value, weight)}, eval output).
     """
-    out = eval_rays(sd, data, S, train_mode, False, train_bn, bn_out, jitter, mm=mm)
+    out = eval_rays(sd, data, S, train_mode, classic, train_bn, bn_out, jitter, mm=mm)
     so = eval_rho_only(sd, solar, S, train_mode, train_bn, bn_out_solar, jitter_solar, mm=mm)
     loss = {}
     loss["Solar_Correction"] = (((so["Solar_Vis"] - so["PV_Exact"].detach()) ** 2).sum(1).mean(), sc_lambda)
     absorb = (1 - (so["PE"].detach() * so["PV_Exact"].detach() * so["Solar_Vis"]).sum(1)).mean()
-    loss["Solar_Correction_2"] = (absorb.detach(), sc_lambda)
-    alb_min = out["Albedo_Color"].min(0).values                     # :374
-    sel = alb_min[alb_min < 0.2]
-    if sel.numel() > 0:
-        alb_loss = ((1.0 - sel / 0.2) ** 2).sum() / out["Albedo_Color"].shape[0]
-    else:
-        alb_loss = torch.zeros((), dtype=alb_min.dtype)
-    x = (out["Sky_Col"] - 0.5) / 0.5                                # :381-389
-    pos = x[x > 0]
-    sky_loss = (pos ** 2).sum() / x.numel() if pos.numel() > 0 else torch.zeros((), dtype=x.dtype)
-    loss["Sky_Color_Var"] = (sky_loss, sc_lambda)
-    loss["Albedo_Color"] = (alb_loss, sc_lambda)
+    loss["Solar_Correction_2"] = (absorb if classic else absorb.detach(), sc_lambda)
+    if not classic:
+        alb_min = out["Albedo_Color"].min(0).values                     # :374
+        sel = alb_min[alb_min < 0.2]
+        if sel.numel() > 0:
+            alb_loss = ((1.0 - sel / 0.2) ** 2).sum() / out["Albedo_Color"].shape[0]
+        else:
+            alb_loss = torch.zeros((), dtype=alb_min.dtype)
+        x = (out["Sky_Col"] - 0.5) / 0.5                                # :381-389
+        pos = x[x > 0]
+        sky_loss = (pos ** 2).sum() / x.numel() if pos.numel() > 0 else torch.zeros((), dtype=x.dtype)
+        loss["Sky_Color_Var"] = (sky_loss, sc_lambda)
+        loss["Albedo_Color"] = (alb_loss, sc_lambda)
     loss["Color"] = (torch.mean((out["Rendered_Col"] - data["GT_Color"]) ** 2), 1.0)
     return loss, out
 

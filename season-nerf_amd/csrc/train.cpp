@@ -50,6 +50,7 @@ struct snerf_trainer {
     // state of the last forward passes (needed by backward)
     int64_t R = 0, Rs = 0;
     int S = 0;
+    int img_flags = 0;                              // flags of the last image-pass forward (bit 0: classic solar model)
     // workspace carve (set by carve())
     struct Pass {
         int64_t R = 0, N = 0;
@@ -479,7 +480,7 @@ int snerf_trainer_forward_image(snerf_trainer* t, int64_t n_rays, int n_samples,
                                 void* stream) {
     RC(check_bound(t, n_rays, n_samples, false));
     if (!d_top || !d_bot || !d_tvals || !d_sun || !d_time || !out) return snerf_set_error(SNERF_E_INVALID, "snerf_trainer_forward_image: bad argument");
-    if (flags & 1) return snerf_set_error(SNERF_E_INVALID, "training with the classic solar model (Solar_Type_2) is not implemented");
+    t->img_flags = flags;
     hipStream_t st = (hipStream_t)stream;
     RC(forward_pass(t, t->img, false, n_rays, n_samples, d_top, d_bot, d_tvals, d_sun, d_time, train_bn != 0, st,
                     per_sample ? per_sample->d_adjust_col : nullptr));
@@ -512,12 +513,16 @@ int snerf_trainer_backward_image(snerf_trainer* t, const float* d_g_rgb, const f
     cb.n_rays = R; cb.n_samples = S; cb.top = P.top; cb.bot = P.bot; cb.rho = P.rho; cb.col = P.col; cb.sv = P.sv; cb.sky = P.sky;
     cb.g_rgb = d_g_rgb; cb.g_albedo = d_g_albedo; cb.g_pe = d_g_pe; cb.d_rho = t->d_rho; cb.d_col = t->d_col; cb.d_sky = t->d_sky;
     cb.rho_prior = d_rho_prior; cb.trust = trust; cb.g_rgb_m = d_g_rgb_merged; cb.g_albedo_m = d_g_albedo_merged;
+    const bool classic = (t->img_flags & 1) != 0;
+    if (classic && d_rho_prior) return snerf_set_error(SNERF_E_INVALID, "classic solar model together with the DSM prior is not implemented");
+    cb.classic = classic ? 1 : 0; cb.d_sv = t->d_sv_raw;       // dL/dSolar_Vis, turned into dL/d(raw) in place below
     HIPCK(launch_composite_bwd(cb, st));
     if (d_g_sky) HIPCK(launch_copy_cols(d_g_sky, 3, t->d_sky, 3, R, 3, true, st));
     HIPCK(hipMemsetAsync(t->d_cls, 0, R * C * sizeof(float), st));
     PointOutArgs po{};
     po.n = N; po.n_samples = S; po.C = C; po.head = P.head.p; po.adj = P.adj.p; po.cls = P.cls; po.col = P.col; po.sv = P.sv;
     po.d_rho = t->d_rho; po.d_col = t->d_col; po.d_head = t->d_head; po.d_adj = t->d_adj; po.d_cls = t->d_cls;
+    if (classic) { po.d_sv = t->d_sv_raw; po.d_sv_raw = t->d_sv_raw; }
     HIPCK(launch_point_out(po, true, st));
     const float* X1 = P.H[8].p;
     // adjust branch
@@ -528,6 +533,12 @@ int snerf_trainer_backward_image(snerf_trainer* t, const float* d_g_rgb, const f
     // sigma / colour heads
     RC(plain_bwd(t, Ls[L_COL], t->d_head, 4, X1, W2, N, t->dX1.p, W2, true, st));
     RC(plain_bwd(t, Ls[L_SIG], t->d_head + 3, 4, X1, W2, N, t->dX1.p, W2, true, st));
+    if (classic) {      // the solar-visibility branch carries gradient from the image (G_NeRF.py:100-108), on into X1
+        RC(plain_bwd(t, Ls[L_S4], t->d_sv_raw, 1, P.Hs[2].p, W2, N, t->dA.p, W2, false, st));
+        RC(sine_bwd(t, Ls[L_S3], Act{t->dA.p, W2}, P.Zs[2], P.Hs[1].p, W2, N, nullptr, Act{t->dB.p, W2}, W2, false, st));
+        RC(sine_bwd(t, Ls[L_S2], Act{t->dB.p, W2}, P.Zs[1], P.Hs[0].p, W2, N, nullptr, Act{t->dA.p, W2}, W2, false, st));
+        RC(sine_bwd(t, Ls[L_S1], Act{t->dA.p, W2}, P.Zs[0], P.In_s1.p, W2 + 28, N, nullptr, Act{t->dX1.p, W2}, W2, true, st));
+    }
     // trunk
     float* cur = t->dA.p;
     float* nxt = t->dB.p;

@@ -109,6 +109,10 @@ struct CompBwdArgs {
     float trust;
     const float *g_rgb_m, *g_albedo_m;          // [R,3] or NULL
     float *d_rho, *d_col, *d_sky;               // [N], [N,3], [R,3] (d_sky is overwritten)
+    // classic solar model (Solar_Type_2, Eval_Tools_2.py:211-212): Rendered_Col = sum PS*Col*(SV + (1-SV)*Sky) per sample;
+    // the solar visibility then carries gradient: d_sv [N] (required when classic != 0)
+    int classic;
+    float* d_sv;
 };
 hipError_t launch_composite_bwd(const CompBwdArgs& a, hipStream_t st);
 

@@ -461,21 +461,23 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const CompBwdArgs A)
 #pragma unroll
     for (int k = 0; k < 3; ++k) { alb[k] = wsum(alb[k]); albm[k] = wsum(albm[k]); }
     u = wsum(u);
+    const bool classic = A.classic != 0;
     const float sv3 = sigmoid_t((u - 0.2f) * 30.f);
-    float dalb[3], dalbm[3], dsky[3], dsv3 = 0.f;
+    float dalb[3], dalbm[3], dsky[3], dsv3 = 0.f, grgb[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        const float F = sv3 + (1.f - sv3) * sky[k];
+        const float F = classic ? 0.f : sv3 + (1.f - sv3) * sky[k];       // classic: the shading factor is per sample (pass 2)
         const float g = A.g_rgb ? A.g_rgb[r * 3 + k] : 0.f;
         const float gm = (prior && A.g_rgb_m) ? A.g_rgb_m[r * 3 + k] : 0.f;
+        grgb[k] = g;
         dalb[k] = g * F + (A.g_albedo ? A.g_albedo[r * 3 + k] : 0.f);
         dalbm[k] = gm * F + ((prior && A.g_albedo_m) ? A.g_albedo_m[r * 3 + k] : 0.f);
         const float dF = g * alb[k] + gm * albm[k];
         dsv3 += dF * (1.f - sky[k]);
-        dsky[k] = dF * (1.f - sv3);
+        dsky[k] = classic ? 0.f : dF * (1.f - sv3);
     }
-    const float du = dsv3 * sv3 * (1.f - sv3) * 30.f;
-    if (lane == 0) { A.d_sky[r * 3] = dsky[0]; A.d_sky[r * 3 + 1] = dsky[1]; A.d_sky[r * 3 + 2] = dsky[2]; }
+    const float du = classic ? 0.f : dsv3 * sv3 * (1.f - sv3) * 30.f;
+    if (!classic && lane == 0) { A.d_sky[r * 3] = dsky[0]; A.d_sky[r * 3 + 1] = dsky[1]; A.d_sky[r * 3 + 2] = dsky[2]; }
     // ---- pass 2: dPS, then dy_s = dPE_s*exp(-y_s) - sum_{k>s} dPV_k*PV_k  (suffix sums, chunks walked backwards)
     float suffix = 0.f, suffix_m = 0.f;
     const int nchunk = (S + 63) / 64;
@@ -501,10 +503,15 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const CompBwdArgs A)
         const float ey = expf(-y);
         const float pe = 1.f - ey;
         float dps = 0.f;
+        const float svs = A.sv[idx];
+        float shade[3] = {0.f, 0.f, 0.f};
         if (in) {
 #pragma unroll
-            for (int k = 0; k < 3; ++k) dps += dalb[k] * A.col[idx * 3 + k];
-            dps += du * A.sv[idx];
+            for (int k = 0; k < 3; ++k) {
+                shade[k] = classic ? svs + (1.f - svs) * sky[k] : 0.f;
+                dps += (dalb[k] + grgb[k] * shade[k]) * A.col[idx * 3 + k];
+            }
+            dps += du * svs;
         }
         const float dpv_pv = in ? dps * pe * pv : 0.f;          // dPV_s * PV_s
         float dpe = in ? dps * pv : 0.f;
@@ -516,7 +523,17 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const CompBwdArgs A)
         float dc[3];
         const float ps = pv * pe;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) dc[k] = dalb[k] * ps;
+        for (int k = 0; k < 3; ++k) dc[k] = (dalb[k] + grgb[k] * shade[k]) * ps;
+        if (classic) {
+            float dsv = 0.f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float t_ = in ? grgb[k] * ps * A.col[idx * 3 + k] : 0.f;
+                dsv += t_ * (1.f - sky[k]);
+                dsky[k] += t_ * (1.f - svs);
+            }
+            if (in) A.d_sv[idx] = dsv;
+        }
         suffix += tot;
         if (prior) {
             const float ym = in ? (rho * tr + A.rho_prior[idx] * (1.f - tr)) * delta : 0.f;
@@ -544,6 +561,11 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const CompBwdArgs A)
 #pragma unroll
             for (int k = 0; k < 3; ++k) A.d_col[idx * 3 + k] = dc[k];
         }
+    }
+    if (classic) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) dsky[k] = wsum(dsky[k]);
+        if (lane == 0) { A.d_sky[r * 3] = dsky[0]; A.d_sky[r * 3 + 1] = dsky[1]; A.d_sky[r * 3 + 2] = dsky[2]; }
     }
 }
 hipError_t launch_composite_bwd(const CompBwdArgs& a, hipStream_t st) {

@@ -105,6 +105,7 @@ class TrainEngine:
                 self.param_list.append(t)
         self._ptrs = [p.data_ptr() for p in self.param_list]
         self._grad_views = None
+        self.classic_solar = getattr(self, "classic_solar", False)
 
     def adopted(self):
         return all(p.data_ptr() == q for p, q in zip(self.param_list, self._ptrs))
@@ -210,7 +211,7 @@ class _ImagePass(torch.autograd.Function):
         fo = _lib.FieldOut(d_rho=o["rho"].data_ptr(), d_solar_vis=o["sv"].data_ptr(), d_col=o["col"].data_ptr(), d_points=o["pts"].data_ptr(),
                            d_adjust_col=o["adjc"].data_ptr())
         _lib.check(eng.L.snerf_trainer_forward_image(eng.h, R, S, top.data_ptr(), bot.data_ptr(), tv.data_ptr(), sun.data_ptr(),
-                                                     tim.data_ptr(), 1 if train_bn else 0, 0, C.byref(co), o["sky"].data_ptr(),
+                                                     tim.data_ptr(), 1 if train_bn else 0, 1 if eng.classic_solar else 0, C.byref(co), o["sky"].data_ptr(),
                                                      o["cls"].data_ptr(), C.byref(fo), eng.stream()), "trainer_forward_image")
         ctx.eng, ctx.prior = eng, None
         extra = {}
@@ -342,6 +343,9 @@ def eval_train(ev, data_dict, net, train_mode, current_step=0):
     eng = _engine_for(net, R, n_solar, S)
     tv = _to_dev(sample_parameters(S, eval_mode=not train_mode), dev)
     prior = (net, current_step / ev.n_steps) if ev.use_prior else None
+    eng.classic_solar = bool(ev.use_classic_solar)            # Solar_Type_2: per-sample shading, Solar_Vis carries gradient
+    if eng.classic_solar and prior is not None:
+        raise NotImplementedError("season_nerf_amd: Solar_Type_2 together with the DSM prior phase is not implemented")
     res = _ImagePass.apply(eng, top, bot, tv, sun, tim, net.training, prior, *eng.param_list)
     rgb, alb, sky, pe, rgb_m, alb_m, pv, ps, dl, cls, rho, sv, col, pts, adjc = res[:15]
     _after_train_forward(net)

@@ -23,7 +23,8 @@ def setup(golden_dir, name="train_W64_R32_S32.npz"):
     net = sn.T_NeRF(int(g["W"]), int(g["C"]), HM=g["hm"]) if prior else sn.T_NeRF(int(g["W"]), int(g["C"]))
     net.load_state_dict(orc.init_weights(int(g["W"]), int(g["C"]), int(g["seed"])))
     net = net.to("cuda").train()
-    args = SimpleNamespace(n_samples=int(g["S"]), Use_Reg=True, Solar_Type_2=False, Use_MSE_loss=True, Use_Solar=True,
+    args = SimpleNamespace(n_samples=int(g["S"]), Use_Reg=True, Solar_Type_2=bool(int(g["classic"])) if "classic" in g else False,
+                           Use_MSE_loss=True, Use_Solar=True,
                            sc_lambda=float(g["sc_lambda"]), number_low_frequency_cases=4)
     ev = sn.All_in_One_Eval(args, torch.device("cuda"), int(g["n_steps"]), prior, None, np.eye(4), np.zeros(3))
     R = g["in_Top"].shape[0]
@@ -49,15 +50,17 @@ def _ref_grads(g):
     return out
 
 
-@pytest.mark.parametrize("name", ["train_W64_R32_S32.npz", "train_prior_W64_R24_S40.npz", "train_W256_R32_S40.npz"])
+@pytest.mark.parametrize("name", ["train_W64_R32_S32.npz", "train_prior_W64_R24_S40.npz", "train_W256_R32_S40.npz",
+                                  "train_classic_W64_R32_S32.npz"])
 def test_train_step_vs_reference(golden_dir, name):
     """name 2: the DSM-prior phase (use_prior=True: supervised + merged composites, Alpha_Adjust loss); name 3: the benchmark
     width (W=256: 64-column-group GEMM for fc5, several column groups per row tile, full 256x256 wgrad blocks, 1280 points =
-    not a multiple of the 512-row tile)."""
+    not a multiple of the 512-row tile); name 4: Solar_Type_2 (per-sample shading, the solar branch differentiated from the image)."""
     sn, g, net, ev, data = setup(golden_dir, name)
     opt = torch.optim.Adam(net.parameters(), lr=float(g["lr"]))
     opt.zero_grad()
     loss, total = run_step(g, net, ev, data)
+    assert set(loss) == {k[5:] for k in g if k.startswith("loss_")}
     for k in loss:
         ref = float(g["loss_" + k])
         print(f"  loss {k:20s} {float(loss[k][0].detach()):.8f} ref {ref:.8f}")

@@ -119,9 +119,9 @@ def _ref_grads(g):
     return out
 
 
-@pytest.mark.parametrize("name", ["train_W64_R32_S32.npz", "train_W256_R32_S40.npz"])
+@pytest.mark.parametrize("name", ["train_W64_R32_S32.npz", "train_W256_R32_S40.npz", "train_classic_W64_R32_S32.npz"])
 def test_train_step_mse(golden_dir, name):
-    """get_loss (MSE) + backward + BN running stats + one Adam step, train-mode BatchNorm."""
+    """get_loss (MSE) + backward + BN running stats + one Adam step, train-mode BatchNorm; third file: Solar_Type_2."""
     g = load(golden_dir, name)
     sd = orc.init_weights(int(g["W"]), int(g["C"]), int(g["seed"]))
     refs = _ref_grads(g)
@@ -132,7 +132,9 @@ def test_train_step_mse(golden_dir, name):
     solar = {k: T(g["solar_" + k]) for k in ["Top", "Bot", "Sun_Angle"]}
     bn1, bn2 = orc.BNState(), orc.BNState()
     loss, _ = orc.get_loss_mse(sd, data, solar, int(g["S"]), float(g["sc_lambda"]), train_mode=True, train_bn=True,
-                               jitter=T(g["jitter"]), jitter_solar=T(g["jitter_solar"]), bn_out=bn1, bn_out_solar=bn2)
+                               jitter=T(g["jitter"]), jitter_solar=T(g["jitter_solar"]), bn_out=bn1, bn_out_solar=bn2,
+                               classic=bool(int(g["classic"])) if "classic" in g else False)
+    assert set(loss) == {k[5:] for k in g if k.startswith("loss_")}
     for k, (v, w) in loss.items():
         close(v, g["loss_" + k], rtol=1e-4, atol=1e-6)
         assert abs(w - float(g["weight_" + k])) < 1e-9

@@ -149,7 +149,7 @@ def gen_eval(W, seed, R, S, tag, with_prior):
     np.savez_compressed(os.path.join(OUT, f"eval_{tag}.npz"), **out)
 
 
-def gen_train(W, seed, R, S, tag, prior=False, subsample=0):
+def gen_train(W, seed, R, S, tag, prior=False, subsample=0, classic=False):
     """subsample > 0: tensors above 4096 elements are stored as every `subsample`-th element (flat order) plus their L2 norm
     (keeps the W=256 fixture small)."""
     hm = None
@@ -168,7 +168,7 @@ def gen_train(W, seed, R, S, tag, prior=False, subsample=0):
     solar = {"Top": tt(starts), "Bot": tt(ends), "Sun_Angle": tt(vec)}
     solar_time = tt(np.tile(encode_time(0.3, 0.1), (R, 1)))
 
-    ev = All_in_One_Eval(args_ns(S), torch.device("cpu"), 10, prior, None, H4, WC)
+    ev = All_in_One_Eval(args_ns(S, classic), torch.device("cpu"), 10, prior, None, H4, WC)
     step = 3 if prior else 0
     ev.solar_creation_tool = lambda n, include_times=True: (solar["Top"], solar["Bot"], solar["Sun_Angle"], solar_time, az_el)
     torch.manual_seed(77 + seed)
@@ -182,7 +182,7 @@ def gen_train(W, seed, R, S, tag, prior=False, subsample=0):
         total = total + loss[k][0] * loss[k][1]
     total.backward()
     out = {"W": W, "C": 4, "seed": seed, "S": S, "lr": 10 ** -4.86, "sc_lambda": 0.03,
-           "jitter": f32(j1), "jitter_solar": f32(j2), "total": f32(total), "step": step, "n_steps": 10}
+           "jitter": f32(j1), "jitter_solar": f32(j2), "total": f32(total), "step": step, "n_steps": 10, "classic": int(classic)}
     if prior:
         out["hm"] = hm
     for k, v in data.items():
@@ -333,6 +333,7 @@ if __name__ == "__main__":
     gen_train(64, 0, 32, 32, "W64_R32_S32")
     gen_train(64, 1, 24, 40, "prior_W64_R24_S40", prior=True)
     gen_train(256, 2, 32, 40, "W256_R32_S40", subsample=37)
+    gen_train(64, 3, 32, 32, "classic_W64_R32_S32", classic=True)
     gen_render(64, 2, "W64_s2")
     gen_render_by_P(64, 2, "W64_s2")
     gen_dsm()
