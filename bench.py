@@ -18,8 +18,28 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
+# The GPU path needs ONE host thread.  On the test boxes the process sees 256 hardware threads but a 16-CPU cgroup quota:
+# OpenMP / BLAS worker pools woken by a tiny host op (the reference's host-side sun-ray generator runs every training step)
+# spin, burn the quota, and the launching thread gets throttled for multiples of the 10 ms scheduler tick - measured as
+# 24 ms -> 40-50 ms per training step.  Pools are therefore kept at one thread unless the user says otherwise; the CPU
+# baseline below raises torch's thread count explicitly, to the cgroup quota.
+for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+    os.environ.setdefault(_v, "1")
+
+import numpy as np   # noqa: E402
+import torch         # noqa: E402
+
+
+def host_cpus():
+    """CPUs this process may actually use: cgroup v2 quota, then affinity, then the machine count."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
@@ -46,7 +66,7 @@ def cpu_baseline():
     """The CPU oracle (a torch-CPU restatement of the reference path, oracle/season_nerf_oracle.py) timed on the host
     cores of this box on a bounded sample of the same workload."""
     from oracle import season_nerf_oracle as orc
-    torch.set_num_threads(min(os.cpu_count() or 1, 32))   # more threads only slow these small GEMMs down
+    torch.set_num_threads(min(host_cpus(), 32))   # more threads only slow these small GEMMs down
     sd = orc.init_weights(W, NC, 0)
     data = {k: v.cpu() for k, v in synth(0, "cpu").items()}
     sub = lambda n: {k: v[:n] for k, v in data.items()}
@@ -157,7 +177,7 @@ def bench_train(a):
                             "traffic": None, "note": "layer-wise path, whole step (not one kernel) priced against the fp32 matrix peak "
                                                      "(MI355X_MICROARCH.md); per-kernel times in profiles/r1"}}
         if not a.no_cpu_baseline:
-            torch.set_num_threads(min(os.cpu_count() or 1, 32))
+            torch.set_num_threads(min(host_cpus(), 32))
             sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in orc.init_weights(W, NC, 0, bn_stats="identity").items()}
             n = 256
             dc = {k: v[:n].cpu() for k, v in d.items()}
@@ -292,7 +312,7 @@ def main():
         achieved = FLOP_PER_SAMPLE * R * S / (field_ms * 1e-3)
         traffic = None          # HBM bytes per launch from the committed PMC passes of this same command (profiles/)
         try:
-            traffic = json.load(open(os.path.join(REPO, "profiles", "r1", "e_traffic.json")))["bytes_per_launch"]
+            traffic = json.load(open(os.path.join(REPO, "profiles", "r1", "f_traffic.json")))["bytes_per_launch"]
         except Exception:
             pass
         out = {

@@ -287,7 +287,10 @@ def _angles_to_local_vecs(el_deg, az_deg, world_center, W2L_H):
     lat = world_center[0] + np.rad2deg(Y / (1000. * R_km))
     lon = world_center[1] + np.rad2deg(X / (1000. * R_km * np.cos(np.deg2rad(world_center[0]))))
     P = np.stack([lat, lon, world_center[2] + Z, np.ones_like(lat)], 0)
-    v = (np.asarray(W2L_H, dtype=np.float64) @ P)[0:3].T
+    Hm = np.asarray(W2L_H, dtype=np.float64)
+    # explicit 4-term sums instead of `H @ P`: same products and order per element, but no BLAS call - a threaded BLAS spins up
+    # its worker pool for this tiny product every step and the spinning workers eat the process's CPU quota (see bench.py)
+    v = np.stack([Hm[i, 0] * P[0] + Hm[i, 1] * P[1] + Hm[i, 2] * P[2] + Hm[i, 3] * P[3] for i in range(3)], 1)
     return v / np.sqrt(np.sum(v ** 2, 1, keepdims=True))
 
 
