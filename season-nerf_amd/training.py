@@ -302,19 +302,22 @@ class create_solor_rays_uniform:
         self.W2L, self.WC = W2L_H, WCW
 
     def __call__(self, n, include_times=False):
+        # Host arithmetic in numpy (never threaded); torch only for the RNG draws the reference takes from torch's CPU
+        # generator, in the same order - a torch CPU op on these [n,3] arrays can wake the whole intra-op thread pool,
+        # whose spinning workers then starve the kernel-launching thread under a container CPU quota.
         az_el = np.random.random(n * 2).reshape([n, 2]) * np.array([[360, 89]]) + np.array([[-180, 1]])
         vec = _angles_to_local_vecs(az_el[:, 1], az_el[:, 0], self.WC, self.W2L)   # vectorised, same arithmetic per ray
         delta = 2 * (vec / vec[:, 2::])
-        starts = torch.ones([n, 3])
-        starts[:, 0] = torch.tensor(2.0) * torch.rand(n) + torch.tensor(-1.0)
-        starts[:, 1] = torch.tensor(2.0) * torch.rand(n) + torch.tensor(-1.0)
-        ends = (starts - delta).float()
-        vec_t = torch.tensor(vec).float()
+        starts = np.ones([n, 3], dtype=np.float32)
+        starts[:, 0] = np.float32(2.0) * torch.rand(n).numpy() + np.float32(-1.0)
+        starts[:, 1] = np.float32(2.0) * torch.rand(n).numpy() + np.float32(-1.0)
+        ends = (starts.astype(np.float64) - delta).astype(np.float32)          # fp32 tensor - float64 array, then .float()
+        vec_t = vec.astype(np.float32)
         if not include_times:
-            return starts, ends, vec_t
-        fr = torch.rand([n, 2]) * (2 * float(np.pi))
-        times = torch.stack([torch.cos(fr[:, 0]), torch.sin(fr[:, 0]), torch.cos(fr[:, 1]), torch.sin(fr[:, 1])], 1)
-        return starts, ends, vec_t, times, az_el
+            return torch.from_numpy(starts), torch.from_numpy(ends), torch.from_numpy(vec_t)
+        fr = torch.rand([n, 2]).numpy() * np.float32(2 * np.pi)
+        times = np.stack([np.cos(fr[:, 0]), np.sin(fr[:, 0]), np.cos(fr[:, 1]), np.sin(fr[:, 1])], 1).astype(np.float32)
+        return torch.from_numpy(starts), torch.from_numpy(ends), torch.from_numpy(vec_t), torch.from_numpy(times), az_el
 
 
 def _after_train_forward(net):

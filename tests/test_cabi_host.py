@@ -219,3 +219,27 @@ def test_packed_streams_reproduce_the_network(lib, W):
     Wd, b = D.layer(32, W4p // 16); sky = gather(k1, slot_H, W4p) @ Wd.T + b
     np.testing.assert_allclose(1 / (1 + np.exp(-sky[:, 0:3])), ref[3].numpy(), **tol)
     lib.snerf_model_destroy(m)
+
+
+def test_sun_ray_generator_matches_reference_draws(golden_dir):
+    """create_solor_rays_uniform (host code, Eval_Tools_2.py:42-108): same numpy / torch RNG draws in the same order as the
+    reference's generator, so seeded runs reproduce its random sun rays (micro.npz: the reference's output for seed 5)."""
+    import numpy as np
+    import torch
+    import season_nerf_amd as sn
+    g = np.load(os.path.join(golden_dir, "micro.npz"))
+    WC = np.array([41.29, -95.9, 300.0])
+    H4 = np.array([[310.0, 12.0, 0.0, -11650.0], [-9.0, 240.0, 0.0, 23390.0], [0.0, 0.0, 0.01, -3.0], [0, 0, 0, 1.0]])
+    np.random.seed(5)
+    torch.manual_seed(5)
+    st, en, ve, ti, ae = sn.create_solor_rays_uniform(H4, WC)(48, include_times=True)
+    assert st.dtype == en.dtype == ve.dtype == ti.dtype == torch.float32
+    np.testing.assert_array_equal(st.numpy(), g["sungen_starts"])
+    np.testing.assert_array_equal(en.numpy(), g["sungen_ends"])
+    np.testing.assert_array_equal(ve.numpy(), g["sungen_vec"])
+    np.testing.assert_allclose(ti.numpy(), g["sungen_times"], rtol=0, atol=1.2e-7)        # numpy vs torch cos/sin: 1 ulp
+    np.testing.assert_array_equal(ae, g["sungen_az_el"])
+    np.random.seed(5)
+    torch.manual_seed(5)
+    three = sn.create_solor_rays_uniform(H4, WC)(48)
+    assert len(three) == 3 and torch.equal(three[0], st)

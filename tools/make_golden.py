@@ -291,6 +291,12 @@ def gen_micro():
     xs, ys, _ = cam.invert_P(r, c, 0.4)
     out["P"], out["invP_row"], out["invP_col"], out["invP_h"] = P, r, c, 0.4
     out["invP_x"], out["invP_y"] = xs, ys
+    # the random sun-ray generator of the solar-correction loss (Eval_Tools_2.py:42-108) for fixed numpy / torch seeds
+    from T_NeRF_Full_2.Eval_Tools_2 import create_solor_rays_uniform
+    np.random.seed(5)
+    torch.manual_seed(5)
+    st, en, ve, ti, ae = create_solor_rays_uniform(H4, WC)(48, include_times=True)
+    out["sungen_starts"], out["sungen_ends"], out["sungen_vec"], out["sungen_times"], out["sungen_az_el"] = f32(st), f32(en), f32(ve), f32(ti), ae
     np.savez_compressed(os.path.join(OUT, "micro.npz"), **out)
 
 
