@@ -7,7 +7,6 @@ Deviation (documented in INTEGRATION.md): tensors of the result dict stay on the
 """
 import ctypes as C
 
-import numpy as np
 import torch
 
 from . import _lib

@@ -17,7 +17,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .evaluator import All_in_One_Eval, sample_parameters, sample_parameters_on
+from .evaluator import All_in_One_Eval, sample_parameters_on
 from .network import T_NeRF
 
 

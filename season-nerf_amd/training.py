@@ -88,6 +88,7 @@ class TrainEngine:
                                         self.adam_v.data_ptr(), self.buffers.data_ptr(), self.ws.data_ptr(), self.ws.numel(),
                                         n_rays, n_solar_rays, n_samples), "trainer_bind")
         self.adam_steps = 0
+        self.classic_solar = False        # Solar_Type_2 shading in the image pass (set per call by eval_train)
 
     def _adopt(self):
         """Move every parameter / BatchNorm statistic of the module into the arenas (values preserved)."""
@@ -105,7 +106,6 @@ class TrainEngine:
                 self.param_list.append(t)
         self._ptrs = [p.data_ptr() for p in self.param_list]
         self._grad_views = None
-        self.classic_solar = getattr(self, "classic_solar", False)
 
     def adopted(self):
         return all(p.data_ptr() == q for p, q in zip(self.param_list, self._ptrs))

@@ -3,7 +3,6 @@ The per-shard compute is a stand-in callable here (the HIP path needs a GPU); wh
 evaluation + gather equals the unsharded evaluation for ragged sizes."""
 import importlib.util
 import os
-import sys
 
 import pytest
 import torch
