@@ -16,3 +16,4 @@ __all__ = ["T_NeRF", "SineLayer", "All_in_One_Eval", "sample_parameters", "Quick
 from .adaptive_loss import AdaptiveLossFunction  # noqa: E402,F401
 from . import validation  # noqa: E402,F401
 from .validation import DSM_Distance, eval_img, image_error  # noqa: E402,F401
+from .trainer import Net_tool  # noqa: E402,F401

@@ -129,3 +129,43 @@ def test_fused_adam_matches_torch_adam(golden_dir):
     total2.backward()
     fa.step()
     assert float(total2.detach()) != float(total.detach())
+
+
+class _Writer:
+    def __init__(self):
+        self.rows = []
+
+    def add_scalar(self, tag, value, step):
+        self.rows.append((tag, float(value), int(step)))
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_net_tool_train_and_eval_step(golden_dir, fused):
+    """Net_tool.train_step / eval_step (mg_run_NeRF.py:288-337) with the reference's optimiser + OneCycleLR set-up: the first
+    step logs the reference's loss values, the schedule advances, parameters move, eval_step leaves the module in train mode."""
+    sn, g, net, ev, data = setup(golden_dir)
+    w = _Writer()
+    tool = sn.Net_tool(net, ev, lr=float(g["lr"]), total_steps=10, writer=w, fused_adam=fused)
+    p0 = net.G_NeRF_net.fc3.linear.weight.detach().clone()
+    torch.manual_seed(77 + int(g["seed"]))
+    loss = tool.train_step(data, int(g["step"]))
+    logged = {t_[9:]: v for t_, v, s_ in w.rows if t_.startswith("Training/")}
+    for k in loss:
+        ref = float(g["loss_" + k])
+        assert abs(logged[k] - ref) <= 2e-5 * max(1.0, abs(ref)) + 1e-6, k
+    lr0 = [v for t_, v, _ in w.rows if t_ == "LR/Learning_Rate"][0]
+    tool.train_step(data, 1)
+    lr1 = [v for t_, v, _ in w.rows if t_ == "LR/Learning_Rate"][1]
+    assert lr1 > lr0 > 0                                          # OneCycleLR warm-up (max_lr / 25 at step 0)
+    assert not torch.equal(net.G_NeRF_net.fc3.linear.weight.detach(), p0)
+    ev_loss = tool.eval_step(data, 1)
+    assert net.training and set(ev_loss) == set(loss)
+    assert all(np.isfinite(float(v[0])) for v in ev_loss.values())
+    assert any(t_.startswith("Testing/") for t_, _, _ in w.rows)
+    # the eval-mode Color loss equals the fused inference render's MSE (running statistics, no jitter)
+    net.eval()
+    with torch.no_grad():
+        out = ev.eval(data, net, 1, False)
+    net.train()
+    mse = float(torch.mean((out["Rendered_Col"] - data["GT_Color"].cuda()) ** 2))
+    assert abs(float(ev_loss["Color"][0]) - mse) <= 1e-6 + 1e-5 * mse
