@@ -231,6 +231,9 @@ int snerf_surface_distance(int64_t n_rays, int n_samples, const float* d_top, co
                            const double* d_dsm, int dsm_rows, int dsm_cols, const double* d_levels, double* d_dist,
                            void* stream);
 int snerf_image_error(int64_t n_pixels, const float* d_image, const float* d_gt, double* d_sums, void* stream);
+/* Eval_Tools_2.get_PV (Eval_Tools_2.py:13-16) as a stand-alone op: PV[r,s] = exp(-sum_{j<s} rho[r,j] * delta[r,j]) for
+ * [n_rays, n_samples] arrays with arbitrary per-sample deltas (snerf_composite_rays fuses the same scan with the shading). */
+int snerf_transmittance(int64_t n_rays, int n_samples, const float* d_rho, const float* d_delta, float* d_pv, void* stream);
 
 /* Name and launch geometry of the dominant kernel (for profiling scripts): fills grid/block/lds bytes. */
 int snerf_field_kernel_info(const snerf_model* m, int64_t n_points, int* grid, int* block, int* lds_bytes);

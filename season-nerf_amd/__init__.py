@@ -6,11 +6,11 @@ from . import parallel
 from . import raytable
 from .training import FusedAdam, TrainEngine, create_solor_rays_uniform
 from .network import T_NeRF, SineLayer
-from .evaluator import All_in_One_Eval, sample_parameters
+from .evaluator import All_in_One_Eval, sample_parameters, get_PV
 from .render import (Quick_Run_Net, component_render_by_dir, component_render_by_P, get_imgs_from_Img_Dict, get_imgs_from_Img_Dict_t_step,
                      render_season_sweep, world_angle_2_local_vec, encode_time)
 
-__all__ = ["T_NeRF", "SineLayer", "All_in_One_Eval", "sample_parameters", "Quick_Run_Net", "component_render_by_dir", "component_render_by_P",
+__all__ = ["T_NeRF", "SineLayer", "All_in_One_Eval", "sample_parameters", "get_PV", "Quick_Run_Net", "component_render_by_dir", "component_render_by_P",
            "get_imgs_from_Img_Dict", "get_imgs_from_Img_Dict_t_step", "render_season_sweep", "world_angle_2_local_vec",
            "encode_time", "parallel", "raytable", "FusedAdam", "TrainEngine", "create_solor_rays_uniform", "_lib"]
 from .adaptive_loss import AdaptiveLossFunction  # noqa: E402,F401

@@ -87,6 +87,7 @@ def lib():
     L.snerf_prior_density.argtypes = [i64, vp, vp, vp, i32, i32, vp, vp, vp]
     L.snerf_surface_distance.argtypes = [i64, i32, vp, vp, vp, vp, i32, i32, vp, vp, vp]
     L.snerf_image_error.argtypes = [i64, vp, vp, vp, vp]
+    L.snerf_transmittance.argtypes = [i64, i32, vp, vp, vp, vp]
     L.snerf_linear_scratch_bytes.restype = C.c_size_t
     L.snerf_linear_scratch_bytes.argtypes = [i32, i32]
     L.snerf_linear_forward.argtypes = [i64, i32, i32, vp, i64, vp, vp, C.c_float, vp, i64, vp, i32, vp, C.c_size_t, vp]
@@ -106,7 +107,7 @@ EXPORTS = ["snerf_last_error", "snerf_abi_version", "snerf_model_create", "snerf
            "snerf_model_finalize", "snerf_model_destroy", "snerf_model_width", "snerf_model_classes",
            "snerf_model_pack_host", "snerf_group_forward", "snerf_field_forward_points", "snerf_field_forward_rays",
            "snerf_composite_rays", "snerf_composite_sweep", "snerf_render_workspace_bytes", "snerf_render_rays", "snerf_rays_from_camera", "snerf_field_kernel_info",
-           "snerf_prior_density", "snerf_surface_distance", "snerf_image_error",
+           "snerf_prior_density", "snerf_surface_distance", "snerf_image_error", "snerf_transmittance",
            "snerf_linear_scratch_bytes", "snerf_linear_forward", "snerf_linear_dgrad", "snerf_linear_wgrad",
            "snerf_trainer_create", "snerf_trainer_destroy", "snerf_trainer_param_floats", "snerf_trainer_buffer_floats",
            "snerf_trainer_tensor_count", "snerf_trainer_tensor_info", "snerf_trainer_workspace_bytes", "snerf_trainer_bind",

@@ -333,6 +333,14 @@ int snerf_image_error(int64_t n_pixels, const float* d_image, const float* d_gt,
     return e == hipSuccess ? SNERF_OK : fail_hip(e, "image error kernel launch");
 }
 
+int snerf_transmittance(int64_t n_rays, int n_samples, const float* d_rho, const float* d_delta, float* d_pv, void* stream) {
+    if (n_rays < 0 || n_samples < 0) return fail(SNERF_E_INVALID, "snerf_transmittance: negative size");
+    if (n_rays == 0 || n_samples == 0) return SNERF_OK;
+    if (!d_rho || !d_delta || !d_pv) return fail(SNERF_E_INVALID, "snerf_transmittance: bad argument");
+    hipError_t e = launch_transmittance(n_rays, n_samples, d_rho, d_delta, d_pv, (hipStream_t)stream);
+    return e == hipSuccess ? SNERF_OK : fail_hip(e, "transmittance kernel launch");
+}
+
 int snerf_field_kernel_info(const snerf_model* m, int64_t n_points, int* grid, int* block, int* lds_bytes) {
     if (!m) return fail(SNERF_E_INVALID, "NULL model");
     int rc = pack_both(const_cast<snerf_model*>(m));

@@ -89,6 +89,33 @@ __global__ __launch_bounds__(256) void image_error_kernel(int64_t n_pix, const f
     }
 }
 
+// Eval_Tools_2.get_PV (:13-16) as a stand-alone op: PV[r,s] = exp(-sum_{j<s} rho[r,j]*delta[r,j]) for arbitrary per-sample
+// deltas (the compositing kernel computes the same scan fused, with delta derived from the ray).  One wavefront per ray.
+__global__ __launch_bounds__(256) void transmittance_kernel(int64_t n_rays, int S, const float* rho, const float* delta, float* pv) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n_rays) return;
+    float carry = 0.f;
+    for (int base = 0; base < S; base += 64) {
+        const int s = base + lane;
+        const bool in = s < S;
+        const float y = in ? rho[r * S + s] * delta[r * S + s] : 0.f;
+        float incl = y;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const float up = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += up;
+        }
+        if (in) pv[r * S + s] = expf(-(carry + incl - y));
+        carry += __shfl(incl, 63, 64);
+    }
+}
+hipError_t launch_transmittance(int64_t n_rays, int S, const float* rho, const float* delta, float* pv, hipStream_t st) {
+    if (n_rays <= 0 || S <= 0) return hipSuccess;
+    hipLaunchKernelGGL(transmittance_kernel, dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, st, n_rays, S, rho, delta, pv);
+    return hipGetLastError();
+}
+
 hipError_t launch_prior_density(int64_t n, const float* pts, const float* delta, const double* hm, int hx, int hy, const float* outside,
                                 float neg_log_term, float* rho, hipStream_t st) {
     if (n <= 0) return hipSuccess;

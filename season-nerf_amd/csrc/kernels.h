@@ -82,6 +82,7 @@ hipError_t launch_prior_density(int64_t n, const float* pts, const float* delta,
 hipError_t launch_surface_distance(int64_t n_rays, int S, const float* top, const float* bot, const float* tvals, const double* dsm, int dx,
                                    int dy, const double* levels, double* dist, hipStream_t st);
 hipError_t launch_image_error(int64_t n_pix, const float* img, const float* gt, double* sums, hipStream_t st);
+hipError_t launch_transmittance(int64_t n_rays, int S, const float* rho, const float* delta, float* pv, hipStream_t st);
 int mlp_lds_bytes(int bias_floats);
 int mlp_tile_points();
 int field_variant_chunks(int W, int C, int variant);

@@ -25,6 +25,24 @@ def sample_parameters(n_samples, eval_mode, include_end_pt=False):
     return ts.float().contiguous()
 
 
+def get_PV(Rhos, Deltas):
+    """Eval_Tools_2.get_PV (:13-16): exclusive-prefix transmittance exp(-cumsum([0, rho*delta]))[:, :-1] of [R,S,1] tensors,
+    one wavefront-scan kernel (snerf_transmittance) instead of cat + cumsum + exp."""
+    if Rhos.device.type != "cuda":
+        raise RuntimeError("season_nerf_amd.get_PV runs on an MI355X only: pass device tensors")
+    if Rhos.shape != Deltas.shape or Rhos.dim() < 2:
+        raise ValueError(f"get_PV: Rhos {tuple(Rhos.shape)} / Deltas {tuple(Deltas.shape)}")
+    R, S = Rhos.shape[0], Rhos.shape[1]
+    rho = Rhos.detach().to(torch.float32).contiguous()
+    dl = Deltas.detach().to(device=rho.device, dtype=torch.float32).contiguous()
+    if rho.numel() != R * S:
+        raise ValueError("get_PV expects [R, S, 1] (or [R, S]) tensors")
+    pv = torch.empty_like(rho)
+    _lib.check(_lib.lib().snerf_transmittance(R, S, rho.data_ptr(), dl.data_ptr(), pv.data_ptr(),
+                                             C.c_void_p(torch.cuda.current_stream(rho.device).cuda_stream)), "snerf_transmittance")
+    return pv
+
+
 _TV_CACHE = {}
 
 

@@ -182,3 +182,20 @@ def test_generic_width_runs_on_layerwise_engine():
     close("g128_Rendered_Col", out["Rendered_Col"], refo["Rendered_Col"].numpy())
     close("g128_PS", out["PS"], refo["PS"].numpy(), rtol=1e-4, atol=2e-5)
     close("g128_Adjust", out["Adjust"], refo["Adjust"].numpy(), rtol=1e-4, atol=1e-4)
+
+
+def test_get_PV_standalone():
+    """Eval_Tools_2.get_PV (:13-16) with arbitrary per-sample deltas, ragged sample counts (not a multiple of 64), S > 64."""
+    import season_nerf_amd as sn
+    from oracle import season_nerf_oracle as orc
+    g = torch.Generator().manual_seed(3)
+    for R, S in ((5, 1), (7, 33), (64, 96), (3, 200)):
+        rho = torch.rand(R, S, 1, generator=g) * 20
+        dl = torch.rand(R, S, 1, generator=g) * 0.05
+        got = sn.get_PV(rho.cuda(), dl.cuda())
+        ref = orc.get_PV(rho, dl)
+        assert got.shape == ref.shape
+        np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), rtol=2e-6, atol=1e-7)
+    assert sn.get_PV(torch.zeros(0, 8, 1).cuda(), torch.zeros(0, 8, 1).cuda()).shape == (0, 8, 1)
+    with pytest.raises(ValueError):
+        sn.get_PV(torch.zeros(4, 8, 1).cuda(), torch.zeros(4, 9, 1).cuda())
