@@ -200,3 +200,24 @@ def test_component_render_by_P(golden_dir):
     im = sn.get_imgs_from_Img_Dict(d, size)                          # the image assembly accepts the by-P dict as well
     assert im["Base_Img"].shape == (size[0], size[1], 3) and np.isnan(im["Base_Img"]).any() and np.isfinite(im["Base_Img"]).any()
 
+
+
+def test_model_directory_and_novel_view(setup, tmp_path):
+    """Seam B5: Final_Model.nn / opts.json / W2C_W2L_H.npy exactly as the reference writes them, and the novel-view entry
+    point of main_run_Season_NeRF.py on top of them."""
+    import json
+    sn, g, net, _ = setup
+    sd = orc.init_weights(int(g["W"]), int(g["C"]), int(g["seed"]))
+    torch.save(sd, tmp_path / "Final_Model.nn")
+    (tmp_path / "opts.json").write_text(json.dumps({"fc_units": int(g["W"]), "number_low_frequency_cases": int(g["C"]), "n_samples": 96,
+                                                    "exp_name": "fixture"}))
+    np.save(tmp_path / "W2C_W2L_H.npy", {"W2C": g["WC"], "W2L_H": g["H"]}, allow_pickle=True)
+    loaded, args = sn.load_model(str(tmp_path))
+    assert args.fc_units == int(g["W"]) and isinstance(loaded, sn.T_NeRF) and next(loaded.parameters()).device.type == "cpu"
+    assert abs(sn.parse_time("04/02") - 91 / 365) < 1e-12
+    size = (12, 12, 48)
+    img, imgs = sn.render_novel_view(str(tmp_path), (80, 0), (30, 90), 0.25, size)
+    close("novel_view", img, g["img_Season_Adj_Img"] * g["img_Shadow_Adjust"])
+    assert img.shape == (12, 12, 3) and "Shadow_Mask" in imgs
+    img2, _ = sn.render_novel_view(str(tmp_path), (80, 0), (30, 90), "04/02", size, exact_shadow=True)
+    assert img2.shape == (12, 12, 3) and np.isfinite(img2).all()
