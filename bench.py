@@ -176,7 +176,7 @@ def bench_train(a):
                "roofline": {"bound": "mfma", "achieved": flop / dt / 1e12, "peak": 157.3, "unit": "TFLOP/s", "frac": flop / dt / 157.3e12,
                             "traffic": None, "note": "layer-wise path, whole step (not one kernel) priced against the fp32 matrix peak "
                                                      "(MI355X_MICROARCH.md); per-kernel times in profiles/r1"}}
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:      # reported at N = 1 only (rank 0)
             torch.set_num_threads(min(host_cpus(), 32))
             sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in orc.init_weights(W, NC, 0, bn_stats="identity").items()}
             n = 256
@@ -332,7 +332,7 @@ def main():
                                  "executes 3 bf16 MFMAs per algorithmic product (error-compensated split) plus padding: "
                                  "executed MFMA rate = %.1f TFLOP/s" % (4440 * 32768 * (R * S / 32) / (field_ms * 1e-3) / 1e12)},
         }
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:      # reported at N = 1 only (rank 0)
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
     if use_dist:
