@@ -161,6 +161,30 @@ def bench_train(a):
     per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))     # stream time of each step (diagnostic)
     # algorithmic FLOPs: image rays 3 x forward; sun rays: trunk+heads+solar forward + 3 x solar/sky heads
     flop = R * S * (3 * FLOP_PER_SAMPLE + 2 * (524800 + 3 * 54656))
+    # HBM bytes the layer-wise design moves per step (every per-point layer is a pass over [points x width] fp32
+    # arrays; per-ray branches are negligible).  Forward of a layer: GEMM (read in, write Z) + sin pass (read Z, write H);
+    # backward: BatchNorm layers 2 + 3 array passes (sums; dZ), plain SineLayers 3, then wgrad (read dZ, in) and dgrad
+    # (read dZ, write d_in); heads: no sin / activation passes.
+    rows = {n: (o, i, k, bn) for n, k, o, i, bn, _ in orc.layer_table(W, NC)}
+    g_ = "G_NeRF_net."
+    trunk = [g_ + f"fc{i}" for i in range(1, 10)]
+    heads = [g_ + "fc10Col", g_ + "fc10Sigma"]
+    solar = [g_ + "fc_solar_1", g_ + "fc_solar_2", g_ + "fc_solar_3", g_ + "fc_solar_4"]
+    adjust = ["adjust_layer_1", "adjust_layer_2", "adjust_layer_3", "adjust_col"]
+
+    def fwd_bytes(names):
+        return sum((i + o) + (2 * o if k == "sine" else 0) for o, i, k, _ in (rows[n] for n in names))
+
+    def bwd_bytes(names, dgrad_first=True):
+        tot = 0
+        for j, n in enumerate(names):
+            o, i, k, bn = rows[n]
+            tot += (5 * o if bn else 3 * o) if k == "sine" else 0
+            tot += (o + i) + ((o + i) if (dgrad_first or j > 0) else 0)
+        return tot
+    img = fwd_bytes(trunk + heads + solar + adjust) + bwd_bytes(trunk, False) + bwd_bytes(heads) + bwd_bytes(adjust)
+    sol = fwd_bytes(trunk + heads + solar) + bwd_bytes(solar, False)
+    hbm_bytes = 4.0 * R * S * (img + sol)
     lname = "Barron adaptive loss" if barron else "MSE loss"
     gemm = os.environ.get("SNERF_TRAIN_GEMM", "bf16x3")
     if rank == 0:
@@ -173,9 +197,12 @@ def bench_train(a):
                           "parallelism": f"rays sharded over {world} GPU(s), one all-reduce of the flat gradient arena, BatchNorm statistics "
                                          + ("over the global batch (all-reduced)" if a.bn_sync == "global" and use_dist else "per rank")},
                "final_loss": float(tot.detach()), "step_ms_median": per_step[len(per_step) // 2], "step_ms_min": per_step[0],
-               "roofline": {"bound": "mfma", "achieved": flop / dt / 1e12, "peak": 157.3, "unit": "TFLOP/s", "frac": flop / dt / 157.3e12,
-                            "traffic": None, "note": "layer-wise path, whole step (not one kernel) priced against the fp32 matrix peak "
-                                                     "(MI355X_MICROARCH.md); per-kernel times in profiles/r1"}}
+               "roofline": {"bound": "hbm", "achieved": hbm_bytes / dt / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": hbm_bytes / dt / 8e12,
+                            "traffic": None, "bytes_per_step": hbm_bytes, "algorithmic_tflops": flop / dt / 1e12,
+                            "note": "whole step, not one kernel: train-mode BatchNorm forces a layer-wise design in which every layer is "
+                                    "a pass over [393216 x width] fp32 arrays; achieved = bytes that design moves per step (counted from "
+                                    "the layer table, DESIGN 5.4) / step time, peak = HBM3E 8 TB/s (MI355X_MICROARCH.md); "
+                                    "per-kernel times in profiles/r1/f_train_kernel_stats.csv"}}
         if not a.no_cpu_baseline and world == 1:      # reported at N = 1 only (rank 0)
             torch.set_num_threads(min(host_cpus(), 32))
             sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in orc.init_weights(W, NC, 0, bn_stats="identity").items()}
