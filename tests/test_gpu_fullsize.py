@@ -69,3 +69,26 @@ def test_ray_independence(full):
     bounds = sn.parallel.shard_bounds(R, 3)
     parts = [ev.eval({k: v[lo:hi] for k, v in data.items()}, net, 0, False)["Rendered_Col"] for lo, hi in bounds]
     np.testing.assert_array_equal(torch.cat(parts).cpu().numpy(), out["Rendered_Col"].cpu().numpy())
+
+
+def test_config0_512x64_whole_batch_vs_oracle(full):
+    """BASELINE configs[0] (the reference's own CPU-runnable case): 512 rays x 64 samples, W=256 - every ray against the oracle,
+    RGB, expected surface depth (mg_run_NeRF.py:188-189) and the per-sample fields."""
+    sn, sd, net, ev, data, _ = full
+    n, s = 512, 64
+    sub = {k: v[:n] for k, v in data.items()}
+    args = SimpleNamespace(n_samples=s, Use_Reg=True, Solar_Type_2=False, Use_MSE_loss=True, Use_Solar=True, sc_lambda=0.03,
+                           number_low_frequency_cases=C)
+    ev64 = sn.All_in_One_Eval(args, torch.device("cuda"), 10, False, None, np.eye(4), np.zeros(3))
+    out = ev64.eval(sub, net, 0, False)
+    rgb, loc, dist = ev64.render_summary(sub, net)
+    with torch.no_grad():
+        ref = orc.eval_rays(sd, sub, s, train_mode=False)
+        rloc, rdist = orc.surface_depth(ref["PS"], ref["sample_pts"], ref["deltas"])
+    np.testing.assert_allclose(out["Rendered_Col"].cpu().numpy(), ref["Rendered_Col"].numpy(), rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(rgb.cpu().numpy(), ref["Rendered_Col"].numpy(), rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(loc.cpu().numpy(), rloc.numpy(), rtol=1e-4, atol=2e-5)             # depth: 1e-4 rel (north star)
+    np.testing.assert_allclose(dist.cpu().numpy(), rdist.numpy(), rtol=1e-4, atol=2e-5)
+    for k, tol in (("Rho", 2e-4), ("Col", 1e-4), ("Solar_Vis", 1e-4), ("PV", 1e-4)):
+        np.testing.assert_allclose(out[k].cpu().numpy(), ref[k].numpy(), rtol=tol, atol=2e-5, err_msg=k)
+    assert torch.equal(out["sample_pts"].cpu(), ref["sample_pts"])                                  # bit-identical sampling
