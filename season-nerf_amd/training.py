@@ -54,43 +54,34 @@ def _ptr(t):
     return t.data_ptr() if t is not None else None
 
 
-class TrainEngine:
-    """Binds a `season_nerf_amd.T_NeRF` to a `snerf_trainer` for fixed (rays, solar rays, samples)."""
+class _ParamStore:
+    """The flat arenas of ONE network: parameters, gradients, Adam moments, BatchNorm running statistics, and the Adam step
+    count.  Shared by every TrainEngine of that network, so engines for different ray counts (a training batch, a validation
+    batch) see the same parameters and the optimiser state survives switching between them."""
 
-    def __init__(self, net, n_rays, n_solar_rays, n_samples):
+    def __init__(self, net, h):
         L = _lib.lib()
-        self.L, self.net = L, net
+        self.net = net
         self.dev = net.get_class_layer.weight.device
-        if self.dev.type != "cuda":
-            raise RuntimeError("season_nerf_amd training runs on an MI355X only: move the module with .to('cuda')")
-        self.h = L.snerf_trainer_create(net.layer_width, net.n_classes)
-        if not self.h:
-            raise RuntimeError("season_nerf_amd: " + L.snerf_last_error().decode())
-        self.R, self.Rs, self.S = n_rays, n_solar_rays, n_samples
-        self.n_params, self.n_buffers = L.snerf_trainer_param_floats(self.h), L.snerf_trainer_buffer_floats(self.h)
+        self.n_params, self.n_buffers = L.snerf_trainer_param_floats(h), L.snerf_trainer_buffer_floats(h)
         dev = self.dev
         self.params = torch.empty(self.n_params, device=dev)
         self.grads = torch.zeros(self.n_params, device=dev)
         self.adam_m = torch.zeros(self.n_params, device=dev)
         self.adam_v = torch.zeros(self.n_params, device=dev)
         self.buffers = torch.empty(max(self.n_buffers, 1), device=dev)
-        self.ws = torch.empty(L.snerf_trainer_workspace_bytes(self.h, n_rays, n_solar_rays, n_samples), dtype=torch.uint8, device=dev)
+        self.adam_steps = 0
         # layout: state_dict key -> (is_buffer, offset, numel)
         self.layout = {}
         key = C.create_string_buffer(128)
         isb, off, num, rows, cols = C.c_int(), C.c_int64(), C.c_int64(), C.c_int(), C.c_int()
-        for i in range(L.snerf_trainer_tensor_count(self.h)):
-            _lib.check(L.snerf_trainer_tensor_info(self.h, i, key, 128, C.byref(isb), C.byref(off), C.byref(num), C.byref(rows),
+        for i in range(L.snerf_trainer_tensor_count(h)):
+            _lib.check(L.snerf_trainer_tensor_info(h, i, key, 128, C.byref(isb), C.byref(off), C.byref(num), C.byref(rows),
                                                    C.byref(cols)), "trainer_tensor_info")
             self.layout[key.value.decode()] = (bool(isb.value), off.value, num.value)
-        self._adopt()
-        _lib.check(L.snerf_trainer_bind(self.h, self.params.data_ptr(), self.grads.data_ptr(), self.adam_m.data_ptr(),
-                                        self.adam_v.data_ptr(), self.buffers.data_ptr(), self.ws.data_ptr(), self.ws.numel(),
-                                        n_rays, n_solar_rays, n_samples), "trainer_bind")
-        self.adam_steps = 0
-        self.classic_solar = False        # Solar_Type_2 shading in the image pass (set per call by eval_train)
+        self.adopt()
 
-    def _adopt(self):
+    def adopt(self):
         """Move every parameter / BatchNorm statistic of the module into the arenas (values preserved)."""
         named = dict(self.net.named_parameters())
         named.update(dict(self.net.named_buffers()))
@@ -105,19 +96,59 @@ class TrainEngine:
                 self.param_keys.append(k)
                 self.param_list.append(t)
         self._ptrs = [p.data_ptr() for p in self.param_list]
-        self._grad_views = None
+        self.grad_views = [self.grads[off:off + num].view(p.shape)
+                           for p, (_, off, num) in ((p, self.layout[k]) for k, p in zip(self.param_keys, self.param_list))]
 
     def adopted(self):
         return all(p.data_ptr() == q for p, q in zip(self.param_list, self._ptrs))
+
+
+class TrainEngine:
+    """Binds a `season_nerf_amd.T_NeRF` to a `snerf_trainer` for fixed (rays, solar rays, samples): the C handle and its
+    workspace; parameters and optimiser state live in the network's shared `_ParamStore`."""
+
+    def __init__(self, net, n_rays, n_solar_rays, n_samples):
+        L = _lib.lib()
+        self.L, self.net = L, net
+        self.dev = net.get_class_layer.weight.device
+        if self.dev.type != "cuda":
+            raise RuntimeError("season_nerf_amd training runs on an MI355X only: move the module with .to('cuda')")
+        self.h = L.snerf_trainer_create(net.layer_width, net.n_classes)
+        if not self.h:
+            raise RuntimeError("season_nerf_amd: " + L.snerf_last_error().decode())
+        self.R, self.Rs, self.S = n_rays, n_solar_rays, n_samples
+        store = getattr(net, "_param_store", None)
+        if store is None or store.dev != self.dev:
+            store = net._param_store = _ParamStore(net, self.h)
+        elif not store.adopted():
+            store.adopt()                      # the module's tensors were replaced (load_state_dict keeps them; .to() may not)
+        self.store = store
+        self.ws = torch.empty(L.snerf_trainer_workspace_bytes(self.h, n_rays, n_solar_rays, n_samples), dtype=torch.uint8, device=self.dev)
+        _lib.check(L.snerf_trainer_bind(self.h, store.params.data_ptr(), store.grads.data_ptr(), store.adam_m.data_ptr(),
+                                        store.adam_v.data_ptr(), store.buffers.data_ptr(), self.ws.data_ptr(), self.ws.numel(),
+                                        n_rays, n_solar_rays, n_samples), "trainer_bind")
+        self.classic_solar = False        # Solar_Type_2 shading in the image pass (set per call by eval_train)
+
+    # the arenas, through the shared store
+    params = property(lambda self: self.store.params)
+    grads = property(lambda self: self.store.grads)
+    adam_m = property(lambda self: self.store.adam_m)
+    adam_v = property(lambda self: self.store.adam_v)
+    buffers = property(lambda self: self.store.buffers)
+    layout = property(lambda self: self.store.layout)
+    param_keys = property(lambda self: self.store.param_keys)
+    param_list = property(lambda self: self.store.param_list)
+    n_params = property(lambda self: self.store.n_params)
+    adam_steps = property(lambda self: self.store.adam_steps)
+
+    def adopted(self):
+        return self.store.adopted()
 
     def attach_grads(self):
         """Make every parameter's .grad a view of the engine's flat gradient arena, which the backward kernels accumulate
         into directly (no per-parameter copies through autograd).  A .grad that is None (optimizer.zero_grad(set_to_none=True))
         gets a zeroed view; a foreign .grad tensor is copied into its slice first."""
-        views = self._grad_views
-        if views is None:
-            views = self._grad_views = [self.grads[off:off + num].view(p.shape)
-                                        for p, (_, off, num) in ((p, self.layout[k]) for k, p in zip(self.param_keys, self.param_list))]
+        views = self.store.grad_views
         state = [0 if p.grad is None else (1 if p.grad.data_ptr() == v.data_ptr() else 2) for p, v in zip(self.param_list, views)]
         if all(s_ == 1 for s_ in state):
             return
@@ -169,8 +200,8 @@ class TrainEngine:
         _lib.check(self.L.snerf_trainer_zero_grad(self.h, self.stream()), "trainer_zero_grad")
 
     def adam_step(self, lr, betas=(0.9, 0.999), eps=1e-8):
-        self.adam_steps += 1
-        _lib.check(self.L.snerf_trainer_adam_step(self.h, float(lr), betas[0], betas[1], eps, self.adam_steps, self.stream()),
+        self.store.adam_steps += 1
+        _lib.check(self.L.snerf_trainer_adam_step(self.h, float(lr), betas[0], betas[1], eps, self.store.adam_steps, self.stream()),
                    "trainer_adam_step")
 
     def __del__(self):
@@ -330,11 +361,23 @@ def _after_train_forward(net):
         net._sig = None
 
 
+_ENGINE_CACHE = 2          # engines (workspaces) kept per network: e.g. the training batch and a validation batch
+
+
 def _engine_for(net, R, Rs, S):
-    eng = getattr(net, "_train_engine", None)
-    if eng is None or (eng.R, eng.Rs, eng.S) != (R, Rs, S) or not eng.adopted():
+    """The engine of `net` for these sizes; the most recently used ones are kept (each owns a multi-GB workspace), all of them
+    on the network's one parameter store."""
+    cache = net.__dict__.setdefault("_train_engines", {})
+    key = (int(R), int(Rs), int(S), str(net.get_class_layer.weight.device))
+    eng = cache.pop(key, None)
+    if eng is not None and not eng.adopted():
+        eng = None
+    if eng is None:
+        while len(cache) >= _ENGINE_CACHE:
+            cache.pop(next(iter(cache)))             # least recently used
         eng = TrainEngine(net, R, Rs, S)
-        net._train_engine = eng
+    cache[key] = eng                                  # most recently used last
+    net._train_engine = eng
     return eng
 
 

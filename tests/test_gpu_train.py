@@ -169,3 +169,33 @@ def test_net_tool_train_and_eval_step(golden_dir, fused):
     net.train()
     mse = float(torch.mean((out["Rendered_Col"] - data["GT_Color"].cuda()) ** 2))
     assert abs(float(ev_loss["Color"][0]) - mse) <= 1e-6 + 1e-5 * mse
+
+
+def test_optimizer_state_survives_engine_switch(golden_dir):
+    """Engines for different ray counts share one parameter / Adam-moment store: interleaving a validation-sized evaluation
+    (different engine, train-mode module) between two training steps must not reset FusedAdam's moments or step count."""
+    sn, g, net, ev, data = setup(golden_dir)
+    opt = sn.FusedAdam(net, lr=1e-3)
+
+    def train_once():
+        opt.zero_grad()
+        _, total = run_step(g, net, ev, data)
+        total.backward()
+        opt.step()
+
+    train_once()
+    eng_a = net._train_engine
+    m_after_1 = eng_a.adam_m.clone()
+    assert float(m_after_1.abs().max()) > 0 and eng_a.adam_steps == 1
+    half = {k: v[:16] for k, v in data.items()}
+    with torch.no_grad():
+        out = ev.eval(half, net, 0, False)                  # 16 rays, module still in train mode -> a second engine
+    eng_b = net._train_engine
+    assert eng_b is not eng_a and eng_b.store is eng_a.store and out["Rendered_Col"].shape == (16, 3)
+    assert torch.equal(eng_b.adam_m, m_after_1) and eng_b.adam_steps == 1
+    p_before = net.G_NeRF_net.fc3.linear.weight.detach().clone()
+    train_once()                                            # back on the first engine (cached), second Adam step
+    assert net._train_engine is eng_a and eng_a.adam_steps == 2
+    assert not torch.equal(eng_a.adam_m, m_after_1) and not torch.equal(net.G_NeRF_net.fc3.linear.weight.detach(), p_before)
+    # parameters are the same storage for both engines
+    assert eng_a.params.data_ptr() == eng_b.params.data_ptr() == net._param_store.params.data_ptr()
