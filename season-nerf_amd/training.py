@@ -21,8 +21,9 @@ from .evaluator import sample_parameters
 class _PinnedRing:
     """Persistent pinned staging buffers for the few small host tensors a training step uploads (sample parameters, the
     random sun rays).  A pageable H2D copy waits for all queued GPU work - a hidden sync per step - and a fresh pinned
-    allocation per upload (hipHostMalloc) is itself expensive; a ring of 16 reusable slots per shape is neither.  A slot is
-    rewritten 16 uploads later, by which time its copy has long left the queue (the stream runs at most ~2 steps ahead)."""
+    allocation per upload (hipHostMalloc) is itself expensive; a ring of 16 reusable slots per shape is neither.  Each slot
+    carries the event of its last copy and is rewritten only after that copy has executed (the wait is a no-op unless the
+    host runs more than 16 uploads ahead of the GPU)."""
     SLOTS = 16
 
     def __init__(self):
@@ -32,11 +33,16 @@ class _PinnedRing:
         key = (tuple(t.shape), torch.device(dev))
         ring = self.rings.get(key)
         if ring is None:
-            ring = self.rings[key] = [[torch.empty(t.shape, dtype=torch.float32).pin_memory() for _ in range(self.SLOTS)], 0]
-        slot = ring[0][ring[1] % self.SLOTS]
+            ring = self.rings[key] = [[[torch.empty(t.shape, dtype=torch.float32).pin_memory(), None] for _ in range(self.SLOTS)], 0]
+        entry = ring[0][ring[1] % self.SLOTS]
         ring[1] += 1
-        slot.copy_(t)
-        return slot.to(dev, non_blocking=True)
+        if entry[1] is not None:
+            entry[1].synchronize()
+        entry[0].copy_(t)
+        out = entry[0].to(dev, non_blocking=True)
+        entry[1] = torch.cuda.Event()
+        entry[1].record(torch.cuda.current_stream(out.device))
+        return out
 
 
 _RING = _PinnedRing()
