@@ -72,7 +72,7 @@ def cpu_baseline():
     sub = lambda n: {k: v[:n] for k, v in data.items()}
     with torch.no_grad():
         orc.eval_rays(sd, sub(128), S, False)              # warm-up
-        n, reps, ts = 1024, 3, []
+        n, reps, ts = 2048, 3, []                   # ~4 s per repetition on 16 cores: 10-15 s of CPU work in total
         for _ in range(reps):
             t0 = time.perf_counter()
             orc.eval_rays(sd, sub(n), S, False)
