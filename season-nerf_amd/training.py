@@ -504,6 +504,29 @@ class FusedAdam(torch.optim.Optimizer):
         self.net = net
         super().__init__(list(net.parameters()), dict(lr=lr, betas=betas, eps=eps))
 
+    def state_dict(self):
+        """Checkpointable state: torch's param_groups plus the flat Adam moments and the step count of the network's store."""
+        sd = super().state_dict()
+        store = getattr(self.net, "_param_store", None)
+        if store is not None:
+            sd["snerf_adam"] = {"step": store.adam_steps, "exp_avg": store.adam_m.detach().cpu().clone(),
+                                "exp_avg_sq": store.adam_v.detach().cpu().clone()}
+        return sd
+
+    def load_state_dict(self, state_dict):
+        state_dict = dict(state_dict)
+        extra = state_dict.pop("snerf_adam", None)
+        super().load_state_dict(state_dict)
+        if extra is not None:
+            store = getattr(self.net, "_param_store", None)
+            if store is None:
+                raise RuntimeError("FusedAdam.load_state_dict: run one training forward first (the parameter store does not exist yet)")
+            if extra["exp_avg"].numel() != store.adam_m.numel():
+                raise ValueError("FusedAdam.load_state_dict: moment size does not match this network")
+            store.adam_m.copy_(extra["exp_avg"])
+            store.adam_v.copy_(extra["exp_avg_sq"])
+            store.adam_steps = int(extra["step"])
+
     def zero_grad(self, set_to_none=False):
         """Zero the gradient arena in one kernel; the parameters keep their .grad views (set_to_none is accepted and ignored)."""
         eng = getattr(self.net, "_train_engine", None)

@@ -199,3 +199,45 @@ def test_optimizer_state_survives_engine_switch(golden_dir):
     assert not torch.equal(eng_a.adam_m, m_after_1) and not torch.equal(net.G_NeRF_net.fc3.linear.weight.detach(), p_before)
     # parameters are the same storage for both engines
     assert eng_a.params.data_ptr() == eng_b.params.data_ptr() == net._param_store.params.data_ptr()
+
+
+def test_checkpoint_resume(golden_dir, tmp_path):
+    """Model + FusedAdam checkpoint / resume: a run resumed from files continues like the uninterrupted one (up to the
+    summation-order noise of the atomically reduced gradients), which a resume without the optimiser state does not."""
+    def fresh():
+        sn, g, net, ev, data = setup(golden_dir)
+        return sn, g, net, ev, data, sn.FusedAdam(net, lr=1e-3)
+
+    def step(g, net, ev, data, opt, seed):
+        torch.manual_seed(seed)
+        opt.zero_grad()
+        loss = ev.get_loss(data, net, 0, True)
+        sum(v * w for v, w in loss.values()).backward()
+        opt.step()
+
+    sn, g, net, ev, data, opt = fresh()
+    step(g, net, ev, data, opt, 1)
+    step(g, net, ev, data, opt, 2)
+    torch.save(net.state_dict(), tmp_path / "model.nn")
+    torch.save(opt.state_dict(), tmp_path / "optim.pt")
+    step(g, net, ev, data, opt, 3)
+    want = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+
+    sn, g, net2, ev2, data2, opt2 = fresh()
+    net2.load_state_dict(torch.load(tmp_path / "model.nn"))
+    with torch.no_grad():
+        ev2.eval(data2, net2, 0, False)                      # builds the engine / parameter store (train-mode module)
+    # that forward touched the BatchNorm running statistics: restore them from the checkpoint again
+    net2.load_state_dict(torch.load(tmp_path / "model.nn"))
+    opt2.load_state_dict(torch.load(tmp_path / "optim.pt"))
+    assert net2._param_store.adam_steps == 2
+    step(g, net2, ev2, data2, opt2, 3)
+    got = {k: v.detach().cpu().clone() for k, v in net2.state_dict().items()}
+    worst = max(float((got[k].float() - v.float()).abs().max()) for k, v in want.items() if v.is_floating_point())
+    assert worst < 2e-5, worst                                # lr = 1e-3: 2 % of one update
+
+    sn, g, net3, ev3, data3, opt3 = fresh()                   # same checkpoint, optimiser state NOT restored
+    net3.load_state_dict(torch.load(tmp_path / "model.nn"))
+    step(g, net3, ev3, data3, opt3, 3)
+    w3 = net3.state_dict()["G_NeRF_net.fc3.linear.weight"].cpu()
+    assert float((w3 - want["G_NeRF_net.fc3.linear.weight"]).abs().max()) > 1e-4
