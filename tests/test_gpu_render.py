@@ -221,3 +221,19 @@ def test_model_directory_and_novel_view(setup, tmp_path):
     assert img.shape == (12, 12, 3) and "Shadow_Mask" in imgs
     img2, _ = sn.render_novel_view(str(tmp_path), (80, 0), (30, 90), "04/02", size, exact_shadow=True)
     assert img2.shape == (12, 12, 3) and np.isfinite(img2).all()
+
+
+def test_sweep_many_time_steps_vs_oracle(setup):
+    """get_imgs_from_Img_Dict_t_step with more class vectors than one kernel pass holds (T = 29 > 12: several passes over the
+    per-sample arrays), arbitrary (non-softmax) class vectors, against the oracle's float64 restatement of mg_Img_Eval.py:192-228."""
+    sn, g, net, args = setup
+    size = (6, 7, 40)
+    d = sn.component_render_by_dir(net, (70, 20), (40, 100), 0.6, size, g["WC"], g["H"], torch.device("cuda"), include_exact_solar=False)
+    rng = np.random.Generator(np.random.PCG64(8))
+    cv = rng.uniform(-0.5, 1.5, (29, 4))
+    got = sn.get_imgs_from_Img_Dict_t_step(d, size, cv)
+    ref = orc.images_t_step({k: np.asarray(v) for k, v in d.items()}, size, cv)
+    assert got.shape == ref.shape == (29, 6, 7, 3)
+    close("sweep29", got, ref, rtol=1e-5, atol=1e-6)
+    one = sn.get_imgs_from_Img_Dict_t_step(d, size, cv[17:18])
+    close("sweep_single", one[0], ref[17], rtol=1e-5, atol=1e-6)
