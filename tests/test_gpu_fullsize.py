@@ -92,3 +92,49 @@ def test_config0_512x64_whole_batch_vs_oracle(full):
     for k, tol in (("Rho", 2e-4), ("Col", 1e-4), ("Solar_Vis", 1e-4), ("PV", 1e-4)):
         np.testing.assert_allclose(out[k].cpu().numpy(), ref[k].numpy(), rtol=tol, atol=2e-5, err_msg=k)
     assert torch.equal(out["sample_pts"].cpu(), ref["sample_pts"])                                  # bit-identical sampling
+
+
+def test_training_step_full_size_cross_check(monkeypatch):
+    """The training step at BASELINE configs[2] size (4096 x 96 image rays + 4096 sun rays, W=256) where no CPU oracle is
+    affordable: the bf16x3 kernels (row GEMM with 128-column groups, K = 319 layer, full 256x256 wgrad blocks, persistent grids
+    over 393 216 points) against the exact-fp32 MFMA path of the same engine, plus linearity of the backward pass."""
+    import season_nerf_amd as sn
+    rng = np.random.Generator(np.random.PCG64(4))
+    t = lambda a: torch.tensor(a, dtype=torch.float32)
+    top = np.concatenate([rng.uniform(-1, 1, (R, 2)), np.ones((R, 1))], 1)
+    bot = np.concatenate([rng.uniform(-1, 1, (R, 2)), -np.ones((R, 1))], 1)
+    sun = rng.uniform(0.1, 1, (R, 3)); sun /= np.linalg.norm(sun, axis=1, keepdims=True)
+    tau = rng.uniform(0, 1, (R, 2))
+    tim = np.stack([np.cos(6.28 * tau[:, 0]), np.sin(6.28 * tau[:, 0]), np.cos(6.28 * tau[:, 1]), np.sin(6.28 * tau[:, 1])], 1)
+    data = {"Top": t(top), "Bot": t(bot), "Sun_Angle": t(sun), "Time_Encoded": t(tim), "GT_Color": t(rng.uniform(0, 1, (R, 3)))}
+    st = np.concatenate([rng.uniform(-1, 1, (R, 2)), np.ones((R, 1))], 1)
+    solar = (t(st), t(st - 2 * sun / sun[:, 2:]), t(sun), torch.zeros(R, 4), None)
+    args = SimpleNamespace(n_samples=S, Use_Reg=True, Solar_Type_2=False, Use_MSE_loss=True, Use_Solar=True, sc_lambda=0.03,
+                           number_low_frequency_cases=C)
+
+    def run(mode, scale=1.0):
+        monkeypatch.setenv("SNERF_TRAIN_GEMM", mode)
+        net = sn.T_NeRF(W, C)
+        net.load_state_dict(orc.init_weights(W, C, 0, bn_stats="identity"))
+        net = net.to("cuda").train()
+        ev = sn.All_in_One_Eval(args, torch.device("cuda"), 10, False, None, np.eye(4), np.zeros(3))
+        ev.solar_creation_tool = lambda n, include_times=True: solar
+        loss = ev.get_loss(data, net, 0, False)             # eval-mode sampling: no RNG between the runs; BatchNorm in train mode
+        total = sum(v * w for v, w in loss.values())
+        (scale * total).backward()
+        grads = {n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None}
+        vals = {k: float(v[0].detach()) for k, v in loss.items()}
+        del net._train_engines, net._train_engine              # release the 20 GB workspace before the next run
+        return vals, grads
+
+    l16, g16 = run("bf16x3")
+    l32, g32 = run("fp32")
+    for k in l32:
+        assert np.isfinite(l16[k]) and abs(l16[k] - l32[k]) <= 2e-5 * max(1.0, abs(l32[k])), (k, l16[k], l32[k])
+    gmax = max(float(v.abs().max()) for v in g32.values())
+    assert gmax > 0
+    worst = max(float((g16[n] - g32[n]).abs().max()) / max(float(g32[n].abs().max()), 1e-3 * gmax) for n in g32)
+    assert worst < 2e-3, worst
+    _, g2 = run("bf16x3", scale=2.0)                         # backward is linear in the output gradient
+    lin = max(float((g2[n] - 2 * g16[n]).abs().max()) / max(float(g16[n].abs().max()), 1e-3 * gmax) for n in g16)
+    assert lin < 2e-3, lin                                   # two runs differ by the summation order of the atomic reductions
