@@ -192,16 +192,22 @@ int snerf_trainer_set_allreduce(snerf_trainer* t, snerf_allreduce_fn fn, void* u
  *   forward: out[m, o] = alpha * (sum_i in[m, i] * weight[o, i] + bias[o]);  d_stats (optional, bf16x3 only, caller-zeroed
  *            double[2][n_out]) += sum_m (out - alpha*bias), sum_m (out - alpha*bias)^2   (train-mode BatchNorm statistics)
  *   dgrad:   grad_in[m, i] (+)= alpha * sum_o grad_out[m, o] * weight[o, i]   for i < n_cols
- *   wgrad:   grad_weight[o, i] += alpha * sum_m grad_out[m, o] * in[m, i]     (always accumulates) */
+ *   wgrad:   grad_weight[o, i] += alpha * sum_m grad_out[m, o] * in[m, i]     (always accumulates)
+ * Activation on load (bf16x3 only; forward and wgrad): with d_act_tab != NULL the first act_cols columns of `in` are taken as the
+ * stored PRE-activation z of the SineLayer below and become sin(2 pi (a z + b)) in registers (one fma + one v_sin_f32);
+ * d_act_tab holds [a | b], each act_cols floats, with BatchNorm and the 1/(2 pi) folded in: a = gamma*istd/(2 pi),
+ * b = (beta - gamma*mu*istd)/(2 pi)  (a = 1/(2 pi), b = 0 without BatchNorm); forward needs act_cols % 8 == 0.
+ * The training engine uses this so that post-activations are never written to HBM. */
 size_t snerf_linear_scratch_bytes(int n_out, int n_in);
 int snerf_linear_forward(int64_t n_points, int n_in, int n_out, const float* d_in, int64_t ld_in, const float* d_weight,
                          const float* d_bias, float alpha, float* d_out, int64_t ld_out, double* d_stats, int precision,
-                         void* d_scratch, size_t scratch_bytes, void* stream);
+                         void* d_scratch, size_t scratch_bytes, const float* d_act_tab, int act_cols, void* stream);
 int snerf_linear_dgrad(int64_t n_points, int n_in, int n_out, const float* d_grad_out, int64_t ld_go, const float* d_weight,
                        int n_cols, float alpha, int accumulate, float* d_grad_in, int64_t ld_gi, int precision,
                        void* d_scratch, size_t scratch_bytes, void* stream);
 int snerf_linear_wgrad(int64_t n_points, int n_in, int n_out, const float* d_grad_out, int64_t ld_go, const float* d_in,
-                       int64_t ld_in, float alpha, float* d_grad_weight, int precision, void* stream);
+                       int64_t ld_in, float alpha, float* d_grad_weight, int precision, const float* d_act_tab, int act_cols,
+                       void* stream);
 /* test introspection: synchronous copy of an internal buffer ("d_rho", "d_col", "d_head", "d_sky", ...) to the host */
 int snerf_trainer_debug_read(snerf_trainer* t, const char* name, float* host_out, int64_t n_floats);
 /* torch.optim.Adam semantics (no weight decay) over the whole parameter arena in one launch; step counts from 1. */

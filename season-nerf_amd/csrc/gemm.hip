@@ -184,9 +184,9 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 
-constexpr int RO_WAVES = 8, RO_MT = 2;                       // 8 waves x (2 x 32) rows = 512 rows per workgroup tile
+constexpr int RO_WAVES = 8, RO_MT = 1;                       // 8 waves x (2 x 32) rows = 512 rows per workgroup tile
 constexpr int RO_ROWS = RO_WAVES * RO_MT * 32;
-constexpr int RO_PF = 2;                                     // k-steps of A loads in flight ahead of the MFMAs
+constexpr int RO_PF = 4;                                     // k-steps of A loads in flight ahead of the MFMAs
 
 __device__ __forceinline__ void split2_bf16(float a, float b, uint32_t& hi, uint32_t& lo) {
     bf16x2_t hv;
@@ -221,7 +221,11 @@ __global__ void split_weights_kernel(const float* W, int rows, int cols, int tra
     }
 }
 
-template <int NT>
+// AOL ("activation on load"): the A operand is the stored PRE-activation Z of the layer below; its first act_cols columns
+// become sin(2 pi (a z + b)) = one fma + one v_sin_f32 (which takes revolutions) while they sit in registers.  The table
+// act_tab = [a | b], each act_cols long, folds BatchNorm and the 1/(2 pi): a = gamma*istd/(2 pi), b = (beta - gamma*mu*istd)/(2 pi)
+// (a = 1/(2 pi), b = 0 for a plain SineLayer) - the post-activation H is never written to HBM.
+template <int NT, bool AOL>
 __global__ __launch_bounds__(512) void gemm_rows_kernel(const GemmX g) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_w[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -281,6 +285,19 @@ __global__ __launch_bounds__(512) void gemm_rows_kernel(const GemmX g) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
         float pf[RO_PF][RO_MT][8];
+        f32x4 tb[2][4];                                        // AOL: table rows of two k-steps (this one and the next)
+        auto load_tab = [&](int ks, f32x4 (&t_)[4]) {
+            const int k0 = ks * 16 + h * 8;
+            if (k0 < g.act_cols) {                             // act_cols is a multiple of 8 (checked by the launcher)
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    const f32x4* p = (const f32x4*)(g.act_tab + (int64_t)a * g.act_cols + k0);
+                    t_[2 * a] = p[0];
+                    t_[2 * a + 1] = p[1];
+                }
+            }
+        };
+        if (AOL) load_tab(0, tb[0]);
 #pragma unroll
         for (int d = 0; d < RO_PF; ++d)
             if (d < KS) load_a(d, pf[d]);
@@ -290,6 +307,17 @@ __global__ __launch_bounds__(512) void gemm_rows_kernel(const GemmX g) {
                 const int ks = ks0 + d;
                 if (ks < KS) {
                     u32x4 ahi[RO_MT], alo[RO_MT];
+                    if (AOL) {
+                        if (ks + 1 < KS) load_tab(ks + 1, tb[(d + 1) & 1]);
+                        if (ks * 16 + h * 8 < g.act_cols) {
+                            const f32x4(&t_)[4] = tb[d & 1];
+#pragma unroll
+                            for (int i = 0; i < RO_MT; ++i)
+#pragma unroll
+                                for (int e = 0; e < 8; ++e)
+                                    pf[d][i][e] = __builtin_amdgcn_sinf(__builtin_fmaf(t_[e >> 2][e & 3], pf[d][i][e], t_[2 + (e >> 2)][e & 3]));
+                        }
+                    }
 #pragma unroll
                     for (int i = 0; i < RO_MT; ++i)
 #pragma unroll
@@ -386,6 +414,8 @@ static int ro_grid_blocks() {
 }
 
 struct WgradX {
+    const float* in_tab;         // optional activation-on-load table for the first in_cols columns of In ([a | b], see gemm_rows_kernel)
+    int in_cols;
     const float *dZ, *In;
     float* dW;
     int64_t M, ldz, ldi, ldw;
@@ -421,6 +451,9 @@ __global__ __launch_bounds__(512) void wgrad_bf16x3_kernel(const WgradX g) {
     const int64_t m_last = m_end - 1;
     float vo[2][8], vi[2][8];
     int gathered_last = 0;
+    // activation on load: this lane's In column is a stored pre-activation -> sin(2 pi (a z + b)) at publish time
+    const bool in_act = g.in_tab != nullptr && ok_i && col_i < g.in_cols;
+    const float c_a = in_act ? g.in_tab[col_i] : 0.f, c_b = in_act ? g.in_tab[g.in_cols + col_i] : 0.f;
     auto gather = [&](int stage) {
         const int64_t ms = m_begin + (int64_t)stage * WG_STAGE;                  // uniform
         const int last_rel = (int)(m_last - ms < 63 ? m_last - ms : 63);         // >= 0: the stage exists
@@ -448,7 +481,12 @@ __global__ __launch_bounds__(512) void wgrad_bf16x3_kernel(const WgradX g) {
                 const bool k0 = h * 8 + ks * 16 + 2 * q <= gathered_last, k1 = h * 8 + ks * 16 + 2 * q + 1 <= gathered_last;
                 split2_bf16((ok_o && k0) ? vo[ks][2 * q] : 0.f, (ok_o && k1) ? vo[ks][2 * q + 1] : 0.f, a, b);
                 oh[q] = a; ol[q] = b;
-                split2_bf16((ok_i && k0) ? vi[ks][2 * q] : 0.f, (ok_i && k1) ? vi[ks][2 * q + 1] : 0.f, a, b);
+                float i0 = vi[ks][2 * q], i1 = vi[ks][2 * q + 1];
+                if (in_act) {
+                    i0 = __builtin_amdgcn_sinf(__builtin_fmaf(c_a, i0, c_b));
+                    i1 = __builtin_amdgcn_sinf(__builtin_fmaf(c_a, i1, c_b));
+                }
+                split2_bf16((ok_i && k0) ? i0 : 0.f, (ok_i && k1) ? i1 : 0.f, a, b);
                 ih[q] = a; il[q] = b;
             }
             const uint32_t f = (uint32_t)((wave * 2 + ks) * 2048 + lane * 16);
@@ -517,7 +555,7 @@ __global__ __launch_bounds__(512) void wgrad_bf16x3_kernel(const WgradX g) {
 }
 
 hipError_t launch_wgrad_bf16x3(const float* dZ, int64_t ldz, const float* In, int64_t ldi, int64_t M, int n_out, int n_in, float alpha,
-                               float* dW, int64_t ldw, hipStream_t st) {
+                               float* dW, int64_t ldw, hipStream_t st, const float* in_tab, int in_cols) {
     if (M <= 0 || n_out <= 0 || n_in <= 0) return hipSuccess;
     if (ldz >= (1 << 24) || ldi >= (1 << 24)) return hipErrorInvalidValue;      // 32-bit lane offsets: 64 rows x ld
     static bool attr_done = false;
@@ -528,6 +566,7 @@ hipError_t launch_wgrad_bf16x3(const float* dZ, int64_t ldz, const float* In, in
         attr_done = true;
     }
     WgradX g{};
+    g.in_tab = in_tab; g.in_cols = in_tab ? in_cols : 0;
     g.dZ = dZ; g.In = In; g.dW = dW; g.M = M; g.ldz = ldz; g.ldi = ldi; g.ldw = ldw; g.n_out = n_out; g.n_in = n_in; g.alpha = alpha;
     const int by = (n_out + 255) / 256, bz = (n_in + 255) / 256;
     int64_t bx = ro_grid_blocks() / (by * bz);
@@ -563,21 +602,23 @@ hipError_t launch_gemm_bf16x3(const GemmX& g, hipStream_t st) {
     const int groups = (g.n_tiles + nt - 1) / nt;
     int blocks = ro_grid_blocks();
     if (blocks / 8 < groups) blocks = groups * 8;            // at least one worker per XCD
-    static bool attr_done[2] = {false, false};
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_rows_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 20 * 2048);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_rows_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 20 * 2048);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_rows_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 32 * 2048);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_rows_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 32 * 2048);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    const bool aol = g.act_tab != nullptr && g.act_cols > 0;
+    if (aol && (g.act_cols % 8 != 0 || g.act_cols > g.K || (uintptr_t)g.act_tab % 16 != 0)) return hipErrorInvalidValue;
     if (nt == 4) {
-        if (!attr_done[0]) {
-            hipError_t e = hipFuncSetAttribute((const void*)gemm_rows_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 20 * 2048);
-            if (e != hipSuccess) return e;
-            attr_done[0] = true;
-        }
-        hipLaunchKernelGGL(gemm_rows_kernel<4>, dim3(blocks), dim3(512), lds, st, g);
+        if (aol) hipLaunchKernelGGL((gemm_rows_kernel<4, true>), dim3(blocks), dim3(512), lds, st, g);
+        else hipLaunchKernelGGL((gemm_rows_kernel<4, false>), dim3(blocks), dim3(512), lds, st, g);
     } else {
-        if (!attr_done[1]) {
-            hipError_t e = hipFuncSetAttribute((const void*)gemm_rows_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 32 * 2048);
-            if (e != hipSuccess) return e;
-            attr_done[1] = true;
-        }
-        hipLaunchKernelGGL(gemm_rows_kernel<2>, dim3(blocks), dim3(512), lds, st, g);
+        if (aol) hipLaunchKernelGGL((gemm_rows_kernel<2, true>), dim3(blocks), dim3(512), lds, st, g);
+        else hipLaunchKernelGGL((gemm_rows_kernel<2, false>), dim3(blocks), dim3(512), lds, st, g);
     }
     return hipGetLastError();
 }

@@ -36,6 +36,10 @@ enum L {
 struct Act {           // a [rows, cols] fp32 matrix inside the workspace
     float* p = nullptr;
     int64_t ld = 0;
+    // activation on load: when tab != nullptr the first `cols` columns hold the PRE-activation of a SineLayer and every
+    // consumer (row GEMM, wgrad) applies sin(2 pi (a z + b)) with tab = [a | b] while loading - the post-activation is not stored
+    const float* tab = nullptr;
+    int cols = 0;
 };
 
 }  // namespace
@@ -58,12 +62,17 @@ struct snerf_trainer {
         float *pts, *rho, *col, *sv, *pe_sun, *pe_time, *Zt1, *Ht1, *Zt2, *Ht2, *logits, *cls, *Zk1, *Hk1, *sky_raw, *sky;
         float* bn;             // [8 layers][4][W]: colsum, m2, mean, istd
         float *top, *bot, *tvals;   // engine-owned copies: the caller's tensors may be recycled before backward
+        // what the consumers of each per-point SineLayer read: the materialised H, or (activation on load) Z + its table
+        Act Hc[9], Hac[3], Hsc[3], In5c, In_s1c, Zc3;
+        float* tabs = nullptr;      // [15 layers][2][W] activation-on-load tables of this pass
+        bool aol = false;
     } img, sol;
     Act dA, dB, dX1;
     float *d_head, *d_adj, *d_rho, *d_col, *d_sky, *d_cls, *d_sv_raw, *rayA, *rayB, *bn_bwd;   // bn_bwd: [2][W]
     uint16_t* w_frag = nullptr;                     // scratch: one weight matrix split into bf16 hi/lo MFMA fragments
     double* bn_stats = nullptr;                     // [2][W] shifted column sums from the GEMM epilogue
     int gemm_mode = 1;                              // 1 = bf16x3 MFMA for forward/dgrad (default), 0 = exact fp32 MFMA everywhere
+    int aol_mode = 1;                               // 1 = activation on load where possible (SNERF_TRAIN_AOL=0: always store H)
     // data-parallel BatchNorm over the global batch: sum-all-reduce of the statistics buffers (snerf_trainer_set_allreduce)
     snerf_allreduce_fn ar_fn = nullptr;
     void* ar_user = nullptr;
@@ -165,6 +174,7 @@ static size_t carve(snerf_trainer* t, char* base, int64_t R, int64_t Rs, int S) 
         P.Zk1 = c.take(Rr * W4); P.Hk1 = c.take(Rr * W4); P.sky_raw = c.take(Rr * 3); P.sky = c.take(Rr * 3);
         P.bn = c.take(8 * 4 * W);
         P.top = c.take(Rr * 3); P.bot = c.take(Rr * 3); P.tvals = c.take(S);
+        P.tabs = c.take(15 * 2 * W);
     }
     const int64_t Nmax = (R > Rs ? R : Rs) * S, Rmax = R > Rs ? R : Rs;
     t->dA = c.mat(Nmax, W + 64);
@@ -200,8 +210,11 @@ static bool rows_ok(const snerf_trainer* t, int64_t M, int K, int N) {
     } while (0)
 
 // Z[M, n_out] = alpha * (In[M, K] W^T + b);  colsum (fp32 path) / stats (bf16x3 path) optional
-static hipError_t linear_fwd(snerf_trainer* t, const LayerP& L, const float* In, int64_t ld_in, int64_t M, float* Z, int64_t ldz,
+static hipError_t linear_fwd(snerf_trainer* t, const LayerP& L, Act InA, int64_t M, float* Z, int64_t ldz,
                              float alpha, float* colsum, hipStream_t st, double* stats = nullptr) {
+    const float* In = InA.p;
+    const int64_t ld_in = InA.ld;
+    if (InA.tab && !rows_ok(t, M, L.n_in, L.n_out)) return hipErrorInvalidValue;        // activation on load needs the row kernel
     if (rows_ok(t, M, L.n_in, L.n_out)) {
         GemmX x{};
         x.n_tiles = (L.n_out + 31) / 32; x.ksteps = (L.n_in + 15) / 16;
@@ -209,6 +222,7 @@ static hipError_t linear_fwd(snerf_trainer* t, const LayerP& L, const float* In,
         if (e != hipSuccess) return e;
         x.A = In; x.frag = t->w_frag; x.C = Z; x.M = M; x.N = L.n_out; x.K = L.n_in; x.lda = ld_in; x.ldc = ldz;
         x.alpha = alpha; x.bias = t->params + L.b; x.stats = stats; x.accumulate = 0;
+        x.act_tab = InA.tab; x.act_cols = InA.tab ? InA.cols : 0;
         return launch_gemm_bf16x3(x, st);
     }
     GemmArgs g{};
@@ -239,10 +253,12 @@ static hipError_t linear_dgrad(snerf_trainer* t, const LayerP& L, const float* d
     return launch_gemm(g, st);
 }
 // dW[n_out, n_in] += alpha * dZ^T In   (split over the point dimension, fp32 atomics)
-static hipError_t linear_wgrad(snerf_trainer* t, const LayerP& L, const float* dZ, int64_t ldz, const float* In, int64_t ld_in,
-                               int64_t M, float alpha, hipStream_t st) {
+static hipError_t linear_wgrad(snerf_trainer* t, const LayerP& L, const float* dZ, int64_t ldz, Act InA, int64_t M, float alpha, hipStream_t st) {
+    const float* In = InA.p;
+    const int64_t ld_in = InA.ld;
     if (t->gemm_mode == 1 && M >= 1024)
-        return launch_wgrad_bf16x3(dZ, ldz, In, ld_in, M, L.n_out, L.n_in, alpha, t->grads + L.w, L.n_in, st);
+        return launch_wgrad_bf16x3(dZ, ldz, In, ld_in, M, L.n_out, L.n_in, alpha, t->grads + L.w, L.n_in, st, InA.tab, InA.tab ? InA.cols : 0);
+    if (InA.tab) return hipErrorInvalidValue;
     GemmArgs g{};
     g.A = dZ; g.B = In; g.C = t->grads + L.w;
     g.M = L.n_out; g.N = L.n_in; g.K = M;
@@ -256,8 +272,9 @@ static hipError_t linear_wgrad(snerf_trainer* t, const LayerP& L, const float* d
 }
 
 // SineLayer forward in train mode: Z = 30(In W^T + b) [stashed], H = sin(BN_batch(Z)) or sin(Z)
-static int sine_fwd(snerf_trainer* t, const LayerP& L, const float* In, int64_t ld_in, int64_t M, Act Z, Act H, float* bnslot,
-                    bool train_bn, hipStream_t st) {
+// tab_out != nullptr: activation on load - no sin pass; the layer's [a | b] table is written instead and H stays unwritten
+static int sine_fwd(snerf_trainer* t, const LayerP& L, Act In, int64_t M, Act Z, Act H, float* bnslot,
+                    bool train_bn, hipStream_t st, float* tab_out = nullptr) {
     const int C = L.n_out;
     const int64_t Mg = M * (t->ar_fn ? t->world : 1);      // rows of the global batch (equal shards per rank)
     if (L.bn) {
@@ -265,12 +282,12 @@ static int sine_fwd(snerf_trainer* t, const LayerP& L, const float* In, int64_t 
         if (train_bn && rows_ok(t, M, L.n_in, L.n_out)) {
             // batch statistics from the GEMM epilogue: shifted sums (shift = 30 b) in double, no extra pass over Z
             HIPCK(hipMemsetAsync(t->bn_stats, 0, 2 * C * sizeof(double), st));
-            HIPCK(linear_fwd(t, L, In, ld_in, M, Z.p, Z.ld, 30.f, nullptr, st, t->bn_stats));
+            HIPCK(linear_fwd(t, L, In, M, Z.p, Z.ld, 30.f, nullptr, st, t->bn_stats));
             RCI(all_reduce(t, t->bn_stats, 2 * C, true, st));          // the shift 30 b is the same on every rank: the sums add
             HIPCK(launch_bn_finalize_shifted(t->bn_stats, t->params + L.b, 30.f, Mg, C, mean, istd, t->buffers + L.rm, t->buffers + L.rv, st));
         } else if (train_bn) {
             HIPCK(hipMemsetAsync(bnslot, 0, 2 * t->W * sizeof(float), st));
-            HIPCK(linear_fwd(t, L, In, ld_in, M, Z.p, Z.ld, 30.f, colsum, st));
+            HIPCK(linear_fwd(t, L, In, M, Z.p, Z.ld, 30.f, colsum, st));
             RCI(all_reduce(t, colsum, C, false, st));
             HIPCK(launch_bn_finalize(colsum, m2, Mg, C, mean, istd, nullptr, nullptr, 0, st));
             ColArgs ca{};
@@ -279,22 +296,24 @@ static int sine_fwd(snerf_trainer* t, const LayerP& L, const float* In, int64_t 
             RCI(all_reduce(t, m2, C, false, st));
             HIPCK(launch_bn_finalize(colsum, m2, Mg, C, mean, istd, t->buffers + L.rm, t->buffers + L.rv, 1, st));
         } else {      // eval-mode statistics (running estimates)
-            HIPCK(linear_fwd(t, L, In, ld_in, M, Z.p, Z.ld, 30.f, nullptr, st));
+            HIPCK(linear_fwd(t, L, In, M, Z.p, Z.ld, 30.f, nullptr, st));
             HIPCK(hipMemcpyAsync(mean, t->buffers + L.rm, C * sizeof(float), hipMemcpyDeviceToDevice, st));
             // istd from running var: reuse finalize stage 1 arithmetic with M = 1 via a tiny dedicated path
             HIPCK(launch_bn_finalize(nullptr, t->buffers + L.rv, 1, C, mean, istd, nullptr, nullptr, 2, st));
         }
-        HIPCK(launch_sin_fwd(Z.p, H.p, M, C, Z.ld, H.ld, mean, istd, t->params + L.g, t->params + L.beta, st));
+        if (tab_out) HIPCK(launch_act_table(mean, istd, t->params + L.g, t->params + L.beta, C, tab_out, st));
+        else HIPCK(launch_sin_fwd(Z.p, H.p, M, C, Z.ld, H.ld, mean, istd, t->params + L.g, t->params + L.beta, st));
     } else {
-        HIPCK(linear_fwd(t, L, In, ld_in, M, Z.p, Z.ld, 30.f, nullptr, st));
-        HIPCK(launch_sin_fwd(Z.p, H.p, M, C, Z.ld, H.ld, nullptr, nullptr, nullptr, nullptr, st));
+        HIPCK(linear_fwd(t, L, In, M, Z.p, Z.ld, 30.f, nullptr, st));
+        if (tab_out) HIPCK(launch_act_table(nullptr, nullptr, nullptr, nullptr, C, tab_out, st));
+        else HIPCK(launch_sin_fwd(Z.p, H.p, M, C, Z.ld, H.ld, nullptr, nullptr, nullptr, nullptr, st));
     }
     return SNERF_OK;
 }
 
 // SineLayer backward.  D holds dL/dH on entry ([M, n_out], ld = D.ld) and dL/dZ on exit (in place).
 // Accumulates weight/bias (and BN affine) gradients; if dIn.p != null writes dL/dIn[:, :n_in_cols].
-static int sine_bwd(snerf_trainer* t, const LayerP& L, Act D, Act Z, const float* In, int64_t ld_in, int64_t M, float* bnslot,
+static int sine_bwd(snerf_trainer* t, const LayerP& L, Act D, Act Z, Act In, int64_t M, float* bnslot,
                     Act dIn, int n_in_cols, bool accumulate_in, hipStream_t st) {
     const int C = L.n_out;
     if (L.bn) {
@@ -304,33 +323,32 @@ static int sine_bwd(snerf_trainer* t, const LayerP& L, Act D, Act Z, const float
         ColArgs ca{};
         ca.mode = 1; ca.M = M; ca.C = C; ca.ld = Z.ld; ca.Z = Z.p; ca.D = D.p; ca.mu = mean; ca.istd = istd;
         ca.gamma = t->params + L.g; ca.beta = t->params + L.beta; ca.out0 = sdy; ca.out1 = sdyx; ca.alpha0 = 1.f;
-        if (D.ld != Z.ld) return snerf_set_error(SNERF_E_INVALID, "sine_bwd: gradient and activation strides differ");
+        ca.ldd = D.ld;
         HIPCK(launch_colreduce(ca, st));
         // d beta = sum dY, d gamma = sum dY*xhat
         HIPCK(launch_copy_cols(sdy, C, t->grads + L.beta, C, 1, C, true, st));       // parameter gradients stay per-rank sums
         HIPCK(launch_copy_cols(sdyx, C, t->grads + L.g, C, 1, C, true, st));
         RCI(all_reduce(t, t->bn_bwd, 2 * t->W, false, st));                           // the BatchNorm backward means are global
-        HIPCK(launch_bn_bwd2(Z.p, D.p, M, C, Z.ld, mean, istd, t->params + L.g, t->params + L.beta, sdy, sdyx, t->grads + L.b, 30.f,
+        HIPCK(launch_bn_bwd2(Z.p, D.p, M, C, Z.ld, D.ld, mean, istd, t->params + L.g, t->params + L.beta, sdy, sdyx, t->grads + L.b, 30.f,
                              M * (t->ar_fn ? t->world : 1), st));
     } else {
         ColArgs ca{};
-        ca.mode = 2; ca.M = M; ca.C = C; ca.ld = Z.ld; ca.Z = Z.p; ca.D = D.p; ca.out0 = t->grads + L.b; ca.alpha0 = 30.f;
-        if (D.ld != Z.ld) return snerf_set_error(SNERF_E_INVALID, "sine_bwd: gradient and activation strides differ");
+        ca.mode = 2; ca.M = M; ca.C = C; ca.ld = Z.ld; ca.ldd = D.ld; ca.Z = Z.p; ca.D = D.p; ca.out0 = t->grads + L.b; ca.alpha0 = 30.f;
         HIPCK(launch_colreduce(ca, st));
     }
-    HIPCK(linear_wgrad(t, L, D.p, D.ld, In, ld_in, M, 30.f, st));
+    HIPCK(linear_wgrad(t, L, D.p, D.ld, In, M, 30.f, st));
     if (dIn.p) HIPCK(linear_dgrad(t, L, D.p, D.ld, M, dIn.p, dIn.ld, n_in_cols, 30.f, accumulate_in, st));
     return SNERF_OK;
 }
 
 // plain Linear (heads): Out[M, n_out] = In W^T + b
-static int plain_fwd(snerf_trainer* t, const LayerP& L, const float* In, int64_t ld_in, int64_t M, float* Out, int64_t ldo, hipStream_t st) {
-    HIPCK(linear_fwd(t, L, In, ld_in, M, Out, ldo, 1.f, nullptr, st));
+static int plain_fwd(snerf_trainer* t, const LayerP& L, Act In, int64_t M, float* Out, int64_t ldo, hipStream_t st) {
+    HIPCK(linear_fwd(t, L, In, M, Out, ldo, 1.f, nullptr, st));
     return SNERF_OK;
 }
-static int plain_bwd(snerf_trainer* t, const LayerP& L, const float* dOut, int64_t ldo, const float* In, int64_t ld_in, int64_t M,
+static int plain_bwd(snerf_trainer* t, const LayerP& L, const float* dOut, int64_t ldo, Act In, int64_t M,
                      float* dIn, int64_t ld_din, bool accumulate, hipStream_t st) {
-    HIPCK(linear_wgrad(t, L, dOut, ldo, In, ld_in, M, 1.f, st));
+    HIPCK(linear_wgrad(t, L, dOut, ldo, In, M, 1.f, st));
     HIPCK(launch_colsum(dOut, M, L.n_out, ldo, 1.f, t->grads + L.b, st));
     if (dIn) HIPCK(linear_dgrad(t, L, dOut, ldo, M, dIn, ld_din, L.n_in, 1.f, accumulate, st));
     return SNERF_OK;
@@ -355,40 +373,51 @@ static int forward_pass(snerf_trainer* t, snerf_trainer::Pass& P, bool solar, in
     pa.n = N; pa.n_samples = S; pa.top = top; pa.bot = bot; pa.tvals = tvals; pa.pe = P.E.p; pa.pts = P.pts;
     HIPCK(launch_pe_points(pa, st));
     HIPCK(launch_copy_cols(P.E.p, 64, P.In5.p + W, W + 64, N, 64, false, st));
+    // Activation on load (per-point layers): store only the pre-activations Z; every consumer applies sin(BN(.)) while loading.
+    // Needs the bf16x3 kernels for every consumer (K <= 512, widths multiples of 16) and enough points for them to be used.
+    const bool aol = t->aol_mode == 1 && t->gemm_mode == 1 && N >= 1024 && W % 16 == 0 && gemm_rows_group_tiles((W + 64 + 15) / 16) > 0;
+    P.aol = aol;
+    auto tab_of = [&](int slot) { return aol ? P.tabs + (int64_t)slot * 2 * W : (float*)nullptr; };       // slots: 0-8 trunk, 9-11 adjust, 12-14 solar
+    auto view = [&](Act Z, Act H, int slot, int n) { return aol ? Act{Z.p, Z.ld, tab_of(slot), n} : H; };
+    // fc4's output lives inside fc5's concat input [ . | PE]: its H without, its Z with activation on load
+    P.Zc3 = aol ? Act{P.In5.p, W + 64} : P.Z[3];
+    for (int l = 0; l < 9; ++l) P.Hc[l] = view(l == 3 ? P.Zc3 : P.Z[l], P.H[l], l, l == 8 ? W2 : W);
+    for (int l = 0; l < 3; ++l) { P.Hac[l] = view(P.Za[l], P.Ha[l], 9 + l, W); P.Hsc[l] = view(P.Zs[l], P.Hs[l], 12 + l, W2); }
+    P.In5c = aol ? Act{P.In5.p, W + 64, tab_of(3), W} : Act{P.In5.p, W + 64};
+    P.In_s1c = aol ? Act{P.In_s1.p, W2 + 28, tab_of(8), W2} : Act{P.In_s1.p, W2 + 28};
     // trunk (G_NeRF.py:80-91)
-    RC(sine_fwd(t, Ls[L_FC1], P.E.p, 64, N, P.Z[0], P.H[0], nullptr, train_bn, st));
+    RC(sine_fwd(t, Ls[L_FC1], Act{P.E.p, 64}, N, P.Z[0], P.H[0], nullptr, train_bn, st, tab_of(0)));
     for (int l = 1; l < 9; ++l) {
-        const float* In = l == 4 ? P.In5.p : P.H[l - 1].p;
-        const int64_t ld = l == 4 ? W + 64 : P.H[l - 1].ld;
-        RC(sine_fwd(t, Ls[L_FC1 + l], In, ld, N, P.Z[l], P.H[l], P.bn + (l - 1) * 4 * W, train_bn, st));
+        const Act In = l == 4 ? P.In5c : P.Hc[l - 1];
+        RC(sine_fwd(t, Ls[L_FC1 + l], In, N, l == 3 ? P.Zc3 : P.Z[l], P.H[l], P.bn + (l - 1) * 4 * W, train_bn, st, tab_of(l)));
     }
-    const float* X1 = P.H[8].p;
-    RC(plain_fwd(t, Ls[L_COL], X1, W2, N, P.head.p, 4, st));
-    RC(plain_fwd(t, Ls[L_SIG], X1, W2, N, P.head.p + 3, 4, st));
+    const Act X1 = P.Hc[8];
+    RC(plain_fwd(t, Ls[L_COL], X1, N, P.head.p, 4, st));
+    RC(plain_fwd(t, Ls[L_SIG], X1, N, P.head.p + 3, 4, st));
     // solar visibility branch (G_NeRF.py:100-108)
     HIPCK(launch_pe_small(sun, 3, 3, 4, R, P.pe_sun, 28, st));
-    HIPCK(launch_copy_cols(X1, W2, P.In_s1.p, W2 + 28, N, W2, false, st));
+    HIPCK(launch_copy_cols(X1.p, X1.ld, P.In_s1.p, W2 + 28, N, W2, false, st));
     HIPCK(launch_bcast_rows(P.pe_sun, 28, P.In_s1.p, W2 + 28, W2, N, S, st));
-    RC(sine_fwd(t, Ls[L_S1], P.In_s1.p, W2 + 28, N, P.Zs[0], P.Hs[0], nullptr, train_bn, st));
-    RC(sine_fwd(t, Ls[L_S2], P.Hs[0].p, W2, N, P.Zs[1], P.Hs[1], nullptr, train_bn, st));
-    RC(sine_fwd(t, Ls[L_S3], P.Hs[1].p, W2, N, P.Zs[2], P.Hs[2], nullptr, train_bn, st));
-    RC(plain_fwd(t, Ls[L_S4], P.Hs[2].p, W2, N, P.sv_raw.p, 1, st));
+    RC(sine_fwd(t, Ls[L_S1], P.In_s1c, N, P.Zs[0], P.Hs[0], nullptr, train_bn, st, tab_of(12)));
+    RC(sine_fwd(t, Ls[L_S2], P.Hsc[0], N, P.Zs[1], P.Hs[1], nullptr, train_bn, st, tab_of(13)));
+    RC(sine_fwd(t, Ls[L_S3], P.Hsc[1], N, P.Zs[2], P.Hs[2], nullptr, train_bn, st, tab_of(14)));
+    RC(plain_fwd(t, Ls[L_S4], P.Hsc[2], N, P.sv_raw.p, 1, st));
     // sky colour head (G_NeRF.py:110-111), per ray
-    RC(sine_fwd(t, Ls[L_K1], P.pe_sun, 28, R, Act{P.Zk1, W4}, Act{P.Hk1, W4}, nullptr, train_bn, st));
-    RC(plain_fwd(t, Ls[L_K2], P.Hk1, W4, R, P.sky_raw, 3, st));
+    RC(sine_fwd(t, Ls[L_K1], Act{P.pe_sun, 28}, R, Act{P.Zk1, W4}, Act{P.Hk1, W4}, nullptr, train_bn, st));
+    RC(plain_fwd(t, Ls[L_K2], Act{P.Hk1, W4}, R, P.sky_raw, 3, st));
     HIPCK(launch_sigmoid(P.sky_raw, P.sky, R * 3, st));
     PointOutArgs po{};
     po.n = N; po.n_samples = S; po.C = C; po.head = P.head.p; po.sv_raw = P.sv_raw.p; po.rho = P.rho; po.sv = P.sv;
     if (!solar) {
         // seasonal colour-adjust branch (T_NeRF_net_v2.py:83-88) and time -> class softmax (:77-78, per ray)
-        RC(sine_fwd(t, Ls[L_A1], X1, W2, N, P.Za[0], P.Ha[0], nullptr, train_bn, st));
-        RC(sine_fwd(t, Ls[L_A2], P.Ha[0].p, W, N, P.Za[1], P.Ha[1], nullptr, train_bn, st));
-        RC(sine_fwd(t, Ls[L_A3], P.Ha[1].p, W, N, P.Za[2], P.Ha[2], nullptr, train_bn, st));
-        RC(plain_fwd(t, Ls[L_AC], P.Ha[2].p, W, N, P.adj.p, 3 * C, st));
+        RC(sine_fwd(t, Ls[L_A1], X1, N, P.Za[0], P.Ha[0], nullptr, train_bn, st, tab_of(9)));
+        RC(sine_fwd(t, Ls[L_A2], P.Hac[0], N, P.Za[1], P.Ha[1], nullptr, train_bn, st, tab_of(10)));
+        RC(sine_fwd(t, Ls[L_A3], P.Hac[1], N, P.Za[2], P.Ha[2], nullptr, train_bn, st, tab_of(11)));
+        RC(plain_fwd(t, Ls[L_AC], P.Hac[2], N, P.adj.p, 3 * C, st));
         HIPCK(launch_pe_small(time, 4, 2, 2, R, P.pe_time, 12, st));
-        RC(sine_fwd(t, Ls[L_T1], P.pe_time, 12, R, Act{P.Zt1, W}, Act{P.Ht1, W}, nullptr, train_bn, st));
-        RC(sine_fwd(t, Ls[L_T2], P.Ht1, W, R, Act{P.Zt2, W}, Act{P.Ht2, W}, nullptr, train_bn, st));
-        RC(plain_fwd(t, Ls[L_CL], P.Ht2, W, R, P.logits, C, st));
+        RC(sine_fwd(t, Ls[L_T1], Act{P.pe_time, 12}, R, Act{P.Zt1, W}, Act{P.Ht1, W}, nullptr, train_bn, st));
+        RC(sine_fwd(t, Ls[L_T2], Act{P.Ht1, W}, R, Act{P.Zt2, W}, Act{P.Ht2, W}, nullptr, train_bn, st));
+        RC(plain_fwd(t, Ls[L_CL], Act{P.Ht2, W}, R, P.logits, C, st));
         HIPCK(launch_softmax(P.logits, P.cls, R, C, st));
         po.adj = P.adj.p; po.cls = P.cls; po.col = P.col; po.adjust_col = adjust_col_out;
     }
@@ -406,6 +435,7 @@ snerf_trainer* snerf_trainer_create(int layer_width, int n_classes) {
     snerf_trainer* t = new snerf_trainer();
     t->W = layer_width; t->C = n_classes; t->W2 = layer_width / 2; t->W4 = layer_width / 4;
     if (const char* e = getenv("SNERF_TRAIN_GEMM")) t->gemm_mode = std::strcmp(e, "fp32") == 0 ? 0 : 1;
+    if (const char* e = getenv("SNERF_TRAIN_AOL")) t->aol_mode = std::strcmp(e, "0") == 0 ? 0 : 1;
     build_layers(t);
     return t;
 }
@@ -524,41 +554,40 @@ int snerf_trainer_backward_image(snerf_trainer* t, const float* d_g_rgb, const f
     po.d_rho = t->d_rho; po.d_col = t->d_col; po.d_head = t->d_head; po.d_adj = t->d_adj; po.d_cls = t->d_cls;
     if (classic) { po.d_sv = t->d_sv_raw; po.d_sv_raw = t->d_sv_raw; }
     HIPCK(launch_point_out(po, true, st));
-    const float* X1 = P.H[8].p;
+    const Act X1 = P.Hc[8];
     // adjust branch
-    RC(plain_bwd(t, Ls[L_AC], t->d_adj, 3 * C, P.Ha[2].p, W, N, t->dA.p, W, false, st));
-    RC(sine_bwd(t, Ls[L_A3], Act{t->dA.p, W}, P.Za[2], P.Ha[1].p, W, N, nullptr, Act{t->dB.p, W}, W, false, st));
-    RC(sine_bwd(t, Ls[L_A2], Act{t->dB.p, W}, P.Za[1], P.Ha[0].p, W, N, nullptr, Act{t->dA.p, W}, W, false, st));
-    RC(sine_bwd(t, Ls[L_A1], Act{t->dA.p, W}, P.Za[0], X1, W2, N, nullptr, Act{t->dX1.p, W2}, W2, false, st));
+    RC(plain_bwd(t, Ls[L_AC], t->d_adj, 3 * C, P.Hac[2], N, t->dA.p, W, false, st));
+    RC(sine_bwd(t, Ls[L_A3], Act{t->dA.p, W}, P.Za[2], P.Hac[1], N, nullptr, Act{t->dB.p, W}, W, false, st));
+    RC(sine_bwd(t, Ls[L_A2], Act{t->dB.p, W}, P.Za[1], P.Hac[0], N, nullptr, Act{t->dA.p, W}, W, false, st));
+    RC(sine_bwd(t, Ls[L_A1], Act{t->dA.p, W}, P.Za[0], X1, N, nullptr, Act{t->dX1.p, W2}, W2, false, st));
     // sigma / colour heads
-    RC(plain_bwd(t, Ls[L_COL], t->d_head, 4, X1, W2, N, t->dX1.p, W2, true, st));
-    RC(plain_bwd(t, Ls[L_SIG], t->d_head + 3, 4, X1, W2, N, t->dX1.p, W2, true, st));
+    RC(plain_bwd(t, Ls[L_COL], t->d_head, 4, X1, N, t->dX1.p, W2, true, st));
+    RC(plain_bwd(t, Ls[L_SIG], t->d_head + 3, 4, X1, N, t->dX1.p, W2, true, st));
     if (classic) {      // the solar-visibility branch carries gradient from the image (G_NeRF.py:100-108), on into X1
-        RC(plain_bwd(t, Ls[L_S4], t->d_sv_raw, 1, P.Hs[2].p, W2, N, t->dA.p, W2, false, st));
-        RC(sine_bwd(t, Ls[L_S3], Act{t->dA.p, W2}, P.Zs[2], P.Hs[1].p, W2, N, nullptr, Act{t->dB.p, W2}, W2, false, st));
-        RC(sine_bwd(t, Ls[L_S2], Act{t->dB.p, W2}, P.Zs[1], P.Hs[0].p, W2, N, nullptr, Act{t->dA.p, W2}, W2, false, st));
-        RC(sine_bwd(t, Ls[L_S1], Act{t->dA.p, W2}, P.Zs[0], P.In_s1.p, W2 + 28, N, nullptr, Act{t->dX1.p, W2}, W2, true, st));
+        RC(plain_bwd(t, Ls[L_S4], t->d_sv_raw, 1, P.Hsc[2], N, t->dA.p, W2, false, st));
+        RC(sine_bwd(t, Ls[L_S3], Act{t->dA.p, W2}, P.Zs[2], P.Hsc[1], N, nullptr, Act{t->dB.p, W2}, W2, false, st));
+        RC(sine_bwd(t, Ls[L_S2], Act{t->dB.p, W2}, P.Zs[1], P.Hsc[0], N, nullptr, Act{t->dA.p, W2}, W2, false, st));
+        RC(sine_bwd(t, Ls[L_S1], Act{t->dA.p, W2}, P.Zs[0], P.In_s1c, N, nullptr, Act{t->dX1.p, W2}, W2, true, st));
     }
     // trunk
     float* cur = t->dA.p;
     float* nxt = t->dB.p;
-    RC(sine_bwd(t, Ls[L_FC9], Act{t->dX1.p, W2}, P.Z[8], P.H[7].p, P.H[7].ld, N, P.bn + 7 * 4 * W, Act{cur, W}, W, false, st));
+    RC(sine_bwd(t, Ls[L_FC9], Act{t->dX1.p, W2}, P.Z[8], P.Hc[7], N, P.bn + 7 * 4 * W, Act{cur, W}, W, false, st));
     for (int l = 7; l >= 1; --l) {
-        const float* In = l == 4 ? P.In5.p : P.H[l - 1].p;
-        const int64_t ld = l == 4 ? W + 64 : P.H[l - 1].ld;
-        RC(sine_bwd(t, Ls[L_FC1 + l], Act{cur, W}, P.Z[l], In, ld, N, P.bn + (l - 1) * 4 * W, Act{nxt, W}, W, false, st));
+        const Act In = l == 4 ? P.In5c : P.Hc[l - 1];
+        RC(sine_bwd(t, Ls[L_FC1 + l], Act{cur, W}, l == 3 ? P.Zc3 : P.Z[l], In, N, P.bn + (l - 1) * 4 * W, Act{nxt, W}, W, false, st));
         float* tmp = cur; cur = nxt; nxt = tmp;
     }
-    RC(sine_bwd(t, Ls[L_FC1], Act{cur, W}, P.Z[0], P.E.p, 64, N, nullptr, Act{nullptr, 0}, 0, false, st));
+    RC(sine_bwd(t, Ls[L_FC1], Act{cur, W}, P.Z[0], Act{P.E.p, 64}, N, nullptr, Act{nullptr, 0}, 0, false, st));
     // time -> class branch (per ray)
     HIPCK(launch_softmax_bwd(P.cls, t->d_cls, t->rayA, R, C, st));
-    RC(plain_bwd(t, Ls[L_CL], t->rayA, C, P.Ht2, W, R, t->rayB, W, false, st));
-    RC(sine_bwd(t, Ls[L_T2], Act{t->rayB, W}, Act{P.Zt2, W}, P.Ht1, W, R, nullptr, Act{t->rayA, W}, W, false, st));
-    RC(sine_bwd(t, Ls[L_T1], Act{t->rayA, W}, Act{P.Zt1, W}, P.pe_time, 12, R, nullptr, Act{nullptr, 0}, 0, false, st));
+    RC(plain_bwd(t, Ls[L_CL], t->rayA, C, Act{P.Ht2, W}, R, t->rayB, W, false, st));
+    RC(sine_bwd(t, Ls[L_T2], Act{t->rayB, W}, Act{P.Zt2, W}, Act{P.Ht1, W}, R, nullptr, Act{t->rayA, W}, W, false, st));
+    RC(sine_bwd(t, Ls[L_T1], Act{t->rayA, W}, Act{P.Zt1, W}, Act{P.pe_time, 12}, R, nullptr, Act{nullptr, 0}, 0, false, st));
     // sky colour head (per ray)
     HIPCK(launch_sigmoid_bwd(P.sky, t->d_sky, t->rayB, R * 3, st));
-    RC(plain_bwd(t, Ls[L_K2], t->rayB, 3, P.Hk1, W4, R, t->rayA, W4, false, st));
-    RC(sine_bwd(t, Ls[L_K1], Act{t->rayA, W4}, Act{P.Zk1, W4}, P.pe_sun, 28, R, nullptr, Act{nullptr, 0}, 0, false, st));
+    RC(plain_bwd(t, Ls[L_K2], t->rayB, 3, Act{P.Hk1, W4}, R, t->rayA, W4, false, st));
+    RC(sine_bwd(t, Ls[L_K1], Act{t->rayA, W4}, Act{P.Zk1, W4}, Act{P.pe_sun, 28}, R, nullptr, Act{nullptr, 0}, 0, false, st));
     return SNERF_OK;
 }
 
@@ -592,10 +621,10 @@ int snerf_trainer_backward_solar(snerf_trainer* t, const float* d_g_solar_vis, v
     PointOutArgs po{};
     po.n = N; po.n_samples = t->S; po.C = t->C; po.head = P.head.p; po.sv = P.sv; po.d_sv = d_g_solar_vis; po.d_sv_raw = t->d_sv_raw;
     HIPCK(launch_point_out(po, true, st));
-    RC(plain_bwd(t, Ls[L_S4], t->d_sv_raw, 1, P.Hs[2].p, W2, N, t->dA.p, W2, false, st));
-    RC(sine_bwd(t, Ls[L_S3], Act{t->dA.p, W2}, P.Zs[2], P.Hs[1].p, W2, N, nullptr, Act{t->dB.p, W2}, W2, false, st));
-    RC(sine_bwd(t, Ls[L_S2], Act{t->dB.p, W2}, P.Zs[1], P.Hs[0].p, W2, N, nullptr, Act{t->dA.p, W2}, W2, false, st));
-    RC(sine_bwd(t, Ls[L_S1], Act{t->dA.p, W2}, P.Zs[0], P.In_s1.p, W2 + 28, N, nullptr, Act{nullptr, 0}, 0, false, st));
+    RC(plain_bwd(t, Ls[L_S4], t->d_sv_raw, 1, P.Hsc[2], N, t->dA.p, W2, false, st));
+    RC(sine_bwd(t, Ls[L_S3], Act{t->dA.p, W2}, P.Zs[2], P.Hsc[1], N, nullptr, Act{t->dB.p, W2}, W2, false, st));
+    RC(sine_bwd(t, Ls[L_S2], Act{t->dB.p, W2}, P.Zs[1], P.Hsc[0], N, nullptr, Act{t->dA.p, W2}, W2, false, st));
+    RC(sine_bwd(t, Ls[L_S1], Act{t->dA.p, W2}, P.Zs[0], P.In_s1c, N, nullptr, Act{nullptr, 0}, 0, false, st));
     return SNERF_OK;
 }
 
@@ -624,7 +653,7 @@ static int linear_mode(int precision, int64_t M, int K, int N) {      // 1 = bf1
 
 int snerf_linear_forward(int64_t n_points, int n_in, int n_out, const float* d_in, int64_t ld_in, const float* d_weight,
                          const float* d_bias, float alpha, float* d_out, int64_t ld_out, double* d_stats, int precision,
-                         void* d_scratch, size_t scratch_bytes, void* stream) {
+                         void* d_scratch, size_t scratch_bytes, const float* d_act_tab, int act_cols, void* stream) {
     if (n_points < 0 || n_in < 1 || n_out < 1) return snerf_set_error(SNERF_E_INVALID, "snerf_linear_forward: bad shape");
     if (n_points == 0) return SNERF_OK;
     if (!d_in || !d_weight || !d_out || ld_in < n_in || ld_out < n_out) return snerf_set_error(SNERF_E_INVALID, "snerf_linear_forward: bad argument");
@@ -636,10 +665,14 @@ int snerf_linear_forward(int64_t n_points, int n_in, int n_out, const float* d_i
         HIPCK(launch_split_weights(d_weight, n_out, n_in, false, (uint16_t*)d_scratch, x.n_tiles, x.ksteps, st));
         x.A = d_in; x.frag = (const uint16_t*)d_scratch; x.C = d_out; x.M = n_points; x.N = n_out; x.K = n_in; x.lda = ld_in; x.ldc = ld_out;
         x.alpha = alpha; x.bias = d_bias; x.stats = d_stats; x.accumulate = 0;
+        if (d_act_tab) {
+            if (act_cols < 8 || act_cols % 8 || act_cols > n_in) return snerf_set_error(SNERF_E_INVALID, "snerf_linear_forward: act_cols must be a multiple of 8 within n_in");
+            x.act_tab = d_act_tab; x.act_cols = act_cols;
+        }
         HIPCK(launch_gemm_bf16x3(x, st));
         return SNERF_OK;
     }
-    if (d_stats) return snerf_set_error(SNERF_E_INVALID, "snerf_linear_forward: column statistics need the bf16x3 path");
+    if (d_stats || d_act_tab) return snerf_set_error(SNERF_E_INVALID, "snerf_linear_forward: column statistics / activation on load need the bf16x3 path");
     GemmArgs g{};
     g.A = d_in; g.B = d_weight; g.C = d_out; g.M = n_points; g.N = n_out; g.K = n_in;
     g.sAm = ld_in; g.sAk = 1; g.sBk = 1; g.sBn = n_in; g.ldc = ld_out;
@@ -674,13 +707,16 @@ int snerf_linear_dgrad(int64_t n_points, int n_in, int n_out, const float* d_gra
 }
 
 int snerf_linear_wgrad(int64_t n_points, int n_in, int n_out, const float* d_grad_out, int64_t ld_go, const float* d_in,
-                       int64_t ld_in, float alpha, float* d_grad_weight, int precision, void* stream) {
+                       int64_t ld_in, float alpha, float* d_grad_weight, int precision, const float* d_act_tab, int act_cols,
+                       void* stream) {
     if (n_points < 0 || n_in < 1 || n_out < 1) return snerf_set_error(SNERF_E_INVALID, "snerf_linear_wgrad: bad shape");
     if (n_points == 0) return SNERF_OK;
     if (!d_grad_out || !d_in || !d_grad_weight || ld_go < n_out || ld_in < n_in) return snerf_set_error(SNERF_E_INVALID, "snerf_linear_wgrad: bad argument");
     hipStream_t st = (hipStream_t)stream;
+    if (d_act_tab && (precision != 1 || act_cols < 1 || act_cols > n_in))
+        return snerf_set_error(SNERF_E_INVALID, "snerf_linear_wgrad: activation on load needs the bf16x3 path and 1 <= act_cols <= n_in");
     if (precision == 1) {
-        HIPCK(launch_wgrad_bf16x3(d_grad_out, ld_go, d_in, ld_in, n_points, n_out, n_in, alpha, d_grad_weight, n_in, st));
+        HIPCK(launch_wgrad_bf16x3(d_grad_out, ld_go, d_in, ld_in, n_points, n_out, n_in, alpha, d_grad_weight, n_in, st, d_act_tab, act_cols));
         return SNERF_OK;
     }
     GemmArgs g{};

@@ -33,13 +33,15 @@ struct GemmX {
     const float* bias;
     double* stats;             // optional [2][N]: += sum_m (v - alpha*bias), += sum_m (v - alpha*bias)^2   (train-mode BatchNorm)
     int accumulate;
+    const float* act_tab;      // optional activation-on-load table [a | b] x act_cols for the leading columns of A: sin(2 pi (a z + b))
+    int act_cols;              // multiple of 8, <= K
 };
 hipError_t launch_split_weights(const float* W, int rows, int cols, bool transpose, uint16_t* frag, int n_tiles, int ksteps, hipStream_t st);
 int gemm_rows_group_tiles(int ksteps);      // 0 = K too large for the LDS-resident weight layout (caller falls back to fp32 MFMA)
 hipError_t launch_gemm_bf16x3(const GemmX& g, hipStream_t st);
 // bf16x3 weight gradient: dW[n_out, n_in] (ld ldw) += alpha * dZ[M, n_out]^T In[M, n_in]   (fp32 atomics over M-chunks)
 hipError_t launch_wgrad_bf16x3(const float* dZ, int64_t ldz, const float* In, int64_t ldi, int64_t M, int n_out, int n_in, float alpha,
-                               float* dW, int64_t ldw, hipStream_t st);
+                               float* dW, int64_t ldw, hipStream_t st, const float* in_tab = nullptr, int in_cols = 0);
 
 // ---- elementwise / reduction kernels of the training path (train_kernels.hip)
 struct PeArgs {            // positions (from rays or explicit) -> PE(pos) [N,64] (63 features + zero pad) and points [N,3]
@@ -60,9 +62,10 @@ struct ColArgs {
     int mode;
     int64_t M;
     int C;
-    int64_t ld;
+    int64_t ld;            // row stride of Z
+    int64_t ldd;           // row stride of D (0 = same as ld)
     const float* Z;        // pre-activation [M, ld]
-    float* D;              // gradient buffer [M, ld] (in place)
+    float* D;              // gradient buffer [M, ldd] (in place)
     const float *mu, *istd, *gamma, *beta;
     float *out0, *out1;
     float alpha0;          // scale of the out0 accumulation (mode 2: 30 = d bias of the Linear)
@@ -79,9 +82,12 @@ hipError_t launch_bn_finalize_shifted(const double* stats, const float* bias, fl
 hipError_t launch_sin_fwd(const float* Z, float* H, int64_t M, int C, int64_t ldz, int64_t ldh, const float* mu, const float* istd,
                           const float* gamma, const float* beta, hipStream_t st);
 // BN backward second pass: dZ = gamma*istd*(dY - sdy/M - xhat*sdyx/M) in place; colsum(dZ) -> out (bias grad)
-hipError_t launch_bn_bwd2(const float* Z, float* D, int64_t M, int C, int64_t ld, const float* mu, const float* istd,
+hipError_t launch_bn_bwd2(const float* Z, float* D, int64_t M, int C, int64_t ld, int64_t ldd, const float* mu, const float* istd,
                           const float* gamma, const float* beta, const float* sdy, const float* sdyx, float* dbias_sum, float alpha,
                           int64_t M_global, hipStream_t st);
+// activation-on-load table of a SineLayer: dst = [a | b] (n each), a = gamma*istd/(2 pi), b = (beta - gamma*mu*istd)/(2 pi);
+// all-NULL statistics = a layer without BatchNorm (a = 1/(2 pi), b = 0)
+hipError_t launch_act_table(const float* mu, const float* istd, const float* gamma, const float* beta, int n, float* dst, hipStream_t st);
 
 // point outputs: rho = softplus(head[:,3]), col = sigmoid(head[:,0:3] + sum_c cls[g,c]*adj[:,c,:]), sv = sigmoid(sv_raw)
 struct PointOutArgs {

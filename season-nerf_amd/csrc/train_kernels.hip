@@ -91,6 +91,7 @@ constexpr int ROWS_PER_BLOCK = 512;
 __global__ __launch_bounds__(256) void colreduce_kernel(const ColArgs A) {
     __shared__ float red0[256], red1[256];
     const int C = A.C;
+    const int64_t ldd = A.ldd ? A.ldd : A.ld;
     const int cp = C >= 256 ? 256 : (C >= 128 ? 128 : (C >= 64 ? 64 : 32));   // columns handled per pass
     const int phases = 256 / cp;
     const int tc = threadIdx.x % cp, tp = threadIdx.x / cp;
@@ -109,12 +110,12 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const ColArgs A) {
                     s0 += d * d;
                 } else if (A.mode == 1) {
                     const float xh = (z - mu) * istd;
-                    const float dy = A.D[r * A.ld + c] * cosf(gm * xh + bt);       // not stored: the dZ pass recomputes it
+                    const float dy = A.D[r * ldd + c] * cosf(gm * xh + bt);       // not stored: the dZ pass recomputes it
                     s0 += dy;
                     s1 += dy * xh;
                 } else {
-                    const float dz = A.D[r * A.ld + c] * cosf(z);
-                    A.D[r * A.ld + c] = dz;
+                    const float dz = A.D[r * ldd + c] * cosf(z);
+                    A.D[r * ldd + c] = dz;
                     s0 += dz;
                 }
             }
@@ -140,6 +141,7 @@ __global__ __launch_bounds__(256) void colpass_vec_kernel(const ColArgs A, int C
     __shared__ float red[2][256][4];
     const int tc = threadIdx.x % cpt, tr = threadIdx.x / cpt, rows_pass = 256 / cpt;
     const bool live = tc < C4;
+    const int64_t ldd = A.ldd ? A.ldd : A.ld;
     float mu[4] = {0.f, 0.f, 0.f, 0.f}, is[4] = {1.f, 1.f, 1.f, 1.f}, gm[4] = {1.f, 1.f, 1.f, 1.f}, bt[4] = {0.f, 0.f, 0.f, 0.f};
     float ma[4] = {0.f, 0.f, 0.f, 0.f}, mb[4] = {0.f, 0.f, 0.f, 0.f};
     if (live && MODE != 2) {
@@ -156,7 +158,7 @@ __global__ __launch_bounds__(256) void colpass_vec_kernel(const ColArgs A, int C
     if (live) {
         for (int64_t r = r0 + tr; r < r1; r += rows_pass) {
             const f32x4_t z = *(const f32x4_t*)(A.Z + r * A.ld + tc * 4);
-            f32x4_t d = *(const f32x4_t*)(A.D + r * A.ld + tc * 4);
+            f32x4_t d = *(const f32x4_t*)(A.D + r * ldd + tc * 4);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 if (MODE == 2) {
@@ -174,7 +176,7 @@ __global__ __launch_bounds__(256) void colpass_vec_kernel(const ColArgs A, int C
                     }
                 }
             }
-            if (MODE != 1) *(f32x4_t*)(A.D + r * A.ld + tc * 4) = d;
+            if (MODE != 1) *(f32x4_t*)(A.D + r * ldd + tc * 4) = d;
         }
     }
 #pragma unroll
@@ -192,7 +194,7 @@ __global__ __launch_bounds__(256) void colpass_vec_kernel(const ColArgs A, int C
     }
 }
 static bool colpass_vec_ok(const ColArgs& a) {
-    return a.C % 4 == 0 && a.C <= 1024 && a.ld % 4 == 0 && (uintptr_t)a.Z % 16 == 0 && (uintptr_t)a.D % 16 == 0;
+    return a.C % 4 == 0 && a.C <= 1024 && a.ld % 4 == 0 && a.ldd % 4 == 0 && (uintptr_t)a.Z % 16 == 0 && (uintptr_t)a.D % 16 == 0;
 }
 template <int MODE>
 static hipError_t launch_colpass_vec(const ColArgs& a, const float* sdy, const float* sdyx, hipStream_t st) {
@@ -258,6 +260,24 @@ hipError_t launch_bn_finalize_shifted(const double* stats, const float* bias, fl
     return hipGetLastError();
 }
 
+__global__ void act_table_kernel(const float* mu, const float* istd, const float* gamma, const float* beta, int n, float* dst) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    const double inv2pi = 0.15915494309189535;
+    double a = inv2pi, b = 0.0;
+    if (mu) {
+        a = (double)gamma[c] * (double)istd[c];
+        b = ((double)beta[c] - a * (double)mu[c]) * inv2pi;
+        a *= inv2pi;
+    }
+    dst[c] = (float)a;
+    dst[n + c] = (float)b;
+}
+hipError_t launch_act_table(const float* mu, const float* istd, const float* gamma, const float* beta, int n, float* dst, hipStream_t st) {
+    hipLaunchKernelGGL(act_table_kernel, dim3((n + 255) / 256), dim3(256), 0, st, mu, istd, gamma, beta, n, dst);
+    return hipGetLastError();
+}
+
 __global__ void sin_fwd_kernel(const float* Z, float* H, int64_t M, int C, int64_t ldz, int64_t ldh, const float* mu,
                                const float* istd, const float* gamma, const float* beta) {
     const int64_t total = M * C;
@@ -309,7 +329,7 @@ hipError_t launch_sin_fwd(const float* Z, float* H, int64_t M, int C, int64_t ld
     return hipGetLastError();
 }
 
-__global__ __launch_bounds__(256) void bn_bwd2_kernel(const float* Z, float* D, int64_t M, int C, int64_t ld, const float* mu,
+__global__ __launch_bounds__(256) void bn_bwd2_kernel(const float* Z, float* D, int64_t M, int C, int64_t ld, int64_t ldd, const float* mu,
                                                       const float* istd, const float* gamma, const float* beta, const float* sdy,
                                                       const float* sdyx, float* dbias_sum, float alpha, float invM) {
     __shared__ float red0[256];
@@ -325,9 +345,9 @@ __global__ __launch_bounds__(256) void bn_bwd2_kernel(const float* Z, float* D, 
             const float m = mu[c], is = istd[c], gm = gamma[c], bt = beta[c], k = gm * is, a = sdy[c] * invM, b = sdyx[c] * invM;
             for (int64_t r = r0 + tp; r < r1; r += phases) {
                 const float xh = (Z[r * ld + c] - m) * is;
-                const float dy = D[r * ld + c] * cosf(gm * xh + bt);          // D holds dL/dH on entry
+                const float dy = D[r * ldd + c] * cosf(gm * xh + bt);         // D holds dL/dH on entry
                 const float dz = k * (dy - a - xh * b);
-                D[r * ld + c] = dz;
+                D[r * ldd + c] = dz;
                 s0 += dz;
             }
         }
@@ -340,16 +360,16 @@ __global__ __launch_bounds__(256) void bn_bwd2_kernel(const float* Z, float* D, 
         __syncthreads();
     }
 }
-hipError_t launch_bn_bwd2(const float* Z, float* D, int64_t M, int C, int64_t ld, const float* mu, const float* istd,
+hipError_t launch_bn_bwd2(const float* Z, float* D, int64_t M, int C, int64_t ld, int64_t ldd, const float* mu, const float* istd,
                           const float* gamma, const float* beta, const float* sdy, const float* sdyx, float* dbias_sum, float alpha,
                           int64_t M_global, hipStream_t st) {
     if (M <= 0) return hipSuccess;
     ColArgs a{};
-    a.mode = 3; a.M = M; a.M_global = M_global; a.C = C; a.ld = ld; a.Z = Z; a.D = D; a.mu = mu; a.istd = istd; a.gamma = gamma; a.beta = beta;
+    a.mode = 3; a.M = M; a.M_global = M_global; a.C = C; a.ld = ld; a.ldd = ldd; a.Z = Z; a.D = D; a.mu = mu; a.istd = istd; a.gamma = gamma; a.beta = beta;
     a.out0 = dbias_sum; a.alpha0 = alpha;
     if (colpass_vec_ok(a)) return launch_colpass_vec<3>(a, sdy, sdyx, st);
     const int64_t blocks = (M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
-    hipLaunchKernelGGL(bn_bwd2_kernel, dim3((unsigned)blocks), dim3(256), 0, st, Z, D, M, C, ld, mu, istd, gamma, beta, sdy, sdyx, dbias_sum, alpha,
+    hipLaunchKernelGGL(bn_bwd2_kernel, dim3((unsigned)blocks), dim3(256), 0, st, Z, D, M, C, ld, ldd ? ldd : ld, mu, istd, gamma, beta, sdy, sdyx, dbias_sum, alpha,
                        1.f / (float)M_global);
     return hipGetLastError();
 }

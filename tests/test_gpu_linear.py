@@ -48,7 +48,7 @@ def test_linear_forward(shape, precision):
     stats = torch.zeros(2, N, dtype=torch.float64, device="cuda")
     sc = _scratch(L, N, K)
     sn._lib.check(L.snerf_linear_forward(M, K, N, A.data_ptr(), lda, Wt.data_ptr(), b.data_ptr(), 30.0, out.data_ptr(), ldc,
-                                         stats.data_ptr() if use_stats else None, precision, sc.data_ptr(), sc.numel(), st), "linear_forward")
+                                         stats.data_ptr() if use_stats else None, precision, sc.data_ptr(), sc.numel(), None, 0, st), "linear_forward")
     ref = 30.0 * (A[:, :K].double() @ Wt.double().T + b.double())
     assert _rel(out[:, :N], ref) < TOL[precision]
     assert bool((out[:, N:] == 7.0).all())                       # padding columns of the output untouched
@@ -98,7 +98,7 @@ def test_linear_wgrad(shape, precision):
     X = torch.randn(M, ld_in, generator=g).cuda()
     base = torch.randn(n_out, n_in, generator=g).cuda()
     dW = base.clone()
-    sn._lib.check(L.snerf_linear_wgrad(M, n_in, n_out, dZ.data_ptr(), ld_go, X.data_ptr(), ld_in, 0.5, dW.data_ptr(), precision, st), "linear_wgrad")
+    sn._lib.check(L.snerf_linear_wgrad(M, n_in, n_out, dZ.data_ptr(), ld_go, X.data_ptr(), ld_in, 0.5, dW.data_ptr(), precision, None, 0, st), "linear_wgrad")
     ref = base.double() + 0.5 * (dZ[:, :n_out].double().T @ X[:, :n_in].double())
     scale = float((0.5 * (dZ[:, :n_out].double().T @ X[:, :n_in].double())).abs().max())
     assert float((dW.double() - ref).abs().max()) / scale < TOL[precision] * 3        # split-K fp32 atomics on top
@@ -107,9 +107,45 @@ def test_linear_wgrad(shape, precision):
 def test_linear_argument_errors():
     sn, L, st = _env()
     a = torch.zeros(8, 8, device="cuda")
-    assert L.snerf_linear_forward(8, 8, 8, a.data_ptr(), 4, a.data_ptr(), None, 1.0, a.data_ptr(), 8, None, 0, None, 0, st) != 0      # ld < n_in
+    assert L.snerf_linear_forward(8, 8, 8, a.data_ptr(), 4, a.data_ptr(), None, 1.0, a.data_ptr(), 8, None, 0, None, 0, None, 0, st) != 0      # ld < n_in
     assert b"bad argument" in L.snerf_last_error()
-    assert L.snerf_linear_forward(8, 8, 8, a.data_ptr(), 8, a.data_ptr(), None, 1.0, a.data_ptr(), 8, None, 1, None, 0, st) != 0      # no scratch
-    assert L.snerf_linear_forward(0, 8, 8, None, 8, None, None, 1.0, None, 8, None, 1, None, 0, st) == 0                                  # empty batch
+    assert L.snerf_linear_forward(8, 8, 8, a.data_ptr(), 8, a.data_ptr(), None, 1.0, a.data_ptr(), 8, None, 1, None, 0, None, 0, st) != 0      # no scratch
+    assert L.snerf_linear_forward(0, 8, 8, None, 8, None, None, 1.0, None, 8, None, 1, None, 0, None, 0, st) == 0                                  # empty batch
     assert L.snerf_linear_dgrad(8, 8, 8, a.data_ptr(), 8, a.data_ptr(), 9, 1.0, 0, a.data_ptr(), 8, 0, None, 0, st) != 0                 # n_cols > n_in
-    assert L.snerf_linear_wgrad(-1, 8, 8, a.data_ptr(), 8, a.data_ptr(), 8, 1.0, a.data_ptr(), 0, st) != 0
+    assert L.snerf_linear_wgrad(-1, 8, 8, a.data_ptr(), 8, a.data_ptr(), 8, 1.0, a.data_ptr(), 0, None, 0, st) != 0
+
+
+ACT = [  # M, K, N, lda, act_cols   (In5-like concat input: transformed leading columns + raw tail; thin head; K = 128)
+    (1300, 319, 256, 320, 256), (2048, 256, 256, 256, 256), (777, 128, 3, 128, 128), (1025, 156, 128, 156, 128), (64, 16, 16, 16, 8)]
+
+
+@pytest.mark.parametrize("shape", ACT)
+def test_activation_on_load(shape):
+    """forward and wgrad with the activation applied while the operand is loaded: in = [sin(gamma*((z-mu)*istd)+beta) | raw],
+    through the folded table a = gamma*istd/2pi, b = (beta - gamma*mu*istd)/2pi and the hardware sine (revolutions)."""
+    sn, L, st = _env()
+    M, K, N, lda, ac = shape
+    g = torch.Generator(device="cpu").manual_seed(M + K)
+    Zp = (torch.randn(M, lda, generator=g) * 4).cuda()                       # SIREN-sized pre-activations
+    mu, istd = torch.randn(ac, generator=g).double(), (torch.rand(ac, generator=g) + 0.5).double()
+    gam, bet = (torch.rand(ac, generator=g) + 0.5).double(), torch.randn(ac, generator=g).double()
+    tab = torch.stack([gam * istd / (2 * np.pi), (bet - gam * mu * istd) / (2 * np.pi)]).float().cuda().contiguous()
+    Wt = (torch.randn(N, K, generator=g) / np.sqrt(K)).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    zd = Zp[:, :K].double()
+    Hd = zd.clone()
+    Hd[:, :ac] = torch.sin(gam.cuda() * ((zd[:, :ac] - mu.cuda()) * istd.cuda()) + bet.cuda())
+    out = torch.zeros(M, N, device="cuda")
+    sc = _scratch(L, N, K)
+    sn._lib.check(L.snerf_linear_forward(M, K, N, Zp.data_ptr(), lda, Wt.data_ptr(), b.data_ptr(), 30.0, out.data_ptr(), N, None, 1,
+                                         sc.data_ptr(), sc.numel(), tab.data_ptr(), ac, st), "linear_forward(act)")
+    ref = 30.0 * (Hd @ Wt.double().T + b.double())
+    assert _rel(out, ref) < 2 * TOL[1]                             # + the argument error of the folded fp32 table (~|arg| * 1e-7)
+    dZ = torch.randn(M, N, generator=g).cuda()
+    dW = torch.zeros(N, K, device="cuda")
+    sn._lib.check(L.snerf_linear_wgrad(M, K, N, dZ.data_ptr(), N, Zp.data_ptr(), lda, 1.0, dW.data_ptr(), 1, tab.data_ptr(), ac, st), "linear_wgrad(act)")
+    refw = dZ.double().T @ Hd
+    assert float((dW.double() - refw).abs().max() / refw.abs().max()) < 3 * TOL[1]
+    # precision 0 cannot do it: loud error
+    assert L.snerf_linear_forward(M, K, N, Zp.data_ptr(), lda, Wt.data_ptr(), b.data_ptr(), 30.0, out.data_ptr(), N, None, 0,
+                                  sc.data_ptr(), sc.numel(), tab.data_ptr(), ac, st) != 0
