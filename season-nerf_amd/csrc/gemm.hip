@@ -245,6 +245,14 @@ __global__ __launch_bounds__(512) void gemm_rows_kernel(const GemmX g) {
         const int n16 = tiles_here * KS * 128;
         for (int i = tid; i < n16; i += 512) dst[i] = src[i];
     }
+    // AOL: the [a | b] table goes behind the weights when the 160 KiB allow it (every lane of a half-wave reads the same
+    // 16 bytes: an LDS broadcast instead of an L1 round trip per k-step); otherwise it is read from global memory
+    const uint8_t* lds_tab = lds_w + (size_t)NT * KS * 2048;
+    const bool tab_in_lds = AOL && g.tab_lds;
+    if (tab_in_lds) {
+        float* dst = (float*)lds_tab;
+        for (int i = tid; i < 2 * g.act_cols; i += 512) dst[i] = g.act_tab[i];
+    }
     __syncthreads();
 
     const bool a_vec = ((uintptr_t)g.A % 16 == 0) && (g.lda % 4 == 0);
@@ -291,7 +299,8 @@ __global__ __launch_bounds__(512) void gemm_rows_kernel(const GemmX g) {
             if (k0 < g.act_cols) {                             // act_cols is a multiple of 8 (checked by the launcher)
 #pragma unroll
                 for (int a = 0; a < 2; ++a) {
-                    const f32x4* p = (const f32x4*)(g.act_tab + (int64_t)a * g.act_cols + k0);
+                    const f32x4* p = tab_in_lds ? (const f32x4*)(lds_tab + ((size_t)a * g.act_cols + k0) * 4)
+                                                : (const f32x4*)(g.act_tab + (int64_t)a * g.act_cols + k0);
                     t_[2 * a] = p[0];
                     t_[2 * a + 1] = p[1];
                 }
@@ -605,19 +614,23 @@ hipError_t launch_gemm_bf16x3(const GemmX& g, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)gemm_rows_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 20 * 2048);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_rows_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 20 * 2048);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_rows_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_rows_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 32 * 2048);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_rows_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 32 * 2048);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_rows_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
     const bool aol = g.act_tab != nullptr && g.act_cols > 0;
     if (aol && (g.act_cols % 8 != 0 || g.act_cols > g.K || (uintptr_t)g.act_tab % 16 != 0)) return hipErrorInvalidValue;
+    GemmX gx = g;
+    gx.tab_lds = 0;
+    size_t lds_total = lds;
+    if (aol && lds + (size_t)g.act_cols * 8 <= 160 * 1024) { gx.tab_lds = 1; lds_total = lds + (size_t)g.act_cols * 8; }
     if (nt == 4) {
-        if (aol) hipLaunchKernelGGL((gemm_rows_kernel<4, true>), dim3(blocks), dim3(512), lds, st, g);
+        if (aol) hipLaunchKernelGGL((gemm_rows_kernel<4, true>), dim3(blocks), dim3(512), lds_total, st, gx);
         else hipLaunchKernelGGL((gemm_rows_kernel<4, false>), dim3(blocks), dim3(512), lds, st, g);
     } else {
-        if (aol) hipLaunchKernelGGL((gemm_rows_kernel<2, true>), dim3(blocks), dim3(512), lds, st, g);
+        if (aol) hipLaunchKernelGGL((gemm_rows_kernel<2, true>), dim3(blocks), dim3(512), lds_total, st, gx);
         else hipLaunchKernelGGL((gemm_rows_kernel<2, false>), dim3(blocks), dim3(512), lds, st, g);
     }
     return hipGetLastError();

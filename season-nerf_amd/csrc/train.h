@@ -35,6 +35,7 @@ struct GemmX {
     int accumulate;
     const float* act_tab;      // optional activation-on-load table [a | b] x act_cols for the leading columns of A: sin(2 pi (a z + b))
     int act_cols;              // multiple of 8, <= K
+    int tab_lds;               // set by the launcher: the table fits in LDS behind the weights
 };
 hipError_t launch_split_weights(const float* W, int rows, int cols, bool transpose, uint16_t* frag, int n_tiles, int ksteps, hipStream_t st);
 int gemm_rows_group_tiles(int ksteps);      // 0 = K too large for the LDS-resident weight layout (caller falls back to fp32 MFMA)
