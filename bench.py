@@ -159,12 +159,13 @@ def bench_train(a):
         dt = float(tt.item())
     dt /= steps
     per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))     # stream time of each step (diagnostic)
+    gemm = os.environ.get("SNERF_TRAIN_GEMM", "bf16x3")
     # algorithmic FLOPs: image rays 3 x forward; sun rays: trunk+heads+solar forward + 3 x solar/sky heads
     flop = R * S * (3 * FLOP_PER_SAMPLE + 2 * (524800 + 3 * 54656))
     # HBM bytes the layer-wise design moves per step (every per-point layer is a pass over [points x width] fp32
-    # arrays; per-ray branches are negligible).  Forward of a layer: GEMM (read in, write Z) + sin pass (read Z, write H);
-    # backward: BatchNorm layers 2 + 3 array passes (sums; dZ), plain SineLayers 3, then wgrad (read dZ, in) and dgrad
-    # (read dZ, write d_in); heads: no sin / activation passes.
+    # arrays; per-ray branches are negligible).  Forward of a layer: one GEMM (read the pre-activation of the layer below -
+    # the activation is applied on load - write Z); backward: BatchNorm layers 2 + 3 array passes (sums; dZ), plain
+    # SineLayers 3, then wgrad (read dZ, in) and dgrad (read dZ, write d_in); heads: no activation passes.
     rows = {n: (o, i, k, bn) for n, k, o, i, bn, _ in orc.layer_table(W, NC)}
     g_ = "G_NeRF_net."
     trunk = [g_ + f"fc{i}" for i in range(1, 10)]
@@ -172,8 +173,10 @@ def bench_train(a):
     solar = [g_ + "fc_solar_1", g_ + "fc_solar_2", g_ + "fc_solar_3", g_ + "fc_solar_4"]
     adjust = ["adjust_layer_1", "adjust_layer_2", "adjust_layer_3", "adjust_col"]
 
+    aol = os.environ.get("SNERF_TRAIN_AOL", "1") != "0" and gemm != "fp32"
+
     def fwd_bytes(names):
-        return sum((i + o) + (2 * o if k == "sine" else 0) for o, i, k, _ in (rows[n] for n in names))
+        return sum((i + o) + (2 * o if (k == "sine" and not aol) else 0) for o, i, k, _ in (rows[n] for n in names))
 
     def bwd_bytes(names, dgrad_first=True):
         tot = 0
@@ -186,12 +189,11 @@ def bench_train(a):
     sol = fwd_bytes(trunk + heads + solar) + bwd_bytes(solar, False)
     hbm_bytes = 4.0 * R * S * (img + sol)
     lname = "Barron adaptive loss" if barron else "MSE loss"
-    gemm = os.environ.get("SNERF_TRAIN_GEMM", "bf16x3")
     if rank == 0:
         out = {"metric": f"training image-ray-samples/s (4096 rays x 96 samples + 4096 sun rays per GPU, {lname}, fused Adam)",
                "value": world * R * S / dt, "unit": "ray-samples/s", "n_gpus": world, "steps": steps, "warmup": warm, "ms_per_step": dt * 1e3,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "f32 storage; " + ("bf16x3 split MFMA GEMMs (forward, dgrad, wgrad), thin layers fp32 MFMA" if gemm != "fp32" else "fp32 MFMA GEMMs"),
+               "dtype": "f32 storage; " + ("bf16x3 split MFMA GEMMs (forward with activation on load, dgrad, wgrad)" if gemm != "fp32" else "fp32 MFMA GEMMs"),
                "data": "synthetic",
                "config": {"workload": f"BASELINE configs[2]: training step 4096x96, T_NeRF(256,4) train-mode BatchNorm, solar branch on, {lname}",
                           "parallelism": f"rays sharded over {world} GPU(s), one all-reduce of the flat gradient arena, BatchNorm statistics "
@@ -202,7 +204,7 @@ def bench_train(a):
                             "note": "whole step, not one kernel: train-mode BatchNorm forces a layer-wise design in which every layer is "
                                     "a pass over [393216 x width] fp32 arrays; achieved = bytes that design moves per step (counted from "
                                     "the layer table, DESIGN 5.4) / step time, peak = HBM3E 8 TB/s (MI355X_MICROARCH.md); "
-                                    "per-kernel times in profiles/r1/f_train_kernel_stats.csv"}}
+                                    "per-kernel times in profiles/r1/g_train_kernel_stats.csv"}}
         if not a.no_cpu_baseline and world == 1:      # reported at N = 1 only (rank 0)
             torch.set_num_threads(min(host_cpus(), 32))
             sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in orc.init_weights(W, NC, 0, bn_stats="identity").items()}
@@ -339,7 +341,7 @@ def main():
         achieved = FLOP_PER_SAMPLE * R * S / (field_ms * 1e-3)
         traffic = None          # HBM bytes per launch from the committed PMC passes of this same command (profiles/)
         try:
-            traffic = json.load(open(os.path.join(REPO, "profiles", "r1", "f_traffic.json")))["bytes_per_launch"]
+            traffic = json.load(open(os.path.join(REPO, "profiles", "r1", "g_traffic.json")))["bytes_per_launch"]
         except Exception:
             pass
         out = {
