@@ -173,8 +173,8 @@ hipError_t launch_gemm(const GemmArgs& g, hipStream_t st) {
 //   A  : fp32 activations / gradients [M, lda], k contiguous - read straight from HBM into MFMA operand registers
 //        (lane (r,h) of a 32x32x16 MFMA holds 8 consecutive k of row r: two 16-byte loads), split into bf16 hi/lo in registers
 //   Bt : weights, pre-split by split_weights_kernel into MFMA fragment order, resident in LDS for the whole kernel
-// Every wave owns its 64 rows: no barrier in the main loop, activations never touch LDS, the compiler is free to keep
-// three k-steps of loads in flight.  Persistent: 1 workgroup (8 waves) per CU loops over 512-row tiles; the n-groups of
+// Every wave owns its 32 rows: no barrier in the main loop, activations never touch LDS, four k-steps of loads are kept
+// in flight.  Persistent: 1 workgroup (8 waves) per CU loops over 256-row tiles; the n-groups of
 // one row tile sit on the same XCD so the second reader of a tile hits that XCD's L2.
 // 3-term error-compensated product (hi*hi + lo*hi + hi*lo, fp32 accumulate): ~1e-5 relative, 16/3 x the fp32-MFMA rate,
 // which makes these GEMMs HBM-bound (403 MB in + 403 MB out per layer at 4096 x 96).
@@ -184,7 +184,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 
-constexpr int RO_WAVES = 8, RO_MT = 1;                       // 8 waves x (2 x 32) rows = 512 rows per workgroup tile
+constexpr int RO_WAVES = 8, RO_MT = 1;                       // 8 waves x 32 rows = 256 rows per workgroup tile (64 accumulators per lane)
 constexpr int RO_ROWS = RO_WAVES * RO_MT * 32;
 constexpr int RO_PF = 4;                                     // k-steps of A loads in flight ahead of the MFMAs
 
