@@ -89,7 +89,6 @@ def bench_train(a):
     are pinned against the reference), backward, gradient all-reduce over RCCL when N > 1, fused Adam."""
     from types import SimpleNamespace
     import season_nerf_amd as sn
-    from oracle import season_nerf_oracle as orc
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
@@ -103,7 +102,7 @@ def bench_train(a):
         dist.init_process_group("nccl", device_id=dev)
     steps, warm = min(a.steps, 20), min(a.warmup, 3)
     net = sn.T_NeRF(W, NC)
-    net.load_state_dict(orc.init_weights(W, NC, 0, bn_stats="identity"))
+    net.load_state_dict(sn.synthetic_state_dict(net, 0, bn_stats="identity"))        # reference init law, fresh BatchNorm
     net = net.to(dev).train()
     barron = a.loss == "barron"
     args = SimpleNamespace(n_samples=S, Use_Reg=True, Solar_Type_2=False, Use_MSE_loss=not barron, Use_Solar=True, sc_lambda=0.03,
@@ -166,7 +165,7 @@ def bench_train(a):
     # arrays; per-ray branches are negligible).  Forward of a layer: one GEMM (read the pre-activation of the layer below -
     # the activation is applied on load - write Z); backward: BatchNorm layers 2 + 3 array passes (sums; dZ), plain
     # SineLayers 3, then wgrad (read dZ, in) and dgrad (read dZ, write d_in); heads: no activation passes.
-    rows = {n: (o, i, k, bn) for n, k, o, i, bn, _ in orc.layer_table(W, NC)}
+    rows = {n: (o, i, "sine" if sine else "lin", bn) for n, o, i, sine, bn in sn.per_point_layer_shapes(net)}
     g_ = "G_NeRF_net."
     trunk = [g_ + f"fc{i}" for i in range(1, 10)]
     heads = [g_ + "fc10Col", g_ + "fc10Sigma"]
@@ -206,6 +205,7 @@ def bench_train(a):
                                     "the layer table, DESIGN 5.4) / step time, peak = HBM3E 8 TB/s (MI355X_MICROARCH.md); "
                                     "per-kernel times in profiles/r1/g_train_kernel_stats.csv"}}
         if not a.no_cpu_baseline and world == 1:      # reported at N = 1 only (rank 0)
+            from oracle import season_nerf_oracle as orc          # CPU-baseline leg only
             torch.set_num_threads(min(host_cpus(), 32))
             sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in orc.init_weights(W, NC, 0, bn_stats="identity").items()}
             n = 256
@@ -256,10 +256,9 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     import season_nerf_amd as sn
-    from oracle import season_nerf_oracle as orc           # weights generator only (reference init law)
     L = sn._lib.lib()
     net = sn.T_NeRF(W, NC)
-    net.load_state_dict(orc.init_weights(W, NC, 0))
+    net.load_state_dict(sn.synthetic_state_dict(net, 0))   # random weights of the reference's init law, random BatchNorm statistics
     net = net.to(dev).eval()
     model = net.device_model()
     d = synth(rank, dev)

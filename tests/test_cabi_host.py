@@ -243,3 +243,24 @@ def test_sun_ray_generator_matches_reference_draws(golden_dir):
     torch.manual_seed(5)
     three = sn.create_solor_rays_uniform(H4, WC)(48)
     assert len(three) == 3 and torch.equal(three[0], st)
+
+
+def test_synthetic_state_dict_follows_the_init_law():
+    """season_nerf_amd.synthetic_state_dict: keys / shapes of T_NeRF.state_dict, ranges of misc.SineLayer.init_weights (misc.py:176-186)."""
+    import season_nerf_amd as sn
+    net = sn.T_NeRF(64, 4)
+    sd = sn.synthetic_state_dict(net, 3)
+    ref = net.state_dict()
+    assert set(sd) == set(ref) and all(tuple(sd[k].shape) == tuple(ref[k].shape) for k in ref)
+    net.load_state_dict(sd)
+    w1, w2 = sd["G_NeRF_net.fc1.linear.weight"], sd["G_NeRF_net.fc2.linear.weight"]
+    assert float(w1.abs().max()) <= 1 / 63 and float(w1.abs().max()) > 0.9 / 63                       # first layer: U(+-1/in)
+    lim = (6 / 64) ** 0.5 / 30
+    assert float(w2.abs().max()) <= lim and float(w2.abs().max()) > 0.9 * lim                         # others: U(+-sqrt(6/in)/30)
+    assert float(sd["adjust_col.weight"].abs().max()) <= 1 / 8                                        # plain Linear: U(+-1/sqrt(in))
+    assert float(sd["G_NeRF_net.fc3.norm.running_var"].min()) >= 0.5
+    fresh = sn.synthetic_state_dict(net, 3, bn_stats="identity")
+    assert float(fresh["G_NeRF_net.fc3.norm.running_mean"].abs().max()) == 0.0
+    assert torch.equal(sn.synthetic_state_dict(net, 3)["time_layer_2.linear.bias"], sd["time_layer_2.linear.bias"])   # deterministic
+    names = [n for n, *_ in sn.per_point_layer_shapes(net)]
+    assert len(names) == 19 and "time_layer_1" not in names and "G_NeRF_net.fc5" in names
