@@ -63,6 +63,13 @@ def allreduce_gradients(module_or_params, group=None, average=True):
     params = [p for p in params if p.requires_grad]
     if not params or not dist.is_initialized() or dist.get_world_size(group) == 1:
         return
+    store = getattr(module_or_params, "_param_store", None)
+    if store is not None and all(p.grad is not None and p.grad.data_ptr() == v.data_ptr() for p, v in zip(store.param_list, store.grad_views)):
+        # a season_nerf_amd.T_NeRF after a training backward: every .grad is a view of one flat arena - reduce it in place
+        dist.all_reduce(store.grads, op=dist.ReduceOp.SUM, group=group)
+        if average:
+            store.grads /= dist.get_world_size(group)
+        return
     flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     if average:
