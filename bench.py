@@ -163,8 +163,8 @@ def bench_train(a):
     flop = R * S * (3 * FLOP_PER_SAMPLE + 2 * (524800 + 3 * 54656))
     # HBM bytes the layer-wise design moves per step (every per-point layer is a pass over [points x width] fp32
     # arrays; per-ray branches are negligible).  Forward of a layer: one GEMM (read the pre-activation of the layer below -
-    # the activation is applied on load - write Z); backward: BatchNorm layers 2 + 3 array passes (sums; dZ), plain
-    # SineLayers 3, then wgrad (read dZ, in) and dgrad (read dZ, write d_in); heads: no activation passes.
+    # the activation is applied on load - write Z); backward: activation backward (see bwd_bytes), then wgrad (read dZ, in)
+    # and dgrad (read dZ, write d_in); heads: no activation passes.
     rows = {n: (o, i, "sine" if sine else "lin", bn) for n, o, i, sine, bn in sn.per_point_layer_shapes(net)}
     g_ = "G_NeRF_net."
     trunk = [g_ + f"fc{i}" for i in range(1, 10)]
@@ -178,10 +178,15 @@ def bench_train(a):
         return sum((i + o) + (2 * o if (k == "sine" and not aol) else 0) for o, i, k, _ in (rows[n] for n in names))
 
     def bwd_bytes(names, dgrad_first=True):
+        # activation backward of a SineLayer: fused into the epilogue of the dgrad above it (reads Z once: o) when that dgrad is
+        # its only producer - every layer except fc9 (its gradient is summed from several branches) - else a reduction sweep;
+        # BatchNorm layers add the dZ sweep (read Z, dY; write dZ: 3 o)
         tot = 0
         for j, n in enumerate(names):
             o, i, k, bn = rows[n]
-            tot += (5 * o if bn else 3 * o) if k == "sine" else 0
+            if k == "sine":
+                fused = aol and not n.endswith("fc9")
+                tot += (o if fused else (2 * o if bn else 3 * o)) + (3 * o if bn else 0)
             tot += (o + i) + ((o + i) if (dgrad_first or j > 0) else 0)
         return tot
     img = fwd_bytes(trunk + heads + solar + adjust) + bwd_bytes(trunk, False) + bwd_bytes(heads) + bwd_bytes(adjust)

@@ -197,14 +197,20 @@ int snerf_trainer_set_allreduce(snerf_trainer* t, snerf_allreduce_fn fn, void* u
  * stored PRE-activation z of the SineLayer below and become sin(2 pi (a z + b)) in registers (one fma + one v_sin_f32);
  * d_act_tab holds [a | b], each act_cols floats, with BatchNorm and the 1/(2 pi) folded in: a = gamma*istd/(2 pi),
  * b = (beta - gamma*mu*istd)/(2 pi)  (a = 1/(2 pi), b = 0 without BatchNorm); forward needs act_cols % 8 == 0.
- * The training engine uses this so that post-activations are never written to HBM. */
+ * The training engine uses this so that post-activations are never written to HBM.
+ * Activation backward in the dgrad epilogue (bf16x3, no accumulation): with d_below_z != NULL, grad_in is dL/dH of the SineLayer
+ * below, whose pre-activation is d_below_z [n_points, ld_below_z] and table d_below_tab ([a | b], n_cols each); what is written
+ * is dL/dH * cos(2 pi (a z + b)), and d_sums (caller-zeroed double[2][n_cols]) += sum_m of it and of it times
+ * xhat = (z - mu)*istd (d_below_mu / d_below_istd, NULL for a layer without BatchNorm: second sum 0). */
 size_t snerf_linear_scratch_bytes(int n_out, int n_in);
 int snerf_linear_forward(int64_t n_points, int n_in, int n_out, const float* d_in, int64_t ld_in, const float* d_weight,
                          const float* d_bias, float alpha, float* d_out, int64_t ld_out, double* d_stats, int precision,
                          void* d_scratch, size_t scratch_bytes, const float* d_act_tab, int act_cols, void* stream);
 int snerf_linear_dgrad(int64_t n_points, int n_in, int n_out, const float* d_grad_out, int64_t ld_go, const float* d_weight,
                        int n_cols, float alpha, int accumulate, float* d_grad_in, int64_t ld_gi, int precision,
-                       void* d_scratch, size_t scratch_bytes, void* stream);
+                       void* d_scratch, size_t scratch_bytes, const float* d_below_z, int64_t ld_below_z,
+                       const float* d_below_tab, const float* d_below_mu, const float* d_below_istd, double* d_sums,
+                       void* stream);
 int snerf_linear_wgrad(int64_t n_points, int n_in, int n_out, const float* d_grad_out, int64_t ld_go, const float* d_in,
                        int64_t ld_in, float alpha, float* d_grad_weight, int precision, const float* d_act_tab, int act_cols,
                        void* stream);

@@ -91,7 +91,7 @@ def lib():
     L.snerf_linear_scratch_bytes.restype = C.c_size_t
     L.snerf_linear_scratch_bytes.argtypes = [i32, i32]
     L.snerf_linear_forward.argtypes = [i64, i32, i32, vp, i64, vp, vp, C.c_float, vp, i64, vp, i32, vp, C.c_size_t, vp, i32, vp]
-    L.snerf_linear_dgrad.argtypes = [i64, i32, i32, vp, i64, vp, i32, C.c_float, i32, vp, i64, i32, vp, C.c_size_t, vp]
+    L.snerf_linear_dgrad.argtypes = [i64, i32, i32, vp, i64, vp, i32, C.c_float, i32, vp, i64, i32, vp, C.c_size_t, vp, i64, vp, vp, vp, vp, vp]
     L.snerf_linear_wgrad.argtypes = [i64, i32, i32, vp, i64, vp, i64, C.c_float, vp, i32, vp, i32, vp]
     L.snerf_field_kernel_info.argtypes = [vp, i64, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     _lib = L

@@ -225,7 +225,11 @@ __global__ void split_weights_kernel(const float* W, int rows, int cols, int tra
 // become sin(2 pi (a z + b)) = one fma + one v_sin_f32 (which takes revolutions) while they sit in registers.  The table
 // act_tab = [a | b], each act_cols long, folds BatchNorm and the 1/(2 pi): a = gamma*istd/(2 pi), b = (beta - gamma*mu*istd)/(2 pi)
 // (a = 1/(2 pi), b = 0 for a plain SineLayer) - the post-activation H is never written to HBM.
-template <int NT, bool AOL>
+// ACT (dgrad only): the value produced is dL/dH of the SineLayer below, whose pre-activation Z (ez) and [a | b] table (etab) are
+// at hand: the epilogue multiplies by cos(2 pi (a z + b)) = dH/d(arg) - one fma + one v_cos_f32 - so that what reaches HBM is
+// dL/d(arg) already, and accumulates the column sums sum v and sum v*xhat (xhat = (z - mu)*istd, BatchNorm only) that the
+// bias / BatchNorm gradients and the BatchNorm backward need: the separate reduction sweep over [points x width] disappears.
+template <int NT, bool AOL, bool ACT>
 __global__ __launch_bounds__(512) void gemm_rows_kernel(const GemmX g) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_w[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -362,7 +366,22 @@ __global__ __launch_bounds__(512) void gemm_rows_kernel(const GemmX g) {
             const int64_t n = (int64_t)(grp * NT + j) * 32 + r;
             const bool nok = j < tiles_here && n < g.N;
             const float bias = (g.bias && nok) ? g.bias[n] : 0.f;
-            const float shift = (g.stats && nok) ? g.alpha * bias : 0.f;
+            const float shift = (!ACT && g.stats && nok) ? g.alpha * bias : 0.f;
+            float zt[RO_MT][16];
+            float e_a = 0.f, e_b = 0.f, e_mu = 0.f, e_is = 0.f;
+            if (ACT) {      // the 16 pre-activations of this column are all in flight before the first cosine (clamped, no branches)
+                const int64_t nc = nok ? n : 0;
+                e_a = g.etab[nc]; e_b = g.etab[g.N + nc];
+                if (g.emu) { e_mu = g.emu[nc]; e_is = g.eistd[nc]; }
+#pragma unroll
+                for (int i = 0; i < RO_MT; ++i)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        int64_t m = row0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                        m = m < g.M ? m : g.M - 1;
+                        zt[i][e] = g.ez[m * g.eld + nc];
+                    }
+            }
 #pragma unroll
             for (int i = 0; i < RO_MT; ++i)
 #pragma unroll
@@ -371,16 +390,24 @@ __global__ __launch_bounds__(512) void gemm_rows_kernel(const GemmX g) {
                     if (nok && m < g.M) {
                         float v = g.alpha * (acc[i][j][e] + bias);
                         float* c = g.C + m * g.ldc + n;
-                        if (g.accumulate) v += *c;
-                        *c = v;
-                        const float d = v - shift;
-                        st1[j] += d;
-                        st2[j] += d * d;
+                        if (!ACT && g.accumulate) v += *c;
+                        if (ACT) {
+                            const float z = zt[i][e];
+                            v *= __builtin_amdgcn_cosf(__builtin_fmaf(e_a, z, e_b));
+                            *c = v;
+                            st1[j] += v;
+                            st2[j] += v * ((z - e_mu) * e_is);
+                        } else {
+                            *c = v;
+                            const float d = v - shift;
+                            st1[j] += d;
+                            st2[j] += d * d;
+                        }
                     }
                 }
         }
     }
-    if (g.stats) {      // per-column sum(v - shift) and sum((v - shift)^2) over this block's rows -> double atomics
+    if (g.stats) {      // per-column sums (forward: sum(v - shift), sum((v - shift)^2); ACT: sum v, sum v*xhat) -> double atomics
         __syncthreads();                                   // weights no longer needed: reuse LDS for the cross-wave reduction
         float* red = (float*)lds_w;                        // [8 waves][NT][2][32]
 #pragma unroll
@@ -613,25 +640,32 @@ hipError_t launch_gemm_bf16x3(const GemmX& g, hipStream_t st) {
     if (blocks / 8 < groups) blocks = groups * 8;            // at least one worker per XCD
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_rows_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 20 * 2048);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_rows_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_rows_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 32 * 2048);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_rows_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
+        const void* fns[6] = {(const void*)gemm_rows_kernel<4, false, false>, (const void*)gemm_rows_kernel<4, true, false>,
+                              (const void*)gemm_rows_kernel<4, false, true>, (const void*)gemm_rows_kernel<2, false, false>,
+                              (const void*)gemm_rows_kernel<2, true, false>, (const void*)gemm_rows_kernel<2, false, true>};
+        for (const void* f : fns) {
+            hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+        }
         attr_done = true;
     }
     const bool aol = g.act_tab != nullptr && g.act_cols > 0;
+    const bool act = g.ez != nullptr;
     if (aol && (g.act_cols % 8 != 0 || g.act_cols > g.K || (uintptr_t)g.act_tab % 16 != 0)) return hipErrorInvalidValue;
+    if (act && (aol || g.accumulate || !g.stats || !g.etab)) return hipErrorInvalidValue;
     GemmX gx = g;
     gx.tab_lds = 0;
     size_t lds_total = lds;
     if (aol && lds + (size_t)g.act_cols * 8 <= 160 * 1024) { gx.tab_lds = 1; lds_total = lds + (size_t)g.act_cols * 8; }
+    const dim3 grid(blocks), block(512);
     if (nt == 4) {
-        if (aol) hipLaunchKernelGGL((gemm_rows_kernel<4, true>), dim3(blocks), dim3(512), lds_total, st, gx);
-        else hipLaunchKernelGGL((gemm_rows_kernel<4, false>), dim3(blocks), dim3(512), lds, st, g);
+        if (act) hipLaunchKernelGGL((gemm_rows_kernel<4, false, true>), grid, block, lds_total, st, gx);
+        else if (aol) hipLaunchKernelGGL((gemm_rows_kernel<4, true, false>), grid, block, lds_total, st, gx);
+        else hipLaunchKernelGGL((gemm_rows_kernel<4, false, false>), grid, block, lds_total, st, gx);
     } else {
-        if (aol) hipLaunchKernelGGL((gemm_rows_kernel<2, true>), dim3(blocks), dim3(512), lds_total, st, gx);
-        else hipLaunchKernelGGL((gemm_rows_kernel<2, false>), dim3(blocks), dim3(512), lds, st, g);
+        if (act) hipLaunchKernelGGL((gemm_rows_kernel<2, false, true>), grid, block, lds_total, st, gx);
+        else if (aol) hipLaunchKernelGGL((gemm_rows_kernel<2, true, false>), grid, block, lds_total, st, gx);
+        else hipLaunchKernelGGL((gemm_rows_kernel<2, false, false>), grid, block, lds_total, st, gx);
     }
     return hipGetLastError();
 }

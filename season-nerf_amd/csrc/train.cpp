@@ -233,8 +233,19 @@ static hipError_t linear_fwd(snerf_trainer* t, const LayerP& L, Act InA, int64_t
     return launch_gemm(g, st);
 }
 // dIn[M, n_cols] (+)= alpha * dZ[M, n_out] W[:, :n_cols]
+// `below` (optional): the SineLayer whose output gradient dIn is.  When the bf16x3 kernel runs and that layer's [a | b] table
+// exists (activation on load), its activation backward (x cos, column sums into t->bn_stats) happens in the epilogue and
+// *fused reports it: the consumer then skips its own reduction sweep.
+struct ActBelow {
+    const LayerP* L;
+    Act Z;
+    const float* tab;
+    float* bnslot;
+};
 static hipError_t linear_dgrad(snerf_trainer* t, const LayerP& L, const float* dZ, int64_t ldz, int64_t M, float* dIn, int64_t ld_in,
-                               int n_cols, float alpha, bool accumulate, hipStream_t st) {
+                               int n_cols, float alpha, bool accumulate, hipStream_t st, const ActBelow* below = nullptr,
+                               bool* fused = nullptr) {
+    if (fused) *fused = false;
     if (rows_ok(t, M, L.n_out, n_cols)) {
         GemmX x{};
         x.n_tiles = (n_cols + 31) / 32; x.ksteps = (L.n_out + 15) / 16;
@@ -243,6 +254,13 @@ static hipError_t linear_dgrad(snerf_trainer* t, const LayerP& L, const float* d
         if (e != hipSuccess) return e;
         x.A = dZ; x.frag = t->w_frag; x.C = dIn; x.M = M; x.N = n_cols; x.K = L.n_out; x.lda = ldz; x.ldc = ld_in;
         x.alpha = alpha; x.bias = nullptr; x.stats = nullptr; x.accumulate = accumulate ? 1 : 0;
+        if (below && below->tab && !accumulate && below->L->n_out == n_cols) {
+            e = hipMemsetAsync(t->bn_stats, 0, 2 * n_cols * sizeof(double), st);
+            if (e != hipSuccess) return e;
+            x.stats = t->bn_stats; x.ez = below->Z.p; x.eld = below->Z.ld; x.etab = below->tab;
+            if (below->L->bn) { x.emu = below->bnslot + 2 * t->W; x.eistd = below->bnslot + 3 * t->W; }
+            if (fused) *fused = true;
+        }
         return launch_gemm_bf16x3(x, st);
     }
     GemmArgs g{};
@@ -314,30 +332,41 @@ static int sine_fwd(snerf_trainer* t, const LayerP& L, Act In, int64_t M, Act Z,
 // SineLayer backward.  D holds dL/dH on entry ([M, n_out], ld = D.ld) and dL/dZ on exit (in place).
 // Accumulates weight/bias (and BN affine) gradients; if dIn.p != null writes dL/dIn[:, :n_in_cols].
 static int sine_bwd(snerf_trainer* t, const LayerP& L, Act D, Act Z, Act In, int64_t M, float* bnslot,
-                    Act dIn, int n_in_cols, bool accumulate_in, hipStream_t st) {
+                    Act dIn, int n_in_cols, bool accumulate_in, hipStream_t st, bool pre_activated = false,
+                    const ActBelow* below = nullptr, bool* fused_below = nullptr) {
+    // pre_activated: the dgrad that produced D already applied this layer's activation backward (D = dL/dH * cos) and left the
+    // column sums in t->bn_stats.  below / fused_below: the same offer for the layer that will consume dIn.
     const int C = L.n_out;
+    if (fused_below) *fused_below = false;
     if (L.bn) {
         float *mean = bnslot + 2 * t->W, *istd = bnslot + 3 * t->W;
         float *sdy = t->bn_bwd, *sdyx = t->bn_bwd + t->W;
-        HIPCK(hipMemsetAsync(t->bn_bwd, 0, 2 * t->W * sizeof(float), st));
-        ColArgs ca{};
-        ca.mode = 1; ca.M = M; ca.C = C; ca.ld = Z.ld; ca.Z = Z.p; ca.D = D.p; ca.mu = mean; ca.istd = istd;
-        ca.gamma = t->params + L.g; ca.beta = t->params + L.beta; ca.out0 = sdy; ca.out1 = sdyx; ca.alpha0 = 1.f;
-        ca.ldd = D.ld;
-        HIPCK(launch_colreduce(ca, st));
-        // d beta = sum dY, d gamma = sum dY*xhat
-        HIPCK(launch_copy_cols(sdy, C, t->grads + L.beta, C, 1, C, true, st));       // parameter gradients stay per-rank sums
-        HIPCK(launch_copy_cols(sdyx, C, t->grads + L.g, C, 1, C, true, st));
-        RCI(all_reduce(t, t->bn_bwd, 2 * t->W, false, st));                           // the BatchNorm backward means are global
+        if (pre_activated) {
+            // d beta += sum dY, d gamma += sum dY*xhat (per-rank sums), and the fp32 copies the dZ pass reads
+            HIPCK(launch_act_sums_finalize(t->bn_stats, C, 1.f, sdy, sdyx, t->grads + L.beta, t->grads + L.g, st));
+        } else {
+            HIPCK(hipMemsetAsync(t->bn_bwd, 0, 2 * t->W * sizeof(float), st));
+            ColArgs ca{};
+            ca.mode = 1; ca.M = M; ca.C = C; ca.ld = Z.ld; ca.Z = Z.p; ca.D = D.p; ca.mu = mean; ca.istd = istd;
+            ca.gamma = t->params + L.g; ca.beta = t->params + L.beta; ca.out0 = sdy; ca.out1 = sdyx; ca.alpha0 = 1.f;
+            ca.ldd = D.ld;
+            HIPCK(launch_colreduce(ca, st));
+            // d beta = sum dY, d gamma = sum dY*xhat
+            HIPCK(launch_copy_cols(sdy, C, t->grads + L.beta, C, 1, C, true, st));       // parameter gradients stay per-rank sums
+            HIPCK(launch_copy_cols(sdyx, C, t->grads + L.g, C, 1, C, true, st));
+        }
+        RCI(all_reduce(t, t->bn_bwd, 2 * t->W, false, st));                               // the BatchNorm backward means are global
         HIPCK(launch_bn_bwd2(Z.p, D.p, M, C, Z.ld, D.ld, mean, istd, t->params + L.g, t->params + L.beta, sdy, sdyx, t->grads + L.b, 30.f,
-                             M * (t->ar_fn ? t->world : 1), st));
+                             M * (t->ar_fn ? t->world : 1), st, pre_activated));
+    } else if (pre_activated) {
+        HIPCK(launch_act_sums_finalize(t->bn_stats, C, 30.f, nullptr, nullptr, t->grads + L.b, nullptr, st));     // d bias = 30 * sum dZ
     } else {
         ColArgs ca{};
         ca.mode = 2; ca.M = M; ca.C = C; ca.ld = Z.ld; ca.ldd = D.ld; ca.Z = Z.p; ca.D = D.p; ca.out0 = t->grads + L.b; ca.alpha0 = 30.f;
         HIPCK(launch_colreduce(ca, st));
     }
     HIPCK(linear_wgrad(t, L, D.p, D.ld, In, M, 30.f, st));
-    if (dIn.p) HIPCK(linear_dgrad(t, L, D.p, D.ld, M, dIn.p, dIn.ld, n_in_cols, 30.f, accumulate_in, st));
+    if (dIn.p) HIPCK(linear_dgrad(t, L, D.p, D.ld, M, dIn.p, dIn.ld, n_in_cols, 30.f, accumulate_in, st, below, fused_below));
     return SNERF_OK;
 }
 
@@ -347,10 +376,11 @@ static int plain_fwd(snerf_trainer* t, const LayerP& L, Act In, int64_t M, float
     return SNERF_OK;
 }
 static int plain_bwd(snerf_trainer* t, const LayerP& L, const float* dOut, int64_t ldo, Act In, int64_t M,
-                     float* dIn, int64_t ld_din, bool accumulate, hipStream_t st) {
+                     float* dIn, int64_t ld_din, bool accumulate, hipStream_t st, const ActBelow* below = nullptr, bool* fused_below = nullptr) {
+    if (fused_below) *fused_below = false;
     HIPCK(linear_wgrad(t, L, dOut, ldo, In, M, 1.f, st));
     HIPCK(launch_colsum(dOut, M, L.n_out, ldo, 1.f, t->grads + L.b, st));
-    if (dIn) HIPCK(linear_dgrad(t, L, dOut, ldo, M, dIn, ld_din, L.n_in, 1.f, accumulate, st));
+    if (dIn) HIPCK(linear_dgrad(t, L, dOut, ldo, M, dIn, ld_din, L.n_in, 1.f, accumulate, st, below, fused_below));
     return SNERF_OK;
 }
 
@@ -556,29 +586,43 @@ int snerf_trainer_backward_image(snerf_trainer* t, const float* d_g_rgb, const f
     HIPCK(launch_point_out(po, true, st));
     const Act X1 = P.Hc[8];
     // adjust branch
-    RC(plain_bwd(t, Ls[L_AC], t->d_adj, 3 * C, P.Hac[2], N, t->dA.p, W, false, st));
-    RC(sine_bwd(t, Ls[L_A3], Act{t->dA.p, W}, P.Za[2], P.Hac[1], N, nullptr, Act{t->dB.p, W}, W, false, st));
-    RC(sine_bwd(t, Ls[L_A2], Act{t->dB.p, W}, P.Za[1], P.Hac[0], N, nullptr, Act{t->dA.p, W}, W, false, st));
-    RC(sine_bwd(t, Ls[L_A1], Act{t->dA.p, W}, P.Za[0], X1, N, nullptr, Act{t->dX1.p, W2}, W2, false, st));
+    // `pre`: did the dgrad that produced this layer's output gradient already apply its activation backward (ActBelow)?
+    auto tab_of = [&](int slot) { return P.aol ? P.tabs + (int64_t)slot * 2 * W : (const float*)nullptr; };   // slots as in forward_pass
+    bool pre = false;
+    {
+        const ActBelow b3{&Ls[L_A3], P.Za[2], tab_of(11), nullptr}, b2{&Ls[L_A2], P.Za[1], tab_of(10), nullptr}, b1{&Ls[L_A1], P.Za[0], tab_of(9), nullptr};
+        RC(plain_bwd(t, Ls[L_AC], t->d_adj, 3 * C, P.Hac[2], N, t->dA.p, W, false, st, &b3, &pre));
+        RC(sine_bwd(t, Ls[L_A3], Act{t->dA.p, W}, P.Za[2], P.Hac[1], N, nullptr, Act{t->dB.p, W}, W, false, st, pre, &b2, &pre));
+        RC(sine_bwd(t, Ls[L_A2], Act{t->dB.p, W}, P.Za[1], P.Hac[0], N, nullptr, Act{t->dA.p, W}, W, false, st, pre, &b1, &pre));
+        RC(sine_bwd(t, Ls[L_A1], Act{t->dA.p, W}, P.Za[0], X1, N, nullptr, Act{t->dX1.p, W2}, W2, false, st, pre));
+    }
     // sigma / colour heads
     RC(plain_bwd(t, Ls[L_COL], t->d_head, 4, X1, N, t->dX1.p, W2, true, st));
     RC(plain_bwd(t, Ls[L_SIG], t->d_head + 3, 4, X1, N, t->dX1.p, W2, true, st));
     if (classic) {      // the solar-visibility branch carries gradient from the image (G_NeRF.py:100-108), on into X1
-        RC(plain_bwd(t, Ls[L_S4], t->d_sv_raw, 1, P.Hsc[2], N, t->dA.p, W2, false, st));
-        RC(sine_bwd(t, Ls[L_S3], Act{t->dA.p, W2}, P.Zs[2], P.Hsc[1], N, nullptr, Act{t->dB.p, W2}, W2, false, st));
-        RC(sine_bwd(t, Ls[L_S2], Act{t->dB.p, W2}, P.Zs[1], P.Hsc[0], N, nullptr, Act{t->dA.p, W2}, W2, false, st));
-        RC(sine_bwd(t, Ls[L_S1], Act{t->dA.p, W2}, P.Zs[0], P.In_s1c, N, nullptr, Act{t->dX1.p, W2}, W2, true, st));
+        const ActBelow s3{&Ls[L_S3], P.Zs[2], tab_of(14), nullptr}, s2{&Ls[L_S2], P.Zs[1], tab_of(13), nullptr}, s1{&Ls[L_S1], P.Zs[0], tab_of(12), nullptr};
+        RC(plain_bwd(t, Ls[L_S4], t->d_sv_raw, 1, P.Hsc[2], N, t->dA.p, W2, false, st, &s3, &pre));
+        RC(sine_bwd(t, Ls[L_S3], Act{t->dA.p, W2}, P.Zs[2], P.Hsc[1], N, nullptr, Act{t->dB.p, W2}, W2, false, st, pre, &s2, &pre));
+        RC(sine_bwd(t, Ls[L_S2], Act{t->dB.p, W2}, P.Zs[1], P.Hsc[0], N, nullptr, Act{t->dA.p, W2}, W2, false, st, pre, &s1, &pre));
+        RC(sine_bwd(t, Ls[L_S1], Act{t->dA.p, W2}, P.Zs[0], P.In_s1c, N, nullptr, Act{t->dX1.p, W2}, W2, true, st, pre));
     }
     // trunk
     float* cur = t->dA.p;
     float* nxt = t->dB.p;
-    RC(sine_bwd(t, Ls[L_FC9], Act{t->dX1.p, W2}, P.Z[8], P.Hc[7], N, P.bn + 7 * 4 * W, Act{cur, W}, W, false, st));
+    auto below_of = [&](int l) {        // trunk layer l (fc{l+1}) as the consumer of a dgrad's output
+        return ActBelow{&Ls[L_FC1 + l], l == 3 ? P.Zc3 : P.Z[l], tab_of(l), l >= 1 ? P.bn + (l - 1) * 4 * W : nullptr};
+    };
+    {
+        const ActBelow b = below_of(7);
+        RC(sine_bwd(t, Ls[L_FC9], Act{t->dX1.p, W2}, P.Z[8], P.Hc[7], N, P.bn + 7 * 4 * W, Act{cur, W}, W, false, st, false, &b, &pre));
+    }
     for (int l = 7; l >= 1; --l) {
         const Act In = l == 4 ? P.In5c : P.Hc[l - 1];
-        RC(sine_bwd(t, Ls[L_FC1 + l], Act{cur, W}, l == 3 ? P.Zc3 : P.Z[l], In, N, P.bn + (l - 1) * 4 * W, Act{nxt, W}, W, false, st));
+        const ActBelow b = below_of(l - 1);
+        RC(sine_bwd(t, Ls[L_FC1 + l], Act{cur, W}, l == 3 ? P.Zc3 : P.Z[l], In, N, P.bn + (l - 1) * 4 * W, Act{nxt, W}, W, false, st, pre, &b, &pre));
         float* tmp = cur; cur = nxt; nxt = tmp;
     }
-    RC(sine_bwd(t, Ls[L_FC1], Act{cur, W}, P.Z[0], Act{P.E.p, 64}, N, nullptr, Act{nullptr, 0}, 0, false, st));
+    RC(sine_bwd(t, Ls[L_FC1], Act{cur, W}, P.Z[0], Act{P.E.p, 64}, N, nullptr, Act{nullptr, 0}, 0, false, st, pre));
     // time -> class branch (per ray)
     HIPCK(launch_softmax_bwd(P.cls, t->d_cls, t->rayA, R, C, st));
     RC(plain_bwd(t, Ls[L_CL], t->rayA, C, Act{P.Ht2, W}, R, t->rayB, W, false, st));
@@ -621,10 +665,13 @@ int snerf_trainer_backward_solar(snerf_trainer* t, const float* d_g_solar_vis, v
     PointOutArgs po{};
     po.n = N; po.n_samples = t->S; po.C = t->C; po.head = P.head.p; po.sv = P.sv; po.d_sv = d_g_solar_vis; po.d_sv_raw = t->d_sv_raw;
     HIPCK(launch_point_out(po, true, st));
-    RC(plain_bwd(t, Ls[L_S4], t->d_sv_raw, 1, P.Hsc[2], N, t->dA.p, W2, false, st));
-    RC(sine_bwd(t, Ls[L_S3], Act{t->dA.p, W2}, P.Zs[2], P.Hsc[1], N, nullptr, Act{t->dB.p, W2}, W2, false, st));
-    RC(sine_bwd(t, Ls[L_S2], Act{t->dB.p, W2}, P.Zs[1], P.Hsc[0], N, nullptr, Act{t->dA.p, W2}, W2, false, st));
-    RC(sine_bwd(t, Ls[L_S1], Act{t->dA.p, W2}, P.Zs[0], P.In_s1c, N, nullptr, Act{nullptr, 0}, 0, false, st));
+    auto tab_of = [&](int slot) { return P.aol ? P.tabs + (int64_t)slot * 2 * t->W : (const float*)nullptr; };
+    const ActBelow s3{&Ls[L_S3], P.Zs[2], tab_of(14), nullptr}, s2{&Ls[L_S2], P.Zs[1], tab_of(13), nullptr}, s1{&Ls[L_S1], P.Zs[0], tab_of(12), nullptr};
+    bool pre = false;
+    RC(plain_bwd(t, Ls[L_S4], t->d_sv_raw, 1, P.Hsc[2], N, t->dA.p, W2, false, st, &s3, &pre));
+    RC(sine_bwd(t, Ls[L_S3], Act{t->dA.p, W2}, P.Zs[2], P.Hsc[1], N, nullptr, Act{t->dB.p, W2}, W2, false, st, pre, &s2, &pre));
+    RC(sine_bwd(t, Ls[L_S2], Act{t->dB.p, W2}, P.Zs[1], P.Hsc[0], N, nullptr, Act{t->dA.p, W2}, W2, false, st, pre, &s1, &pre));
+    RC(sine_bwd(t, Ls[L_S1], Act{t->dA.p, W2}, P.Zs[0], P.In_s1c, N, nullptr, Act{nullptr, 0}, 0, false, st, pre));
     return SNERF_OK;
 }
 
@@ -683,7 +730,8 @@ int snerf_linear_forward(int64_t n_points, int n_in, int n_out, const float* d_i
 
 int snerf_linear_dgrad(int64_t n_points, int n_in, int n_out, const float* d_grad_out, int64_t ld_go, const float* d_weight,
                        int n_cols, float alpha, int accumulate, float* d_grad_in, int64_t ld_gi, int precision, void* d_scratch,
-                       size_t scratch_bytes, void* stream) {
+                       size_t scratch_bytes, const float* d_below_z, int64_t ld_below_z, const float* d_below_tab,
+                       const float* d_below_mu, const float* d_below_istd, double* d_sums, void* stream) {
     if (n_points < 0 || n_in < 1 || n_out < 1 || n_cols < 1 || n_cols > n_in) return snerf_set_error(SNERF_E_INVALID, "snerf_linear_dgrad: bad shape");
     if (n_points == 0) return SNERF_OK;
     if (!d_grad_out || !d_weight || !d_grad_in || ld_go < n_out || ld_gi < n_cols) return snerf_set_error(SNERF_E_INVALID, "snerf_linear_dgrad: bad argument");
@@ -695,9 +743,15 @@ int snerf_linear_dgrad(int64_t n_points, int n_in, int n_out, const float* d_gra
         HIPCK(launch_split_weights(d_weight, n_out, n_in, true, (uint16_t*)d_scratch, x.n_tiles, x.ksteps, st));
         x.A = d_grad_out; x.frag = (const uint16_t*)d_scratch; x.C = d_grad_in; x.M = n_points; x.N = n_cols; x.K = n_out; x.lda = ld_go; x.ldc = ld_gi;
         x.alpha = alpha; x.bias = nullptr; x.stats = nullptr; x.accumulate = accumulate ? 1 : 0;
+        if (d_below_z) {
+            if (!d_below_tab || !d_sums || accumulate || ld_below_z < n_cols || (!d_below_mu) != (!d_below_istd))
+                return snerf_set_error(SNERF_E_INVALID, "snerf_linear_dgrad: the activation-backward epilogue needs table and sums, no accumulation");
+            x.ez = d_below_z; x.eld = ld_below_z; x.etab = d_below_tab; x.emu = d_below_mu; x.eistd = d_below_istd; x.stats = d_sums;
+        }
         HIPCK(launch_gemm_bf16x3(x, st));
         return SNERF_OK;
     }
+    if (d_below_z) return snerf_set_error(SNERF_E_INVALID, "snerf_linear_dgrad: the activation-backward epilogue needs the bf16x3 path");
     GemmArgs g{};
     g.A = d_grad_out; g.B = d_weight; g.C = d_grad_in; g.M = n_points; g.N = n_cols; g.K = n_out;
     g.sAm = ld_go; g.sAk = 1; g.sBk = n_in; g.sBn = 1; g.ldc = ld_gi;

@@ -36,6 +36,12 @@ struct GemmX {
     const float* act_tab;      // optional activation-on-load table [a | b] x act_cols for the leading columns of A: sin(2 pi (a z + b))
     int act_cols;              // multiple of 8, <= K
     int tab_lds;               // set by the launcher: the table fits in LDS behind the weights
+    // activation-backward epilogue (dgrad): C = dL/dH of the SineLayer below -> written as dL/d(arg) = C * cos(2 pi (a z + b));
+    // ez = that layer's pre-activation [M, eld], etab = its [a | b] table (N columns), emu/eistd = its BatchNorm statistics
+    // (NULL without BatchNorm); stats (required) receives sum v and sum v*xhat per column
+    const float* ez;
+    int64_t eld;
+    const float *etab, *emu, *eistd;
 };
 hipError_t launch_split_weights(const float* W, int rows, int cols, bool transpose, uint16_t* frag, int n_tiles, int ksteps, hipStream_t st);
 int gemm_rows_group_tiles(int ksteps);      // 0 = K too large for the LDS-resident weight layout (caller falls back to fp32 MFMA)
@@ -85,7 +91,8 @@ hipError_t launch_sin_fwd(const float* Z, float* H, int64_t M, int C, int64_t ld
 // BN backward second pass: dZ = gamma*istd*(dY - sdy/M - xhat*sdyx/M) in place; colsum(dZ) -> out (bias grad)
 hipError_t launch_bn_bwd2(const float* Z, float* D, int64_t M, int C, int64_t ld, int64_t ldd, const float* mu, const float* istd,
                           const float* gamma, const float* beta, const float* sdy, const float* sdyx, float* dbias_sum, float alpha,
-                          int64_t M_global, hipStream_t st);
+                          int64_t M_global, hipStream_t st, bool d_is_dy = false);
+hipError_t launch_act_sums_finalize(const double* stats, int C, float scale0, float* out0, float* out1, float* acc0, float* acc1, hipStream_t st);
 // activation-on-load table of a SineLayer: dst = [a | b] (n each), a = gamma*istd/(2 pi), b = (beta - gamma*mu*istd)/(2 pi);
 // all-NULL statistics = a layer without BatchNorm (a = 1/(2 pi), b = 0)
 hipError_t launch_act_table(const float* mu, const float* istd, const float* gamma, const float* beta, int n, float* dst, hipStream_t st);

@@ -135,7 +135,8 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const ColArgs A) {
 // columns (constants in registers) and walks down a 512-row chunk; partial sums meet in LDS, one atomic per column and block.
 //   MODE 1  BatchNorm reduction: sum dY, sum dY*xhat with dY = dH*cos(gamma*xhat+beta)   (reads Z, D; writes nothing)
 //   MODE 2  plain layer: D <- dH*cos(z), out0 += alpha0 * sum
-//   MODE 3  BatchNorm dZ: D <- gamma*istd*(dY - mean(dY) - xhat*mean(dY*xhat)), out0 += alpha0 * sum   (sdy/sdyx via mu2/istd2)
+//   MODE 3  BatchNorm dZ: D <- gamma*istd*(dY - mean(dY) - xhat*mean(dY*xhat)), out0 += alpha0 * sum, dY = dH*cos(.) recomputed
+//   MODE 4  the same with D already holding dY (a dgrad epilogue applied the cosine)
 template <int MODE>
 __global__ __launch_bounds__(256) void colpass_vec_kernel(const ColArgs A, int C4, int cpt, const float* sdy, const float* sdyx) {
     __shared__ float red[2][256][4];
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(256) void colpass_vec_kernel(const ColArgs A, int C
         for (int q = 0; q < 4; ++q) {
             const int c = tc * 4 + q;
             mu[q] = A.mu[c]; is[q] = A.istd[c]; gm[q] = A.gamma[c]; bt[q] = A.beta[c];
-            if (MODE == 3) { const float invM = 1.f / (float)A.M_global; ma[q] = sdy[c] * invM; mb[q] = sdyx[c] * invM; }
+            if (MODE >= 3) { const float invM = 1.f / (float)A.M_global; ma[q] = sdy[c] * invM; mb[q] = sdyx[c] * invM; }
         }
     }
     float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(256) void colpass_vec_kernel(const ColArgs A, int C
                     s0[q] += d[q];
                 } else {
                     const float xh = (z[q] - mu[q]) * is[q];
-                    const float dy = d[q] * cosf(gm[q] * xh + bt[q]);
+                    const float dy = MODE == 4 ? d[q] : d[q] * cosf(gm[q] * xh + bt[q]);
                     if (MODE == 1) {
                         s0[q] += dy;
                         s1[q] += dy * xh;
@@ -260,6 +261,22 @@ hipError_t launch_bn_finalize_shifted(const double* stats, const float* bias, fl
     return hipGetLastError();
 }
 
+// sums of a fused activation-backward epilogue (double [2][C]) -> fp32 vectors out0 = scale0*S0, out1 = S1 (optional) and
+// accumulated into parameter gradients acc0 += scale0*S0, acc1 += S1 (optional)
+__global__ void act_sums_finalize_kernel(const double* stats, int C, float scale0, float* out0, float* out1, float* acc0, float* acc1) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float s0 = scale0 * (float)stats[c], s1 = (float)stats[C + c];
+    if (out0) out0[c] = s0;
+    if (out1) out1[c] = s1;
+    if (acc0) acc0[c] += s0;
+    if (acc1) acc1[c] += s1;
+}
+hipError_t launch_act_sums_finalize(const double* stats, int C, float scale0, float* out0, float* out1, float* acc0, float* acc1, hipStream_t st) {
+    hipLaunchKernelGGL(act_sums_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, stats, C, scale0, out0, out1, acc0, acc1);
+    return hipGetLastError();
+}
+
 __global__ void act_table_kernel(const float* mu, const float* istd, const float* gamma, const float* beta, int n, float* dst) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n) return;
@@ -331,7 +348,7 @@ hipError_t launch_sin_fwd(const float* Z, float* H, int64_t M, int C, int64_t ld
 
 __global__ __launch_bounds__(256) void bn_bwd2_kernel(const float* Z, float* D, int64_t M, int C, int64_t ld, int64_t ldd, const float* mu,
                                                       const float* istd, const float* gamma, const float* beta, const float* sdy,
-                                                      const float* sdyx, float* dbias_sum, float alpha, float invM) {
+                                                      const float* sdyx, float* dbias_sum, float alpha, float invM, int d_is_dy) {
     __shared__ float red0[256];
     const int cp = C >= 256 ? 256 : (C >= 128 ? 128 : (C >= 64 ? 64 : 32));
     const int phases = 256 / cp;
@@ -345,7 +362,7 @@ __global__ __launch_bounds__(256) void bn_bwd2_kernel(const float* Z, float* D, 
             const float m = mu[c], is = istd[c], gm = gamma[c], bt = beta[c], k = gm * is, a = sdy[c] * invM, b = sdyx[c] * invM;
             for (int64_t r = r0 + tp; r < r1; r += phases) {
                 const float xh = (Z[r * ld + c] - m) * is;
-                const float dy = D[r * ldd + c] * cosf(gm * xh + bt);         // D holds dL/dH on entry
+                const float dy = d_is_dy ? D[r * ldd + c] : D[r * ldd + c] * cosf(gm * xh + bt);     // D holds dL/dH (or dL/dY) on entry
                 const float dz = k * (dy - a - xh * b);
                 D[r * ldd + c] = dz;
                 s0 += dz;
@@ -362,15 +379,15 @@ __global__ __launch_bounds__(256) void bn_bwd2_kernel(const float* Z, float* D, 
 }
 hipError_t launch_bn_bwd2(const float* Z, float* D, int64_t M, int C, int64_t ld, int64_t ldd, const float* mu, const float* istd,
                           const float* gamma, const float* beta, const float* sdy, const float* sdyx, float* dbias_sum, float alpha,
-                          int64_t M_global, hipStream_t st) {
+                          int64_t M_global, hipStream_t st, bool d_is_dy) {
     if (M <= 0) return hipSuccess;
     ColArgs a{};
     a.mode = 3; a.M = M; a.M_global = M_global; a.C = C; a.ld = ld; a.ldd = ldd; a.Z = Z; a.D = D; a.mu = mu; a.istd = istd; a.gamma = gamma; a.beta = beta;
     a.out0 = dbias_sum; a.alpha0 = alpha;
-    if (colpass_vec_ok(a)) return launch_colpass_vec<3>(a, sdy, sdyx, st);
+    if (colpass_vec_ok(a)) return d_is_dy ? launch_colpass_vec<4>(a, sdy, sdyx, st) : launch_colpass_vec<3>(a, sdy, sdyx, st);
     const int64_t blocks = (M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
     hipLaunchKernelGGL(bn_bwd2_kernel, dim3((unsigned)blocks), dim3(256), 0, st, Z, D, M, C, ld, ldd ? ldd : ld, mu, istd, gamma, beta, sdy, sdyx, dbias_sum, alpha,
-                       1.f / (float)M_global);
+                       1.f / (float)M_global, d_is_dy ? 1 : 0);
     return hipGetLastError();
 }
 

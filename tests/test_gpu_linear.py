@@ -77,7 +77,7 @@ def test_linear_dgrad(shape, precision, accumulate):
     dIn = base.clone()
     sc = _scratch(L, n_out, n_in)
     sn._lib.check(L.snerf_linear_dgrad(M, n_in, n_out, dZ.data_ptr(), ld_go, Wt.data_ptr(), n_cols, 30.0, accumulate, dIn.data_ptr(), ld_gi,
-                                       precision, sc.data_ptr(), sc.numel(), st), "linear_dgrad")
+                                       precision, sc.data_ptr(), sc.numel(), None, 0, None, None, None, None, st), "linear_dgrad")
     ref = 30.0 * (dZ[:, :n_out].double() @ Wt.double()[:, :n_cols]) + (base[:, :n_cols].double() if accumulate else 0.0)
     assert _rel(dIn[:, :n_cols], ref) < TOL[precision]
     assert torch.equal(dIn[:, n_cols:], base[:, n_cols:])
@@ -111,7 +111,7 @@ def test_linear_argument_errors():
     assert b"bad argument" in L.snerf_last_error()
     assert L.snerf_linear_forward(8, 8, 8, a.data_ptr(), 8, a.data_ptr(), None, 1.0, a.data_ptr(), 8, None, 1, None, 0, None, 0, st) != 0      # no scratch
     assert L.snerf_linear_forward(0, 8, 8, None, 8, None, None, 1.0, None, 8, None, 1, None, 0, None, 0, st) == 0                                  # empty batch
-    assert L.snerf_linear_dgrad(8, 8, 8, a.data_ptr(), 8, a.data_ptr(), 9, 1.0, 0, a.data_ptr(), 8, 0, None, 0, st) != 0                 # n_cols > n_in
+    assert L.snerf_linear_dgrad(8, 8, 8, a.data_ptr(), 8, a.data_ptr(), 9, 1.0, 0, a.data_ptr(), 8, 0, None, 0, None, 0, None, None, None, None, st) != 0                 # n_cols > n_in
     assert L.snerf_linear_wgrad(-1, 8, 8, a.data_ptr(), 8, a.data_ptr(), 8, 1.0, a.data_ptr(), 0, None, 0, st) != 0
 
 
@@ -149,3 +149,38 @@ def test_activation_on_load(shape):
     # precision 0 cannot do it: loud error
     assert L.snerf_linear_forward(M, K, N, Zp.data_ptr(), lda, Wt.data_ptr(), b.data_ptr(), 30.0, out.data_ptr(), N, None, 0,
                                   sc.data_ptr(), sc.numel(), tab.data_ptr(), ac, st) != 0
+
+
+@pytest.mark.parametrize("shape", [(1500, 256, 256, True), (1029, 128, 128, False), (2048, 319, 256, True), (700, 256, 12, False)])
+def test_dgrad_activation_backward_epilogue(shape):
+    """dgrad whose epilogue already applies the activation backward of the SineLayer below (x cos) and reduces the column sums."""
+    sn, L, st = _env()
+    M, n_in, n_out, bn = shape
+    n_cols = 256 if n_in == 319 else n_in
+    g = torch.Generator(device="cpu").manual_seed(M)
+    dZ = torch.randn(M, n_out, generator=g).cuda()
+    Wt = (torch.randn(n_out, n_in, generator=g) / np.sqrt(n_out)).cuda()
+    Zb = (torch.randn(M, n_cols + 4, generator=g) * 4).cuda()                              # pre-activation of the layer below
+    mu, istd = torch.randn(n_cols, generator=g).double(), (torch.rand(n_cols, generator=g) + 0.5).double()
+    gam, bet = (torch.rand(n_cols, generator=g) + 0.5).double(), torch.randn(n_cols, generator=g).double()
+    if not bn:
+        mu, istd, gam, bet = torch.zeros(n_cols).double(), torch.ones(n_cols).double(), torch.ones(n_cols).double(), torch.zeros(n_cols).double()
+    tab = torch.stack([gam * istd / (2 * np.pi), (bet - gam * mu * istd) / (2 * np.pi)]).float().cuda().contiguous()
+    mu_f, is_f = mu.float().cuda(), istd.float().cuda()
+    out = torch.zeros(M, n_cols, device="cuda")
+    sums = torch.zeros(2, n_cols, dtype=torch.float64, device="cuda")
+    sc = _scratch(L, n_out, n_in)
+    sn._lib.check(L.snerf_linear_dgrad(M, n_in, n_out, dZ.data_ptr(), n_out, Wt.data_ptr(), n_cols, 30.0, 0, out.data_ptr(), n_cols, 1,
+                                       sc.data_ptr(), sc.numel(), Zb.data_ptr(), n_cols + 4, tab.data_ptr(),
+                                       mu_f.data_ptr() if bn else None, is_f.data_ptr() if bn else None, sums.data_ptr(), st), "dgrad(act)")
+    zd = Zb[:, :n_cols].double()
+    xh = (zd - mu.cuda()) * istd.cuda()
+    ref = 30.0 * (dZ.double() @ Wt.double()[:, :n_cols]) * torch.cos(gam.cuda() * xh + bet.cuda())
+    assert _rel(out, ref) < 2 * TOL[1]
+    s_ = sums.cpu().numpy()
+    np.testing.assert_allclose(s_[0], ref.sum(0).cpu().numpy(), rtol=0, atol=3e-4 * float(ref.abs().sum(0).max()))
+    want1 = (ref * xh).sum(0).cpu().numpy() if bn else np.zeros(n_cols)
+    np.testing.assert_allclose(s_[1], want1, rtol=0, atol=3e-4 * float((ref * xh).abs().sum(0).max()) + 1e-12)
+    # accumulate together with the epilogue is refused
+    assert L.snerf_linear_dgrad(M, n_in, n_out, dZ.data_ptr(), n_out, Wt.data_ptr(), n_cols, 30.0, 1, out.data_ptr(), n_cols, 1, sc.data_ptr(),
+                                sc.numel(), Zb.data_ptr(), n_cols + 4, tab.data_ptr(), None, None, sums.data_ptr(), st) != 0
