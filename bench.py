@@ -208,7 +208,7 @@ def bench_train(a):
                             "note": "whole step, not one kernel: train-mode BatchNorm forces a layer-wise design in which every layer is "
                                     "a pass over [393216 x width] fp32 arrays; achieved = bytes that design moves per step (counted from "
                                     "the layer table, DESIGN 5.4) / step time, peak = HBM3E 8 TB/s (MI355X_MICROARCH.md); "
-                                    "per-kernel times in profiles/r1/g_train_kernel_stats.csv"}}
+                                    "per-kernel times in profiles/r1/h_train_kernel_stats.csv"}}
         if not a.no_cpu_baseline and world == 1:      # reported at N = 1 only (rank 0)
             from oracle import season_nerf_oracle as orc          # CPU-baseline leg only
             torch.set_num_threads(min(host_cpus(), 32))
@@ -345,7 +345,7 @@ def main():
         achieved = FLOP_PER_SAMPLE * R * S / (field_ms * 1e-3)
         traffic = None          # HBM bytes per launch from the committed PMC passes of this same command (profiles/)
         try:
-            traffic = json.load(open(os.path.join(REPO, "profiles", "r1", "g_traffic.json")))["bytes_per_launch"]
+            traffic = json.load(open(os.path.join(REPO, "profiles", "r1", "h_traffic.json")))["bytes_per_launch"]
         except Exception:
             pass
         out = {
