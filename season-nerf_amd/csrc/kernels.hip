@@ -600,7 +600,8 @@ __global__ __launch_bounds__(256) void composite_kernel(const CompArgs A) {
     float carry = 0.f, carry_m = 0.f;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, svsum = 0.f, acc = 0.f, l0 = 0.f, l1 = 0.f, l2 = 0.f, dist = 0.f;
     float c0 = 0.f, c1 = 0.f, c2 = 0.f;          // classic-solar colour
-    float m0 = 0.f, m1 = 0.f, m2 = 0.f;          // prior-merged albedo
+    float m0 = 0.f, m1 = 0.f, m2 = 0.f;          // prior-merged albedo (classic: merged, per-sample shaded colour)
+    float ma0 = 0.f, ma1 = 0.f, ma2 = 0.f;       // classic + prior: the merged albedo itself
     for (int base = 0; base < S; base += 64) {
         const int s = base + lane;
         const bool in = s < S;
@@ -648,6 +649,7 @@ __global__ __launch_bounds__(256) void composite_kernel(const CompArgs A) {
                 m0 += psm * k0 * (sv + (1.f - sv) * sky0);
                 m1 += psm * k1 * (sv + (1.f - sv) * sky1);
                 m2 += psm * k2 * (sv + (1.f - sv) * sky2);
+                ma0 += psm * k0; ma1 += psm * k1; ma2 += psm * k2;
             } else {
                 m0 += psm * k0; m1 += psm * k1; m2 += psm * k2;
             }
@@ -658,12 +660,13 @@ __global__ __launch_bounds__(256) void composite_kernel(const CompArgs A) {
     l0 = wave_sum(l0); l1 = wave_sum(l1); l2 = wave_sum(l2); dist = wave_sum(dist);
     if (classic) { c0 = wave_sum(c0); c1 = wave_sum(c1); c2 = wave_sum(c2); }
     if (A.rho_prior) { m0 = wave_sum(m0); m1 = wave_sum(m1); m2 = wave_sum(m2); }
+    if (A.rho_prior && classic) { ma0 = wave_sum(ma0); ma1 = wave_sum(ma1); ma2 = wave_sum(ma2); }
     if (lane == 0) {
         const float sv3 = sigmoid_f((svsum - 0.2f) * 30.f);                 // Eval_Tools_2.py:214 (un-merged PS)
         const float f0 = sv3 + (1.f - sv3) * sky0, f1 = sv3 + (1.f - sv3) * sky1, f2 = sv3 + (1.f - sv3) * sky2;
         float r0, r1, r2, al0 = a0, al1 = a1, al2 = a2;
         if (A.rho_prior) {                                                  // Rendered_Col_Merged, :243-248
-            if (classic) { r0 = m0; r1 = m1; r2 = m2; } else { r0 = m0 * f0; r1 = m1 * f1; r2 = m2 * f2; al0 = m0; al1 = m1; al2 = m2; }
+            if (classic) { r0 = m0; r1 = m1; r2 = m2; al0 = ma0; al1 = ma1; al2 = ma2; } else { r0 = m0 * f0; r1 = m1 * f1; r2 = m2 * f2; al0 = m0; al1 = m1; al2 = m2; }
         } else if (classic) { r0 = c0; r1 = c1; r2 = c2; }
         else { r0 = a0 * f0; r1 = a1 * f1; r2 = a2 * f2; }
         if (A.out.rgb) { A.out.rgb[r * 3] = r0; A.out.rgb[r * 3 + 1] = r1; A.out.rgb[r * 3 + 2] = r2; }

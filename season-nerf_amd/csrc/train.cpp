@@ -574,7 +574,6 @@ int snerf_trainer_backward_image(snerf_trainer* t, const float* d_g_rgb, const f
     cb.g_rgb = d_g_rgb; cb.g_albedo = d_g_albedo; cb.g_pe = d_g_pe; cb.d_rho = t->d_rho; cb.d_col = t->d_col; cb.d_sky = t->d_sky;
     cb.rho_prior = d_rho_prior; cb.trust = trust; cb.g_rgb_m = d_g_rgb_merged; cb.g_albedo_m = d_g_albedo_merged;
     const bool classic = (t->img_flags & 1) != 0;
-    if (classic && d_rho_prior) return snerf_set_error(SNERF_E_INVALID, "classic solar model together with the DSM prior is not implemented");
     cb.classic = classic ? 1 : 0; cb.d_sv = t->d_sv_raw;       // dL/dSolar_Vis, turned into dL/d(raw) in place below
     HIPCK(launch_composite_bwd(cb, st));
     if (d_g_sky) HIPCK(launch_copy_cols(d_g_sky, 3, t->d_sky, 3, R, 3, true, st));

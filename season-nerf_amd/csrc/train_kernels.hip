@@ -500,13 +500,14 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const CompBwdArgs A)
     u = wsum(u);
     const bool classic = A.classic != 0;
     const float sv3 = sigmoid_t((u - 0.2f) * 30.f);
-    float dalb[3], dalbm[3], dsky[3], dsv3 = 0.f, grgb[3];
+    float dalb[3], dalbm[3], dsky[3], dsv3 = 0.f, grgb[3], grgbm[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const float F = classic ? 0.f : sv3 + (1.f - sv3) * sky[k];       // classic: the shading factor is per sample (pass 2)
         const float g = A.g_rgb ? A.g_rgb[r * 3 + k] : 0.f;
         const float gm = (prior && A.g_rgb_m) ? A.g_rgb_m[r * 3 + k] : 0.f;
         grgb[k] = g;
+        grgbm[k] = classic ? gm : 0.f;                 // classic: Rendered_Col_Merged is shaded per sample too
         dalb[k] = g * F + (A.g_albedo ? A.g_albedo[r * 3 + k] : 0.f);
         dalbm[k] = gm * F + ((prior && A.g_albedo_m) ? A.g_albedo_m[r * 3 + k] : 0.f);
         const float dF = g * alb[k] + gm * albm[k];
@@ -561,15 +562,14 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const CompBwdArgs A)
         const float ps = pv * pe;
 #pragma unroll
         for (int k = 0; k < 3; ++k) dc[k] = (dalb[k] + grgb[k] * shade[k]) * ps;
+        float dsv = 0.f;
         if (classic) {
-            float dsv = 0.f;
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 const float t_ = in ? grgb[k] * ps * A.col[idx * 3 + k] : 0.f;
                 dsv += t_ * (1.f - sky[k]);
                 dsky[k] += t_ * (1.f - svs);
             }
-            if (in) A.d_sv[idx] = dsv;
         }
         suffix += tot;
         if (prior) {
@@ -581,7 +581,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const CompBwdArgs A)
             float dpsm = 0.f;
             if (in) {
 #pragma unroll
-                for (int k = 0; k < 3; ++k) dpsm += dalbm[k] * A.col[idx * 3 + k];
+                for (int k = 0; k < 3; ++k) dpsm += (dalbm[k] + grgbm[k] * shade[k]) * A.col[idx * 3 + k];
             }
             const float dpvm_pvm = in ? dpsm * pem * pvm : 0.f;
             const float incl3 = wscan_incl(dpvm_pvm, lane);
@@ -590,9 +590,17 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const CompBwdArgs A)
             d_rho += tr * (dpsm * pvm * eym - later_m) * delta;
             const float psm = pvm * pem;
 #pragma unroll
-            for (int k = 0; k < 3; ++k) dc[k] += dalbm[k] * psm;
+            for (int k = 0; k < 3; ++k) {
+                dc[k] += (dalbm[k] + grgbm[k] * shade[k]) * psm;
+                if (classic) {
+                    const float t_ = in ? grgbm[k] * psm * A.col[idx * 3 + k] : 0.f;
+                    dsv += t_ * (1.f - sky[k]);
+                    dsky[k] += t_ * (1.f - svs);
+                }
+            }
             suffix_m += totm;
         }
+        if (classic && in) A.d_sv[idx] = dsv;
         if (in) {
             A.d_rho[idx] = d_rho;
 #pragma unroll

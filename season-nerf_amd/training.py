@@ -217,7 +217,7 @@ class TrainEngine:
             pass
 
 
-def _composite(eng, top, bot, tv, rho, col, sv, sky, prior=None, trust=1.0, want=("pv", "pe", "ps")):
+def _composite(eng, top, bot, tv, rho, col, sv, sky, prior=None, trust=1.0, want=("pv", "pe", "ps"), classic=False):
     """snerf_composite_rays on [R,S,*] tensors; returns dict of requested outputs."""
     R, S, dev = rho.shape[0], rho.shape[1], rho.device
     e = lambda *s: torch.empty(*s, device=dev)
@@ -225,7 +225,7 @@ def _composite(eng, top, bot, tv, rho, col, sv, sky, prior=None, trust=1.0, want
     o = {k: e(*shapes[k]) for k in want}
     co = _lib.CompositeOut(**{"d_" + k: v.data_ptr() for k, v in o.items()})
     _lib.check(eng.L.snerf_composite_rays(R, S, top.data_ptr(), bot.data_ptr(), tv.data_ptr(), rho.data_ptr(), col.data_ptr(),
-                                          sv.data_ptr(), sky.data_ptr(), 0, _ptr(prior), float(trust), C.byref(co), eng.stream()),
+                                          sv.data_ptr(), sky.data_ptr(), 1 if classic else 0, _ptr(prior), float(trust), C.byref(co), eng.stream()),
                "composite_rays")
     return o
 
@@ -257,7 +257,8 @@ class _ImagePass(torch.autograd.Function):
             net, trust = prior
             rs = net.Supervised_Sample(o["pts"].reshape(-1, 3), o["delta"].reshape(-1, 1)).reshape(R, S, 1).float().contiguous()
             sup = _composite(eng, top, bot, tv, rs, o["col"], o["sv"], o["sky"])
-            mer = _composite(eng, top, bot, tv, o["rho"], o["col"], o["sv"], o["sky"], prior=rs, trust=trust, want=("rgb", "albedo"))
+            mer = _composite(eng, top, bot, tv, o["rho"], o["col"], o["sv"], o["sky"], prior=rs, trust=trust, want=("rgb", "albedo"),
+                             classic=eng.classic_solar)
             rgb_m, alb_m = mer["rgb"], mer["albedo"]
             rho_m = o["rho"] * trust + rs * (1 - trust)
             mm = _composite(eng, top, bot, tv, rho_m, o["col"], o["sv"], o["sky"])
@@ -399,8 +400,6 @@ def eval_train(ev, data_dict, net, train_mode, current_step=0):
     tv = _to_dev(sample_parameters(S, eval_mode=not train_mode), dev)
     prior = (net, current_step / ev.n_steps) if ev.use_prior else None
     eng.classic_solar = bool(ev.use_classic_solar)            # Solar_Type_2: per-sample shading, Solar_Vis carries gradient
-    if eng.classic_solar and prior is not None:
-        raise NotImplementedError("season_nerf_amd: Solar_Type_2 together with the DSM prior phase is not implemented")
     res = _ImagePass.apply(eng, top, bot, tv, sun, tim, net.training, prior, *eng.param_list)
     rgb, alb, sky, pe, rgb_m, alb_m, pv, ps, dl, cls, rho, sv, col, pts, adjc = res[:15]
     _after_train_forward(net)
@@ -412,8 +411,11 @@ def eval_train(ev, data_dict, net, train_mode, current_step=0):
     if ev.use_prior:
         keys = ["PV_Supervised", "PE_Supervised", "PS_Supervised", "PV_Merged", "PE_Merged", "PS_Merged", "Rho_Merged"]
         out.update(dict(zip(keys, res[15:])))
-        sv3 = torch.sigmoid(((sv * ps).sum(1) - .2) * 30)
-        out["Rendered_Col_Supervised"] = ((out["PS_Supervised"] * col).sum(1) * (sv3 + (1 - sv3) * sky)).detach()
+        if ev.use_classic_solar:                                  # Eval_Tools_2.py:228-229
+            out["Rendered_Col_Supervised"] = (out["PS_Supervised"] * col * (sv + (1 - sv) * sky_e)).sum(1).detach()
+        else:
+            sv3 = torch.sigmoid(((sv * ps).sum(1) - .2) * 30)
+            out["Rendered_Col_Supervised"] = ((out["PS_Supervised"] * col).sum(1) * (sv3 + (1 - sv3) * sky)).detach()
         out["Rendered_Col_Merged"] = rgb_m
         out["Albedo_Color"] = alb_m                               # the reference overwrites it with the merged one (:243)
     return out

@@ -117,6 +117,11 @@ def test_eval_vs_reference(golden_dir, name):
             close("prior_" + k, o[k], g["prior_" + k])
         for k in ["PS_Supervised", "PS_Merged", "PE_Supervised"]:
             close("prior_" + k, o[k], g["prior_" + k], rtol=1e-4, atol=2e-5)
+        # Solar_Type_2 in the prior phase: per-sample shading in all three renderings, merged albedo
+        evcp = sn().All_in_One_Eval(args_ns(S, classic=True), dev, int(g["prior_n_steps"]), True, None, np.eye(4), np.zeros(3))
+        o = evcp.eval(data, net_p, int(g["prior_step"]), False)
+        for k in ["Rendered_Col", "Rendered_Col_Supervised", "Rendered_Col_Merged", "Albedo_Color"]:
+            close("cprior_" + k, o[k], g["cprior_" + k])
 
 
 def test_eval_vs_oracle_ragged():

@@ -109,6 +109,10 @@ def test_eval_rays(golden_dir, name):
             for k in ["Rendered_Col", "Rendered_Col_Supervised", "Rendered_Col_Merged", "PS_Supervised", "PS_Merged",
                       "Rho_Merged", "Albedo_Color", "PE_Supervised"]:
                 close(o[k], g["prior_" + k], rtol=1e-4, atol=2e-5)
+            o = orc.eval_rays(sd, data, S, False, classic_solar=True, use_prior=True, hm=g["hm"],
+                              trust=int(g["prior_step"]) / int(g["prior_n_steps"]))          # Solar_Type_2 in the prior phase
+            for k in ["Rendered_Col", "Rendered_Col_Supervised", "Rendered_Col_Merged", "Albedo_Color"]:
+                close(o[k], g["cprior_" + k], rtol=1e-4, atol=2e-5)
 
 
 def _ref_grads(g):

@@ -146,6 +146,11 @@ def gen_eval(W, seed, R, S, tag, with_prior):
             for k in ["Rendered_Col", "Rendered_Col_Supervised", "Rendered_Col_Merged", "PS_Supervised", "PS_Merged",
                       "Rho_Merged", "Albedo_Color", "PE_Supervised"]:
                 out["prior_" + k] = f32(r[k])
+            # the DSM-prior phase with the classic solar model (Solar_Type_2): per-sample shading in all three renderings
+            evcp = All_in_One_Eval(args_ns(S, classic=True), torch.device("cpu"), 10, True, None, H4, WC)
+            r = evcp.eval(data, net, 3, False)
+            for k in ["Rendered_Col", "Rendered_Col_Supervised", "Rendered_Col_Merged", "Albedo_Color"]:
+                out["cprior_" + k] = f32(r[k])
     np.savez_compressed(os.path.join(OUT, f"eval_{tag}.npz"), **out)
 
 
@@ -340,6 +345,7 @@ if __name__ == "__main__":
     gen_train(64, 1, 24, 40, "prior_W64_R24_S40", prior=True)
     gen_train(256, 2, 32, 40, "W256_R32_S40", subsample=37)
     gen_train(64, 3, 32, 32, "classic_W64_R32_S32", classic=True)
+    gen_train(64, 4, 24, 40, "classic_prior_W64_R24_S40", prior=True, classic=True)
     gen_render(64, 2, "W64_s2")
     gen_render_by_P(64, 2, "W64_s2")
     gen_dsm()
