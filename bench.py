@@ -180,13 +180,15 @@ def bench_train(a):
     def bwd_bytes(names, dgrad_first=True):
         # activation backward of a SineLayer: fused into the epilogue of the dgrad above it (reads Z once: o) when that dgrad is
         # its only producer - every layer except fc9 (its gradient is summed from several branches) - else a reduction sweep;
-        # BatchNorm layers add the dZ sweep (read Z, dY; write dZ: 3 o)
+        # BatchNorm layers add the dZ computation (a sweep: read Z, dY, write dZ = 3 o - or folded into wgrad, see below)
         tot = 0
         for j, n in enumerate(names):
             o, i, k, bn = rows[n]
             if k == "sine":
                 fused = aol and not n.endswith("fc9")
-                tot += (o if fused else (2 * o if bn else 3 * o)) + (3 * o if bn else 0)
+                tot += o if fused else (2 * o if bn else 3 * o)
+                if bn:      # dZ: inside the weight-gradient kernel (reads Z, rewrites dY in place: 2 o) where the layer has <= 256 inputs
+                    tot += 2 * o if (fused and i <= 256) else 3 * o
             tot += (o + i) + ((o + i) if (dgrad_first or j > 0) else 0)
         return tot
     img = fwd_bytes(trunk + heads + solar + adjust) + bwd_bytes(trunk, False) + bwd_bytes(heads) + bwd_bytes(adjust)

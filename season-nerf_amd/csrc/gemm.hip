@@ -452,7 +452,17 @@ static int ro_grid_blocks() {
 struct WgradX {
     const float* in_tab;         // optional activation-on-load table for the first in_cols columns of In ([a | b], see gemm_rows_kernel)
     int in_cols;
-    const float *dZ, *In;
+    // BNZ (optional): dZ holds dL/dY of a BatchNorm SineLayer on entry; the BatchNorm backward
+    //   dZ = gamma*istd*(dY - mean(dY) - xhat*mean(dY*xhat)),  xhat = (z - mu)*istd
+    // is applied to each gathered value, written back IN PLACE (every element is gathered by exactly one lane when the grid has
+    // one z-block) and summed per column into dbias (+= bias_alpha * sum dZ): the separate dZ sweep disappears
+    const float* z;
+    int64_t ldzz;
+    const float *bn_gamma, *bn_mu, *bn_istd, *bn_sdy, *bn_sdyx;
+    float bn_inv_m, bias_alpha;
+    float* dbias;
+    float* dZ;
+    const float* In;
     float* dW;
     int64_t M, ldz, ldi, ldw;
     int n_out, n_in;
@@ -462,7 +472,7 @@ struct WgradX {
 
 constexpr int WG_STAGE = 32;
 
-template <bool FULL>            // FULL: every 256 x 256 block of dW is complete (no tile or column masks in the hot loop)
+template <bool FULL, bool BNZ>  // FULL: every 256 x 256 block of dW is complete (no tile or column masks in the hot loop)
 __global__ __launch_bounds__(512) void wgrad_bf16x3_kernel(const WgradX g) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_f[];          // [2 buffers][2 operands][8 tiles][2 ksteps][hi,lo][1 KiB]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -485,8 +495,15 @@ __global__ __launch_bounds__(512) void wgrad_bf16x3_kernel(const WgradX g) {
     const uint32_t ldz = (uint32_t)g.ldz, ldi = (uint32_t)g.ldi;
     const uint32_t co = ok_o ? (uint32_t)col_o : 0u, ci = ok_i ? (uint32_t)col_i : 0u;
     const int64_t m_last = m_end - 1;
-    float vo[2][8], vi[2][8];
+    float vo[2][8], vi[2][8], vz[BNZ ? 2 : 1][BNZ ? 8 : 1];
     int gathered_last = 0;
+    int64_t gathered_ms = 0;
+    // BNZ: constants of this lane's dZ column
+    const uint32_t ldzz = BNZ ? (uint32_t)g.ldzz : 0u;
+    const float z_is = (BNZ && ok_o) ? g.bn_istd[col_o] : 0.f, z_mu = (BNZ && ok_o) ? g.bn_mu[col_o] : 0.f;
+    const float z_k = (BNZ && ok_o) ? g.bn_gamma[col_o] * z_is : 0.f;
+    const float z_ma = (BNZ && ok_o) ? g.bn_sdy[col_o] * g.bn_inv_m : 0.f, z_mb = (BNZ && ok_o) ? g.bn_sdyx[col_o] * g.bn_inv_m : 0.f;
+    float z_sum = 0.f;
     // activation on load: this lane's In column is a stored pre-activation -> sin(2 pi (a z + b)) at publish time
     const bool in_act = g.in_tab != nullptr && ok_i && col_i < g.in_cols;
     const float c_a = in_act ? g.in_tab[col_i] : 0.f, c_b = in_act ? g.in_tab[g.in_cols + col_i] : 0.f;
@@ -495,6 +512,7 @@ __global__ __launch_bounds__(512) void wgrad_bf16x3_kernel(const WgradX g) {
         const int last_rel = (int)(m_last - ms < 63 ? m_last - ms : 63);         // >= 0: the stage exists
         const float* bo = g.dZ + ms * g.ldz;
         const float* bi = g.In + ms * g.ldi;
+        const float* bz = BNZ ? g.z + ms * g.ldzz : nullptr;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -503,11 +521,34 @@ __global__ __launch_bounds__(512) void wgrad_bf16x3_kernel(const WgradX g) {
                 const uint32_t kr = (uint32_t)(k < last_rel ? k : last_rel);
                 vo[ks][e] = bo[kr * ldz + co];          // raw: masking waits for publish, so nothing here depends on the
                 vi[ks][e] = bi[kr * ldi + ci];          // loads and they stay in flight across the MFMA block
+                if (BNZ) vz[ks][e] = bz[kr * ldzz + co];
             }
         gathered_last = last_rel;
+        gathered_ms = ms;
     };
     auto publish = [&](int buf) {
         uint8_t* base = lds_f + buf * 65536;
+        if (BNZ) {      // dY -> dZ in registers, back to HBM in place (rows past the range are clamped duplicates of the last row: same value)
+            float* wb = g.dZ + gathered_ms * g.ldz;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float dz = z_k * (vo[ks][e] - z_ma - ((vz[ks][e] - z_mu) * z_is) * z_mb);
+                    vo[ks][e] = dz;
+                    z_sum += (h * 8 + ks * 16 + e <= gathered_last) ? dz : 0.f;
+                }
+            if (ok_o) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int k = h * 8 + ks * 16 + e;
+                        const uint32_t kr = (uint32_t)(k < gathered_last ? k : gathered_last);
+                        wb[kr * ldz + co] = vo[ks][e];
+                    }
+            }
+        }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             u32x4 oh, ol, ih, il;
@@ -575,6 +616,10 @@ __global__ __launch_bounds__(512) void wgrad_bf16x3_kernel(const WgradX g) {
         if (s + 1 < n_stages) publish((s + 1) & 1);          // that buffer was last read in stage s-1, behind the previous barrier
         __syncthreads();
     }
+    if (BNZ && g.dbias) {      // d bias += bias_alpha * sum_m dZ[m, col]: the two half-waves hold the two row halves of the column
+        const float tot = z_sum + __shfl_xor(z_sum, 32, 64);
+        if (h == 0 && ok_o) atomicAdd(g.dbias + col_o, g.bias_alpha * tot);
+    }
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -590,15 +635,18 @@ __global__ __launch_bounds__(512) void wgrad_bf16x3_kernel(const WgradX g) {
         }
 }
 
-hipError_t launch_wgrad_bf16x3(const float* dZ, int64_t ldz, const float* In, int64_t ldi, int64_t M, int n_out, int n_in, float alpha,
-                               float* dW, int64_t ldw, hipStream_t st, const float* in_tab, int in_cols) {
+hipError_t launch_wgrad_bf16x3(float* dZ, int64_t ldz, const float* In, int64_t ldi, int64_t M, int n_out, int n_in, float alpha,
+                               float* dW, int64_t ldw, hipStream_t st, const float* in_tab, int in_cols, const WgradBN* bn) {
     if (M <= 0 || n_out <= 0 || n_in <= 0) return hipSuccess;
     if (ldz >= (1 << 24) || ldi >= (1 << 24)) return hipErrorInvalidValue;      // 32-bit lane offsets: 64 rows x ld
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)wgrad_bf16x3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wgrad_bf16x3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-        if (e != hipSuccess) return e;
+        const void* fns[4] = {(const void*)wgrad_bf16x3_kernel<true, false>, (const void*)wgrad_bf16x3_kernel<false, false>,
+                              (const void*)wgrad_bf16x3_kernel<true, true>, (const void*)wgrad_bf16x3_kernel<false, true>};
+        for (const void* f : fns) {
+            hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+            if (e != hipSuccess) return e;
+        }
         attr_done = true;
     }
     WgradX g{};
@@ -612,10 +660,18 @@ hipError_t launch_wgrad_bf16x3(const float* dZ, int64_t ldz, const float* In, in
     if (rows < 4 * WG_STAGE) rows = 4 * WG_STAGE;
     bx = (M + rows - 1) / rows;
     g.rows_per_block = rows;
-    if (n_out % 256 == 0 && n_in % 256 == 0)
-        hipLaunchKernelGGL(wgrad_bf16x3_kernel<true>, dim3((unsigned)bx, by, bz), dim3(512), 131072, st, g);
-    else
-        hipLaunchKernelGGL(wgrad_bf16x3_kernel<false>, dim3((unsigned)bx, by, bz), dim3(512), 131072, st, g);
+    const bool full = n_out % 256 == 0 && n_in % 256 == 0;
+    const dim3 grid((unsigned)bx, by, bz), block(512);
+    if (bn) {
+        if (bz != 1) return hipErrorInvalidValue;            // in-place dZ: every element must be gathered exactly once
+        g.z = bn->z; g.ldzz = bn->ldz; g.bn_gamma = bn->gamma; g.bn_mu = bn->mu; g.bn_istd = bn->istd; g.bn_sdy = bn->sdy; g.bn_sdyx = bn->sdyx;
+        g.bn_inv_m = bn->inv_m; g.bias_alpha = bn->bias_alpha; g.dbias = bn->dbias;
+        if (full) hipLaunchKernelGGL((wgrad_bf16x3_kernel<true, true>), grid, block, 131072, st, g);
+        else hipLaunchKernelGGL((wgrad_bf16x3_kernel<false, true>), grid, block, 131072, st, g);
+    } else {
+        if (full) hipLaunchKernelGGL((wgrad_bf16x3_kernel<true, false>), grid, block, 131072, st, g);
+        else hipLaunchKernelGGL((wgrad_bf16x3_kernel<false, false>), grid, block, 131072, st, g);
+    }
     return hipGetLastError();
 }
 

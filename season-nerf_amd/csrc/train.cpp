@@ -271,11 +271,15 @@ static hipError_t linear_dgrad(snerf_trainer* t, const LayerP& L, const float* d
     return launch_gemm(g, st);
 }
 // dW[n_out, n_in] += alpha * dZ^T In   (split over the point dimension, fp32 atomics)
-static hipError_t linear_wgrad(snerf_trainer* t, const LayerP& L, const float* dZ, int64_t ldz, Act InA, int64_t M, float alpha, hipStream_t st) {
+// can the BatchNorm dZ pass ride in the weight-gradient kernel?  (bf16x3 path, one block column over the inputs: in-place dZ)
+static bool wgrad_bn_ok(const snerf_trainer* t, const LayerP& L, int64_t M) { return t->gemm_mode == 1 && M >= 1024 && L.n_in <= 256; }
+static hipError_t linear_wgrad(snerf_trainer* t, const LayerP& L, float* dZ, int64_t ldz, Act InA, int64_t M, float alpha, hipStream_t st,
+                               const WgradBN* bn = nullptr) {
     const float* In = InA.p;
     const int64_t ld_in = InA.ld;
     if (t->gemm_mode == 1 && M >= 1024)
-        return launch_wgrad_bf16x3(dZ, ldz, In, ld_in, M, L.n_out, L.n_in, alpha, t->grads + L.w, L.n_in, st, InA.tab, InA.tab ? InA.cols : 0);
+        return launch_wgrad_bf16x3(dZ, ldz, In, ld_in, M, L.n_out, L.n_in, alpha, t->grads + L.w, L.n_in, st, InA.tab, InA.tab ? InA.cols : 0, bn);
+    if (bn) return hipErrorInvalidValue;
     if (InA.tab) return hipErrorInvalidValue;
     GemmArgs g{};
     g.A = dZ; g.B = In; g.C = t->grads + L.w;
@@ -356,8 +360,16 @@ static int sine_bwd(snerf_trainer* t, const LayerP& L, Act D, Act Z, Act In, int
             HIPCK(launch_copy_cols(sdyx, C, t->grads + L.g, C, 1, C, true, st));
         }
         RCI(all_reduce(t, t->bn_bwd, 2 * t->W, false, st));                               // the BatchNorm backward means are global
+        const int64_t Mg = M * (t->ar_fn ? t->world : 1);
+        if (pre_activated && wgrad_bn_ok(t, L, M)) {
+            // D holds dL/dY: the dZ sweep rides in the weight-gradient kernel (dY -> dZ in registers, written back in place)
+            WgradBN bn{Z.p, Z.ld, t->params + L.g, mean, istd, sdy, sdyx, 1.f / (float)Mg, 30.f, t->grads + L.b};
+            HIPCK(linear_wgrad(t, L, D.p, D.ld, In, M, 30.f, st, &bn));
+            if (dIn.p) HIPCK(linear_dgrad(t, L, D.p, D.ld, M, dIn.p, dIn.ld, n_in_cols, 30.f, accumulate_in, st, below, fused_below));
+            return SNERF_OK;
+        }
         HIPCK(launch_bn_bwd2(Z.p, D.p, M, C, Z.ld, D.ld, mean, istd, t->params + L.g, t->params + L.beta, sdy, sdyx, t->grads + L.b, 30.f,
-                             M * (t->ar_fn ? t->world : 1), st, pre_activated));
+                             Mg, st, pre_activated));
     } else if (pre_activated) {
         HIPCK(launch_act_sums_finalize(t->bn_stats, C, 30.f, nullptr, nullptr, t->grads + L.b, nullptr, st));     // d bias = 30 * sum dZ
     } else {
@@ -375,7 +387,7 @@ static int plain_fwd(snerf_trainer* t, const LayerP& L, Act In, int64_t M, float
     HIPCK(linear_fwd(t, L, In, M, Out, ldo, 1.f, nullptr, st));
     return SNERF_OK;
 }
-static int plain_bwd(snerf_trainer* t, const LayerP& L, const float* dOut, int64_t ldo, Act In, int64_t M,
+static int plain_bwd(snerf_trainer* t, const LayerP& L, float* dOut, int64_t ldo, Act In, int64_t M,
                      float* dIn, int64_t ld_din, bool accumulate, hipStream_t st, const ActBelow* below = nullptr, bool* fused_below = nullptr) {
     if (fused_below) *fused_below = false;
     HIPCK(linear_wgrad(t, L, dOut, ldo, In, M, 1.f, st));
@@ -769,7 +781,7 @@ int snerf_linear_wgrad(int64_t n_points, int n_in, int n_out, const float* d_gra
     if (d_act_tab && (precision != 1 || act_cols < 1 || act_cols > n_in))
         return snerf_set_error(SNERF_E_INVALID, "snerf_linear_wgrad: activation on load needs the bf16x3 path and 1 <= act_cols <= n_in");
     if (precision == 1) {
-        HIPCK(launch_wgrad_bf16x3(d_grad_out, ld_go, d_in, ld_in, n_points, n_out, n_in, alpha, d_grad_weight, n_in, st, d_act_tab, act_cols));
+        HIPCK(launch_wgrad_bf16x3(const_cast<float*>(d_grad_out), ld_go, d_in, ld_in, n_points, n_out, n_in, alpha, d_grad_weight, n_in, st, d_act_tab, act_cols));      // read-only without the BatchNorm option
         return SNERF_OK;
     }
     GemmArgs g{};

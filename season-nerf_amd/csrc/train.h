@@ -47,8 +47,18 @@ hipError_t launch_split_weights(const float* W, int rows, int cols, bool transpo
 int gemm_rows_group_tiles(int ksteps);      // 0 = K too large for the LDS-resident weight layout (caller falls back to fp32 MFMA)
 hipError_t launch_gemm_bf16x3(const GemmX& g, hipStream_t st);
 // bf16x3 weight gradient: dW[n_out, n_in] (ld ldw) += alpha * dZ[M, n_out]^T In[M, n_in]   (fp32 atomics over M-chunks)
-hipError_t launch_wgrad_bf16x3(const float* dZ, int64_t ldz, const float* In, int64_t ldi, int64_t M, int n_out, int n_in, float alpha,
-                               float* dW, int64_t ldw, hipStream_t st, const float* in_tab = nullptr, int in_cols = 0);
+// optional BatchNorm backward folded into the weight-gradient kernel (dZ holds dL/dY on entry, dL/dZ on exit; needs n_in <= 256)
+struct WgradBN {
+    const float* z;            // pre-activation of this layer [M, ldz]
+    int64_t ldz;
+    const float *gamma, *mu, *istd, *sdy, *sdyx;
+    float inv_m;               // 1 / rows of the (global) batch the means were taken over
+    float bias_alpha;
+    float* dbias;              // += bias_alpha * sum_m dZ
+};
+hipError_t launch_wgrad_bf16x3(float* dZ, int64_t ldz, const float* In, int64_t ldi, int64_t M, int n_out, int n_in, float alpha,
+                               float* dW, int64_t ldw, hipStream_t st, const float* in_tab = nullptr, int in_cols = 0,
+                               const WgradBN* bn = nullptr);
 
 // ---- elementwise / reduction kernels of the training path (train_kernels.hip)
 struct PeArgs {            // positions (from rays or explicit) -> PE(pos) [N,64] (63 features + zero pad) and points [N,3]

@@ -234,11 +234,16 @@ def test_checkpoint_resume(golden_dir, tmp_path):
     assert net2._param_store.adam_steps == 2
     step(g, net2, ev2, data2, opt2, 3)
     got = {k: v.detach().cpu().clone() for k, v in net2.state_dict().items()}
+    # the atomically reduced gradients differ run to run in the last bits, and Adam turns near-zero gradients into visible
+    # +-lr jitter on single elements: compare the typical (mean) deviation, which a lost optimiser state raises by 100x
+    key = "G_NeRF_net.fc3.linear.weight"
+    resumed = float((got[key] - want[key]).abs().mean())
+    assert resumed < 5e-6, resumed                            # lr = 1e-3
     worst = max(float((got[k].float() - v.float()).abs().max()) for k, v in want.items() if v.is_floating_point())
-    assert worst < 2e-5, worst                                # lr = 1e-3: 2 % of one update
+    assert worst < 5e-4, worst
 
     sn, g, net3, ev3, data3, opt3 = fresh()                   # same checkpoint, optimiser state NOT restored
     net3.load_state_dict(torch.load(tmp_path / "model.nn"))
     step(g, net3, ev3, data3, opt3, 3)
-    w3 = net3.state_dict()["G_NeRF_net.fc3.linear.weight"].cpu()
-    assert float((w3 - want["G_NeRF_net.fc3.linear.weight"]).abs().max()) > 1e-4
+    w3 = net3.state_dict()[key].cpu()
+    assert float((w3 - want[key]).abs().mean()) > 20 * max(resumed, 1e-6)
