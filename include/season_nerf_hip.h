@@ -198,7 +198,7 @@ int snerf_trainer_set_allreduce(snerf_trainer* t, snerf_allreduce_fn fn, void* u
  * d_act_tab holds [a | b], each act_cols floats, with BatchNorm and the 1/(2 pi) folded in: a = gamma*istd/(2 pi),
  * b = (beta - gamma*mu*istd)/(2 pi)  (a = 1/(2 pi), b = 0 without BatchNorm); forward needs act_cols % 8 == 0.
  * The training engine uses this so that post-activations are never written to HBM.
- * Activation backward in the dgrad epilogue (bf16x3, no accumulation): with d_below_z != NULL, grad_in is dL/dH of the SineLayer
+ * Activation backward in the dgrad epilogue (bf16x3; with `accumulate` this call must be the last producer): with d_below_z != NULL, grad_in is dL/dH of the SineLayer
  * below, whose pre-activation is d_below_z [n_points, ld_below_z] and table d_below_tab ([a | b], n_cols each); what is written
  * is dL/dH * cos(2 pi (a z + b)), and d_sums (caller-zeroed double[2][n_cols]) += sum_m of it and of it times
  * xhat = (z - mu)*istd (d_below_mu / d_below_istd, NULL for a layer without BatchNorm: second sum 0). */

@@ -390,7 +390,7 @@ __global__ __launch_bounds__(512) void gemm_rows_kernel(const GemmX g) {
                     if (nok && m < g.M) {
                         float v = g.alpha * (acc[i][j][e] + bias);
                         float* c = g.C + m * g.ldc + n;
-                        if (!ACT && g.accumulate) v += *c;
+                        if (g.accumulate) v += *c;                       // ACT: this dgrad is the last of several producers of dL/dH
                         if (ACT) {
                             const float z = zt[i][e];
                             v *= __builtin_amdgcn_cosf(__builtin_fmaf(e_a, z, e_b));
@@ -708,7 +708,7 @@ hipError_t launch_gemm_bf16x3(const GemmX& g, hipStream_t st) {
     const bool aol = g.act_tab != nullptr && g.act_cols > 0;
     const bool act = g.ez != nullptr;
     if (aol && (g.act_cols % 8 != 0 || g.act_cols > g.K || (uintptr_t)g.act_tab % 16 != 0)) return hipErrorInvalidValue;
-    if (act && (aol || g.accumulate || !g.stats || !g.etab)) return hipErrorInvalidValue;
+    if (act && (aol || !g.stats || !g.etab)) return hipErrorInvalidValue;
     GemmX gx = g;
     gx.tab_lds = 0;
     size_t lds_total = lds;

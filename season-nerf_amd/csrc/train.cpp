@@ -254,7 +254,7 @@ static hipError_t linear_dgrad(snerf_trainer* t, const LayerP& L, const float* d
         if (e != hipSuccess) return e;
         x.A = dZ; x.frag = t->w_frag; x.C = dIn; x.M = M; x.N = n_cols; x.K = L.n_out; x.lda = ldz; x.ldc = ld_in;
         x.alpha = alpha; x.bias = nullptr; x.stats = nullptr; x.accumulate = accumulate ? 1 : 0;
-        if (below && below->tab && !accumulate && below->L->n_out == n_cols) {
+        if (below && below->tab && below->L->n_out == n_cols) {      // with `accumulate` the caller guarantees this is the last producer
             e = hipMemsetAsync(t->bn_stats, 0, 2 * n_cols * sizeof(double), st);
             if (e != hipSuccess) return e;
             x.stats = t->bn_stats; x.ez = below->Z.p; x.eld = below->Z.ld; x.etab = below->tab;
@@ -345,11 +345,12 @@ static int sine_bwd(snerf_trainer* t, const LayerP& L, Act D, Act Z, Act In, int
     if (L.bn) {
         float *mean = bnslot + 2 * t->W, *istd = bnslot + 3 * t->W;
         float *sdy = t->bn_bwd, *sdyx = t->bn_bwd + t->W;
+        HIPCK(hipMemsetAsync(t->bn_bwd, 0, 2 * t->W * sizeof(float), st));      // [2][W]: a narrower layer leaves the tails zero (the
+                                                                                 // whole buffer goes through the sync-BatchNorm all-reduce)
         if (pre_activated) {
             // d beta += sum dY, d gamma += sum dY*xhat (per-rank sums), and the fp32 copies the dZ pass reads
             HIPCK(launch_act_sums_finalize(t->bn_stats, C, 1.f, sdy, sdyx, t->grads + L.beta, t->grads + L.g, st));
         } else {
-            HIPCK(hipMemsetAsync(t->bn_bwd, 0, 2 * t->W * sizeof(float), st));
             ColArgs ca{};
             ca.mode = 1; ca.M = M; ca.C = C; ca.ld = Z.ld; ca.Z = Z.p; ca.D = D.p; ca.mu = mean; ca.istd = istd;
             ca.gamma = t->params + L.g; ca.beta = t->params + L.beta; ca.out0 = sdy; ca.out1 = sdyx; ca.alpha0 = 1.f;
@@ -608,14 +609,18 @@ int snerf_trainer_backward_image(snerf_trainer* t, const float* d_g_rgb, const f
         RC(sine_bwd(t, Ls[L_A1], Act{t->dA.p, W}, P.Za[0], X1, N, nullptr, Act{t->dX1.p, W2}, W2, false, st, pre));
     }
     // sigma / colour heads
+    // dL/dX1 is summed from the adjust branch, the two heads and (classic solar) the solar branch: the LAST of these dgrads
+    // also applies fc9's activation backward in its epilogue
+    const ActBelow b9{&Ls[L_FC9], P.Z[8], tab_of(8), P.bn + 7 * 4 * W};
+    bool pre9 = false;
     RC(plain_bwd(t, Ls[L_COL], t->d_head, 4, X1, N, t->dX1.p, W2, true, st));
-    RC(plain_bwd(t, Ls[L_SIG], t->d_head + 3, 4, X1, N, t->dX1.p, W2, true, st));
+    RC(plain_bwd(t, Ls[L_SIG], t->d_head + 3, 4, X1, N, t->dX1.p, W2, true, st, classic ? nullptr : &b9, classic ? nullptr : &pre9));
     if (classic) {      // the solar-visibility branch carries gradient from the image (G_NeRF.py:100-108), on into X1
         const ActBelow s3{&Ls[L_S3], P.Zs[2], tab_of(14), nullptr}, s2{&Ls[L_S2], P.Zs[1], tab_of(13), nullptr}, s1{&Ls[L_S1], P.Zs[0], tab_of(12), nullptr};
         RC(plain_bwd(t, Ls[L_S4], t->d_sv_raw, 1, P.Hsc[2], N, t->dA.p, W2, false, st, &s3, &pre));
         RC(sine_bwd(t, Ls[L_S3], Act{t->dA.p, W2}, P.Zs[2], P.Hsc[1], N, nullptr, Act{t->dB.p, W2}, W2, false, st, pre, &s2, &pre));
         RC(sine_bwd(t, Ls[L_S2], Act{t->dB.p, W2}, P.Zs[1], P.Hsc[0], N, nullptr, Act{t->dA.p, W2}, W2, false, st, pre, &s1, &pre));
-        RC(sine_bwd(t, Ls[L_S1], Act{t->dA.p, W2}, P.Zs[0], P.In_s1c, N, nullptr, Act{t->dX1.p, W2}, W2, true, st, pre));
+        RC(sine_bwd(t, Ls[L_S1], Act{t->dA.p, W2}, P.Zs[0], P.In_s1c, N, nullptr, Act{t->dX1.p, W2}, W2, true, st, pre, &b9, &pre9));
     }
     // trunk
     float* cur = t->dA.p;
@@ -625,7 +630,7 @@ int snerf_trainer_backward_image(snerf_trainer* t, const float* d_g_rgb, const f
     };
     {
         const ActBelow b = below_of(7);
-        RC(sine_bwd(t, Ls[L_FC9], Act{t->dX1.p, W2}, P.Z[8], P.Hc[7], N, P.bn + 7 * 4 * W, Act{cur, W}, W, false, st, false, &b, &pre));
+        RC(sine_bwd(t, Ls[L_FC9], Act{t->dX1.p, W2}, P.Z[8], P.Hc[7], N, P.bn + 7 * 4 * W, Act{cur, W}, W, false, st, pre9, &b, &pre));
     }
     for (int l = 7; l >= 1; --l) {
         const Act In = l == 4 ? P.In5c : P.Hc[l - 1];
@@ -755,8 +760,8 @@ int snerf_linear_dgrad(int64_t n_points, int n_in, int n_out, const float* d_gra
         x.A = d_grad_out; x.frag = (const uint16_t*)d_scratch; x.C = d_grad_in; x.M = n_points; x.N = n_cols; x.K = n_out; x.lda = ld_go; x.ldc = ld_gi;
         x.alpha = alpha; x.bias = nullptr; x.stats = nullptr; x.accumulate = accumulate ? 1 : 0;
         if (d_below_z) {
-            if (!d_below_tab || !d_sums || accumulate || ld_below_z < n_cols || (!d_below_mu) != (!d_below_istd))
-                return snerf_set_error(SNERF_E_INVALID, "snerf_linear_dgrad: the activation-backward epilogue needs table and sums, no accumulation");
+            if (!d_below_tab || !d_sums || ld_below_z < n_cols || (!d_below_mu) != (!d_below_istd))
+                return snerf_set_error(SNERF_E_INVALID, "snerf_linear_dgrad: the activation-backward epilogue needs table and sums");
             x.ez = d_below_z; x.eld = ld_below_z; x.etab = d_below_tab; x.emu = d_below_mu; x.eistd = d_below_istd; x.stats = d_sums;
         }
         HIPCK(launch_gemm_bf16x3(x, st));

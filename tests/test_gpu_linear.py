@@ -181,6 +181,13 @@ def test_dgrad_activation_backward_epilogue(shape):
     np.testing.assert_allclose(s_[0], ref.sum(0).cpu().numpy(), rtol=0, atol=3e-4 * float(ref.abs().sum(0).max()))
     want1 = (ref * xh).sum(0).cpu().numpy() if bn else np.zeros(n_cols)
     np.testing.assert_allclose(s_[1], want1, rtol=0, atol=3e-4 * float((ref * xh).abs().sum(0).max()) + 1e-12)
-    # accumulate together with the epilogue is refused
-    assert L.snerf_linear_dgrad(M, n_in, n_out, dZ.data_ptr(), n_out, Wt.data_ptr(), n_cols, 30.0, 1, out.data_ptr(), n_cols, 1, sc.data_ptr(),
-                                sc.numel(), Zb.data_ptr(), n_cols + 4, tab.data_ptr(), None, None, sums.data_ptr(), st) != 0
+    # with accumulation (the last of several producers of dL/dH): (previous + this product) * cos
+    prev = torch.randn(M, n_cols, generator=g).cuda()
+    out2 = prev.clone()
+    sums.zero_()
+    sn._lib.check(L.snerf_linear_dgrad(M, n_in, n_out, dZ.data_ptr(), n_out, Wt.data_ptr(), n_cols, 30.0, 1, out2.data_ptr(), n_cols, 1,
+                                       sc.data_ptr(), sc.numel(), Zb.data_ptr(), n_cols + 4, tab.data_ptr(),
+                                       mu_f.data_ptr() if bn else None, is_f.data_ptr() if bn else None, sums.data_ptr(), st), "dgrad(act, accumulate)")
+    ref2 = (30.0 * (dZ.double() @ Wt.double()[:, :n_cols]) + prev.double()) * torch.cos(gam.cuda() * xh + bet.cuda())
+    assert _rel(out2, ref2) < 2 * TOL[1]
+    np.testing.assert_allclose(sums.cpu().numpy()[0], ref2.sum(0).cpu().numpy(), rtol=0, atol=3e-4 * float(ref2.abs().sum(0).max()))
