@@ -178,14 +178,14 @@ def bench_train(a):
         return sum((i + o) + (2 * o if (k == "sine" and not aol) else 0) for o, i, k, _ in (rows[n] for n in names))
 
     def bwd_bytes(names, dgrad_first=True):
-        # activation backward of a SineLayer: fused into the epilogue of the dgrad above it (reads Z once: o) when that dgrad is
-        # its only producer - every layer except fc9 (its gradient is summed from several branches) - else a reduction sweep;
+        # activation backward of a SineLayer: fused into the epilogue of the (last) dgrad that produces its output gradient
+        # (reads Z once: o), else a reduction sweep;
         # BatchNorm layers add the dZ computation (a sweep: read Z, dY, write dZ = 3 o - or folded into wgrad, see below)
         tot = 0
         for j, n in enumerate(names):
             o, i, k, bn = rows[n]
             if k == "sine":
-                fused = aol and not n.endswith("fc9")
+                fused = aol
                 tot += o if fused else (2 * o if bn else 3 * o)
                 if bn:      # dZ: inside the weight-gradient kernel (reads Z, rewrites dY in place: 2 o) where the layer has <= 256 inputs
                     tot += 2 * o if (fused and i <= 256) else 3 * o
@@ -210,7 +210,7 @@ def bench_train(a):
                             "note": "whole step, not one kernel: train-mode BatchNorm forces a layer-wise design in which every layer is "
                                     "a pass over [393216 x width] fp32 arrays; achieved = bytes that design moves per step (counted from "
                                     "the layer table, DESIGN 5.4) / step time, peak = HBM3E 8 TB/s (MI355X_MICROARCH.md); "
-                                    "per-kernel times in profiles/r1/h_train_kernel_stats.csv"}}
+                                    "per-kernel times in profiles/r1/i_train_kernel_stats.csv"}}
         if not a.no_cpu_baseline and world == 1:      # reported at N = 1 only (rank 0)
             from oracle import season_nerf_oracle as orc          # CPU-baseline leg only
             torch.set_num_threads(min(host_cpus(), 32))
@@ -349,7 +349,7 @@ def main():
         achieved = FLOP_PER_SAMPLE * R * S / (field_ms * 1e-3)
         traffic = None          # HBM bytes per launch from the committed PMC passes of this same command (profiles/)
         try:
-            traffic = json.load(open(os.path.join(REPO, "profiles", "r1", "h_traffic.json")))["bytes_per_launch"]
+            traffic = json.load(open(os.path.join(REPO, "profiles", "r1", "i_traffic.json")))["bytes_per_launch"]
         except Exception:
             pass
         out = {
