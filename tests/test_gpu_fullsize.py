@@ -138,3 +138,38 @@ def test_training_step_full_size_cross_check(monkeypatch):
     _, g2 = run("bf16x3", scale=2.0)                         # backward is linear in the output gradient
     lin = max(float((g2[n] - 2 * g16[n]).abs().max()) / max(float(g16[n].abs().max()), 1e-3 * gmax) for n in g16)
     assert lin < 2e-3, lin                                   # two runs differ by the summation order of the atomic reductions
+
+
+def test_training_trajectory_fused_vs_fp32(monkeypatch):
+    """12 optimiser steps at the benchmark size: the fused bf16x3 pipeline (activation on load, activation backward in the dgrad
+    epilogue, BatchNorm dZ inside wgrad) follows the loss trajectory of the unfused exact-fp32 pipeline, and the loss goes down."""
+    import season_nerf_amd as sn
+    rng = np.random.Generator(np.random.PCG64(6))
+    t = lambda a: torch.tensor(a, dtype=torch.float32)
+    top = np.concatenate([rng.uniform(-1, 1, (R, 2)), np.ones((R, 1))], 1)
+    bot = np.concatenate([rng.uniform(-1, 1, (R, 2)), -np.ones((R, 1))], 1)
+    sun = rng.uniform(0.1, 1, (R, 3)); sun /= np.linalg.norm(sun, axis=1, keepdims=True)
+    tau = rng.uniform(0, 1, (R, 2))
+    tim = np.stack([np.cos(6.28 * tau[:, 0]), np.sin(6.28 * tau[:, 0]), np.cos(6.28 * tau[:, 1]), np.sin(6.28 * tau[:, 1])], 1)
+    data = {"Top": t(top), "Bot": t(bot), "Sun_Angle": t(sun), "Time_Encoded": t(tim), "GT_Color": t(rng.uniform(0, 1, (R, 3)))}
+    args = SimpleNamespace(n_samples=S, Use_Reg=True, Solar_Type_2=False, Use_MSE_loss=True, Use_Solar=True, sc_lambda=0.03,
+                           number_low_frequency_cases=C)
+    WC, H4 = np.array([41.29, -95.9, 300.0]), np.array([[310.0, 12.0, 0.0, -11650.0], [-9.0, 240.0, 0.0, 23390.0], [0.0, 0.0, 0.01, -3.0], [0, 0, 0, 1.0]])
+
+    def run(mode):
+        monkeypatch.setenv("SNERF_TRAIN_GEMM", mode)
+        net = sn.T_NeRF(W, C)
+        net.load_state_dict(sn.synthetic_state_dict(net, 0, bn_stats="identity"))
+        net = net.to("cuda").train()
+        ev = sn.All_in_One_Eval(args, torch.device("cuda"), 10, False, None, H4, WC)
+        tool = sn.Net_tool(net, ev, lr=3e-4, total_steps=12)
+        np.random.seed(0)
+        torch.manual_seed(0)                                  # same jitter and random sun rays in both runs
+        vals = [float(tool.train_step(data, i)["Color"][0].detach()) for i in range(12)]
+        assert all(bool(torch.isfinite(p).all()) for p in net.parameters())
+        del net._train_engines, net._train_engine
+        return vals
+
+    fused, exact = run("bf16x3"), run("fp32")
+    np.testing.assert_allclose(fused, exact, rtol=2e-3)
+    assert fused[-1] < 0.9 * fused[0]
