@@ -247,3 +247,41 @@ def test_checkpoint_resume(golden_dir, tmp_path):
     step(g, net3, ev3, data3, opt3, 3)
     w3 = net3.state_dict()[key].cpu()
     assert float((w3 - want[key]).abs().mean()) > 20 * max(resumed, 1e-6)
+
+
+def test_ragged_batch_vs_oracle():
+    """33 rays x 37 samples = 1221 points: not a multiple of the 32-row wave tile, the 256-row workgroup tile or the 32-point
+    wgrad stage - the fused bf16x3 pipeline (masked tiles, clamped gathers, in-place BatchNorm dZ on a partial stage) against the
+    oracle's autograd."""
+    import season_nerf_amd as sn
+    W, C, R, S = 64, 4, 33, 37
+    sd = orc.init_weights(W, C, 9, bn_stats="identity")
+    net = sn.T_NeRF(W, C)
+    net.load_state_dict(sd)
+    net = net.to("cuda").train()
+    rng = np.random.Generator(np.random.PCG64(12))
+    sun = rng.uniform(0.1, 1, (R, 3)); sun /= np.linalg.norm(sun, axis=1, keepdims=True)
+    tau = rng.uniform(0, 1, (R, 2))
+    data = {"Top": T(np.concatenate([rng.uniform(-1, 1, (R, 2)), np.ones((R, 1))], 1)),
+            "Bot": T(np.concatenate([rng.uniform(-1, 1, (R, 2)), -np.ones((R, 1))], 1)), "Sun_Angle": T(sun),
+            "Time_Encoded": T(np.stack([np.cos(6.28 * tau[:, 0]), np.sin(6.28 * tau[:, 0]), np.cos(6.28 * tau[:, 1]), np.sin(6.28 * tau[:, 1])], 1)),
+            "GT_Color": T(rng.uniform(0, 1, (R, 3)))}
+    st = np.concatenate([rng.uniform(-1, 1, (R, 2)), np.ones((R, 1))], 1)
+    solar = {"Top": T(st), "Bot": T(st - 2 * sun / sun[:, 2:]), "Sun_Angle": T(sun)}
+    args = SimpleNamespace(n_samples=S, Use_Reg=True, Solar_Type_2=False, Use_MSE_loss=True, Use_Solar=True, sc_lambda=0.03,
+                           number_low_frequency_cases=C)
+    ev = sn.All_in_One_Eval(args, torch.device("cuda"), 10, False, None, np.eye(4), np.zeros(3))
+    ev.solar_creation_tool = lambda n, include_times=True: (solar["Top"], solar["Bot"], solar["Sun_Angle"], torch.zeros(R, 4), None)
+    loss = ev.get_loss(data, net, 0, False)                          # eval-mode sampling (no jitter), batch-statistics BatchNorm
+    total = sum(v * w for v, w in loss.values())
+    total.backward()
+    sd_g = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
+    ref_loss, _ = orc.get_loss_mse(sd_g, data, solar, S, 0.03, train_mode=False, train_bn=True)
+    orc.total_loss(ref_loss).backward()
+    for k, (v, w) in ref_loss.items():
+        assert abs(float(loss[k][0].detach()) - float(v)) <= 2e-5 * max(1.0, abs(float(v))) + 1e-6, k
+    params = dict(net.named_parameters())
+    live = [n for n, v in sd_g.items() if v.is_floating_point() and v.grad is not None and float(v.grad.abs().max()) > 0]
+    gmax = max(float(sd_g[n].grad.abs().max()) for n in live)
+    worst = max(float((params[n].grad.cpu() - sd_g[n].grad).abs().max()) / max(float(sd_g[n].grad.abs().max()), 1e-3 * gmax) for n in live)
+    assert worst < 2e-3, worst
