@@ -33,34 +33,45 @@ __device__ __forceinline__ void pe_sc(float x, int j, float& c, float& s) {
     s = (float)sin(ang);
 }
 
+// one lane per output feature: a wavefront writes one 256-byte row of PE(pos) per pass (coalesced; the thread-per-point form
+// scattered 64 dword stores over 64 rows and moved 13x the bytes).  cos(a) is evaluated as sin(a + 1/4 revolution): the reduced
+// argument f is exact in fp64, so is f + 0.25
 __global__ void pe_points_kernel(const PeArgs A) {
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < A.n; i += (int64_t)gridDim.x * blockDim.x) {
-        float x[3];
+    const int64_t total = A.n * 64;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = e >> 6;
+        const int f = (int)(e & 63);
+        const int k = f - 3;
+        const int d = f < 3 ? f : (f == 63 ? 0 : k / 20);
+        float x;
         if (A.points) {
-            x[0] = A.points[i * 3]; x[1] = A.points[i * 3 + 1]; x[2] = A.points[i * 3 + 2];
+            x = A.points[i * 3 + d];
         } else {
             const int64_t r = i / A.n_samples;
             const int s = (int)(i - r * A.n_samples);
             const float t = A.tvals[s], omt = __fsub_rn(1.f, t);
-#pragma unroll
-            for (int d = 0; d < 3; ++d) x[d] = __fadd_rn(__fmul_rn(A.top[r * 3 + d], omt), __fmul_rn(A.bot[r * 3 + d], t));
+            x = __fadd_rn(__fmul_rn(A.top[r * 3 + d], omt), __fmul_rn(A.bot[r * 3 + d], t));
         }
-        if (A.pts) { A.pts[i * 3] = x[0]; A.pts[i * 3 + 1] = x[1]; A.pts[i * 3 + 2] = x[2]; }
-        float* o = A.pe + i * 64;
-        o[0] = x[0]; o[1] = x[1]; o[2] = x[2];
-#pragma unroll
-        for (int d = 0; d < 3; ++d)
-            for (int j = 0; j < 10; ++j) {
-                float c, s;
-                pe_sc(x[d], j, c, s);
-                o[3 + 20 * d + j] = c;
-                o[3 + 20 * d + 10 + j] = s;
-            }
-        o[63] = 0.f;
+        float v;
+        if (f < 3) {
+            v = x;
+            if (A.pts) A.pts[i * 3 + f] = x;
+        } else if (f == 63) {
+            v = 0.f;
+        } else {
+            const int q = k - 20 * d;               // 0..9 cos, 10..19 sin
+            const int j = q < 10 ? q : q - 10;
+            const float a0 = __fmul_rn(x, 1.57079637050628662109375f);
+            const double r = (double)a0 * 0.15915494309189533576888 * (double)(1 << j);
+            double fr = r - floor(r);
+            if (q < 10) fr += 0.25;
+            v = (float)sin(fr * 6.283185307179586476925287);
+        }
+        A.pe[e] = v;
     }
 }
 hipError_t launch_pe_points(const PeArgs& a, hipStream_t st) {
-    LAUNCH_1D(pe_points_kernel, a.n, st, a);
+    LAUNCH_1D(pe_points_kernel, a.n * 64, st, a);
     return hipGetLastError();
 }
 
