@@ -63,7 +63,7 @@ struct snerf_trainer {
         float* bn;             // [8 layers][4][W]: colsum, m2, mean, istd
         float *top, *bot, *tvals;   // engine-owned copies: the caller's tensors may be recycled before backward
         // what the consumers of each per-point SineLayer read: the materialised H, or (activation on load) Z + its table
-        Act Hc[9], Hac[3], Hsc[3], In5c, In_s1c, Zc3;
+        Act Hc[9], Hac[3], Hsc[3], In5c, In_s1c, Zc3, Zc8;
         float* tabs = nullptr;      // [15 layers][2][W] activation-on-load tables of this pass
         bool aol = false;
     } img, sol;
@@ -414,8 +414,8 @@ static int forward_pass(snerf_trainer* t, snerf_trainer::Pass& P, bool solar, in
     auto& Ls = t->layers;
     PeArgs pa{};
     pa.n = N; pa.n_samples = S; pa.top = top; pa.bot = bot; pa.tvals = tvals; pa.pe = P.E.p; pa.pts = P.pts;
+    pa.pe2 = P.In5.p + W; pa.ld2 = W + 64;                  // second copy: the PE columns of fc5's concat input
     HIPCK(launch_pe_points(pa, st));
-    HIPCK(launch_copy_cols(P.E.p, 64, P.In5.p + W, W + 64, N, 64, false, st));
     // Activation on load (per-point layers): store only the pre-activations Z; every consumer applies sin(BN(.)) while loading.
     // Needs the bf16x3 kernels for every consumer (K <= 512, widths multiples of 16) and enough points for them to be used.
     const bool aol = t->aol_mode == 1 && t->gemm_mode == 1 && N >= 1024 && W % 16 == 0 && gemm_rows_group_tiles((W + 64 + 15) / 16) > 0;
@@ -423,8 +423,11 @@ static int forward_pass(snerf_trainer* t, snerf_trainer::Pass& P, bool solar, in
     auto tab_of = [&](int slot) { return aol ? P.tabs + (int64_t)slot * 2 * W : (float*)nullptr; };       // slots: 0-8 trunk, 9-11 adjust, 12-14 solar
     auto view = [&](Act Z, Act H, int slot, int n) { return aol ? Act{Z.p, Z.ld, tab_of(slot), n} : H; };
     // fc4's output lives inside fc5's concat input [ . | PE]: its H without, its Z with activation on load
+    // likewise fc9's inside fc_solar_1's concat input [ . | PE(sun)]
     P.Zc3 = aol ? Act{P.In5.p, W + 64} : P.Z[3];
-    for (int l = 0; l < 9; ++l) P.Hc[l] = view(l == 3 ? P.Zc3 : P.Z[l], P.H[l], l, l == 8 ? W2 : W);
+    P.Zc8 = aol ? Act{P.In_s1.p, W2 + 28} : P.Z[8];
+    auto zof = [&](int l) { return l == 3 ? P.Zc3 : (l == 8 ? P.Zc8 : P.Z[l]); };
+    for (int l = 0; l < 9; ++l) P.Hc[l] = view(zof(l), P.H[l], l, l == 8 ? W2 : W);
     for (int l = 0; l < 3; ++l) { P.Hac[l] = view(P.Za[l], P.Ha[l], 9 + l, W); P.Hsc[l] = view(P.Zs[l], P.Hs[l], 12 + l, W2); }
     P.In5c = aol ? Act{P.In5.p, W + 64, tab_of(3), W} : Act{P.In5.p, W + 64};
     P.In_s1c = aol ? Act{P.In_s1.p, W2 + 28, tab_of(8), W2} : Act{P.In_s1.p, W2 + 28};
@@ -432,14 +435,14 @@ static int forward_pass(snerf_trainer* t, snerf_trainer::Pass& P, bool solar, in
     RC(sine_fwd(t, Ls[L_FC1], Act{P.E.p, 64}, N, P.Z[0], P.H[0], nullptr, train_bn, st, tab_of(0)));
     for (int l = 1; l < 9; ++l) {
         const Act In = l == 4 ? P.In5c : P.Hc[l - 1];
-        RC(sine_fwd(t, Ls[L_FC1 + l], In, N, l == 3 ? P.Zc3 : P.Z[l], P.H[l], P.bn + (l - 1) * 4 * W, train_bn, st, tab_of(l)));
+        RC(sine_fwd(t, Ls[L_FC1 + l], In, N, zof(l), P.H[l], P.bn + (l - 1) * 4 * W, train_bn, st, tab_of(l)));
     }
     const Act X1 = P.Hc[8];
     RC(plain_fwd(t, Ls[L_COL], X1, N, P.head.p, 4, st));
     RC(plain_fwd(t, Ls[L_SIG], X1, N, P.head.p + 3, 4, st));
     // solar visibility branch (G_NeRF.py:100-108)
     HIPCK(launch_pe_small(sun, 3, 3, 4, R, P.pe_sun, 28, st));
-    HIPCK(launch_copy_cols(X1.p, X1.ld, P.In_s1.p, W2 + 28, N, W2, false, st));
+    if (!aol) HIPCK(launch_copy_cols(X1.p, X1.ld, P.In_s1.p, W2 + 28, N, W2, false, st));
     HIPCK(launch_bcast_rows(P.pe_sun, 28, P.In_s1.p, W2 + 28, W2, N, S, st));
     RC(sine_fwd(t, Ls[L_S1], P.In_s1c, N, P.Zs[0], P.Hs[0], nullptr, train_bn, st, tab_of(12)));
     RC(sine_fwd(t, Ls[L_S2], P.Hsc[0], N, P.Zs[1], P.Hs[1], nullptr, train_bn, st, tab_of(13)));
@@ -611,7 +614,7 @@ int snerf_trainer_backward_image(snerf_trainer* t, const float* d_g_rgb, const f
     // sigma / colour heads
     // dL/dX1 is summed from the adjust branch, the two heads and (classic solar) the solar branch: the LAST of these dgrads
     // also applies fc9's activation backward in its epilogue
-    const ActBelow b9{&Ls[L_FC9], P.Z[8], tab_of(8), P.bn + 7 * 4 * W};
+    const ActBelow b9{&Ls[L_FC9], P.Zc8, tab_of(8), P.bn + 7 * 4 * W};
     bool pre9 = false;
     RC(plain_bwd(t, Ls[L_COL], t->d_head, 4, X1, N, t->dX1.p, W2, true, st));
     RC(plain_bwd(t, Ls[L_SIG], t->d_head + 3, 4, X1, N, t->dX1.p, W2, true, st, classic ? nullptr : &b9, classic ? nullptr : &pre9));
@@ -626,11 +629,11 @@ int snerf_trainer_backward_image(snerf_trainer* t, const float* d_g_rgb, const f
     float* cur = t->dA.p;
     float* nxt = t->dB.p;
     auto below_of = [&](int l) {        // trunk layer l (fc{l+1}) as the consumer of a dgrad's output
-        return ActBelow{&Ls[L_FC1 + l], l == 3 ? P.Zc3 : P.Z[l], tab_of(l), l >= 1 ? P.bn + (l - 1) * 4 * W : nullptr};
+        return ActBelow{&Ls[L_FC1 + l], l == 3 ? P.Zc3 : (l == 8 ? P.Zc8 : P.Z[l]), tab_of(l), l >= 1 ? P.bn + (l - 1) * 4 * W : nullptr};
     };
     {
         const ActBelow b = below_of(7);
-        RC(sine_bwd(t, Ls[L_FC9], Act{t->dX1.p, W2}, P.Z[8], P.Hc[7], N, P.bn + 7 * 4 * W, Act{cur, W}, W, false, st, pre9, &b, &pre));
+        RC(sine_bwd(t, Ls[L_FC9], Act{t->dX1.p, W2}, P.Zc8, P.Hc[7], N, P.bn + 7 * 4 * W, Act{cur, W}, W, false, st, pre9, &b, &pre));
     }
     for (int l = 7; l >= 1; --l) {
         const Act In = l == 4 ? P.In5c : P.Hc[l - 1];

@@ -67,6 +67,8 @@ struct PeArgs {            // positions (from rays or explicit) -> PE(pos) [N,64
     const float *points, *top, *bot, *tvals;
     float* pe;             // [N,64]
     float* pts;            // [N,3] or NULL
+    float* pe2;            // optional second copy of PE with row stride ld2 (a concat buffer's columns), or NULL
+    int64_t ld2;
 };
 hipError_t launch_pe_points(const PeArgs& a, hipStream_t st);
 // per-row encodings of small vectors: sun [G,3] -> [G,28] (27 + pad), time[:,0:2] [G,4] -> [G,12] (10 + pad)

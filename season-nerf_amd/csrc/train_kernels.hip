@@ -68,6 +68,7 @@ __global__ void pe_points_kernel(const PeArgs A) {
             v = (float)sin(fr * 6.283185307179586476925287);
         }
         A.pe[e] = v;
+        if (A.pe2) A.pe2[i * A.ld2 + f] = v;
     }
 }
 hipError_t launch_pe_points(const PeArgs& a, hipStream_t st) {
