@@ -272,13 +272,25 @@ static hipError_t linear_dgrad(snerf_trainer* t, const LayerP& L, const float* d
 }
 // dW[n_out, n_in] += alpha * dZ^T In   (split over the point dimension, fp32 atomics)
 // can the BatchNorm dZ pass ride in the weight-gradient kernel?  (bf16x3 path, one block column over the inputs: in-place dZ)
-static bool wgrad_bn_ok(const snerf_trainer* t, const LayerP& L, int64_t M) { return t->gemm_mode == 1 && M >= 1024 && L.n_in <= 256; }
+// A layer with more than 256 inputs (fc5: [fc4 | PE]) goes as two launches: the first 256 input columns with the dZ pass, then the
+// rest on the finished dZ.
+static bool wgrad_bn_ok(const snerf_trainer* t, const LayerP& L, int64_t M, const Act& In) {
+    return t->gemm_mode == 1 && M >= 1024 && (L.n_in <= 256 || !In.tab || In.cols <= 256);
+}
 static hipError_t linear_wgrad(snerf_trainer* t, const LayerP& L, float* dZ, int64_t ldz, Act InA, int64_t M, float alpha, hipStream_t st,
                                const WgradBN* bn = nullptr) {
     const float* In = InA.p;
     const int64_t ld_in = InA.ld;
-    if (t->gemm_mode == 1 && M >= 1024)
+    if (t->gemm_mode == 1 && M >= 1024) {
+        if (bn && L.n_in > 256) {
+            const int n0 = 256, tc = InA.tab ? InA.cols : 0;
+            if (tc > n0) return hipErrorInvalidValue;
+            hipError_t e = launch_wgrad_bf16x3(dZ, ldz, In, ld_in, M, L.n_out, n0, alpha, t->grads + L.w, L.n_in, st, InA.tab, tc, bn);
+            if (e != hipSuccess) return e;
+            return launch_wgrad_bf16x3(dZ, ldz, In + n0, ld_in, M, L.n_out, L.n_in - n0, alpha, t->grads + L.w + n0, L.n_in, st, nullptr, 0, nullptr);
+        }
         return launch_wgrad_bf16x3(dZ, ldz, In, ld_in, M, L.n_out, L.n_in, alpha, t->grads + L.w, L.n_in, st, InA.tab, InA.tab ? InA.cols : 0, bn);
+    }
     if (bn) return hipErrorInvalidValue;
     if (InA.tab) return hipErrorInvalidValue;
     GemmArgs g{};
@@ -362,7 +374,7 @@ static int sine_bwd(snerf_trainer* t, const LayerP& L, Act D, Act Z, Act In, int
         }
         RCI(all_reduce(t, t->bn_bwd, 2 * t->W, false, st));                               // the BatchNorm backward means are global
         const int64_t Mg = M * (t->ar_fn ? t->world : 1);
-        if (pre_activated && wgrad_bn_ok(t, L, M)) {
+        if (pre_activated && wgrad_bn_ok(t, L, M, In)) {
             // D holds dL/dY: the dZ sweep rides in the weight-gradient kernel (dY -> dZ in registers, written back in place)
             WgradBN bn{Z.p, Z.ld, t->params + L.g, mean, istd, sdy, sdyx, 1.f / (float)Mg, 30.f, t->grads + L.b};
             HIPCK(linear_wgrad(t, L, D.p, D.ld, In, M, 30.f, st, &bn));

@@ -65,7 +65,11 @@ __global__ void pe_points_kernel(const PeArgs A) {
             const double r = (double)a0 * 0.15915494309189533576888 * (double)(1 << j);
             double fr = r - floor(r);
             if (q < 10) fr += 0.25;
-            v = (float)sin(fr * 6.283185307179586476925287);
+            // fold the exact fraction of a revolution into [-1/4, 1/4] (still exact), then one fp32 sinpi: the only rounding is the
+            // fp32 conversion of the folded argument (relative 2^-24)
+            double g = fr - rint(fr);
+            if (fabs(g) > 0.25) g = copysign(0.5, g) - g;
+            v = sinpif(2.f * (float)g);
         }
         A.pe[e] = v;
         if (A.pe2) A.pe2[i * A.ld2 + f] = v;
