@@ -13,6 +13,9 @@
 // one-float-per-lane operands (A[i=l&31][k=l>>5], B[k=l>>5][j=l&31]) are conflict-free ds_read_b32.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+
+#include <type_traits>
 
 #include "train.h"
 
@@ -430,6 +433,240 @@ __global__ __launch_bounds__(512) void gemm_rows_kernel(const GemmX g) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Full-tile form of gemm_rows_kernel, the one the training step runs on: K a multiple of 16 (or zero-padded to one), every
+// n-group complete, 16-byte aligned rows.  Same arithmetic, same fragment layout; what changes is that NO global load sits inside a
+// branch, so hipcc counts them precisely (`s_waitcnt vmcnt(2*(PF-1))` instead of the `vmcnt(0)` at the loop head that the
+// guarded loads of the general kernel force), and the A stream becomes a real software pipeline:
+//   * PF k-steps of A in flight per wave, refilled slot by slot right after the slot is split;
+//   * the refills of a tile's last PF k-steps fetch the first PF k-steps of the wave's NEXT tile, so the epilogue (stores,
+//     activation backward) overlaps their latency and a tile starts with its operands landed;
+//   * the weights reach LDS eight 16-byte loads per thread at a time instead of one round trip per 8 KiB.
+// AOL: 0 none, 1 [a | b] table in LDS.  ACT: 0 none, 1 activation backward in the epilogue (without `accumulate`).
+// The A stream of the full-tile kernel is issued and awaited by hand.  With compiler-visible loads hipcc emits `s_waitcnt vmcnt(0)`
+// at the head of the k-loop for the plain and LDS-table variants (every refill of the previous round awaited at once: no
+// overlap), whatever the surrounding code looks like; it does count precisely for the variants that have other global loads in
+// the tile loop.  Hand-issued loads sidestep the question: loads complete in issue order, so `vmcnt(N)` with N = the number of
+// A loads issued after the awaited pair is exact in the k-loop and merely conservative when compiler-issued stores/loads are
+// younger still (they only add to the count).  The registers are handed to the compiler by the wait (its "+v" operands).
+__device__ __forceinline__ void a8_issue(const float* p, f32x4& x, f32x4& y) {
+    asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16" : "=&v"(x), "=&v"(y) : "v"(p));
+}
+template <int N>
+__device__ __forceinline__ void a8_wait(f32x4& x, f32x4& y) {
+    asm volatile("s_waitcnt vmcnt(%2) ; a8_wait %0 %1" : "+v"(x), "+v"(y) : "n"(N));
+}
+
+template <int NT, int PF, int AOL, int ACT>
+__global__ __launch_bounds__(512) void gemm_rows_full_kernel(const GemmX g) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_w[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int KS = g.ksteps;                                        // multiple of PF
+    const int n_groups = g.n_tiles / NT;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
+    const int workers_per_xcd = slots / n_groups;
+    if (slot >= workers_per_xcd * n_groups) return;
+    const int grp = slot % n_groups, worker = (slot / n_groups) * 8 + xcd, n_workers = workers_per_xcd * 8;
+
+    {
+        const u32x4* src = (const u32x4*)(g.frag + (int64_t)grp * NT * KS * 1024);
+        u32x4* dst = (u32x4*)lds_w;
+        const int n16 = NT * KS * 128;
+        int i0 = tid;
+        for (; i0 + 7 * 512 < n16; i0 += 512 * 8) {                  // n16 is a multiple of 512
+            u32x4 v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = src[i0 + q * 512];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) dst[i0 + q * 512] = v[q];
+        }
+        for (; i0 < n16; i0 += 512) dst[i0] = src[i0];
+    }
+    const uint8_t* lds_tab = lds_w + (size_t)NT * KS * 2048;
+    if (AOL == 1) {
+        float* dst = (float*)lds_tab;
+        for (int i = tid; i < 2 * g.act_cols; i += 512) dst[i] = g.act_tab[i];
+    }
+    // per-column constants of this lane's NT output columns (the activation-backward ones are fetched per column in the epilogue:
+    // that variant has no registers to spare)
+    float biasv[NT], shiftv[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int64_t n = (int64_t)(grp * NT + j) * 32 + r;
+        biasv[j] = (!ACT && g.bias) ? g.bias[n] : 0.f;
+        shiftv[j] = (!ACT && g.stats) ? g.alpha * biasv[j] : 0.f;
+    }
+    __syncthreads();
+
+    const int64_t n_row_tiles = (g.M + RO_ROWS - 1) / RO_ROWS;
+    float st1[NT], st2[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) st1[j] = st2[j] = 0.f;
+
+    auto a_ptr = [&](int64_t rt) {
+        int64_t m = rt * RO_ROWS + wave * 32 + r;
+        m = m < g.M ? m : g.M - 1;                                  // loads stay in bounds, stores are masked
+        return g.A + m * g.lda + h * 8;
+    };
+    // epilogue addressing through buffer instructions: descriptor (scalar) + per-lane byte offset (lz / lc, one register each,
+    // loop-invariant) + wave-uniform row offset (scalar) + 128 j as the immediate - no 64-bit vector address arithmetic
+    const int lz = ACT ? (int)(4 * h * g.eld + grp * NT * 32 + r) * 4 : 0;
+    const int lc = (int)(4 * h * g.ldc + grp * NT * 32 + r) * 4;
+    const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc((void*)g.C, 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_z = __builtin_amdgcn_make_buffer_rsrc((void*)(ACT ? g.ez : g.A), 0, -1, 0x00020000);
+    int64_t rt = worker;
+    const float* arow = a_ptr(rt < n_row_tiles ? rt : n_row_tiles - 1);
+    f32x4 px[PF], py[PF];
+#pragma unroll
+    for (int d = 0; d < PF; ++d) a8_issue(arow + d * 16, px[d], py[d]);
+
+    for (; rt < n_row_tiles; rt += n_workers) {
+        const int64_t rn = rt + n_workers;
+        const float* anext = a_ptr(rn < n_row_tiles ? rn : rt);
+        f32x16 acc[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+        f32x4 tb[2][4];
+        auto load_tab = [&](int ks, f32x4 (&t_)[4]) {
+            int k0 = ks * 16 + h * 8;
+            k0 = k0 < g.act_cols ? k0 : g.act_cols - 8;            // clamped: the loads are unconditional
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const f32x4* p = AOL == 1 ? (const f32x4*)(lds_tab + ((size_t)a * g.act_cols + k0) * 4)
+                                          : (const f32x4*)(g.act_tab + (int64_t)a * g.act_cols + k0);
+                t_[2 * a] = p[0];
+                t_[2 * a + 1] = p[1];
+            }
+        };
+        if (AOL) load_tab(0, tb[0]);
+        for (int ks0 = 0; ks0 < KS; ks0 += PF) {
+            const float* src = (ks0 + PF < KS) ? arow + (ks0 + PF) * 16 : anext;
+#pragma unroll
+            for (int d = 0; d < PF; ++d) {
+                const int ks = ks0 + d;
+                a8_wait<2 * (PF - 1)>(px[d], py[d]);                 // the PF-1 younger refills stay in flight
+                float a8[8] = {px[d][0], px[d][1], px[d][2], px[d][3], py[d][0], py[d][1], py[d][2], py[d][3]};
+                if (AOL) {
+                    load_tab(ks + 1 < KS ? ks + 1 : ks, tb[(d + 1) & 1]);
+                    if (ks * 16 < g.act_cols) {                     // act_cols is a multiple of 16 here: uniform
+                        const f32x4(&t_)[4] = tb[d & 1];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e)
+                            a8[e] = __builtin_amdgcn_sinf(__builtin_fmaf(t_[e >> 2][e & 3], a8[e], t_[2 + (e >> 2)][e & 3]));
+                    }
+                }
+                u32x4 ahi, alo;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    uint32_t hh, ll;
+                    split2_bf16(a8[2 * q], a8[2 * q + 1], hh, ll);
+                    ahi[q] = hh;
+                    alo[q] = ll;
+                }
+                a8_issue(src + d * 16, px[d], py[d]);                // refill the slot just consumed (next tile's on the last round)
+                // one scheduling barrier per k-step: the MFMAs below may still interleave with the next k-step's wait,
+                // activation and split VALU work, but nothing wanders further
+                __builtin_amdgcn_sched_barrier(0);
+                const bf16x8 Ahi = __builtin_bit_cast(bf16x8, ahi), Alo = __builtin_bit_cast(bf16x8, alo);
+                const uint32_t base = (uint32_t)ks * 2048u + (uint32_t)lane * 16u;
+                bf16x8 Bhi[NT], Blo[NT];
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    Bhi[j] = __builtin_bit_cast(bf16x8, *(const u32x4*)(lds_w + base + (uint32_t)j * KS * 2048u));
+                    Blo[j] = __builtin_bit_cast(bf16x8, *(const u32x4*)(lds_w + base + (uint32_t)j * KS * 2048u + 1024u));
+                }
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Alo, Bhi[j], acc[j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ahi, Blo[j], acc[j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ahi, Bhi[j], acc[j], 0, 0, 0);
+            }
+        }
+        // epilogue: D[row = (e&3) + 8(e>>2) + 4h, col = r]
+        const int64_t rowu = rt * RO_ROWS + wave * 32;
+        const int64_t row0 = rowu + 4 * h;
+        auto epilogue = [&](auto interior_tag) {
+            constexpr bool INTERIOR = decltype(interior_tag)::value;      // no row of the workgroup tile is masked: branch-free
+            float zt[2][16], ec[2][4];
+            auto fetch = [&](int j, float (&z_)[16], float (&c_)[4]) {    // ACT: pre-activations and [a, b, mu, istd] of column j
+                const int64_t n = (int64_t)(grp * NT + j) * 32 + r;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int64_t ro = (e & 3) + 8 * (e >> 2);
+                    if (INTERIOR) {
+                        z_[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_z, lz + j * 128, (int)((rowu + ro) * g.eld * 4), 0));
+                    } else {
+                        int64_t m = row0 + ro;
+                        m = m < g.M ? m : g.M - 1;
+                        z_[e] = g.ez[m * g.eld + n];
+                    }
+                }
+                c_[0] = g.etab[n]; c_[1] = g.etab[g.N + n];
+                c_[2] = g.emu[n]; c_[3] = g.eistd[n];                     // the launcher substitutes zeros for a layer without BatchNorm
+            };
+            if (ACT) fetch(0, zt[0], ec[0]);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int64_t n = (int64_t)(grp * NT + j) * 32 + r;
+                if (ACT) {      // column j+1's operands fly while column j is finished; the barriers keep hipcc from hoisting all four
+                    if (j + 1 < NT) fetch(j + 1, zt[(j + 1) & 1], ec[(j + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int64_t ro = (e & 3) + 8 * (e >> 2);
+                    float v = g.alpha * (acc[j][e] + biasv[j]);
+                    if (ACT) v *= __builtin_amdgcn_cosf(__builtin_fmaf(ec[j & 1][0], zt[j & 1][e], ec[j & 1][1]));
+                    const bool ok = INTERIOR || row0 + ro < g.M;
+                    if (INTERIOR) {
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rs_c, lc + j * 128, (int)((rowu + ro) * g.ldc * 4), 0);
+                    } else if (ok) {
+                        g.C[(row0 + ro) * g.ldc + n] = v;
+                    }
+                    if (ACT) {
+                        const float s1 = v, s2 = v * ((zt[j & 1][e] - ec[j & 1][2]) * ec[j & 1][3]);
+                        st1[j] += ok ? s1 : 0.f;
+                        st2[j] += ok ? s2 : 0.f;
+                    } else {
+                        const float d = v - shiftv[j];
+                        st1[j] += ok ? d : 0.f;
+                        st2[j] += ok ? d * d : 0.f;
+                    }
+                }
+                if (ACT) __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        if (rt * RO_ROWS + RO_ROWS <= g.M) epilogue(std::true_type{});
+        else epilogue(std::false_type{});
+        arow = anext;
+    }
+    if (g.stats) {
+        __syncthreads();
+        float* red = (float*)lds_w;                        // [8 waves][NT][2][32]
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            float a = st1[j] + __shfl_xor(st1[j], 32, 64), b = st2[j] + __shfl_xor(st2[j], 32, 64);
+            if (h == 0) {
+                red[((wave * NT + j) * 2 + 0) * 32 + r] = a;
+                red[((wave * NT + j) * 2 + 1) * 32 + r] = b;
+            }
+        }
+        __syncthreads();
+        if (tid < NT * 64) {
+            const int j = tid >> 6, which = (tid >> 5) & 1, c = tid & 31;
+            double s = 0.0;
+#pragma unroll
+            for (int w = 0; w < RO_WAVES; ++w) s += (double)red[((w * NT + j) * 2 + which) * 32 + c];
+            const int64_t n = (int64_t)(grp * NT + j) * 32 + c;
+            atomicAdd(g.stats + which * g.N + n, s);
+        }
+    }
+}
+
 // =====================================================================================================
 // bf16x3 weight-gradient GEMM:   dW[o, i] += alpha * sum_m dZ[m, o] * In[m, i]           (K = #points, split over workgroups)
 // Both operands are point-major, so the 8 consecutive-k values an MFMA lane needs are 8 rows of one column: each lane gathers
@@ -684,6 +921,40 @@ hipError_t launch_split_weights(const float* W, int rows, int cols, bool transpo
     return hipGetLastError();
 }
 
+// a device array of zeros (grown on demand, never freed: a few KiB), for optional per-column inputs
+static const float* zeros_dev(int64_t n) {
+    static float* p = nullptr;
+    static int64_t cap = 0;
+    if (n > cap) {
+        int64_t want = n < 4096 ? 4096 : n;
+        float* q = nullptr;
+        if (hipMalloc(&q, want * sizeof(float)) != hipSuccess) return nullptr;
+        if (hipMemset(q, 0, want * sizeof(float)) != hipSuccess) return nullptr;
+        p = q; cap = want;                                         // the old block stays alive for launches already queued
+    }
+    return p;
+}
+
+template <int NT, int PF>
+static hipError_t launch_full(const GemmX& gx, int aol_mode, int act_mode, dim3 grid, size_t lds, hipStream_t st) {
+#define SNERF_GO(A_, C_)                                                                                              \
+    do {                                                                                                              \
+        static bool done = false;                                                                                     \
+        auto k = gemm_rows_full_kernel<NT, PF, A_, C_>;                                                               \
+        if (!done) {                                                                                                  \
+            hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            if (e != hipSuccess) return e;                                                                            \
+            done = true;                                                                                              \
+        }                                                                                                             \
+        hipLaunchKernelGGL(k, grid, dim3(512), lds, st, gx);                                                          \
+    } while (0)
+    if (act_mode == 1) SNERF_GO(0, 1);
+    else if (aol_mode == 1) SNERF_GO(1, 0);
+    else SNERF_GO(0, 0);
+#undef SNERF_GO
+    return hipGetLastError();
+}
+
 int gemm_rows_group_tiles(int ksteps) { return ksteps <= 20 ? 4 : (ksteps <= 32 ? 2 : 0); }     // n-tiles whose weights fit the 160 KiB LDS
 
 hipError_t launch_gemm_bf16x3(const GemmX& g, hipStream_t st) {
@@ -714,6 +985,45 @@ hipError_t launch_gemm_bf16x3(const GemmX& g, hipStream_t st) {
     size_t lds_total = lds;
     if (aol && lds + (size_t)g.act_cols * 8 <= 160 * 1024) { gx.tab_lds = 1; lds_total = lds + (size_t)g.act_cols * 8; }
     const dim3 grid(blocks), block(512);
+    {   // the pipelined full-tile kernel wherever the shape allows it (every per-point layer of the training step)
+        static int full_mode = -1, pf_force = 0;
+        if (full_mode < 0) {
+            const char* e1 = getenv("SNERF_GEMM_FULL");
+            const char* e2 = getenv("SNERF_GEMM_PF");
+            full_mode = (e1 && e1[0] == '0') ? 0 : 1;
+            pf_force = e2 ? atoi(e2) : 0;
+        }
+        const int KS = g.ksteps;
+        const bool k_ok = g.K % 16 == 0 || (g.a_padded && g.lda >= (int64_t)KS * 16);
+        const bool a_vec = ((uintptr_t)g.A % 16 == 0) && (g.lda % 4 == 0);
+        int pf = KS % 8 == 0 ? 8 : (KS % 4 == 0 ? 4 : (KS % 2 == 0 ? 2 : 0));
+        if (act && pf > 4) pf = 4;                               // the activation-backward epilogue needs the registers
+        if (pf_force && pf_force <= pf && KS % pf_force == 0 && (pf_force == 8 || pf_force == 4 || pf_force == 2)) pf = pf_force;
+        // activation on load wants its table in LDS: with 20 k-steps four n-tiles fill the 160 KiB, so that layer runs two per group
+        int ntf = nt;
+        if (aol && ntf == 4 && (size_t)4 * KS * 2048 + (size_t)g.act_cols * 8 > 160 * 1024) ntf = 2;
+        const size_t lds_f = (size_t)ntf * KS * 2048 + (aol ? (size_t)g.act_cols * 8 : 0);
+        if (full_mode && k_ok && a_vec && pf && g.n_tiles % ntf == 0 && g.N == (int64_t)g.n_tiles * 32 && (!aol || g.act_cols % 16 == 0) &&
+            !g.accumulate && lds_f <= 160 * 1024 && g.M * g.ldc < (1ll << 29) && (!act || g.M * g.eld < (1ll << 29))) {      // 32-bit byte offsets
+            const int groups_f = g.n_tiles / ntf;
+            int blocks_f = ro_grid_blocks();
+            if (blocks_f / 8 < groups_f) blocks_f = groups_f * 8;
+            const dim3 grid_f(blocks_f);
+            gx.tab_lds = aol ? 1 : 0;
+            const int aol_mode = aol ? 1 : 0, act_mode = act ? 1 : 0;
+            if (act && !gx.emu) {                                  // a layer without BatchNorm: xhat sums are defined as 0
+                gx.emu = zeros_dev(g.N);
+                gx.eistd = gx.emu;
+                if (!gx.emu) return hipErrorOutOfMemory;
+            }
+            return ntf == 4 ? (pf == 8 ? launch_full<4, 8>(gx, aol_mode, act_mode, grid_f, lds_f, st)
+                                       : pf == 4 ? launch_full<4, 4>(gx, aol_mode, act_mode, grid_f, lds_f, st)
+                                                 : launch_full<4, 2>(gx, aol_mode, act_mode, grid_f, lds_f, st))
+                            : (pf == 8 ? launch_full<2, 8>(gx, aol_mode, act_mode, grid_f, lds_f, st)
+                                       : pf == 4 ? launch_full<2, 4>(gx, aol_mode, act_mode, grid_f, lds_f, st)
+                                                 : launch_full<2, 2>(gx, aol_mode, act_mode, grid_f, lds_f, st));
+        }
+    }
     if (nt == 4) {
         if (act) hipLaunchKernelGGL((gemm_rows_kernel<4, false, true>), grid, block, lds_total, st, gx);
         else if (aol) hipLaunchKernelGGL((gemm_rows_kernel<4, true, false>), grid, block, lds_total, st, gx);

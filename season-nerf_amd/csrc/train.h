@@ -42,6 +42,7 @@ struct GemmX {
     const float* ez;
     int64_t eld;
     const float *etab, *emu, *eistd;
+    int a_padded;              // caller's promise: columns K .. 16*ksteps-1 of A exist (lda covers them) and hold zeros
 };
 hipError_t launch_split_weights(const float* W, int rows, int cols, bool transpose, uint16_t* frag, int n_tiles, int ksteps, hipStream_t st);
 int gemm_rows_group_tiles(int ksteps);      // 0 = K too large for the LDS-resident weight layout (caller falls back to fp32 MFMA)

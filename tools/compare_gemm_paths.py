@@ -1,0 +1,57 @@
+"""Bit-exact comparison of the pipelined full-tile row GEMM against the general row kernel (same arithmetic, same summation
+order): run once per mode in a child process (the mode is read once per process), compare the saved outputs.
+usage (GPU box): python3 tools/compare_gemm_paths.py"""
+import os, subprocess, sys
+import numpy as np
+HERE = os.path.dirname(os.path.abspath(__file__))
+if len(sys.argv) > 1:
+    sys.path.insert(0, os.path.dirname(HERE))
+    import importlib, ctypes as C
+    import torch
+    sn = importlib.import_module("season_nerf_amd")
+    L = sn._lib.lib()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    out = {}
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    rnd = lambda *s: torch.randn(*s, device="cuda", generator=g)
+    for (M, K, N, lda, aol, stats) in [(4096 * 8, 256, 256, 256, 256, True), (4096 * 8 + 77, 256, 256, 256, 0, False), (30001, 320, 256, 320, 256, True),
+                                       (25600, 64, 256, 64, 0, True), (25600, 256, 128, 256, 256, True), (25611, 160, 128, 160, 128, False), (4096, 128, 128, 156, 128, False),
+                                       (20000, 128, 256, 128, 128, False)]:
+        A = rnd(M, lda); W_ = rnd(N, K) / K ** 0.5; b = rnd(N)
+        o = torch.full((M, N), -7.0, device="cuda")
+        tab = torch.rand(2 * max(aol, 8), device="cuda", generator=g)
+        sc = torch.empty(L.snerf_linear_scratch_bytes(N, K), dtype=torch.uint8, device="cuda")
+        stt = torch.zeros(2 * N, dtype=torch.float64, device="cuda")
+        sn._lib.check(L.snerf_linear_forward(M, K, N, A.data_ptr(), lda, W_.data_ptr(), b.data_ptr(), 30.0, o.data_ptr(), N, stt.data_ptr() if stats else None, 1,
+                                             sc.data_ptr(), sc.numel(), tab.data_ptr() if aol else None, aol, st), "fwd")
+        out[f"fwd_{M}_{K}_{N}_{aol}"] = o.cpu().numpy()
+        if stats: out[f"fwdstats_{M}_{K}_{N}_{aol}"] = stt.cpu().numpy()
+    for (M, n_out, n_cols, act, bn) in [(4096 * 8, 256, 256, True, True), (30001, 256, 256, True, False), (25600, 128, 256, True, True), (25611, 256, 128, True, True),
+                                        (25600, 256, 256, False, False), (20000, 128, 128, True, False)]:
+        dZ = rnd(M, n_out); W_ = rnd(n_out, n_cols) / n_out ** 0.5
+        gi = torch.full((M, n_cols), -7.0, device="cuda"); z = rnd(M, n_cols)
+        tab = torch.rand(2 * n_cols, device="cuda", generator=g); mu = rnd(n_cols); istd = torch.rand(n_cols, device="cuda", generator=g) + 0.5
+        sums = torch.zeros(2 * n_cols, dtype=torch.float64, device="cuda")
+        sc = torch.empty(L.snerf_linear_scratch_bytes(n_out, n_cols), dtype=torch.uint8, device="cuda")
+        sn._lib.check(L.snerf_linear_dgrad(M, n_cols, n_out, dZ.data_ptr(), n_out, W_.data_ptr(), n_cols, 30.0, 0, gi.data_ptr(), n_cols, 1, sc.data_ptr(), sc.numel(),
+                                           z.data_ptr() if act else None, n_cols, tab.data_ptr() if act else None, mu.data_ptr() if (act and bn) else None,
+                                           istd.data_ptr() if (act and bn) else None, sums.data_ptr() if act else None, st), "dgrad")
+        out[f"dgrad_{M}_{n_out}_{n_cols}_{act}_{bn}"] = gi.cpu().numpy()
+        if act: out[f"dgradsums_{M}_{n_out}_{n_cols}_{bn}"] = sums.cpu().numpy()
+    np.savez(sys.argv[1], **out)
+    sys.exit(0)
+os.makedirs("/tmp/cmp", exist_ok=True)
+for mode in ("0", "1"):
+    env = dict(os.environ, SNERF_GEMM_FULL=mode)
+    subprocess.check_call([sys.executable, __file__, f"/tmp/cmp/m{mode}.npz"], env=env)
+a, b = np.load("/tmp/cmp/m0.npz"), np.load("/tmp/cmp/m1.npz")
+bad = 0
+for k in a.files:
+    if "stats" in k or "sums" in k:      # double atomics over workgroups: order-dependent in the last bits
+        ok = np.allclose(a[k], b[k], rtol=1e-7, atol=1e-6)
+    else:
+        ok = np.array_equal(a[k], b[k])
+    print(("ok   " if ok else "DIFF ") + k, "" if ok else float(np.abs(a[k] - b[k]).max()))
+    bad += not ok
+print("mismatches:", bad)
+sys.exit(1 if bad else 0)
