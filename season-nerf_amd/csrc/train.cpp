@@ -40,6 +40,8 @@ struct Act {           // a [rows, cols] fp32 matrix inside the workspace
     // consumer (row GEMM, wgrad) applies sin(2 pi (a z + b)) with tab = [a | b] while loading - the post-activation is not stored
     const float* tab = nullptr;
     int cols = 0;
+    // the columns between the layer's n_in and the next multiple of 16 exist and hold zeros (row GEMM: no K tail to guard)
+    bool padded = false;
 };
 
 }  // namespace
@@ -164,7 +166,7 @@ static size_t carve(snerf_trainer* t, char* base, int64_t R, int64_t Rs, int S) 
         P.head = c.mat(N, 4);
         for (int l = 0; l < 3; ++l) { P.Za[l] = c.mat(N, W); P.Ha[l] = c.mat(N, W); }
         P.adj = c.mat(N, 3 * C);
-        P.In_s1 = c.mat(N, W2 + 28);
+        P.In_s1 = c.mat(N, W2 + 32);         // [fc9 | PE(sun) 27 + 1 | 4 zero columns]: 16-column granules for the row GEMM
         for (int l = 0; l < 3; ++l) { P.Zs[l] = c.mat(N, W2); P.Hs[l] = c.mat(N, W2); }
         P.sv_raw = c.mat(N, 1);
         P.pts = c.take(N * 3); P.rho = c.take(N); P.col = c.take(N * 3); P.sv = c.take(N);
@@ -223,6 +225,7 @@ static hipError_t linear_fwd(snerf_trainer* t, const LayerP& L, Act InA, int64_t
         x.A = In; x.frag = t->w_frag; x.C = Z; x.M = M; x.N = L.n_out; x.K = L.n_in; x.lda = ld_in; x.ldc = ldz;
         x.alpha = alpha; x.bias = t->params + L.b; x.stats = stats; x.accumulate = 0;
         x.act_tab = InA.tab; x.act_cols = InA.tab ? InA.cols : 0;
+        x.a_padded = (InA.padded && ld_in >= (int64_t)x.ksteps * 16) ? 1 : 0;
         return launch_gemm_bf16x3(x, st);
     }
     GemmArgs g{};
@@ -437,14 +440,14 @@ static int forward_pass(snerf_trainer* t, snerf_trainer::Pass& P, bool solar, in
     // fc4's output lives inside fc5's concat input [ . | PE]: its H without, its Z with activation on load
     // likewise fc9's inside fc_solar_1's concat input [ . | PE(sun)]
     P.Zc3 = aol ? Act{P.In5.p, W + 64} : P.Z[3];
-    P.Zc8 = aol ? Act{P.In_s1.p, W2 + 28} : P.Z[8];
+    P.Zc8 = aol ? Act{P.In_s1.p, P.In_s1.ld} : P.Z[8];
     auto zof = [&](int l) { return l == 3 ? P.Zc3 : (l == 8 ? P.Zc8 : P.Z[l]); };
     for (int l = 0; l < 9; ++l) P.Hc[l] = view(zof(l), P.H[l], l, l == 8 ? W2 : W);
     for (int l = 0; l < 3; ++l) { P.Hac[l] = view(P.Za[l], P.Ha[l], 9 + l, W); P.Hsc[l] = view(P.Zs[l], P.Hs[l], 12 + l, W2); }
     P.In5c = aol ? Act{P.In5.p, W + 64, tab_of(3), W} : Act{P.In5.p, W + 64};
-    P.In_s1c = aol ? Act{P.In_s1.p, W2 + 28, tab_of(8), W2} : Act{P.In_s1.p, W2 + 28};
+    P.In_s1c = aol ? Act{P.In_s1.p, P.In_s1.ld, tab_of(8), W2, true} : Act{P.In_s1.p, P.In_s1.ld, nullptr, 0, true};
     // trunk (G_NeRF.py:80-91)
-    RC(sine_fwd(t, Ls[L_FC1], Act{P.E.p, 64}, N, P.Z[0], P.H[0], nullptr, train_bn, st, tab_of(0)));
+    RC(sine_fwd(t, Ls[L_FC1], Act{P.E.p, 64, nullptr, 0, true}, N, P.Z[0], P.H[0], nullptr, train_bn, st, tab_of(0)));
     for (int l = 1; l < 9; ++l) {
         const Act In = l == 4 ? P.In5c : P.Hc[l - 1];
         RC(sine_fwd(t, Ls[L_FC1 + l], In, N, zof(l), P.H[l], P.bn + (l - 1) * 4 * W, train_bn, st, tab_of(l)));
@@ -454,8 +457,8 @@ static int forward_pass(snerf_trainer* t, snerf_trainer::Pass& P, bool solar, in
     RC(plain_fwd(t, Ls[L_SIG], X1, N, P.head.p + 3, 4, st));
     // solar visibility branch (G_NeRF.py:100-108)
     HIPCK(launch_pe_small(sun, 3, 3, 4, R, P.pe_sun, 28, st));
-    if (!aol) HIPCK(launch_copy_cols(X1.p, X1.ld, P.In_s1.p, W2 + 28, N, W2, false, st));
-    HIPCK(launch_bcast_rows(P.pe_sun, 28, P.In_s1.p, W2 + 28, W2, N, S, st));
+    if (!aol) HIPCK(launch_copy_cols(X1.p, X1.ld, P.In_s1.p, P.In_s1.ld, N, W2, false, st));
+    HIPCK(launch_bcast_rows(P.pe_sun, 28, P.In_s1.p, P.In_s1.ld, W2, N, S, st));
     RC(sine_fwd(t, Ls[L_S1], P.In_s1c, N, P.Zs[0], P.Hs[0], nullptr, train_bn, st, tab_of(12)));
     RC(sine_fwd(t, Ls[L_S2], P.Hsc[0], N, P.Zs[1], P.Hs[1], nullptr, train_bn, st, tab_of(13)));
     RC(sine_fwd(t, Ls[L_S3], P.Hsc[1], N, P.Zs[2], P.Hs[2], nullptr, train_bn, st, tab_of(14)));
@@ -553,6 +556,8 @@ int snerf_trainer_bind(snerf_trainer* t, float* d_params, float* d_grads, float*
     t->ws = (char*)d_workspace; t->ws_bytes = workspace_bytes;
     t->R = n_rays; t->Rs = n_solar_rays; t->S = n_samples;
     carve(t, t->ws, n_rays, n_solar_rays, n_samples);
+    for (snerf_trainer::Pass* P : {&t->img, &t->sol})      // the zero pad columns of the solar branch's concat input
+        if (P->N > 0) HIPCK(hipMemset(P->In_s1.p, 0, (size_t)P->N * P->In_s1.ld * sizeof(float)));
     return SNERF_OK;
 }
 
