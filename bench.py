@@ -195,6 +195,11 @@ def bench_train(a):
     sol = fwd_bytes(trunk + heads + solar) + bwd_bytes(solar, False)
     hbm_bytes = 4.0 * R * S * (img + sol)
     lname = "Barron adaptive loss" if barron else "MSE loss"
+    traffic = None      # HBM bytes per step from the committed PMC passes of this same command (tools/train_traffic.sh)
+    try:
+        traffic = json.load(open(os.path.join(REPO, "profiles", "r1", "j_train_traffic.json")))["bytes_per_step"]
+    except Exception:
+        pass
     if rank == 0:
         out = {"metric": f"training image-ray-samples/s (4096 rays x 96 samples + 4096 sun rays per GPU, {lname}, fused Adam)",
                "value": world * R * S / dt, "unit": "ray-samples/s", "n_gpus": world, "steps": steps, "warmup": warm, "ms_per_step": dt * 1e3,
@@ -206,11 +211,11 @@ def bench_train(a):
                                          + ("over the global batch (all-reduced)" if a.bn_sync == "global" and use_dist else "per rank")},
                "final_loss": float(tot.detach()), "step_ms_median": per_step[len(per_step) // 2], "step_ms_min": per_step[0],
                "roofline": {"bound": "hbm", "achieved": hbm_bytes / dt / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": hbm_bytes / dt / 8e12,
-                            "traffic": None, "bytes_per_step": hbm_bytes, "algorithmic_tflops": flop / dt / 1e12,
+                            "traffic": traffic, "bytes_per_step": hbm_bytes, "algorithmic_tflops": flop / dt / 1e12,
                             "note": "whole step, not one kernel: train-mode BatchNorm forces a layer-wise design in which every layer is "
                                     "a pass over [393216 x width] fp32 arrays; achieved = bytes that design moves per step (counted from "
                                     "the layer table, DESIGN 5.4) / step time, peak = HBM3E 8 TB/s (MI355X_MICROARCH.md); "
-                                    "per-kernel times in profiles/r1/i_train_kernel_stats.csv"}}
+                                    "per-kernel times in profiles/r1/j_train_kernel_stats.csv"}}
         if not a.no_cpu_baseline and world == 1:      # reported at N = 1 only (rank 0)
             from oracle import season_nerf_oracle as orc          # CPU-baseline leg only
             torch.set_num_threads(min(host_cpus(), 32))
@@ -349,7 +354,7 @@ def main():
         achieved = FLOP_PER_SAMPLE * R * S / (field_ms * 1e-3)
         traffic = None          # HBM bytes per launch from the committed PMC passes of this same command (profiles/)
         try:
-            traffic = json.load(open(os.path.join(REPO, "profiles", "r1", "i_traffic.json")))["bytes_per_launch"]
+            traffic = json.load(open(os.path.join(REPO, "profiles", "r1", "j_traffic.json")))["bytes_per_launch"]
         except Exception:
             pass
         out = {

@@ -494,7 +494,7 @@ __global__ __launch_bounds__(512) void gemm_rows_full_kernel(const GemmX g) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int64_t n = (int64_t)(grp * NT + j) * 32 + r;
-        biasv[j] = (!ACT && g.bias) ? g.bias[n] : 0.f;
+        biasv[j] = (!ACT && g.bias && n < g.N) ? g.bias[n] : 0.f;
         shiftv[j] = (!ACT && g.stats) ? g.alpha * biasv[j] : 0.f;
     }
     __syncthreads();
@@ -512,8 +512,10 @@ __global__ __launch_bounds__(512) void gemm_rows_full_kernel(const GemmX g) {
     // epilogue addressing through buffer instructions: descriptor (scalar) + per-lane byte offset (lz / lc, one register each,
     // loop-invariant) + wave-uniform row offset (scalar) + 128 j as the immediate - no 64-bit vector address arithmetic
     const int lz = ACT ? (int)(4 * h * g.eld + grp * NT * 32 + r) * 4 : 0;
-    const int lc = (int)(4 * h * g.ldc + grp * NT * 32 + r) * 4;
-    const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc((void*)g.C, 0, -1, 0x00020000);
+    // a thin layer (N < 32, one n-tile): lanes past N get an offset beyond the descriptor's range - the hardware drops their stores
+    const bool nok0 = NT > 1 || grp * 32 + r < g.N;
+    const int lc = nok0 ? (int)(4 * h * g.ldc + grp * NT * 32 + r) * 4 : (int)0x80000000;
+    const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc((void*)g.C, 0, (int)(g.M * g.ldc * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_z = __builtin_amdgcn_make_buffer_rsrc((void*)(ACT ? g.ez : g.A), 0, -1, 0x00020000);
     int64_t rt = worker;
     const float* arow = a_ptr(rt < n_row_tiles ? rt : n_row_tiles - 1);
@@ -624,7 +626,7 @@ __global__ __launch_bounds__(512) void gemm_rows_full_kernel(const GemmX g) {
                     const bool ok = INTERIOR || row0 + ro < g.M;
                     if (INTERIOR) {
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rs_c, lc + j * 128, (int)((rowu + ro) * g.ldc * 4), 0);
-                    } else if (ok) {
+                    } else if (ok && nok0) {
                         g.C[(row0 + ro) * g.ldc + n] = v;
                     }
                     if (ACT) {
@@ -662,7 +664,7 @@ __global__ __launch_bounds__(512) void gemm_rows_full_kernel(const GemmX g) {
 #pragma unroll
             for (int w = 0; w < RO_WAVES; ++w) s += (double)red[((w * NT + j) * 2 + which) * 32 + c];
             const int64_t n = (int64_t)(grp * NT + j) * 32 + c;
-            atomicAdd(g.stats + which * g.N + n, s);
+            if (n < g.N) atomicAdd(g.stats + which * g.N + n, s);
         }
     }
 }
@@ -948,7 +950,10 @@ static hipError_t launch_full(const GemmX& gx, int aol_mode, int act_mode, dim3 
         }                                                                                                             \
         hipLaunchKernelGGL(k, grid, dim3(512), lds, st, gx);                                                          \
     } while (0)
-    if (act_mode == 1) SNERF_GO(0, 1);
+    if (act_mode == 1) {
+        if constexpr (NT > 1) SNERF_GO(0, 1);
+        else return hipErrorInvalidValue;
+    }
     else if (aol_mode == 1) SNERF_GO(1, 0);
     else SNERF_GO(0, 0);
 #undef SNERF_GO
@@ -1002,8 +1007,9 @@ hipError_t launch_gemm_bf16x3(const GemmX& g, hipStream_t st) {
         // activation on load wants its table in LDS: with 20 k-steps four n-tiles fill the 160 KiB, so that layer runs two per group
         int ntf = nt;
         if (aol && ntf == 4 && (size_t)4 * KS * 2048 + (size_t)g.act_cols * 8 > 160 * 1024) ntf = 2;
+        if (g.n_tiles == 1 && !act) ntf = 1;                      // thin heads (1..32 outputs)
         const size_t lds_f = (size_t)ntf * KS * 2048 + (aol ? (size_t)g.act_cols * 8 : 0);
-        if (full_mode && k_ok && a_vec && pf && g.n_tiles % ntf == 0 && g.N == (int64_t)g.n_tiles * 32 && (!aol || g.act_cols % 16 == 0) &&
+        if (full_mode && k_ok && a_vec && pf && g.n_tiles % ntf == 0 && (g.N == (int64_t)g.n_tiles * 32 || ntf == 1) && (!aol || g.act_cols % 16 == 0) &&
             !g.accumulate && lds_f <= 160 * 1024 && g.M * g.ldc < (1ll << 29) && (!act || g.M * g.eld < (1ll << 29))) {      // 32-bit byte offsets
             const int groups_f = g.n_tiles / ntf;
             int blocks_f = ro_grid_blocks();
@@ -1016,6 +1022,9 @@ hipError_t launch_gemm_bf16x3(const GemmX& g, hipStream_t st) {
                 gx.eistd = gx.emu;
                 if (!gx.emu) return hipErrorOutOfMemory;
             }
+            if (ntf == 1)
+                return pf == 8 ? launch_full<1, 8>(gx, aol_mode, 0, grid_f, lds_f, st)
+                               : pf == 4 ? launch_full<1, 4>(gx, aol_mode, 0, grid_f, lds_f, st) : launch_full<1, 2>(gx, aol_mode, 0, grid_f, lds_f, st);
             return ntf == 4 ? (pf == 8 ? launch_full<4, 8>(gx, aol_mode, act_mode, grid_f, lds_f, st)
                                        : pf == 4 ? launch_full<4, 4>(gx, aol_mode, act_mode, grid_f, lds_f, st)
                                                  : launch_full<4, 2>(gx, aol_mode, act_mode, grid_f, lds_f, st))

@@ -444,7 +444,7 @@ static int forward_pass(snerf_trainer* t, snerf_trainer::Pass& P, bool solar, in
     auto zof = [&](int l) { return l == 3 ? P.Zc3 : (l == 8 ? P.Zc8 : P.Z[l]); };
     for (int l = 0; l < 9; ++l) P.Hc[l] = view(zof(l), P.H[l], l, l == 8 ? W2 : W);
     for (int l = 0; l < 3; ++l) { P.Hac[l] = view(P.Za[l], P.Ha[l], 9 + l, W); P.Hsc[l] = view(P.Zs[l], P.Hs[l], 12 + l, W2); }
-    P.In5c = aol ? Act{P.In5.p, W + 64, tab_of(3), W} : Act{P.In5.p, W + 64};
+    P.In5c = aol ? Act{P.In5.p, W + 64, tab_of(3), W, true} : Act{P.In5.p, W + 64, nullptr, 0, true};      // column W+63 is the PE's zero pad
     P.In_s1c = aol ? Act{P.In_s1.p, P.In_s1.ld, tab_of(8), W2, true} : Act{P.In_s1.p, P.In_s1.ld, nullptr, 0, true};
     // trunk (G_NeRF.py:80-91)
     RC(sine_fwd(t, Ls[L_FC1], Act{P.E.p, 64, nullptr, 0, true}, N, P.Z[0], P.H[0], nullptr, train_bn, st, tab_of(0)));

@@ -48,7 +48,7 @@ a, b = np.load("/tmp/cmp/m0.npz"), np.load("/tmp/cmp/m1.npz")
 bad = 0
 for k in a.files:
     if "stats" in k or "sums" in k:      # double atomics over workgroups: order-dependent in the last bits
-        ok = np.allclose(a[k], b[k], rtol=1e-7, atol=1e-6)
+        ok = np.allclose(a[k], b[k], rtol=1e-6, atol=1e-5 * float(k.split("_")[1]))      # fp32 per-lane partial sums, grouped differently
     else:
         ok = np.array_equal(a[k], b[k])
     print(("ok   " if ok else "DIFF ") + k, "" if ok else float(np.abs(a[k] - b[k]).max()))
