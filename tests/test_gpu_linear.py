@@ -191,3 +191,15 @@ def test_dgrad_activation_backward_epilogue(shape):
     ref2 = (30.0 * (dZ.double() @ Wt.double()[:, :n_cols]) + prev.double()) * torch.cos(gam.cuda() * xh + bet.cuda())
     assert _rel(out2, ref2) < 2 * TOL[1]
     np.testing.assert_allclose(sums.cpu().numpy()[0], ref2.sum(0).cpu().numpy(), rtol=0, atol=3e-4 * float(ref2.abs().sum(0).max()))
+
+
+def test_full_tile_kernel_bit_identical_to_general_kernel():
+    """gemm_rows_full_kernel (hand-issued A stream, cross-tile prefetch, buffer-addressed epilogue) against gemm_rows_kernel on
+    the same inputs: same fragments, same summation order -> identical bits in every output (forward with and without activation
+    on load, thin heads, zero-padded K, dgrad with the activation-backward epilogue); column sums agree to fp32 partial-sum
+    rounding.  The path is chosen per process (SNERF_GEMM_FULL), so the two runs are child processes."""
+    import subprocess, sys, os
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "compare_gemm_paths.py")
+    r = subprocess.run([sys.executable, tool], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "mismatches: 0" in r.stdout

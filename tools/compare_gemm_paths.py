@@ -16,9 +16,9 @@ if len(sys.argv) > 1:
     rnd = lambda *s: torch.randn(*s, device="cuda", generator=g)
     for (M, K, N, lda, aol, stats) in [(4096 * 8, 256, 256, 256, 256, True), (4096 * 8 + 77, 256, 256, 256, 0, False), (30001, 320, 256, 320, 256, True),
                                        (25600, 64, 256, 64, 0, True), (25600, 256, 128, 256, 256, True), (25611, 160, 128, 160, 128, False), (4096, 128, 128, 156, 128, False),
-                                       (20000, 128, 256, 128, 128, False)]:
+                                       (20000, 128, 256, 128, 128, False), (20000, 128, 3, 128, 128, False), (33333, 256, 12, 256, 256, False), (20000, 128, 1, 132, 0, False)]:
         A = rnd(M, lda); W_ = rnd(N, K) / K ** 0.5; b = rnd(N)
-        o = torch.full((M, N), -7.0, device="cuda")
+        o = torch.full((M, N), -7.0, device="cuda")      # untouched cells must stay -7 in both paths
         tab = torch.rand(2 * max(aol, 8), device="cuda", generator=g)
         sc = torch.empty(L.snerf_linear_scratch_bytes(N, K), dtype=torch.uint8, device="cuda")
         stt = torch.zeros(2 * N, dtype=torch.float64, device="cuda")
