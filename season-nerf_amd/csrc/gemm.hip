@@ -642,6 +642,10 @@ __global__ __launch_bounds__(512) void gemm_rows_full_kernel(const GemmX g) {
                 if (ACT) __builtin_amdgcn_sched_barrier(0);
             }
         };
+        if (ACT) {      // this variant's epilogue spills registers: the prefetched operands must have landed before it may touch them
+#pragma unroll
+            for (int d = 0; d < PF; ++d) a8_wait<0>(px[d], py[d]);
+        }
         if (rt * RO_ROWS + RO_ROWS <= g.M) epilogue(std::true_type{});
         else epilogue(std::false_type{});
         arow = anext;
