@@ -258,9 +258,7 @@ static hipError_t linear_dgrad(snerf_trainer* t, const LayerP& L, const float* d
         x.A = dZ; x.frag = t->w_frag; x.C = dIn; x.M = M; x.N = n_cols; x.K = L.n_out; x.lda = ldz; x.ldc = ld_in;
         x.alpha = alpha; x.bias = nullptr; x.stats = nullptr; x.accumulate = accumulate ? 1 : 0;
         if (below && below->tab && below->L->n_out == n_cols) {      // with `accumulate` the caller guarantees this is the last producer
-            e = hipMemsetAsync(t->bn_stats, 0, 2 * n_cols * sizeof(double), st);
-            if (e != hipSuccess) return e;
-            x.stats = t->bn_stats; x.ez = below->Z.p; x.eld = below->Z.ld; x.etab = below->tab;
+            x.stats = t->bn_stats; x.ez = below->Z.p; x.eld = below->Z.ld; x.etab = below->tab;      // sums: zero here (cleared by their last consumer)
             if (below->L->bn) { x.emu = below->bnslot + 2 * t->W; x.eistd = below->bnslot + 3 * t->W; }
             if (fused) *fused = true;
         }
@@ -318,10 +316,12 @@ static int sine_fwd(snerf_trainer* t, const LayerP& L, Act In, int64_t M, Act Z,
         float *colsum = bnslot, *m2 = bnslot + t->W, *mean = bnslot + 2 * t->W, *istd = bnslot + 3 * t->W;
         if (train_bn && rows_ok(t, M, L.n_in, L.n_out)) {
             // batch statistics from the GEMM epilogue: shifted sums (shift = 30 b) in double, no extra pass over Z
-            HIPCK(hipMemsetAsync(t->bn_stats, 0, 2 * C * sizeof(double), st));
+            // t->bn_stats is zero here: every consumer of the sums clears them (and each pass starts with one memset)
             HIPCK(linear_fwd(t, L, In, M, Z.p, Z.ld, 30.f, nullptr, st, t->bn_stats));
             RCI(all_reduce(t, t->bn_stats, 2 * C, true, st));          // the shift 30 b is the same on every rank: the sums add
-            HIPCK(launch_bn_finalize_shifted(t->bn_stats, t->params + L.b, 30.f, Mg, C, mean, istd, t->buffers + L.rm, t->buffers + L.rv, st));
+            HIPCK(launch_bn_finalize_shifted(t->bn_stats, t->params + L.b, 30.f, Mg, C, mean, istd, t->buffers + L.rm, t->buffers + L.rv,
+                                             t->params + L.g, t->params + L.beta, tab_out, st));
+            if (tab_out) return SNERF_OK;                               // the table is written; no sin pass with activation on load
         } else if (train_bn) {
             HIPCK(hipMemsetAsync(bnslot, 0, 2 * t->W * sizeof(float), st));
             HIPCK(linear_fwd(t, L, In, M, Z.p, Z.ld, 30.f, colsum, st));
@@ -342,8 +342,8 @@ static int sine_fwd(snerf_trainer* t, const LayerP& L, Act In, int64_t M, Act Z,
         else HIPCK(launch_sin_fwd(Z.p, H.p, M, C, Z.ld, H.ld, mean, istd, t->params + L.g, t->params + L.beta, st));
     } else {
         HIPCK(linear_fwd(t, L, In, M, Z.p, Z.ld, 30.f, nullptr, st));
-        if (tab_out) HIPCK(launch_act_table(nullptr, nullptr, nullptr, nullptr, C, tab_out, st));
-        else HIPCK(launch_sin_fwd(Z.p, H.p, M, C, Z.ld, H.ld, nullptr, nullptr, nullptr, nullptr, st));
+        // without BatchNorm the table is the constant [1/(2 pi) | 0]: written once at bind time (const_tables)
+        if (!tab_out) HIPCK(launch_sin_fwd(Z.p, H.p, M, C, Z.ld, H.ld, nullptr, nullptr, nullptr, nullptr, st));
     }
     return SNERF_OK;
 }
@@ -423,6 +423,8 @@ static int forward_pass(snerf_trainer* t, snerf_trainer::Pass& P, bool solar, in
                         float* adjust_col_out = nullptr) {
     const int W = t->W, W2 = t->W2, W4 = t->W4, C = t->C;
     const int64_t N = R * S;
+    // the column-sum scratch starts every pass at zero (its consumers clear what they read: no memset per layer)
+    HIPCK(hipMemsetAsync(t->bn_stats, 0, (size_t)(4 * W + 2) * sizeof(float), st));
     HIPCK(hipMemcpyAsync(P.top, top, R * 3 * sizeof(float), hipMemcpyDeviceToDevice, st));
     HIPCK(hipMemcpyAsync(P.bot, bot, R * 3 * sizeof(float), hipMemcpyDeviceToDevice, st));
     HIPCK(hipMemcpyAsync(P.tvals, tvals, S * sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -556,8 +558,15 @@ int snerf_trainer_bind(snerf_trainer* t, float* d_params, float* d_grads, float*
     t->ws = (char*)d_workspace; t->ws_bytes = workspace_bytes;
     t->R = n_rays; t->Rs = n_solar_rays; t->S = n_samples;
     carve(t, t->ws, n_rays, n_solar_rays, n_samples);
-    for (snerf_trainer::Pass* P : {&t->img, &t->sol})      // the zero pad columns of the solar branch's concat input
+    for (snerf_trainer::Pass* P : {&t->img, &t->sol}) {
+        // the zero pad columns of the solar branch's concat input
         if (P->N > 0) HIPCK(hipMemset(P->In_s1.p, 0, (size_t)P->N * P->In_s1.ld * sizeof(float)));
+        // activation-on-load tables of the layers without BatchNorm (fc1, adjust 1-3, solar 1-3) are constants: [1/(2 pi) | 0]
+        const int slots[7] = {0, 9, 10, 11, 12, 13, 14};
+        for (int sl : slots) HIPCK(launch_act_table(nullptr, nullptr, nullptr, nullptr, sl >= 12 ? t->W2 : t->W, P->tabs + (int64_t)sl * 2 * t->W, nullptr));
+    }
+    HIPCK(hipMemset(t->bn_stats, 0, (size_t)(4 * t->W + 2) * sizeof(float)));
+    HIPCK(hipDeviceSynchronize());
     return SNERF_OK;
 }
 
@@ -611,6 +620,7 @@ int snerf_trainer_backward_image(snerf_trainer* t, const float* d_g_rgb, const f
     HIPCK(launch_composite_bwd(cb, st));
     if (d_g_sky) HIPCK(launch_copy_cols(d_g_sky, 3, t->d_sky, 3, R, 3, true, st));
     HIPCK(hipMemsetAsync(t->d_cls, 0, R * C * sizeof(float), st));
+    HIPCK(hipMemsetAsync(t->bn_stats, 0, (size_t)(4 * W + 2) * sizeof(float), st));      // column-sum scratch: zero at the start of the pass
     PointOutArgs po{};
     po.n = N; po.n_samples = S; po.C = C; po.head = P.head.p; po.adj = P.adj.p; po.cls = P.cls; po.col = P.col; po.sv = P.sv;
     po.d_rho = t->d_rho; po.d_col = t->d_col; po.d_head = t->d_head; po.d_adj = t->d_adj; po.d_cls = t->d_cls;
@@ -698,6 +708,7 @@ int snerf_trainer_backward_solar(snerf_trainer* t, const float* d_g_solar_vis, v
     const int W2 = t->W2;
     const int64_t N = P.N;
     auto& Ls = t->layers;
+    HIPCK(hipMemsetAsync(t->bn_stats, 0, (size_t)(4 * t->W + 2) * sizeof(float), st));
     PointOutArgs po{};
     po.n = N; po.n_samples = t->S; po.C = t->C; po.head = P.head.p; po.sv = P.sv; po.d_sv = d_g_solar_vis; po.d_sv_raw = t->d_sv_raw;
     HIPCK(launch_point_out(po, true, st));

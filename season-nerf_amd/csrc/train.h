@@ -97,15 +97,17 @@ hipError_t launch_colreduce(const ColArgs& a, hipStream_t st);
 hipError_t launch_bn_finalize(const float* colsum, const float* m2, int64_t M, int C, float* mean, float* istd,
                               float* running_mean, float* running_var, int stage, hipStream_t st);
 // H = sin(gamma*(Z-mu)*istd + beta) (bn) or sin(Z)
-hipError_t launch_bn_finalize_shifted(const double* stats, const float* bias, float alpha, int64_t M, int C, float* mean, float* istd,
-                                      float* running_mean, float* running_var, hipStream_t st);
+// consumes AND clears the sums; tab (optional): the layer's activation-on-load table [a | b] from gamma / beta and the new statistics
+hipError_t launch_bn_finalize_shifted(double* stats, const float* bias, float alpha, int64_t M, int C, float* mean, float* istd,
+                                      float* running_mean, float* running_var, const float* gamma, const float* beta, float* tab,
+                                      hipStream_t st);
 hipError_t launch_sin_fwd(const float* Z, float* H, int64_t M, int C, int64_t ldz, int64_t ldh, const float* mu, const float* istd,
                           const float* gamma, const float* beta, hipStream_t st);
 // BN backward second pass: dZ = gamma*istd*(dY - sdy/M - xhat*sdyx/M) in place; colsum(dZ) -> out (bias grad)
 hipError_t launch_bn_bwd2(const float* Z, float* D, int64_t M, int C, int64_t ld, int64_t ldd, const float* mu, const float* istd,
                           const float* gamma, const float* beta, const float* sdy, const float* sdyx, float* dbias_sum, float alpha,
                           int64_t M_global, hipStream_t st, bool d_is_dy = false);
-hipError_t launch_act_sums_finalize(const double* stats, int C, float scale0, float* out0, float* out1, float* acc0, float* acc1, hipStream_t st);
+hipError_t launch_act_sums_finalize(double* stats, int C, float scale0, float* out0, float* out1, float* acc0, float* acc1, hipStream_t st);      // consumes and clears the sums
 // activation-on-load table of a SineLayer: dst = [a | b] (n each), a = gamma*istd/(2 pi), b = (beta - gamma*mu*istd)/(2 pi);
 // all-NULL statistics = a layer without BatchNorm (a = 1/(2 pi), b = 0)
 hipError_t launch_act_table(const float* mu, const float* istd, const float* gamma, const float* beta, int n, float* dst, hipStream_t st);

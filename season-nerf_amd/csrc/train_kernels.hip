@@ -256,39 +256,56 @@ hipError_t launch_bn_finalize(const float* colsum, const float* m2, int64_t M, i
 }
 
 // train-mode statistics from the shifted sums of the GEMM epilogue: S1 = sum(z - s), S2 = sum((z - s)^2), s = alpha*bias
-__global__ void bn_finalize_shifted_kernel(const double* stats, const float* bias, float alpha, int64_t M, int C, float* mean, float* istd,
-                                           float* running_mean, float* running_var) {
+// Also (one launch instead of three): writes the layer's activation-on-load table [a | b] (act_table_kernel's arithmetic on the
+// rounded fp32 mean / istd just stored) when tab != nullptr, and clears the sums it consumed, so that the next producer finds
+// zeros without a memset in between.
+__global__ void bn_finalize_shifted_kernel(double* stats, const float* bias, float alpha, int64_t M, int C, float* mean, float* istd,
+                                           float* running_mean, float* running_var, const float* gamma, const float* beta, float* tab) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     const double m1 = stats[c] / (double)M, m2 = stats[C + c] / (double)M;
+    stats[c] = 0.0;
+    stats[C + c] = 0.0;
     const double mu = (double)(alpha * bias[c]) + m1;
     double var_b = m2 - m1 * m1;                                    // biased: normalisation (torch BatchNorm1d)
     if (var_b < 0.0) var_b = 0.0;
-    mean[c] = (float)mu;
-    istd[c] = 1.f / sqrtf((float)var_b + 1e-5f);
+    const float mean_f = (float)mu, istd_f = 1.f / sqrtf((float)var_b + 1e-5f);
+    mean[c] = mean_f;
+    istd[c] = istd_f;
     const double var_u = M > 1 ? var_b * (double)M / (double)(M - 1) : var_b;    // unbiased: running estimate
     running_mean[c] = 0.99f * running_mean[c] + 0.01f * (float)mu;
     running_var[c] = 0.99f * running_var[c] + 0.01f * (float)var_u;
+    if (tab) {
+        const double inv2pi = 0.15915494309189535;
+        double a = (double)gamma[c] * (double)istd_f;
+        const double b = ((double)beta[c] - a * (double)mean_f) * inv2pi;
+        a *= inv2pi;
+        tab[c] = (float)a;
+        tab[C + c] = (float)b;
+    }
 }
-hipError_t launch_bn_finalize_shifted(const double* stats, const float* bias, float alpha, int64_t M, int C, float* mean, float* istd,
-                                      float* running_mean, float* running_var, hipStream_t st) {
+hipError_t launch_bn_finalize_shifted(double* stats, const float* bias, float alpha, int64_t M, int C, float* mean, float* istd,
+                                      float* running_mean, float* running_var, const float* gamma, const float* beta, float* tab,
+                                      hipStream_t st) {
     hipLaunchKernelGGL(bn_finalize_shifted_kernel, dim3((C + 255) / 256), dim3(256), 0, st, stats, bias, alpha, M, C, mean, istd,
-                       running_mean, running_var);
+                       running_mean, running_var, gamma, beta, tab);
     return hipGetLastError();
 }
 
 // sums of a fused activation-backward epilogue (double [2][C]) -> fp32 vectors out0 = scale0*S0, out1 = S1 (optional) and
 // accumulated into parameter gradients acc0 += scale0*S0, acc1 += S1 (optional)
-__global__ void act_sums_finalize_kernel(const double* stats, int C, float scale0, float* out0, float* out1, float* acc0, float* acc1) {
+__global__ void act_sums_finalize_kernel(double* stats, int C, float scale0, float* out0, float* out1, float* acc0, float* acc1) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     const float s0 = scale0 * (float)stats[c], s1 = (float)stats[C + c];
+    stats[c] = 0.0;                                  // consumed: the next producer finds zeros
+    stats[C + c] = 0.0;
     if (out0) out0[c] = s0;
     if (out1) out1[c] = s1;
     if (acc0) acc0[c] += s0;
     if (acc1) acc1[c] += s1;
 }
-hipError_t launch_act_sums_finalize(const double* stats, int C, float scale0, float* out0, float* out1, float* acc0, float* acc1, hipStream_t st) {
+hipError_t launch_act_sums_finalize(double* stats, int C, float scale0, float* out0, float* out1, float* acc0, float* acc1, hipStream_t st) {
     hipLaunchKernelGGL(act_sums_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, stats, C, scale0, out0, out1, acc0, acc1);
     return hipGetLastError();
 }
