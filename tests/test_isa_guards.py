@@ -14,6 +14,15 @@ SRC = os.path.join(REPO, "season-nerf_amd", "csrc", "gemm.hip")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 
+def _vregs(text):
+    out = set()
+    for a, b in re.findall(r"v\[(\d+):(\d+)\]", text):
+        out.update(range(int(a), int(b) + 1))
+    for a in re.findall(r"\bv(\d+)\b", text):
+        out.add(int(a))
+    return out
+
+
 @pytest.mark.skipif(not (os.path.exists(HIPCC) or shutil.which("hipcc")), reason="hipcc not available")
 def test_full_tile_kernels_do_not_spill_pending_loads(tmp_path):
     out = tmp_path / "gemm.s"
@@ -37,6 +46,21 @@ def test_full_tile_kernels_do_not_spill_pending_loads(tmp_path):
         assert waits >= pf, (nt, pf, aol, act, waits)
         if not act:
             assert scratch == 0, f"gemm_rows_full_kernel<{nt},{pf},{aol},{act}> spills ({scratch} scratch ops) while A loads are pending"
+        else:      # spills allowed, but never of a register with a hand-issued load in flight (program-order scan)
+            pending, in_asm = set(), False
+            for l in body:
+                t = l.strip()
+                if t.startswith(";;#ASMSTART"):
+                    in_asm = True
+                elif t.startswith(";;#ASMEND"):
+                    in_asm = False
+                elif in_asm and t.startswith("global_load_dwordx4"):
+                    pending |= _vregs(t.split(",")[0])
+                elif in_asm and "a8_wait" in t:
+                    pending -= _vregs(t.split("a8_wait")[1])
+                elif "scratch_store" in t:
+                    hit = _vregs(t.split(";")[0]) & pending
+                    assert not hit, f"gemm_rows_full_kernel<{nt},{pf},{aol},{act}> spills v{sorted(hit)} while its load is in flight: {t}"
         seen += 1
         i = j
     assert seen >= 18
