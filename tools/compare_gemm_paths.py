@@ -38,6 +38,35 @@ if len(sys.argv) > 1:
                                            istd.data_ptr() if (act and bn) else None, sums.data_ptr() if act else None, st), "dgrad")
         out[f"dgrad_{M}_{n_out}_{n_cols}_{act}_{bn}"] = gi.cpu().numpy()
         if act: out[f"dgradsums_{M}_{n_out}_{n_cols}_{bn}"] = sums.cpu().numpy()
+    n_fuzz = int(os.environ.get("SNERF_CMP_FUZZ", "0"))      # extra random shapes (same seed in both modes)
+    rs = np.random.RandomState(11)
+    for it in range(n_fuzz):
+        M = int(rs.randint(1024, 40000))
+        K = 16 * int(rs.randint(1, 21))
+        N = int(rs.choice([1, 3, 12, 31, 32, 64, 96, 128, 160, 192, 224, 256]))
+        lda = K + 4 * int(rs.randint(0, 3))
+        aol = 16 * int(rs.randint(0, K // 16 + 1))
+        stats = bool(rs.randint(0, 2)) and N % 32 == 0
+        A = rnd(M, lda); W_ = rnd(N, K) / K ** 0.5; b = rnd(N)
+        ldc = N + int(rs.randint(0, 2)) * 4
+        o = torch.full((M, ldc), -7.0, device="cuda")
+        tab = torch.rand(2 * max(aol, 8), device="cuda", generator=g)
+        sc = torch.empty(L.snerf_linear_scratch_bytes(N, K), dtype=torch.uint8, device="cuda")
+        stt = torch.zeros(2 * N, dtype=torch.float64, device="cuda")
+        sn._lib.check(L.snerf_linear_forward(M, K, N, A.data_ptr(), lda, W_.data_ptr(), b.data_ptr(), 30.0, o.data_ptr(), ldc, stt.data_ptr() if stats else None, 1,
+                                             sc.data_ptr(), sc.numel(), tab.data_ptr() if aol else None, aol, st), "fwd")
+        out[f"fz{it}fwd_{M}_{K}_{N}_{aol}_{lda}_{ldc}"] = o.cpu().numpy()
+        n_out, n_cols = 16 * int(rs.randint(1, 17)), int(rs.choice([32, 64, 128, 160, 256]))
+        act, bn = bool(rs.randint(0, 2)), bool(rs.randint(0, 2))
+        dZ = rnd(M, n_out); W2_ = rnd(n_out, n_cols) / n_out ** 0.5
+        gi = torch.full((M, n_cols), -7.0, device="cuda"); z = rnd(M, n_cols)
+        tab2 = torch.rand(2 * n_cols, device="cuda", generator=g); mu = rnd(n_cols); istd = torch.rand(n_cols, device="cuda", generator=g) + 0.5
+        sums = torch.zeros(2 * n_cols, dtype=torch.float64, device="cuda")
+        sc2 = torch.empty(L.snerf_linear_scratch_bytes(n_out, n_cols), dtype=torch.uint8, device="cuda")
+        sn._lib.check(L.snerf_linear_dgrad(M, n_cols, n_out, dZ.data_ptr(), n_out, W2_.data_ptr(), n_cols, 30.0, 0, gi.data_ptr(), n_cols, 1, sc2.data_ptr(), sc2.numel(),
+                                           z.data_ptr() if act else None, n_cols, tab2.data_ptr() if act else None, mu.data_ptr() if (act and bn) else None,
+                                           istd.data_ptr() if (act and bn) else None, sums.data_ptr() if act else None, st), "dgrad")
+        out[f"fz{it}dgrad_{M}_{n_out}_{n_cols}_{act}_{bn}"] = gi.cpu().numpy()
     np.savez(sys.argv[1], **out)
     sys.exit(0)
 os.makedirs("/tmp/cmp", exist_ok=True)
