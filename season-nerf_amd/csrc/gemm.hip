@@ -650,6 +650,11 @@ __global__ __launch_bounds__(512) void gemm_rows_full_kernel(const GemmX g) {
         else epilogue(std::false_type{});
         arow = anext;
     }
+    // The last round's refills (and the first loads of a worker without tiles) are never consumed.  They must have landed
+    // before the code below may reuse their registers: a late-landing load would overwrite whatever lives there by then
+    // (an address, for instance).  The wait also keeps the registers allocated up to this point.
+#pragma unroll
+    for (int d = 0; d < PF; ++d) a8_wait<0>(px[d], py[d]);
     if (g.stats) {
         __syncthreads();
         float* red = (float*)lds_w;                        // [8 waves][NT][2][32]
