@@ -8,8 +8,8 @@ A "step" = one pass of the hot path over one ray batch: per-ray group network (s
     python bench.py [--gpus N] [--steps K] [--warmup W]          (N>1: launched by torch.distributed.run)
 
 Prints ONE JSON line on rank 0.  Multi-GPU: every rank renders its own 4096-ray tile (weak scaling, rays are
-independent) and the rendered RGB tiles are all-gathered over RCCL each step (the tile exchange of a tiled
-novel-view render); value = total ray-samples of all ranks / max-over-ranks time.
+independent) and the rendered RGB tiles are all-gathered over RCCL, 8 steps per asynchronous collective (the tile
+exchange of a tiled novel-view render); value = total ray-samples of all ranks / max-over-ranks time.
 """
 import argparse
 import ctypes as C
@@ -284,16 +284,10 @@ def main():
     e = lambda *s: torch.empty(*s, device=dev)
     cls, sky_raw, sky = e(R, NC), e(R, 3), e(R, 3)
     rho, sv, col = e(R * S), e(R * S), e(R * S, 3)
-    # RGB tiles of G consecutive steps share one all-gather (fewer, larger collectives: a 48 KB tile per step is pure launch
-    # latency), and the tile groups are double-buffered so that the gather of one group (RCCL's own stream) overlaps the
-    # kernels of the next
-    G = 8
-    groups = [e(G, R, 3), e(G, R, 3)]
-    gathered = [e(world, G, R, 3), e(world, G, R, 3)] if use_dist else None
-    pending = [None, None]
+    # RGB tiles of 8 consecutive steps share one asynchronous all-gather on double-buffered tile groups (parallel.TileGroupGather)
+    tg = sn.parallel.TileGroupGather((R, 3), group=8, device=dev) if use_dist else None
+    rgb_local = e(R, 3)
     fo = sn._lib.FieldOut(d_rho=rho.data_ptr(), d_solar_vis=sv.data_ptr(), d_col=col.data_ptr())
-    cos = [[sn._lib.CompositeOut(d_rgb=grp[k].data_ptr()) for k in range(G)] for grp in groups]
-    counter = [0]
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps)]
@@ -307,42 +301,26 @@ def main():
                                                  1, sun.data_ptr(), cls.data_ptr(), C.byref(fo), st), "field")
         if i is not None:
             ev1[i].record()
-        n = counter[0]
-        counter[0] += 1
-        b, k = (n // G) & 1, n % G
-        if k == 0 and pending[b] is not None:
-            pending[b].wait()                  # the gather that last read this tile group (two groups ago)
-            pending[b] = None
+        out = tg.slot() if use_dist else rgb_local
+        co = sn._lib.CompositeOut(d_rgb=out.data_ptr())
         sn._lib.check(L.snerf_composite_rays(R, S, top.data_ptr(), bot.data_ptr(), tv.data_ptr(), rho.data_ptr(),
-                                             col.data_ptr(), sv.data_ptr(), sky.data_ptr(), 0, None, 1.0, C.byref(cos[b][k]), st),
+                                             col.data_ptr(), sv.data_ptr(), sky.data_ptr(), 0, None, 1.0, C.byref(co), st),
                       "composite")
-        if use_dist and k == G - 1:
-            pending[b] = dist.all_gather_into_tensor(gathered[b], groups[b], async_op=True)
-
-    def flush():                               # a last, partly filled group is gathered as a whole
-        n = counter[0]
-        if use_dist and n % G:
-            b = (n // G) & 1
-            pending[b] = dist.all_gather_into_tensor(gathered[b], groups[b], async_op=True)
+        if use_dist:
+            tg.commit()
 
     for _ in range(a.warmup):
         step()
-    flush()
-    for w in pending:
-        if w is not None:
-            w.wait()
-    pending[0] = pending[1] = None
-    counter[0] = 0
+    if use_dist:
+        tg.reset()
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(a.steps):
         step(i)
-    flush()
-    for w in pending:
-        if w is not None:
-            w.wait()
+    if use_dist:
+        tg.flush()
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()

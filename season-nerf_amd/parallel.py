@@ -40,6 +40,66 @@ def gather_rows(local, n_total, group=None):
     return torch.cat([buf[k * mx: k * mx + (hi - lo)] for k, (lo, hi) in enumerate(bounds)], 0)
 
 
+class TileGroupGather:
+    """Asynchronous all-gather of per-step result tiles, `group` steps per collective (fewer, larger collectives: one 48 KB RGB
+    tile per step is pure launch latency - measured 10 % of a 1.4 ms render step against 1.3 % with 8 steps per gather).
+    Tile groups are double-buffered: the gather of one group overlaps the kernels that fill the next.
+
+        tg = TileGroupGather((R, 3), group=8, device=dev)
+        for i in range(steps):
+            out = tg.slot()            # [R, 3] view: let the kernel of step i write its tile here (current stream)
+            ...launch...
+            tg.commit()                # starts the gather when the group is full
+        tg.flush()                     # gathers a last, partly filled group and waits for everything
+        tiles = tg.gathered(k)         # [world, R, 3] of step k (valid for the last two groups)
+    """
+
+    def __init__(self, tile_shape, group=8, device=None, dtype=torch.float32, pg=None):
+        self.pg, self.G = pg, int(group)
+        self.world = dist.get_world_size(pg) if dist.is_initialized() else 1
+        self.tiles = [torch.empty((self.G,) + tuple(tile_shape), dtype=dtype, device=device) for _ in range(2)]
+        self.full = [torch.empty((self.world, self.G) + tuple(tile_shape), dtype=dtype, device=device) for _ in range(2)]
+        self.pending = [None, None]
+        self.n = 0
+
+    def slot(self):
+        b, k = (self.n // self.G) & 1, self.n % self.G
+        if k == 0 and self.pending[b] is not None:
+            self.pending[b].wait()                 # the gather that last read this tile group (two groups ago)
+            self.pending[b] = None
+        return self.tiles[b][k]
+
+    def _start(self, b):
+        if dist.is_initialized():
+            flat = self.full[b].view((self.world * self.G,) + tuple(self.tiles[b].shape[1:]))      # concatenation form: every backend takes it
+            self.pending[b] = dist.all_gather_into_tensor(flat, self.tiles[b], group=self.pg, async_op=True)
+        else:
+            self.full[b][0].copy_(self.tiles[b])
+
+    def commit(self):
+        b, k = (self.n // self.G) & 1, self.n % self.G
+        self.n += 1
+        if k == self.G - 1:
+            self._start(b)
+
+    def flush(self):
+        if self.n % self.G:
+            self._start((self.n // self.G) & 1)
+        for b in (0, 1):
+            if self.pending[b] is not None:
+                self.pending[b].wait()
+                self.pending[b] = None
+
+    def reset(self):
+        self.flush()
+        self.n = 0
+
+    def gathered(self, step):
+        """[world, *tile_shape] of `step` (after the gather of its group has been waited for, e.g. by flush())."""
+        b, k = (step // self.G) & 1, step % self.G
+        return self.full[b][:, k]
+
+
 class ShardedEval:
     """Wraps an evaluator's `eval`: each rank evaluates its ray shard, per-ray results are all-gathered."""
 

@@ -82,3 +82,34 @@ def _grad_worker(rank, world, port):
 
 def test_allreduce_gradients_two_ranks():
     mp.spawn(_grad_worker, args=(2, 29500 + (os.getpid() + 777) % 2000), nprocs=2, join=True)
+
+
+def _tile_worker(rank, world, port, steps, group):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    par = _load_parallel()
+    tg = par.TileGroupGather((5, 3), group=group, device="cpu")
+    for i in range(steps):
+        tg.slot().fill_(100.0 * rank + i)          # "the kernel of step i writes its tile"
+        tg.commit()
+    tg.flush()
+    first_valid = max(0, (steps - 1) // group - 1) * group      # the last two tile groups are still held
+    for k in range(first_valid, steps):
+        got = tg.gathered(k)
+        assert got.shape == (world, 5, 3)
+        for r in range(world):
+            assert torch.all(got[r] == 100.0 * r + k), (k, r, got[r][0])
+    tg.reset()                                       # reusable after a reset (warm-up -> timed region in bench.py)
+    tg.slot().fill_(7.0 + rank)
+    tg.commit()
+    tg.flush()
+    assert torch.all(tg.gathered(0)[1 - rank] == 7.0 + (1 - rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("steps,group", [(8, 3), (6, 3), (1, 8), (17, 8)])
+def test_tile_group_gather_two_ranks(steps, group):
+    """The grouped, double-buffered asynchronous tile all-gather that bench.py's N > 1 render path uses."""
+    port = 31500 + (os.getpid() + 7 * steps + group) % 2000
+    mp.spawn(_tile_worker, args=(2, port, steps, group), nprocs=2, join=True)
