@@ -46,21 +46,22 @@ def test_full_tile_kernels_do_not_spill_pending_loads(tmp_path):
         assert waits >= pf, (nt, pf, aol, act, waits)
         if not act:
             assert scratch == 0, f"gemm_rows_full_kernel<{nt},{pf},{aol},{act}> spills ({scratch} scratch ops) while A loads are pending"
-        else:      # spills allowed, but never of a register with a hand-issued load in flight (program-order scan)
-            pending, in_asm = set(), False
-            for l in body:
-                t = l.strip()
-                if t.startswith(";;#ASMSTART"):
-                    in_asm = True
-                elif t.startswith(";;#ASMEND"):
-                    in_asm = False
-                elif in_asm and t.startswith("global_load_dwordx4"):
-                    pending |= _vregs(t.split(",")[0])
-                elif in_asm and "a8_wait" in t:
-                    pending -= _vregs(t.split("a8_wait")[1])
-                elif "scratch_store" in t:
-                    hit = _vregs(t.split(";")[0]) & pending
-                    assert not hit, f"gemm_rows_full_kernel<{nt},{pf},{aol},{act}> spills v{sorted(hit)} while its load is in flight: {t}"
+        # every variant: no spill and no register move may touch a register with a hand-issued load in flight (program-order scan)
+        pending, in_asm = set(), False
+        for l in body:
+            t = l.strip()
+            code = t.split(";")[0]
+            if t.startswith(";;#ASMSTART"):
+                in_asm = True
+            elif t.startswith(";;#ASMEND"):
+                in_asm = False
+            elif in_asm and t.startswith("global_load_dwordx4"):
+                pending |= _vregs(t.split(",")[0])
+            elif in_asm and "a8_wait" in t:
+                pending -= _vregs(t.split("a8_wait")[1])
+            elif "scratch_" in code or code.startswith("v_mov") or code.startswith("v_accvgpr"):
+                hit = _vregs(code) & pending
+                assert not hit, f"gemm_rows_full_kernel<{nt},{pf},{aol},{act}> moves / spills v{sorted(hit)} while its load is in flight: {t}"
         seen += 1
         i = j
     assert seen >= 18
