@@ -5,9 +5,15 @@ T_NeRF(256, 4) (eval-mode BN, random weights of the reference's init law), synth
 A "step" = one pass of the hot path over one ray batch: per-ray group network (season classes + sky colour)
 -> fused field network (sampling + PE + SIREN MLP + heads) -> wave-scan compositing, inputs resident in HBM.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]          (N>1: launched by torch.distributed.run)
+    python bench.py [--gpus N] [--steps K] [--warmup W]
 
-Prints ONE JSON line on rank 0.  Multi-GPU: every rank renders its own 4096-ray tile (weak scaling, rays are
+N > 1: one process per GPU.  Either the driver starts the ranks (`python -m torch.distributed.run --nproc-per-node N ... bench.py
+--gpus N`: RANK / WORLD_SIZE set), or a bare `python bench.py --gpus N` starts them itself - as a CHILD process running
+torch.distributed.run, before this process has touched the GPU - and exits with the child's status.
+
+Prints ONE JSON line on rank 0.  At N = 1 the line also carries the training step of BASELINE configs[2] as extra keys
+(`train_ms_per_step`, `train_roofline`, `train_cpu_baseline`; MSE colour loss = the reference-pinned path), the evaluator-seam
+time (`eval_seam_ms`) and the 512 x 512 x 96 + 12-step sweep render, all measured outside the headline timed region.  Multi-GPU: every rank renders its own 4096-ray tile (weak scaling, rays are
 independent) and the rendered RGB tiles are all-gathered over RCCL, 8 steps per asynchronous collective (the tile
 exchange of a tiled novel-view render); value = total ray-samples of all ranks / max-over-ranks time.
 """
@@ -83,24 +89,24 @@ def cpu_baseline():
                       f"median of {reps} after warm-up"}
 
 
-def bench_train(a):
-    """BASELINE configs[2]: training step = zero_grad, get_loss (image rays + R random sun rays, train-mode BatchNorm,
-    Barron adaptive colour loss by default - `--loss mse` selects the reference's other colour loss, the one whose gradients
-    are pinned against the reference), backward, gradient all-reduce over RCCL when N > 1, fused Adam."""
+def bench_train(a, standalone=True):
+    """BASELINE configs[2]: training step = zero_grad, get_loss (image rays + R random sun rays, train-mode BatchNorm, MSE
+    colour loss by default - the path whose losses and gradients are pinned to the reference at this very size,
+    tests/golden/train_W256_R4096_S96.npz; `--loss barron` selects the parity-unpinned adaptive loss), backward, gradient
+    all-reduce over RCCL when N > 1, fused Adam.  Returns the result dict on rank 0 (None elsewhere).
+    standalone=False: called from the render benchmark at N = 1 (no process group, its own step counts)."""
     from types import SimpleNamespace
     import season_nerf_amd as sn
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
-    if a.gpus > 1 and world != a.gpus:
-        raise SystemExit(f"--gpus {a.gpus} needs torch.distributed.run with {a.gpus} ranks (WORLD_SIZE={world})")
     torch.cuda.set_device(dev)
     dist = None
-    use_dist = world > 1 or "RANK" in os.environ          # under torch.distributed.run the RCCL path runs even with one rank
+    use_dist = standalone and (world > 1 or "RANK" in os.environ)      # under torch.distributed.run the RCCL path runs even with one rank
     if use_dist:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
-    steps, warm = min(a.steps, 20), min(a.warmup, 3)
+    steps, warm = (min(a.steps, 20), min(a.warmup, 3)) if standalone else (12, 3)
     net = sn.T_NeRF(W, NC)
     net.load_state_dict(sn.synthetic_state_dict(net, 0, bn_stats="identity"))        # reference init law, fresh BatchNorm
     net = net.to(dev).train()
@@ -113,31 +119,16 @@ def bench_train(a):
     ev = sn.All_in_One_Eval(args, dev, 10, False, ada, H4, WC)
     d = synth(rank, dev)
     d["GT_Color"] = torch.rand(R, 3, device=dev)
-    opt = sn.FusedAdam(net, lr=10 ** -4.86)
-    opt_ada = torch.optim.Adam(ada.parameters(), lr=10 ** -4.86) if barron else None      # Net_Tool_2.py:115 (second Adam)
+    # the reference's optimisation step as the training seam runs it (trainer.Net_tool.train_step = mg_run_NeRF.py:288-326):
+    # FusedAdam (all-reduces the flat gradient arena under data parallelism) + a second Adam on the loss object's parameters
+    # (their gradients travel as one small all-reduce) + OneCycleLR on both
+    tool = sn.Net_tool(net, ev, 10 ** -4.86, total_steps=steps + warm + 1, lr_alpha_scale=1000.0, writer=None)
     np.random.seed(rank)
     torch.manual_seed(rank)
 
     def step():
-        opt.zero_grad()
-        if opt_ada is not None:
-            opt_ada.zero_grad()
-        loss = ev.get_loss(d, net, 0, True)
-        total = sum(v * w for v, w in loss.values())
-        total.backward()
-        opt.step()                       # all-reduces the flat gradient arena when torch.distributed is initialised
-        if opt_ada is not None:
-            if use_dist:                 # the two 3-element gradients of the loss object travel as one message
-                ps = [p_ for p_ in ada.parameters() if p_.grad is not None]
-                flat = torch.cat([p_.grad.reshape(-1) for p_ in ps])
-                dist.all_reduce(flat)
-                flat /= world
-                o = 0
-                for p_ in ps:
-                    p_.grad.copy_(flat[o:o + p_.numel()].view_as(p_.grad))
-                    o += p_.numel()
-            opt_ada.step()
-        return total
+        loss = tool.train_step(d, 0)
+        return sum(v.detach() * w for v, w in loss.values())
 
     step()                                   # builds the engine
     if a.bn_sync == "global" and use_dist:
@@ -202,7 +193,7 @@ def bench_train(a):
     lname = "Barron adaptive loss" if barron else "MSE loss"
     traffic = None      # HBM bytes per step from the committed PMC passes of this same command (tools/train_traffic.sh)
     try:
-        traffic = json.load(open(os.path.join(REPO, "profiles", "r1", "j_train_traffic.json")))["bytes_per_step"]
+        traffic = json.load(open(_profile_file("train_traffic.json")))["bytes_per_step"]
     except Exception:
         pass
     if rank == 0:
@@ -220,7 +211,7 @@ def bench_train(a):
                             "note": "whole step, not one kernel: train-mode BatchNorm forces a layer-wise design in which every layer is "
                                     "a pass over [393216 x width] fp32 arrays; achieved = bytes that design moves per step (counted from "
                                     "the layer table, DESIGN 5.4) / step time, peak = HBM3E 8 TB/s (MI355X_MICROARCH.md); "
-                                    "per-kernel times in profiles/r1/j_train_kernel_stats.csv"}}
+                                    "per-kernel times in profiles/*/train_kernel_stats.csv"}}
         if not a.no_cpu_baseline and world == 1:      # reported at N = 1 only (rank 0)
             from oracle import season_nerf_oracle as orc          # CPU-baseline leg only
             torch.set_num_threads(min(host_cpus(), 32))
@@ -237,33 +228,80 @@ def bench_train(a):
             tc = time.perf_counter() - t0
             out["cpu_baseline"] = {"value": n * S / tc, "unit": "ray-samples/s", "cores": torch.get_num_threads(), "kind": "port",
                                    "sample": f"one MSE training step (forward both passes + backward) on {n} rays x {S} samples, torch-CPU oracle"}
-        print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()
+    return out if rank == 0 else None
+
+
+def _profile_file(name):
+    """Newest committed profile summary of that name (profiles/r<N>/<name> or profiles/r<N>/<letter>_<name>)."""
+    import glob
+    import re
+    c = [f for f in glob.glob(os.path.join(REPO, "profiles", "r*", "*" + name)) if re.fullmatch(r"([a-z]_)?" + re.escape(name), os.path.basename(f))]
+    if not c:
+        raise FileNotFoundError(name)
+    return sorted(c, key=lambda f: (int(os.path.basename(os.path.dirname(f))[1:]), os.path.basename(f)))[-1]
+
+
+def launcher_selftest(a, world, rank):
+    """CPU-only check of the N > 1 start-up path (tests/test_parallel_gloo.py): every rank joins a gloo group, one all-reduce,
+    rank 0 prints one JSON line.  No GPU, no kernels - it exists so that `python bench.py --gpus N` is exercised where no GPU is."""
+    import torch.distributed as dist
+    dist.init_process_group("gloo")
+    t = torch.tensor([float(rank + 1)])
+    dist.all_reduce(t)
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"launcher_selftest": True, "n_gpus": world, "backend": "gloo", "rank_sum": float(t.item()),
+                          "self_launched": "TORCHELASTIC_RUN_ID" in os.environ}))
+    dist.destroy_process_group()
+
+
+def self_launch(a, argv):
+    """`python bench.py --gpus N` with no rank environment: start the N ranks as a child `torch.distributed.run` and exit with
+    its status.  Runs BEFORE anything has initialised the GPU in this process (never re-launch from a process that has)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true", help="skip the auxiliary 512x512 sweep measurement (counter passes)")
     ap.add_argument("--workload", default="render", choices=["render", "train"],
                     help="render = headline (BASELINE configs[1]); train = configs[2]: one training step, 4096x96 + 4096 sun rays")
-    ap.add_argument("--loss", default="barron", choices=["barron", "mse"], help="colour loss of --workload train")
+    ap.add_argument("--loss", default="mse", choices=["barron", "mse"], help="colour loss of --workload train (mse = reference-pinned)")
+    ap.add_argument("--no-train", action="store_true", help="render workload: skip the extra training-step measurement (train_* keys)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help=argparse.SUPPRESS)   # gloo: CPU test of the launcher only
     ap.add_argument("--bn_sync", default="local", choices=["local", "global"],
                     help="--workload train, N > 1: BatchNorm statistics per rank, or over the global batch (RCCL all-reduces of the "
                          "per-layer statistics: the single-process reference's semantics)")
     a = ap.parse_args()
-    if a.workload == "train":
-        return bench_train(a)
-
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a, sys.argv[1:]))          # child ranks; nothing here has touched the GPU
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.gpus > 1 and world != a.gpus:
-        raise SystemExit(f"--gpus {a.gpus} needs torch.distributed.run with {a.gpus} ranks (WORLD_SIZE={world})")
+    if a.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but the launcher started {world} ranks")
+    if a.backend == "gloo":
+        return launcher_selftest(a, world, rank)
+    if a.workload == "train":
+        out = bench_train(a)
+        if out is not None:
+            print(json.dumps(out))
+        return
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
@@ -350,12 +388,44 @@ def main():
         except Exception as ex:      # never let the auxiliary measurement break the headline line
             extra = {"image_sweep_error": repr(ex)}
 
+    if rank == 0 and world == 1:
+        # the same batch through the evaluator seam (All_in_One_Eval.eval: allocates its result tensors, returns the whole
+        # per-sample dict) - what a reference caller pays per call on top of the raw C-ABI step above
+        from types import SimpleNamespace
+        eargs = SimpleNamespace(n_samples=S, Use_Reg=True, Solar_Type_2=False, Use_MSE_loss=True, Use_Solar=True, sc_lambda=0.03,
+                                number_low_frequency_cases=NC)
+        ev_seam = sn.All_in_One_Eval(eargs, dev, 10, False, None, np.eye(4), np.zeros(3))
+        with torch.no_grad():
+            for _ in range(3):
+                ev_seam.eval(d, net, 0, False)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            n_seam = 50
+            for _ in range(n_seam):
+                res = ev_seam.eval(d, net, 0, False)
+            torch.cuda.synchronize()
+            extra["eval_seam_ms"] = (time.perf_counter() - t1) / n_seam * 1e3
+            extra["eval_seam_note"] = "All_in_One_Eval.eval(data_dict on the GPU, net, 0, False): full 14-key result dict, wall clock per call"
+            del res
+        if not a.no_train:
+            del rho, sv, col
+            torch.cuda.empty_cache()
+            try:
+                tr = bench_train(argparse.Namespace(**{**vars(a), "loss": "mse"}), standalone=False)
+                extra.update({"train_ms_per_step": tr["ms_per_step"], "train_value": tr["value"], "train_unit": tr["unit"],
+                              "train_metric": tr["metric"], "train_steps": tr["steps"], "train_final_loss": tr["final_loss"],
+                              "train_dtype": tr["dtype"], "train_roofline": tr["roofline"], "train_config": tr["config"]})
+                if "cpu_baseline" in tr:
+                    extra["train_cpu_baseline"] = tr["cpu_baseline"]
+            except Exception as ex:      # never let the auxiliary measurement break the headline line
+                extra["train_error"] = repr(ex)
+
     if rank == 0:
         value = world * R * S * a.steps / dt
         achieved = FLOP_PER_SAMPLE * R * S / (field_ms * 1e-3)
         traffic = None          # HBM bytes per launch from the committed PMC passes of this same command (profiles/)
         try:
-            traffic = json.load(open(os.path.join(REPO, "profiles", "r1", "j_traffic.json")))["bytes_per_launch"]
+            traffic = json.load(open(_profile_file("traffic.json")))["bytes_per_launch"]
         except Exception:
             pass
         out = {

@@ -133,10 +133,14 @@ typedef struct snerf_sweep_out {
     float* d_base;           /* [R,3] */
     float* d_shadow_adjust;  /* [R,3] */
     float* d_raw_shadow;     /* [R] */
+    float* d_classic;        /* [T,R,3] sum_s PS*sigmoid(col_raw + class_t@Adjust)*(SV + (1-SV)*sky): the per-sample shading of
+                              * get_imgs_from_Img_Dict(use_classic_shadows=True), mg_Img_Eval.py:165-170 */
 } snerf_sweep_out;
 
+/* d_deltas (optional, [R,S]): explicit segment lengths, e.g. the `Deltas` array of a host-side image dict; when given,
+ * d_top / d_bot / d_tvals are not read (may be NULL) and flags bit1 is ignored. */
 int snerf_composite_sweep(int64_t n_rays, int n_samples, int n_classes, int n_times, const float* d_top,
-                          const float* d_bot, const float* d_tvals, const float* d_rho, const float* d_col_raw,
+                          const float* d_bot, const float* d_tvals, const float* d_deltas, const float* d_rho, const float* d_col_raw,
                           const float* d_adjust, const float* d_solar_vis, const float* d_sky, const float* d_class_vecs,
                           int flags, const snerf_sweep_out* out, void* stream);
 
@@ -171,6 +175,13 @@ int snerf_trainer_forward_image(snerf_trainer* t, int64_t n_rays, int n_samples,
 int snerf_trainer_backward_image(snerf_trainer* t, const float* d_g_rgb, const float* d_g_albedo, const float* d_g_sky,
                                  const float* d_g_pe, const float* d_rho_prior, float trust, const float* d_g_rgb_merged,
                                  const float* d_g_albedo_merged, void* stream);
+/* Seam B1 in train mode - `T_NeRF.forward(X, Solar_Angle, Time)` called on points with an autograd graph attached
+ * (T_NeRF_net_v2.py:75-105, called so by the reference's evaluator at Eval_Tools_2.py:174-176): backward of the last
+ * snerf_trainer_forward_image from gradients with respect to the PER-SAMPLE network outputs - dL/dRho [N], dL/dCol [N,3],
+ * dL/dSolar_Vis [N], dL/dSky_Col per ray [R,3], dL/dclasses per ray [R,C]; each optional (NULL = zero).  ACCUMULATES into the
+ * gradient arena like snerf_trainer_backward_image. */
+int snerf_trainer_backward_points(snerf_trainer* t, const float* d_g_rho, const float* d_g_col, const float* d_g_solar_vis,
+                                  const float* d_g_sky, const float* d_g_classes, void* stream);
 /* sun-ray pass: T_NeRF.forward_Solar + PV_Exact / PE (end-point sampling is the caller's d_tvals). */
 int snerf_trainer_forward_solar(snerf_trainer* t, int64_t n_rays, int n_samples, const float* d_top, const float* d_bot,
                                 const float* d_tvals, const float* d_sun, int train_bn, float* d_solar_vis, float* d_pv,

@@ -20,7 +20,7 @@ class CompositeOut(C.Structure):
 
 
 class SweepOut(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("d_season", "d_shaded", "d_base", "d_shadow_adjust", "d_raw_shadow")]
+    _fields_ = [(n, C.c_void_p) for n in ("d_season", "d_shaded", "d_base", "d_shadow_adjust", "d_raw_shadow", "d_classic")]
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p)      # snerf_allreduce_fn
@@ -58,7 +58,7 @@ def lib():
     L.snerf_render_workspace_bytes.argtypes = [i64, i32, i32]
     L.snerf_render_rays.argtypes = [vp, i64, i32, vp, vp, vp, vp, vp, i32, vp, C.POINTER(FieldOut),
                                     C.POINTER(CompositeOut), vp, C.c_size_t, vp]
-    L.snerf_composite_sweep.argtypes = [i64, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, C.POINTER(SweepOut), vp]
+    L.snerf_composite_sweep.argtypes = [i64, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, C.POINTER(SweepOut), vp]
     f32p = vp
     L.snerf_trainer_create.restype = vp
     L.snerf_trainer_create.argtypes = [i32, i32]
@@ -77,6 +77,7 @@ def lib():
     L.snerf_trainer_forward_image.argtypes = [vp, i64, i32, vp, vp, vp, vp, vp, i32, i32, C.POINTER(CompositeOut), vp, vp,
                                               C.POINTER(FieldOut), vp]
     L.snerf_trainer_backward_image.argtypes = [vp, vp, vp, vp, vp, vp, C.c_float, vp, vp, vp]
+    L.snerf_trainer_backward_points.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     L.snerf_trainer_forward_solar.argtypes = [vp, i64, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp]
     L.snerf_trainer_backward_solar.argtypes = [vp, vp, vp]
     L.snerf_trainer_zero_grad.argtypes = [vp, vp]
@@ -111,5 +112,5 @@ EXPORTS = ["snerf_last_error", "snerf_abi_version", "snerf_model_create", "snerf
            "snerf_linear_scratch_bytes", "snerf_linear_forward", "snerf_linear_dgrad", "snerf_linear_wgrad",
            "snerf_trainer_create", "snerf_trainer_destroy", "snerf_trainer_param_floats", "snerf_trainer_buffer_floats",
            "snerf_trainer_tensor_count", "snerf_trainer_tensor_info", "snerf_trainer_workspace_bytes", "snerf_trainer_bind",
-           "snerf_trainer_forward_image", "snerf_trainer_backward_image", "snerf_trainer_forward_solar",
+           "snerf_trainer_forward_image", "snerf_trainer_backward_image", "snerf_trainer_backward_points", "snerf_trainer_forward_solar",
            "snerf_trainer_backward_solar", "snerf_trainer_zero_grad", "snerf_trainer_set_allreduce", "snerf_trainer_adam_step", "snerf_trainer_debug_read"]

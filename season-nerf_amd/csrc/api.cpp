@@ -37,7 +37,7 @@ struct snerf_model {
 extern "C" {
 
 const char* snerf_last_error(void) { return g_err.c_str(); }
-int snerf_abi_version(void) { return 3; }
+int snerf_abi_version(void) { return 4; }
 
 snerf_model* snerf_model_create(int layer_width, int n_classes) {
     if (layer_width != 64 && layer_width != 256) {
@@ -276,16 +276,17 @@ int snerf_render_rays(const snerf_model* m, int64_t n_rays, int n_samples, const
 }
 
 int snerf_composite_sweep(int64_t n_rays, int n_samples, int n_classes, int n_times, const float* d_top,
-                          const float* d_bot, const float* d_tvals, const float* d_rho, const float* d_col_raw,
+                          const float* d_bot, const float* d_tvals, const float* d_deltas, const float* d_rho, const float* d_col_raw,
                           const float* d_adjust, const float* d_solar_vis, const float* d_sky, const float* d_class_vecs,
                           int flags, const snerf_sweep_out* out, void* stream) {
     if (n_rays == 0 || n_times == 0) return SNERF_OK;
-    if (n_rays < 0 || n_samples < 1 || n_times < 0 || n_classes < 1 || n_classes > kMaxClasses || !d_top || !d_bot ||
-        !d_tvals || !d_rho || !d_col_raw || !d_adjust || !d_solar_vis || !d_sky || !d_class_vecs || !out)
+    if (n_rays < 0 || n_samples < 1 || n_times < 0 || n_classes < 1 || n_classes > kMaxClasses ||
+        (!d_deltas && (!d_top || !d_bot || !d_tvals)) || !d_rho || !d_col_raw || !d_adjust || !d_solar_vis || !d_sky || !d_class_vecs || !out)
         return fail(SNERF_E_INVALID, "snerf_composite_sweep: bad argument");
     SweepArgs a{};
     a.n_rays = n_rays; a.n_samples = n_samples; a.n_classes = n_classes; a.n_times = n_times; a.flags = flags;
-    a.top = d_top; a.bot = d_bot; a.tvals = d_tvals; a.rho = d_rho; a.col_raw = d_col_raw; a.adjust = d_adjust;
+    a.top = d_top; a.bot = d_bot; a.tvals = d_tvals; a.deltas = d_deltas; a.classic = out->d_classic;
+    a.rho = d_rho; a.col_raw = d_col_raw; a.adjust = d_adjust;
     a.solar_vis = d_solar_vis; a.sky = d_sky; a.class_vecs = d_class_vecs;
     a.season = out->d_season; a.shaded = out->d_shaded; a.base = out->d_base; a.shadow_adjust = out->d_shadow_adjust;
     a.raw_shadow = out->d_raw_shadow;

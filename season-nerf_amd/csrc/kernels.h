@@ -67,10 +67,12 @@ struct SweepArgs {
     int64_t n_rays;
     int n_samples, n_classes, n_times, flags;
     const float *top, *bot, *tvals;
+    const float* deltas;       // optional [R,S]: explicit segment lengths (then top / bot / tvals are not read)
     const float *rho, *col_raw, *adjust, *solar_vis;
     const float* sky;          // [3]
     const float* class_vecs;   // [T,C]
     float *season, *shaded;    // [T,R,3]
+    float* classic;            // optional [T,R,3]: sum_s PS * sigmoid(.) * (SV + (1-SV)*sky)  (mg_Img_Eval.py:165-170)
     float *base, *shadow_adjust, *raw_shadow;   // [R,3], [R,3], [R]
 };
 hipError_t launch_sweep(const SweepArgs& a, hipStream_t st);

@@ -602,15 +602,19 @@ int snerf_trainer_forward_image(snerf_trainer* t, int64_t n_rays, int n_samples,
     return SNERF_OK;
 }
 
+// Backward of the image pass through the network, from the per-sample gradients already sitting in the workspace:
+// t->d_rho [N], t->d_col [N,3], t->d_sky [R,3] and - when `classic` (the solar visibility carries gradient) - dL/dSolar_Vis
+// in t->d_sv_raw [N].  d_g_classes (optional, [R,C]) is added to the class-probability gradient.
+static int network_backward_image(snerf_trainer* t, bool classic, const float* d_g_classes, hipStream_t st);
+
 int snerf_trainer_backward_image(snerf_trainer* t, const float* d_g_rgb, const float* d_g_albedo, const float* d_g_sky,
                                  const float* d_g_pe, const float* d_rho_prior, float trust, const float* d_g_rgb_merged,
                                  const float* d_g_albedo_merged, void* stream) {
     if (!t || !t->ws) return snerf_set_error(SNERF_E_STATE, "trainer not bound");
     hipStream_t st = (hipStream_t)stream;
     snerf_trainer::Pass& P = t->img;
-    const int W = t->W, W2 = t->W2, W4 = t->W4, C = t->C, S = t->S;
-    const int64_t R = P.R, N = P.N;
-    auto& Ls = t->layers;
+    const int S = t->S;
+    const int64_t R = P.R;
     CompBwdArgs cb{};
     cb.n_rays = R; cb.n_samples = S; cb.top = P.top; cb.bot = P.bot; cb.rho = P.rho; cb.col = P.col; cb.sv = P.sv; cb.sky = P.sky;
     cb.g_rgb = d_g_rgb; cb.g_albedo = d_g_albedo; cb.g_pe = d_g_pe; cb.d_rho = t->d_rho; cb.d_col = t->d_col; cb.d_sky = t->d_sky;
@@ -619,7 +623,34 @@ int snerf_trainer_backward_image(snerf_trainer* t, const float* d_g_rgb, const f
     cb.classic = classic ? 1 : 0; cb.d_sv = t->d_sv_raw;       // dL/dSolar_Vis, turned into dL/d(raw) in place below
     HIPCK(launch_composite_bwd(cb, st));
     if (d_g_sky) HIPCK(launch_copy_cols(d_g_sky, 3, t->d_sky, 3, R, 3, true, st));
-    HIPCK(hipMemsetAsync(t->d_cls, 0, R * C * sizeof(float), st));
+    return network_backward_image(t, classic, nullptr, st);
+}
+
+// Seam B1 in train mode (T_NeRF.forward called on points with autograd, T_NeRF_net_v2.py:75-105): backward from gradients with
+// respect to the per-sample network outputs instead of the composited colours.  Any of the pointers may be NULL (= zero).
+int snerf_trainer_backward_points(snerf_trainer* t, const float* d_g_rho, const float* d_g_col, const float* d_g_solar_vis,
+                                  const float* d_g_sky, const float* d_g_classes, void* stream) {
+    if (!t || !t->ws) return snerf_set_error(SNERF_E_STATE, "trainer not bound");
+    hipStream_t st = (hipStream_t)stream;
+    snerf_trainer::Pass& P = t->img;
+    const int64_t R = P.R, N = P.N;
+    auto put = [&](float* dst, const float* src, int64_t n) -> hipError_t {
+        return src ? hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, st) : hipMemsetAsync(dst, 0, n * sizeof(float), st);
+    };
+    HIPCK(put(t->d_rho, d_g_rho, N));
+    HIPCK(put(t->d_col, d_g_col, N * 3));
+    HIPCK(put(t->d_sky, d_g_sky, R * 3));
+    if (d_g_solar_vis) HIPCK(put(t->d_sv_raw, d_g_solar_vis, N));
+    return network_backward_image(t, d_g_solar_vis != nullptr, d_g_classes, st);
+}
+
+static int network_backward_image(snerf_trainer* t, bool classic, const float* d_g_classes, hipStream_t st) {
+    snerf_trainer::Pass& P = t->img;
+    const int W = t->W, W2 = t->W2, W4 = t->W4, C = t->C, S = t->S;
+    const int64_t R = P.R, N = P.N;
+    auto& Ls = t->layers;
+    if (d_g_classes) HIPCK(hipMemcpyAsync(t->d_cls, d_g_classes, R * C * sizeof(float), hipMemcpyDeviceToDevice, st));
+    else HIPCK(hipMemsetAsync(t->d_cls, 0, R * C * sizeof(float), st));
     HIPCK(hipMemsetAsync(t->bn_stats, 0, (size_t)(4 * W + 2) * sizeof(float), st));      // column-sum scratch: zero at the start of the pass
     PointOutArgs po{};
     po.n = N; po.n_samples = S; po.C = C; po.head = P.head.p; po.adj = P.adj.p; po.cls = P.cls; po.col = P.col; po.sv = P.sv;

@@ -2,8 +2,11 @@
 HIP C-ABI.  Same constructor, same `state_dict` keys/shapes (SURVEY App. C - `Final_Model.nn` loads unchanged), same
 forward variants and return conventions; the arithmetic runs in the gfx950 kernels, never in PyTorch.
 
-Training-mode BatchNorm / autograd through the kernels is not implemented yet: calling a forward while
-`self.training` is True raises instead of silently computing something else.
+Eval mode (`.eval()`, BatchNorm running statistics): the fused register-resident MFMA kernels (widths 64 / 256), no autograd.
+Train mode (`.train()`, batch-statistics BatchNorm): `forward`, `forward_seperate`, `forward_full_eval` and `forward_Solar`
+run on the layer-wise training engine and return tensors with an autograd graph whose backward is the engine's HIP backward
+(gradients land in the parameters' `.grad`) - so the reference's own evaluator trains through this class unchanged.
+Not differentiable (returned without a graph): `Adjust_col`, and `Col_raw` / `Adjust` of the `forward_seperate` family.
 """
 import ctypes as C
 import math
@@ -103,6 +106,15 @@ class T_NeRF(nn.Module):
         self._handle, self._sig = h, sig
         return h
 
+    def __getstate__(self):
+        """Copies (copy.deepcopy, pickle, torch.save of the module) must not share the raw C handles: the device model, the
+        training engines and the parameter store stay with the original; a copy re-packs / re-adopts lazily on first use."""
+        d = self.__dict__.copy()
+        d["_handle"], d["_sig"], d["_hm_dev"] = None, None, None
+        for k in ("_train_engine", "_train_engines", "_param_store"):
+            d.pop(k, None)
+        return d
+
     def release(self):
         if self._handle is not None:
             _lib.lib().snerf_model_destroy(self._handle)
@@ -119,10 +131,6 @@ class T_NeRF(nn.Module):
         return self.get_class_layer.weight.device
 
     def _prep(self, *tensors):
-        if self.training:
-            raise NotImplementedError(
-                "season_nerf_amd.T_NeRF: train-mode (batch-statistics BatchNorm + autograd) forward is not implemented "
-                "by the HIP path yet; call .eval() first")
         dev = self.device
         if dev.type != "cuda":
             raise RuntimeError("season_nerf_amd.T_NeRF runs on an MI355X only: move the module with .to('cuda')")
@@ -177,9 +185,21 @@ class T_NeRF(nn.Module):
     def _process_time(self, Time):
         return Time[:, 0:2]
 
+    def _train_points(self, X, sun, tim):
+        from . import training
+        return training.points_forward_train(self, X, sun, tim)
+
+    def _no_train_graph(self, what):
+        if self.training and torch.is_grad_enabled():
+            raise NotImplementedError(f"season_nerf_amd.T_NeRF.{what}: no autograd graph in train mode (the reference's training "
+                                      "step does not differentiate it); call it under torch.no_grad() or in .eval() mode")
+
     def forward(self, X, Solar_Angle, Time):
         """-> Rho[N,1], Col[N,3], Solar_Vis[N,1], Sky_Col[N,3], output_class[N,C], Adjust_col[N,3]  (:75-105)"""
         X, sun, tim = self._prep(X, Solar_Angle, Time)
+        if self.training:
+            rho, col, sv, sky, cls, adjc, _, _ = self._train_points(X, sun, tim)
+            return rho, col, sv, sky, cls, adjc
         if self.layer_width not in FUSED_WIDTHS:
             o = self._generic_points(X, sun, tim)
             return o["rho"], o["col"], o["sv"], o["sky"], o["cls"], o["adjc"]
@@ -190,6 +210,9 @@ class T_NeRF(nn.Module):
     def forward_seperate(self, X, Solar_Angle, Time):
         """Col raw and Adjust[N,C,3] unmixed (:131-151)."""
         X, sun, tim = self._prep(X, Solar_Angle, Time)
+        if self.training:
+            rho, _, sv, sky, cls, _, col_raw, adj = self._train_points(X, sun, tim)
+            return rho, col_raw, sv, sky, cls, adj
         if self.layer_width not in FUSED_WIDTHS:
             o = self._generic_points(X, sun, tim)
             return o["rho"], o["col_raw"], o["sv"], o["sky"], o["cls"], o["adj"]
@@ -202,16 +225,24 @@ class T_NeRF(nn.Module):
     def forward_Solar(self, X, Solar_Angle, Time):
         """-> softplus(Rho), sigmoid(Solar_Vis), Sky raw (:154-157)."""
         X, sun, tim = self._prep(X, Solar_Angle, Time)
-        if self.layer_width not in FUSED_WIDTHS:
-            o = self._generic_points(X, sun, tim)
-            sky = o["sky"].clamp(1e-7, 1 - 1e-7)
-            return o["rho"], o["sv"], torch.log(sky / (1 - sky))       # raw sky = logit of the sigmoided head output
+        if self.training or self.layer_width not in FUSED_WIDTHS:
+            # the engine's sun-ray pass returns the raw sky head output itself (no logit round trip)
+            from . import training
+            if self.training:
+                return training.solar_points_forward_train(self, X, sun)
+            with torch.no_grad():
+                return tuple(t.detach() for t in training.solar_points_forward_train(self, X, sun))
         _, sky_raw, _ = self._groups(tim, sun)
         o = self._field_points(1, X, sun, None, ["d_rho", "d_solar_vis"])
         return o["d_rho"], o["d_solar_vis"], sky_raw
 
     def forward_Classic_Sigma_Only(self, X):
         (X,) = self._prep(X)
+        self._no_train_graph("forward_Classic_Sigma_Only")
+        if self.training:        # batch-statistics BatchNorm: the trunk + density head of the engine's sun-ray pass
+            from . import training
+            with torch.no_grad():
+                return training.solar_points_forward_train(self, X, torch.ones(X.shape[0], 3, device=X.device))[0].detach()
         if self.layer_width not in FUSED_WIDTHS:
             z = torch.zeros(X.shape[0], 4, device=X.device)
             return self._generic_points(X, torch.ones(X.shape[0], 3, device=X.device), z)["rho"]
@@ -219,6 +250,7 @@ class T_NeRF(nn.Module):
 
     def get_class_only(self, Time):
         (tim,) = self._prep(Time)
+        self._no_train_graph("get_class_only")          # the time branch has no BatchNorm: train and eval mode agree
         sun = torch.zeros(tim.shape[0], 3, device=tim.device)
         if self.layer_width not in FUSED_WIDTHS:
             return self._generic_points(torch.zeros(tim.shape[0], 3, device=tim.device), sun + 1.0, tim)["cls"]

@@ -268,7 +268,7 @@ def component_render_by_dir(the_network, view_el_az, sun_el_az, time_frac, out_i
     return res
 
 
-def _sweep(d, class_vecs, solar_key):
+def _sweep(d, class_vecs, solar_key, classic=False):
     """Run the sweep kernel on a device dict; class_vecs [T,C] numpy.  Returns dict of device tensors."""
     dev = d["Rho"].device
     L = _lib.lib()
@@ -278,22 +278,43 @@ def _sweep(d, class_vecs, solar_key):
     T = cv.shape[0]
     e = lambda *s: torch.empty(*s, device=dev)
     season, shaded, base, sadj, raw = e(T, R, 3), e(T, R, 3), e(R, 3), e(R, 3), e(R)
+    cls_img = e(T, R, 3) if classic else None
     so = _lib.SweepOut(d_season=season.data_ptr(), d_shaded=shaded.data_ptr(), d_base=base.data_ptr(),
-                       d_shadow_adjust=sadj.data_ptr(), d_raw_shadow=raw.data_ptr())
+                       d_shadow_adjust=sadj.data_ptr(), d_raw_shadow=raw.data_ptr(), d_classic=cls_img.data_ptr() if classic else None)
     sv = d[solar_key].contiguous()
-    _lib.check(L.snerf_composite_sweep(R, S, Cn, T, d["top"].data_ptr(), d["bot"].data_ptr(), d["tv"].data_ptr(),
+    p = lambda k: d[k].data_ptr() if d.get(k) is not None else None
+    _lib.check(L.snerf_composite_sweep(R, S, Cn, T, p("top"), p("bot"), p("tv"), p("Deltas_explicit"),
                                        d["Rho"].data_ptr(), d["Base_Col"].data_ptr(), d["Adjust_col"].data_ptr(),
                                        sv.data_ptr(), d["Sky"].data_ptr(), cv.data_ptr(), 2, C.byref(so),
                                        C.c_void_p(torch.cuda.current_stream().cuda_stream)), "composite_sweep")
-    return {"season": season, "shaded": shaded, "base": base, "shadow_adjust": sadj, "raw_shadow": raw}
+    return {"season": season, "shaded": shaded, "base": base, "shadow_adjust": sadj, "raw_shadow": raw, "classic": cls_img}
 
 
 def _device_dict(Img_Dict, device="cuda"):
+    """The device tensors behind an image dict.  Dicts from this package's renderers carry them; a plain dict of (float64)
+    numpy arrays with the reference's keys (`component_render_by_dir` of the reference, mg_Img_Eval.py:17-115, or a dict
+    loaded from disk) is uploaded once - its `Deltas` array is used as it stands, `Sky_Col[0,0]` / `Output_class[0,0]` are the
+    per-image vectors (mg_Img_Eval.py:125-126)."""
     if getattr(Img_Dict, "dev", None) is not None:
         return Img_Dict.dev
-    raise TypeError("season_nerf_amd: image assembly needs the dict returned by season_nerf_amd.component_render_by_dir "
-                    "(it carries the device tensors); a plain numpy dict would require a CPU path, which this package "
-                    "does not provide")
+    need = ["Rho", "Deltas", "Base_Col", "Est_Solar_Vis", "Sky_Col", "Output_class", "Adjust_col"]
+    missing = [k for k in need if k not in Img_Dict]
+    if missing:
+        raise KeyError(f"season_nerf_amd: image dict lacks {missing}")
+    dev = torch.device(device)
+    if dev.type != "cuda" or not torch.cuda.is_available():
+        raise RuntimeError("season_nerf_amd: image assembly runs on an MI355X only")
+    f = lambda a: torch.as_tensor(np.ascontiguousarray(np.asarray(a, dtype=np.float32)), device=dev)
+    d = {"Rho": f(Img_Dict["Rho"]), "Deltas_explicit": f(Img_Dict["Deltas"]), "Base_Col": f(Img_Dict["Base_Col"]),
+         "Est_Solar_Vis": f(Img_Dict["Est_Solar_Vis"]), "Adjust_col": f(Img_Dict["Adjust_col"]),
+         "Sky": f(np.asarray(Img_Dict["Sky_Col"])[0, 0]), "Class": f(np.asarray(Img_Dict["Output_class"])[0, 0])}
+    if "Exact_Solar" in Img_Dict:
+        d["Exact_Solar"] = f(Img_Dict["Exact_Solar"])
+    try:
+        Img_Dict.dev = d              # cache on dict subclasses that allow attributes
+    except AttributeError:
+        pass
+    return d
 
 
 def _scatter(vals, ij, hw, k=None):
@@ -303,29 +324,33 @@ def _scatter(vals, ij, hw, k=None):
 
 
 def get_imgs_from_Img_Dict(Img_Dict, out_img_size: tuple, use_classic_shadows: bool = False):
-    """mg_Img_Eval.py:123-190 (use_classic_shadows=False branch).  Keys: Base_Img, Season_Adj_Img, Extreme_Imgs,
-    Shadow_Adjust, Shadow_Mask, Raw_Shadow_Mask, Sky_Col, Time_Class (+ the *_Exact family)."""
-    if use_classic_shadows:
-        raise NotImplementedError("use_classic_shadows=True is not implemented on the HIP path")
+    """mg_Img_Eval.py:123-190.  Keys: Base_Img, Season_Adj_Img, Extreme_Imgs, Shadow_Adjust, Shadow_Mask, Raw_Shadow_Mask,
+    Sky_Col, Time_Class (+ the *_Exact family).  use_classic_shadows: `Shadow_Adjust` (and `Shadow_Adjust_Exact`) hold, where a
+    ray exists, the quasi shadow mask  sum_s PS sigma(.) (SV + (1-SV) Sky) / (Season colour + 1e-8)  of :165-181."""
     d = _device_dict(Img_Dict)
-    ij, hw = Img_Dict["Image_Points"], out_img_size
+    ij, hw = np.asarray(Img_Dict["Image_Points"]), out_img_size
     Cn = d["Adjust_col"].shape[2]
     cv = np.concatenate([d["Class"].cpu().numpy().reshape(1, Cn), np.eye(Cn)], 0)        # season class + the C extremes
-    o = _sweep(d, cv, "Est_Solar_Vis")
+    o = _sweep(d, cv, "Est_Solar_Vis", classic=use_classic_shadows)
     f = lambda t: t.cpu().numpy().astype(np.float64)
     raw = _scatter(f(o["raw_shadow"]), ij, hw)
     mask = 1 / (1 + np.exp(-(raw - .2) * 30))
     sky = f(d["Sky"])
-    res = {"Base_Img": _scatter(f(o["base"]), ij, hw, 3), "Season_Adj_Img": _scatter(f(o["season"][0]), ij, hw, 3),
+    season0 = f(o["season"][0])
+    res = {"Base_Img": _scatter(f(o["base"]), ij, hw, 3), "Season_Adj_Img": _scatter(season0, ij, hw, 3),
            "Extreme_Imgs": [_scatter(f(o["season"][1 + i]), ij, hw, 3) for i in range(Cn)],
            "Shadow_Adjust": np.expand_dims(mask, -1) + np.expand_dims(1 - mask, -1) * sky.reshape([1, 1, 3]),
            "Shadow_Mask": mask, "Raw_Shadow_Mask": raw, "Sky_Col": sky, "Time_Class": f(d["Class"])}
+    if use_classic_shadows:
+        res["Shadow_Adjust"][ij[:, 0], ij[:, 1]] = f(o["classic"][0]) / (season0 + 1e-8)
     if "Exact_Solar" in d:
-        oe = _sweep(d, cv[:1], "Exact_Solar")
+        oe = _sweep(d, cv[:1], "Exact_Solar", classic=use_classic_shadows)
         raw_e = _scatter(f(oe["raw_shadow"]), ij, hw)
         mask_e = 1 / (1 + np.exp(-(raw_e - .2) * 30))
         res["Shadow_Adjust_Exact"] = np.expand_dims(mask_e, -1) + np.expand_dims(1 - mask_e, -1) * sky.reshape([1, 1, 3])
         res["Shadow_Mask_Exact"], res["Raw_Shadow_Mask_Exact"] = mask_e, raw_e
+        if use_classic_shadows:
+            res["Shadow_Adjust_Exact"][ij[:, 0], ij[:, 1]] = f(oe["classic"][0]) / (season0 + 1e-8)
     return res
 
 
@@ -333,7 +358,7 @@ def get_imgs_from_Img_Dict_t_step(Img_Dict, out_img_size: tuple, class_vecs_arra
     """mg_Img_Eval.py:192-228: [T, H, W, 3] shaded images for T class vectors; exact solar visibility wins if present."""
     d = _device_dict(Img_Dict)
     o = _sweep(d, np.asarray(class_vecs_array), "Exact_Solar" if "Exact_Solar" in d else "Est_Solar_Vis")
-    ij, hw = Img_Dict["Image_Points"], out_img_size
+    ij, hw = np.asarray(Img_Dict["Image_Points"]), out_img_size
     sh = o["shaded"].cpu().numpy().astype(np.float64)
     return np.array([_scatter(sh[t], ij, hw, 3) for t in range(sh.shape[0])])
 

@@ -77,6 +77,7 @@ class _ParamStore:
         self.adam_v = torch.zeros(self.n_params, device=dev)
         self.buffers = torch.empty(max(self.n_buffers, 1), device=dev)
         self.adam_steps = 0
+        self.bn_sync = None           # (group,) once sync_batchnorm(True) was called: every engine of this network registers it
         # layout: state_dict key -> (is_buffer, offset, numel)
         self.layout = {}
         key = C.create_string_buffer(128)
@@ -134,6 +135,9 @@ class TrainEngine:
                                         store.adam_v.data_ptr(), store.buffers.data_ptr(), self.ws.data_ptr(), self.ws.numel(),
                                         n_rays, n_solar_rays, n_samples), "trainer_bind")
         self.classic_solar = False        # Solar_Type_2 shading in the image pass (set per call by eval_train)
+        self._ar_cb = None
+        if store.bn_sync is not None:     # global-batch BatchNorm is a property of the NETWORK: a new engine (another batch size)
+            self.sync_batchnorm(True, store.bn_sync[0])       # must issue the same collectives as its siblings on the other ranks
 
     # the arenas, through the shared store
     params = property(lambda self: self.store.params)
@@ -174,12 +178,21 @@ class TrainEngine:
         calls on its statistics buffers - 2 small collectives per BatchNorm layer in forward, 1 in backward, all in stream
         order.  Every rank must use the same ray counts."""
         import torch.distributed as dist
+        siblings = [e_ for e_ in self.net.__dict__.get("_train_engines", {}).values() if e_ is not self]
         if not enable:
             _lib.check(self.L.snerf_trainer_set_allreduce(self.h, None, None, 1), "trainer_set_allreduce")
             self._ar_cb = None
+            if self.store.bn_sync is not None:
+                self.store.bn_sync = None
+                for e_ in siblings:
+                    e_.sync_batchnorm(False)
             return
         if not (dist.is_available() and dist.is_initialized()):
             raise RuntimeError("sync_batchnorm needs an initialised torch.distributed process group")
+        if self.store.bn_sync is None or self.store.bn_sync[0] is not group:
+            self.store.bn_sync = (group,)
+            for e_ in siblings:            # engines that already exist for other batch sizes follow
+                e_.sync_batchnorm(True, group)
         base, nbytes = self.ws.data_ptr(), self.ws.numel()
 
         def allreduce(user, ptr, count, is_double, stream):
@@ -311,6 +324,97 @@ class _SolarPass(torch.autograd.Function):
             g = g_sv.contiguous()
             _lib.check(eng.L.snerf_trainer_backward_solar(eng.h, g.data_ptr(), eng.stream()), "trainer_backward_solar")
         return (None,) * (6 + len(eng.param_list))
+
+
+_ZERO_TV = {}
+
+
+def _zero_tv(dev):
+    """The one sample parameter of a 'ray' that is a single explicit point: t = 0, i.e. point = Top * 1 + Bot * 0 = Top."""
+    key = torch.device(dev)
+    if key not in _ZERO_TV:
+        _ZERO_TV[key] = torch.zeros(1, device=dev)
+    return _ZERO_TV[key]
+
+
+class _PointsPass(torch.autograd.Function):
+    """Seam B1 in train mode: `T_NeRF.forward(X, Solar_Angle, Time)` on N explicit points with batch-statistics BatchNorm and an
+    autograd graph (T_NeRF_net_v2.py:75-105; the reference's evaluator calls it so, Eval_Tools_2.py:174-176).  The engine runs
+    the points as N rays of one sample (per-point sun / time, as the reference computes them).  Differentiable outputs:
+    Rho, Col, Solar_Vis, Sky_Col, output_class; Adjust_col / Col_raw / Adjust are returned without a graph."""
+
+    @staticmethod
+    def forward(ctx, eng, X, sun, tim, train_bn, *params):
+        N, dev, Cn = eng.R, eng.dev, eng.net.n_classes
+        if any(p.requires_grad for p in params):
+            eng.attach_grads()
+        e = lambda *s: torch.empty(*s, device=dev)
+        rho, col, sv, sky, cls, adjc, col_raw, adj, rgb = e(N, 1), e(N, 3), e(N, 1), e(N, 3), e(N, Cn), e(N, 3), e(N, 3), e(N, Cn, 3), e(N, 3)
+        co = _lib.CompositeOut(d_rgb=rgb.data_ptr())
+        fo = _lib.FieldOut(d_rho=rho.data_ptr(), d_solar_vis=sv.data_ptr(), d_col=col.data_ptr(), d_adjust_col=adjc.data_ptr(),
+                           d_col_raw=col_raw.data_ptr(), d_adjust=adj.data_ptr())
+        tv = _zero_tv(dev)
+        _lib.check(eng.L.snerf_trainer_forward_image(eng.h, N, 1, X.data_ptr(), X.data_ptr(), tv.data_ptr(), sun.data_ptr(), tim.data_ptr(),
+                                                     1 if train_bn else 0, 0, C.byref(co), sky.data_ptr(), cls.data_ptr(), C.byref(fo),
+                                                     eng.stream()), "trainer_forward_image")
+        ctx.eng = eng
+        ctx.mark_non_differentiable(adjc, col_raw, adj)
+        return rho, col, sv, sky, cls, adjc, col_raw, adj
+
+    @staticmethod
+    def backward(ctx, g_rho, g_col, g_sv, g_sky, g_cls, *_):
+        eng = ctx.eng
+        c = lambda g: g.contiguous() if g is not None else None
+        g_rho, g_col, g_sv, g_sky, g_cls = c(g_rho), c(g_col), c(g_sv), c(g_sky), c(g_cls)
+        eng.attach_grads()
+        _lib.check(eng.L.snerf_trainer_backward_points(eng.h, _ptr(g_rho), _ptr(g_col), _ptr(g_sv), _ptr(g_sky), _ptr(g_cls), eng.stream()),
+                   "trainer_backward_points")
+        return (None,) * (5 + len(eng.param_list))
+
+
+class _SolarPointsPass(torch.autograd.Function):
+    """`T_NeRF.forward_Solar` in train mode on explicit points (T_NeRF_net_v2.py:154-157, G_NeRF.py:141-145: the trunk runs
+    without gradient, only the solar-visibility branch is differentiated).  Sky raw is returned without a graph."""
+
+    @staticmethod
+    def forward(ctx, eng, X, sun, train_bn, *params):
+        N, dev = eng.Rs, eng.dev
+        e = lambda *s: torch.empty(*s, device=dev)
+        sv, pv, pe, sky_raw, rho, pts, dl = e(N, 1), e(N, 1), e(N, 1), e(N, 3), e(N, 1), e(N, 3), e(N, 1)
+        tv = _zero_tv(dev)
+        _lib.check(eng.L.snerf_trainer_forward_solar(eng.h, N, 1, X.data_ptr(), X.data_ptr(), tv.data_ptr(), sun.data_ptr(),
+                                                     1 if train_bn else 0, sv.data_ptr(), pv.data_ptr(), pe.data_ptr(), sky_raw.data_ptr(),
+                                                     rho.data_ptr(), pts.data_ptr(), dl.data_ptr(), eng.stream()), "trainer_forward_solar")
+        ctx.eng = eng
+        ctx.mark_non_differentiable(rho, sky_raw)
+        return rho, sv, sky_raw
+
+    @staticmethod
+    def backward(ctx, _g_rho, g_sv, _g_sky):
+        eng = ctx.eng
+        if g_sv is not None:
+            eng.attach_grads()
+            g = g_sv.contiguous()
+            _lib.check(eng.L.snerf_trainer_backward_solar(eng.h, g.data_ptr(), eng.stream()), "trainer_backward_solar")
+        return (None,) * (4 + len(eng.param_list))
+
+
+def points_forward_train(net, X, sun, tim):
+    """(Rho, Col, Solar_Vis, Sky_Col, output_class, Adjust_col, Col_raw, Adjust) of a train-mode network on N points."""
+    N = X.shape[0]
+    eng = _engine_for(net, N, N, 1)
+    out = _PointsPass.apply(eng, X, sun, tim, net.training, *eng.param_list)
+    _after_train_forward(net)
+    return out
+
+
+def solar_points_forward_train(net, X, sun):
+    """(softplus Rho, sigmoid Solar_Vis, Sky raw) of `forward_Solar` on a train-mode network."""
+    N = X.shape[0]
+    eng = _engine_for(net, N, N, 1)
+    out = _SolarPointsPass.apply(eng, X, sun, net.training, *eng.param_list)
+    _after_train_forward(net)
+    return out
 
 
 def _angles_to_local_vecs(el_deg, az_deg, world_center, W2L_H):
@@ -505,6 +609,13 @@ class FusedAdam(torch.optim.Optimizer):
     def __init__(self, net, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
         self.net = net
         super().__init__(list(net.parameters()), dict(lr=lr, betas=betas, eps=eps))
+        # a NEW optimiser starts from zero moments and step 0, as a new torch.optim.Adam does (the reference builds one at
+        # every learning-phase entry, Net_Tool_2.py:111-121); the moments live in the network's store, so clear them here
+        store = getattr(net, "_param_store", None)
+        if store is not None:
+            store.adam_m.zero_()
+            store.adam_v.zero_()
+            store.adam_steps = 0
 
     def state_dict(self):
         """Checkpointable state: torch's param_groups plus the flat Adam moments and the step count of the network's store."""

@@ -30,7 +30,7 @@ def test_exports_match_header(lib):
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
     import season_nerf_amd as sn
     assert sorted(sn._lib.EXPORTS) == declared
-    assert lib.snerf_abi_version() == 3
+    assert lib.snerf_abi_version() == 4
 
 
 def test_error_paths(lib):

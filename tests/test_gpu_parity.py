@@ -151,8 +151,10 @@ def test_eval_vs_oracle_ragged():
 def test_fails_loudly():
     net, _ = make_net(64, 4, 0)
     net.train()
-    with pytest.raises(NotImplementedError):
-        net.forward(torch.zeros(4, 3).cuda(), torch.ones(4, 3).cuda(), torch.ones(4, 4).cuda())
+    with pytest.raises(NotImplementedError):     # forwards without an autograd graph refuse to run with gradients enabled
+        net.get_class_only(torch.ones(4, 4).cuda())
+    with pytest.raises(RuntimeError):            # a CPU module never silently computes on the host
+        sn().T_NeRF(64, 4).eval().forward(torch.zeros(4, 3), torch.ones(4, 3), torch.ones(4, 4))
     with pytest.raises(RuntimeError):        # no kernel at all for a width that is not a multiple of 4
         sn().T_NeRF(90, 4).to("cuda").eval().forward_Classic_Sigma_Only(torch.zeros(4, 3).cuda())
 

@@ -84,6 +84,29 @@ def test_render_by_dir_and_sweep(setup):
     close("own_class", own[0], im["Season_Adj_Img"] * im["Shadow_Adjust"], rtol=1e-5, atol=1e-6)
 
 
+def test_classic_shadows_and_plain_dict(setup):
+    """get_imgs_from_Img_Dict(use_classic_shadows=True) (mg_Img_Eval.py:165-170) against the reference's image, and the image
+    assembly on a PLAIN dict of float64 numpy arrays (what the reference's own component_render_by_dir returns / a dict loaded
+    from disk): same images as from this package's dict."""
+    sn, g, net, args = setup
+    size = (12, 12, 48)
+    d = sn.component_render_by_dir(net, (80, 0), (30, 90), 0.25, size, g["WC"], g["H"], torch.device("cuda"), include_exact_solar=False)
+    imc = sn.get_imgs_from_Img_Dict(d, size, True)
+    close("imgc_Shadow_Adjust", imc["Shadow_Adjust"], g["imgc_Shadow_Adjust"], rtol=2e-5, atol=2e-6)
+    im = sn.get_imgs_from_Img_Dict(d, size, False)
+    plain = {k: np.array(v, dtype=np.float64) for k, v in d.items() if k != "Image_Points"}
+    plain["Image_Points"] = np.array(d["Image_Points"])
+    assert type(plain) is dict
+    im2 = sn.get_imgs_from_Img_Dict(plain, size, False)
+    for k in ["Base_Img", "Season_Adj_Img", "Shadow_Adjust", "Shadow_Mask", "Raw_Shadow_Mask"]:
+        close("plain_" + k, im2[k], im[k], rtol=1e-6, atol=1e-7)
+        close("plain_ref_" + k, im2[k], g["img_" + k])
+    imc2 = sn.get_imgs_from_Img_Dict(plain, size, True)
+    close("plain_imgc", imc2["Shadow_Adjust"], g["imgc_Shadow_Adjust"], rtol=2e-5, atol=2e-6)
+    sw = sn.get_imgs_from_Img_Dict_t_step(plain, size, g["sweep_classes"])
+    close("plain_sweep", sw, g["sweep_imgs"])
+
+
 def test_exact_solar_by_dir(setup):
     sn, g, net, args = setup
     d = sn.component_render_by_dir(net, (80, 0), (30, 90), 0.25, (4, 4, 24), g["WC"], g["H"], torch.device("cuda"),

@@ -81,9 +81,9 @@ def test_train_step_vs_reference(golden_dir, name):
         err = np.abs(got - ref).max() / scale
         worst = max(worst, err)
         if "gnorm_" + n in g:
-            assert abs(float(params[n].grad.double().norm()) - float(g["gnorm_" + n])) <= 2e-3 * float(g["gnorm_" + n]), n
+            assert abs(float(params[n].grad.double().norm()) - float(g["gnorm_" + n])) <= 5e-4 * float(g["gnorm_" + n]), n
     print(f"  worst relative gradient error {worst:.2e}")
-    assert worst < 2e-3
+    assert worst < 5e-4             # measured 1-3e-4
     for n in ("adjust_rho.weight", "adjust_solar_vis.bias", "adjust_sky_col.weight"):      # dead heads stay without gradient
         assert params[n].grad is None or float(params[n].grad.abs().max()) == 0.0
     # BatchNorm running statistics after the two train-mode passes
@@ -285,3 +285,134 @@ def test_ragged_batch_vs_oracle():
     gmax = max(float(sd_g[n].grad.abs().max()) for n in live)
     worst = max(float((params[n].grad.cpu() - sd_g[n].grad).abs().max()) / max(float(sd_g[n].grad.abs().max()), 1e-3 * gmax) for n in live)
     assert worst < 2e-3, worst
+
+
+def _reference_style_loss(net, g, data, solar, dev):
+    """The reference's evaluator flow written with plain torch ops around `Network(X, Sun, Time)` / `Network.forward_Solar`
+    calls (Eval_Tools_2.py:165-215, 297-337, 340-420; MSE loss, Use_Solar, no prior): only seam B1 is ours here - the
+    compositing and the loss terms run in torch autograd, as they do in the reference."""
+    S = int(g["S"])
+    torch.manual_seed(77 + int(g["seed"]))
+    R = data["Top"].shape[0]
+    pts, deltas = orc.sample_pt_coarse(data["Top"], data["Bot"], S, False)                       # consumes the first t.rand(S)
+    X = pts.reshape(-1, 3).to(dev)
+    sun = data["Sun_Angle"].unsqueeze(1).expand(R, S, 3).reshape(-1, 3).to(dev)
+    tim = data["Time_Encoded"].unsqueeze(1).expand(R, S, 4).reshape(-1, 4).to(dev)
+    rho, col, sv, sky, cls, adjc = net(X, sun, tim)
+    assert rho.requires_grad and col.requires_grad and sky.requires_grad
+    rho, sv, col, sky = rho.reshape(R, S, 1), sv.reshape(R, S, 1), col.reshape(R, S, 3), sky.reshape(R, S, 3)
+    out = orc.composite(rho, deltas.to(dev), col, sv, sky)
+    spts, sdl = orc.sample_pt_coarse(solar["Top"], solar["Bot"], S, False, include_end_pt=True)   # the second draw
+    ssun = solar["Sun_Angle"].unsqueeze(1).expand(R, S, 3).reshape(-1, 3).to(dev)
+    srho, ssv, _ = net.forward_Solar(spts.reshape(-1, 3).to(dev), ssun, torch.zeros(R * S, 4, device=dev))
+    srho, ssv, sdl = srho.reshape(R, S, 1), ssv.reshape(R, S, 1), sdl.to(dev)
+    pv_exact, pe_s = orc.get_PV(srho, sdl), 1 - torch.exp(-srho * sdl)
+    lam = float(g["sc_lambda"])
+    loss = {"Solar_Correction": (((ssv - pv_exact.detach()) ** 2).sum(1).mean(), lam)}
+    alb_min = out["Albedo_Color"].min(0).values
+    loss["Albedo_Color"] = (torch.where(alb_min < .2, (1. - alb_min / .2) ** 2, torch.zeros_like(alb_min)).sum() / R, lam)
+    x = (sky - .5) / .5
+    loss["Sky_Color_Var"] = (torch.where(x > 0, x ** 2, torch.zeros_like(x)).sum() / x.numel(), lam)
+    loss["Color"] = (torch.mean((out["Rendered_Col"] - data["GT_Color"].to(dev)) ** 2), 1.0)
+    return loss
+
+
+@pytest.mark.parametrize("name", ["train_W64_R32_S32.npz", "train_W256_R32_S40.npz"])
+def test_seam_B1_train_mode_network_under_reference_style_evaluator(golden_dir, name):
+    """`T_NeRF.forward` / `forward_Solar` in .train() return autograd-connected tensors, so an evaluator
+    that is NOT ours (the reference's compositing + losses, here restated with torch ops) trains through the HIP network:
+    loss values, every parameter gradient and the BatchNorm running statistics equal the reference's full training step."""
+    sn, g, net, ev, data = setup(golden_dir, name)
+    dev = torch.device("cuda")
+    solar = {"Top": T(g["solar_Top"]), "Bot": T(g["solar_Bot"]), "Sun_Angle": T(g["solar_Sun_Angle"])}
+    opt = torch.optim.Adam(net.parameters(), lr=float(g["lr"]))
+    opt.zero_grad()
+    loss = _reference_style_loss(net, g, data, solar, dev)
+    for k, (v, w) in loss.items():
+        ref = float(g["loss_" + k])
+        assert abs(float(v.detach()) - ref) <= 2e-5 * max(1.0, abs(ref)) + 1e-6, (k, float(v.detach()), ref)
+    sum(v * w for v, w in loss.values()).backward()
+    refs = _ref_grads(g)
+    params = dict(net.named_parameters())
+    gmax = max(np.abs(v).max() for v, _ in refs.values())
+    worst = 0
+    for n, (ref, step) in refs.items():
+        assert params[n].grad is not None, n
+        got = params[n].grad.cpu().numpy().reshape(-1)[::step]
+        worst = max(worst, np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-3 * gmax))
+    print(f"  worst relative gradient error through seam B1: {worst:.2e}")
+    assert worst < 5e-4
+    sd = net.state_dict()
+    for k in g:
+        if k.startswith("bn_"):
+            np.testing.assert_allclose(sd[k[3:]].cpu().numpy(), g[k], rtol=1e-4, atol=1e-5, err_msg=k)
+    # per-point outputs of the train-mode forward equal the evaluator's own train-mode pass on the same points
+    assert int(sd["G_NeRF_net.fc2.norm.num_batches_tracked"]) == 2
+
+
+def test_train_mode_forward_variants_and_guards(golden_dir):
+    sn, g, net, ev, data = setup(golden_dir)
+    dev = torch.device("cuda")
+    N = 96
+    X = torch.rand(N, 3, device=dev) * 2 - 1
+    sun = torch.nn.functional.normalize(torch.rand(N, 3, device=dev), dim=1)
+    tim = torch.rand(N, 4, device=dev)
+    net.train()
+    a = net(X, sun, tim)
+    b = net.forward_seperate(X, sun, tim)
+    assert [tuple(t.shape) for t in a] == [(N, 1), (N, 3), (N, 1), (N, 3), (N, 4), (N, 3)]
+    assert tuple(b[1].shape) == (N, 3) and tuple(b[5].shape) == (N, 4, 3)
+    # Col = sigmoid(Col_raw + sum_c class_c Adjust_c) ties the two variants together (T_NeRF_net_v2.py:89-98)
+    col = torch.sigmoid(b[1] + (b[5] * b[4].unsqueeze(2)).sum(1))
+    np.testing.assert_allclose(a[1].detach().cpu().numpy(), col.detach().cpu().numpy(), rtol=0, atol=2e-6)
+    with pytest.raises(NotImplementedError):
+        net.forward_Classic_Sigma_Only(X)
+    with torch.no_grad():
+        r1 = net.forward_Classic_Sigma_Only(X)
+        r2 = net.forward_Solar(X, sun, tim)[0]
+    np.testing.assert_allclose(r1.cpu().numpy(), r2.cpu().numpy(), rtol=1e-5, atol=1e-6)     # both: batch-statistics trunk + density head
+    import copy
+    twin = copy.deepcopy(net)                      # ADVICE r1: copies must not share the C handles / arenas
+    assert twin._handle is None and "_param_store" not in twin.__dict__
+    twin.eval(); net.eval()
+    np.testing.assert_allclose(twin(X, sun, tim)[0].cpu().numpy(), net(X, sun, tim)[0].cpu().numpy(), rtol=0, atol=0)
+
+
+def test_full_size_training_step_vs_reference(golden_dir):
+    """BASELINE configs[2] at its real size, pinned to the REFERENCE: one training step of 4096 rays x 96
+    samples + 4096 sun rays at W = 256 (393 216 points per pass: every CU runs many 512-row tiles, persistent grids, atomics
+    under full contention) against tests/golden/train_W256_R4096_S96.npz, which tools/make_golden.py produced by running
+    the reference itself (43 s on 8 CPU cores)."""
+    sn, g, net, ev, data = setup(golden_dir, "train_W256_R4096_S96.npz")
+    opt = sn.FusedAdam(net, lr=float(g["lr"]))
+    opt.zero_grad()
+    loss, total = run_step(g, net, ev, data)
+    for k in loss:
+        ref = float(g["loss_" + k])
+        print(f"  loss {k:20s} {float(loss[k][0].detach()):.8f} ref {ref:.8f}")
+        assert abs(float(loss[k][0].detach()) - ref) <= 2e-5 * max(1.0, abs(ref)) + 1e-6, k
+    assert abs(float(total.detach()) - float(g["total"])) <= 1e-4 * abs(float(g["total"]))
+    total.backward()
+    refs = _ref_grads(g)
+    params = dict(net.named_parameters())
+    gmax = max(np.abs(v).max() for v, _ in refs.values())
+    worst, worst_n = 0, None
+    for n, (ref, step) in refs.items():
+        got = params[n].grad.cpu().numpy().reshape(-1)[::step]
+        if n.endswith(".linear.bias") and n.replace(".linear.bias", ".norm.weight") in refs:
+            # a bias in front of BatchNorm has an exactly-zero gradient (the batch mean is subtracted): the reference holds
+            # rounding noise there (|g| ~ 1e-8 against gmax ~ 1e-1) and so do we - both must be negligible, not equal
+            assert np.abs(ref).max() < 1e-5 * gmax and np.abs(got).max() < 1e-5 * gmax, (n, np.abs(ref).max(), np.abs(got).max())
+            continue
+        err = np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-3 * gmax)
+        print(f"    {n:45s} |ref|max {np.abs(ref).max():.3e} err {err:.2e}")
+        if err > worst:
+            worst, worst_n = err, n
+        if "gnorm_" + n in g:
+            assert abs(float(params[n].grad.double().norm()) - float(g["gnorm_" + n])) <= 5e-4 * float(g["gnorm_" + n]), n
+    print(f"  worst relative gradient error {worst:.2e} ({worst_n})")
+    assert worst < 2e-4              # measured 6e-5 (fc10Sigma.weight); every weight matrix of the trunk <= 2.5e-5
+    sd = net.state_dict()
+    for k in g:
+        if k.startswith("bn_"):
+            np.testing.assert_allclose(sd[k[3:]].cpu().numpy(), g[k], rtol=1e-4, atol=1e-5, err_msg=k)

@@ -113,3 +113,52 @@ def test_tile_group_gather_two_ranks(steps, group):
     """The grouped, double-buffered asynchronous tile all-gather that bench.py's N > 1 render path uses."""
     port = 31500 + (os.getpid() + 7 * steps + group) % 2000
     mp.spawn(_tile_worker, args=(2, port, steps, group), nprocs=2, join=True)
+
+
+def test_bench_self_launches_ranks():
+    """`python bench.py --gpus 2` with no rank environment starts its own ranks (a child torch.distributed.run, before any GPU
+    call) - VERDICT r1 item 2.  Exercised here with the gloo self-test backend: no GPU, no kernels, the real launch path."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--backend", "gloo"], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout                      # ONE JSON line, from rank 0
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rank_sum"] == 3.0 and out["self_launched"] is True
+
+
+def _ada_worker(rank, world, port):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    spec = importlib.util.spec_from_file_location("season_nerf_amd", os.path.join(REPO, "season-nerf_amd", "__init__.py"),
+                                                  submodule_search_locations=[os.path.join(REPO, "season-nerf_amd")])
+    import sys
+    pkg = importlib.util.module_from_spec(spec)
+    sys.modules["season_nerf_amd"] = pkg
+    spec.loader.exec_module(pkg)
+    from season_nerf_amd.trainer import _allreduce_mean_grads
+    ada = pkg.AdaptiveLossFunction(3, torch.float32, "cpu", alpha_hi=2.99, alpha_init=2.0, scale_init=0.03, scale_lo=0.01)
+    opt = torch.optim.Adam(ada.parameters(), lr=1e-2)
+    g = torch.Generator().manual_seed(100 + rank)                     # every rank sees different residuals (its own ray shard)
+    for _ in range(3):
+        opt.zero_grad()
+        torch.mean(ada.lossfun(torch.randn(64, 3, generator=g) * 0.1)).backward()
+        _allreduce_mean_grads(list(ada.parameters()))
+        opt.step()
+    flat = torch.cat([p.detach().reshape(-1) for p in ada.parameters()])
+    both = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(both, flat)
+    assert torch.equal(both[0], both[1]), "adaptive-loss parameters diverged across ranks"
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_adaptive_loss_parameters_stay_identical_across_ranks():
+    """the second Adam (loss alpha / scale) must see all-reduced gradients under data parallelism, or the replicas
+    optimise different objectives.  Net_tool.train_step calls `_allreduce_mean_grads` before `optim2.step()`."""
+    port = 29500 + (os.getpid() + 77) % 2000
+    mp.spawn(_ada_worker, args=(2, port), nprocs=2, join=True)

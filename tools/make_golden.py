@@ -241,6 +241,7 @@ def gen_render(W, seed, tag):
     im = get_imgs_from_Img_Dict(d, size, False)
     for k in ["Base_Img", "Season_Adj_Img", "Shadow_Adjust", "Shadow_Mask", "Raw_Shadow_Mask"]:
         out["img_" + k] = im[k]
+    out["imgc_Shadow_Adjust"] = get_imgs_from_Img_Dict(d, size, True)["Shadow_Adjust"]       # use_classic_shadows (:165-170)
     taus = np.arange(12) / 12.0
     with torch.no_grad():
         cls = net.get_class_only(torch.tensor(np.stack([encode_time(t) for t in taus]), dtype=torch.float32)).numpy()
@@ -302,7 +303,27 @@ def gen_micro():
     torch.manual_seed(5)
     st, en, ve, ti, ae = create_solor_rays_uniform(H4, WC)(48, include_times=True)
     out["sungen_starts"], out["sungen_ends"], out["sungen_vec"], out["sungen_times"], out["sungen_az_el"] = f32(st), f32(en), f32(ve), f32(ti), ae
+    out.update(gen_schedule())
     np.savez_compressed(os.path.join(OUT, "micro.npz"), **out)
+
+
+def gen_schedule():
+    """Save points of the training driver (misc.get_output_loc_lin_first, misc.py:35-53, as T_NeRF_Net_Tool.__init__ calls it,
+    Net_Tool_2.py:52-55) and the reference's OneCycleLR trajectory (Net_Tool_2.py:123-130) for the default lite settings."""
+    out = {}
+    for n_steps, n_out, gap in [(10000, 8, 1000), (40000, 32, 1000), (1000, 2, 1000), (4000, 8, 1000), (0, 0, 1000), (2, 1, 1000)]:
+        out[f"outloc_{n_steps}_{n_out}_{gap}"] = np.asarray(misc.get_output_loc_lin_first(n_steps, n_out, gap))
+    lr, total = 10 ** -4.86 * 3, 1000                                   # main_lite.py:75,67 (5000 steps: phase 1 = 1000)
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.Adam([p], lr=lr)
+    sch = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=lr, total_steps=total, base_momentum=0.85, max_momentum=0.95, cycle_momentum=False)
+    lrs = []
+    for _ in range(total - 1):
+        opt.step()
+        sch.step()
+        lrs.append(sch.get_last_lr()[0])
+    out["onecycle_lr"], out["onecycle_max_lr"], out["onecycle_total"] = np.array(lrs), lr, total
+    return out
 
 
 def gen_dsm():
@@ -336,6 +357,29 @@ def gen_dsm():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
+    if "--only-classic-shadows" in sys.argv:      # add the use_classic_shadows image to the existing render fixture
+        net, _ = make_net(64, 4, 2)
+        size = (12, 12, 48)
+        d = component_render_by_dir(net, (80, 0), (30, 90), 0.25, size, WC, H4, torch.device("cpu"), include_exact_solar=False)
+        path = os.path.join(OUT, "render_W64_s2.npz")
+        old = dict(np.load(path, allow_pickle=False))
+        assert np.array_equal(old["img_Shadow_Adjust"], get_imgs_from_Img_Dict(d, size, False)["Shadow_Adjust"])
+        old["imgc_Shadow_Adjust"] = get_imgs_from_Img_Dict(d, size, True)["Shadow_Adjust"]
+        np.savez_compressed(path, **old)
+        sys.exit(0)
+    if "--only-schedule" in sys.argv:             # add the training-schedule known answers to the existing micro fixture
+        path = os.path.join(OUT, "micro.npz")
+        old = dict(np.load(path, allow_pickle=False))
+        old.update(gen_schedule())
+        np.savez_compressed(path, **old)
+        sys.exit(0)
+    if "--only-full-train" in sys.argv:
+        # BASELINE configs[2] at its full size: ONE reference training step, 4096 rays x 96 samples + 4096 sun rays, W = 256,
+        # MSE loss (43 s and ~40 GB of autograd state on the 8 CPUs of the build container).  Gradients of the big tensors are
+        # stored as every 37th element plus their L2 norm, so the fixture stays below 1 MB.
+        gen_train(256, 5, 4096, 96, "W256_R4096_S96", subsample=37)
+        print("train_W256_R4096_S96.npz", os.path.getsize(os.path.join(OUT, "train_W256_R4096_S96.npz")))
+        sys.exit(0)
     gen_micro()
     gen_net(64, 0, 384, "W64_s0")
     gen_net(256, 1, 768, "W256_s1")
@@ -344,6 +388,7 @@ if __name__ == "__main__":
     gen_train(64, 0, 32, 32, "W64_R32_S32")
     gen_train(64, 1, 24, 40, "prior_W64_R24_S40", prior=True)
     gen_train(256, 2, 32, 40, "W256_R32_S40", subsample=37)
+    gen_train(256, 5, 4096, 96, "W256_R4096_S96", subsample=37)       # full-size configs[2] step (also: --only-full-train)
     gen_train(64, 3, 32, 32, "classic_W64_R32_S32", classic=True)
     gen_train(64, 4, 24, 40, "classic_prior_W64_R24_S40", prior=True, classic=True)
     gen_render(64, 2, "W64_s2")
