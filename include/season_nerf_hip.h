@@ -47,8 +47,23 @@ void snerf_model_destroy(snerf_model* m);
 int snerf_model_width(const snerf_model* m);
 int snerf_model_classes(const snerf_model* m);
 
+/* Arithmetic of the fused per-point (field) network; set before snerf_model_finalize.  The reference computes in fp32
+ * (plain torch, T_NeRF_net_v2.py:75-105); the north-star bar is 1e-4 relative on RGB / depth against it.
+ *   SNERF_PREC_BF16X3  3-term error-compensated bf16 MFMA products, fp32 accumulate: RGB ~3e-6, per-sample outputs ~1e-5 (default)
+ *   SNERF_PREC_BF16    one bf16 MFMA per product (first layer keeps 3 terms): RGB 2-3e-3 - outside the bar, "fast" mode
+ *   SNERF_PREC_I8X3    16-bit fixed point in two int8 digits on the int8 MFMA pipe, exact integer accumulation:
+ *                      RGB ~2e-5, per-sample outputs ~1e-4; inputs (sample positions, sun vectors) must lie in [-1,1]
+ * The per-group network (class softmax, sky colour: one row per ray) always runs in BF16X3. */
+#define SNERF_PREC_BF16X3 0
+#define SNERF_PREC_BF16 1
+#define SNERF_PREC_I8X3 2
+int snerf_model_set_precision(snerf_model* m, int precision);
+int snerf_model_precision(const snerf_model* m);
+
 /* Host-only packing (no GPU): sizes and bytes of the packed programs, for tests and offline tooling.
- * program 0 = per-point field network, 1 = per-group (time/sun) network.  Buffers may be NULL to query sizes. */
+ * program 0 = per-point field network, 1 = per-group (time/sun) network (bf16 hi/lo fragment pairs + bias table);
+ * program 2 = the field network in the int8-digit format (T/L digit fragment pairs + per-row [scale | bias] tables),
+ * only under SNERF_PREC_I8X3.  Buffers may be NULL to query sizes. */
 int snerf_model_pack_host(snerf_model* m, int program, uint8_t* stream_out, size_t* stream_bytes,
                           float* bias_out, size_t* bias_floats);
 

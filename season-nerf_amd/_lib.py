@@ -48,6 +48,8 @@ def lib():
     L.snerf_model_destroy.restype = None
     L.snerf_model_width.argtypes = [vp]
     L.snerf_model_classes.argtypes = [vp]
+    L.snerf_model_set_precision.argtypes = [vp, i32]
+    L.snerf_model_precision.argtypes = [vp]
     L.snerf_model_pack_host.argtypes = [vp, i32, vp, C.POINTER(C.c_size_t), vp, C.POINTER(C.c_size_t)]
     L.snerf_group_forward.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp]
     L.snerf_field_forward_points.argtypes = [vp, i32, i64, vp, i64, vp, vp, C.POINTER(FieldOut), vp]
@@ -99,6 +101,9 @@ def lib():
     return L
 
 
+PRECISIONS = {"bf16x3": 0, "bf16": 1, "i8x3": 2}      # SNERF_PREC_* of include/season_nerf_hip.h
+
+
 def check(rc, what):
     if rc != 0:
         raise RuntimeError(f"season_nerf_amd: {what} failed (code {rc}): {lib().snerf_last_error().decode()}")
@@ -106,6 +111,7 @@ def check(rc, what):
 
 EXPORTS = ["snerf_last_error", "snerf_abi_version", "snerf_model_create", "snerf_model_set_tensor",
            "snerf_model_finalize", "snerf_model_destroy", "snerf_model_width", "snerf_model_classes",
+           "snerf_model_set_precision", "snerf_model_precision",
            "snerf_model_pack_host", "snerf_group_forward", "snerf_field_forward_points", "snerf_field_forward_rays",
            "snerf_composite_rays", "snerf_composite_sweep", "snerf_render_workspace_bytes", "snerf_render_rays", "snerf_rays_from_camera", "snerf_field_kernel_info",
            "snerf_prior_density", "snerf_surface_distance", "snerf_image_error", "snerf_transmittance",

@@ -1,32 +1,71 @@
 """Build the gfx950 shared library in-tree:  python season-nerf_amd/build.py  [--force]
 
-One hipcc invocation; the .so lands next to this file (git-ignored, but it travels to the GPU box)."""
+Every source is compiled to its own object (in parallel, cached under build/obj by modification time of the source
+and of the headers) and linked into libseason_nerf_hip.so next to this file (git-ignored, but it travels to the
+GPU box).  `build(force=True)` - what `__graft_entry__.build()` asks for - recompiles everything: a fresh .so on
+disk proves nothing about the toolchain."""
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(REPO, "build", "obj")
 LIB = os.path.join(HERE, "libseason_nerf_hip.so")
-SOURCES = ["kernels.hip", "api.cpp", "pack.cpp", "gemm.hip", "train_kernels.hip", "train.cpp", "dsm.hip"]
-DEPS = SOURCES + ["kernels.h", "pack.h", "program.h", "train.h", os.path.join("..", "..", "include", "season_nerf_hip.h")]
+SOURCES = ["kernels.hip", "kernels_i8.hip", "api.cpp", "pack.cpp", "gemm.hip", "train_kernels.hip", "train.cpp", "dsm.hip"]
+HEADERS = ["kernels.h", "mlp_device.h", "pack.h", "program.h", "train.h", os.path.join("..", "..", "include", "season_nerf_hip.h")]
+FLAGS = ["-std=c++17", "-O3", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off",
+         "-mllvm", "-amdgpu-mfma-vgpr-form=1",    # MFMA accumulators in VGPRs: no v_accvgpr_read per epilogue element
+         "-Wno-unused-command-line-argument"]
+
+
+def _hipcc():
+    return os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+def _newest_header():
+    return max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS if os.path.exists(os.path.join(CSRC, h)))
+
+
+def _obj(src):
+    return os.path.join(OBJ, src + ".o")
+
+
+def _stale(src, hdr_t):
+    o = _obj(src)
+    if not os.path.exists(o):
+        return True
+    t = os.path.getmtime(o)
+    return os.path.getmtime(os.path.join(CSRC, src)) > t or hdr_t > t
 
 
 def needs_build():
     if not os.path.exists(LIB):
         return True
+    hdr_t = _newest_header()
     t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
+    return any(os.path.getmtime(os.path.join(CSRC, s)) > t for s in SOURCES) or hdr_t > t
 
 
-def build(force=False, verbose=True):
+def _compile(src, verbose):
+    cmd = [_hipcc()] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", _obj(src)]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+
+
+def build(force=False, verbose=True, jobs=None):
     if not force and not needs_build():
         return LIB
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "-std=c++17", "-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-ffp-contract=off",
-           "-mllvm", "-amdgpu-mfma-vgpr-form=1",    # MFMA accumulators in VGPRs: no v_accvgpr_read per epilogue element
-           "-Wno-unused-command-line-argument",
-           "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    os.makedirs(OBJ, exist_ok=True)
+    hdr_t = _newest_header()
+    todo = [s for s in SOURCES if force or _stale(s, hdr_t)]
+    jobs = jobs or min(len(todo) or 1, max(1, (os.cpu_count() or 2) - 1), 6)
+    with ThreadPoolExecutor(max_workers=jobs) as ex:
+        list(ex.map(lambda s: _compile(s, verbose), todo))
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + [_obj(s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -26,18 +26,22 @@ static int fail_hip(hipError_t e, const char* what) {
 
 struct snerf_model {
     int W = 0, C = 0;
+    int precision = SNERF_PREC_BF16X3;
     Weights w;
     bool finalized = false;
     Packed host[2];
+    Packed host_i8;                  // field program in the int8-digit format (precision SNERF_PREC_I8X3 only)
     uint8_t* d_stream[2] = {nullptr, nullptr};
     float* d_bias[2] = {nullptr, nullptr};
+    uint8_t* d_stream_i8 = nullptr;
+    float* d_table_i8 = nullptr;
     int n_cu = 0;
 };
 
 extern "C" {
 
 const char* snerf_last_error(void) { return g_err.c_str(); }
-int snerf_abi_version(void) { return 4; }
+int snerf_abi_version(void) { return 5; }
 
 snerf_model* snerf_model_create(int layer_width, int n_classes) {
     if (layer_width != 64 && layer_width != 256) {
@@ -54,6 +58,16 @@ snerf_model* snerf_model_create(int layer_width, int n_classes) {
     m->C = n_classes;
     return m;
 }
+
+int snerf_model_set_precision(snerf_model* m, int precision) {
+    if (!m) return fail(SNERF_E_INVALID, "NULL model");
+    if (m->finalized) return fail(SNERF_E_STATE, "model already finalized (set the precision before snerf_model_finalize)");
+    if (precision != SNERF_PREC_BF16X3 && precision != SNERF_PREC_BF16 && precision != SNERF_PREC_I8X3)
+        return fail(SNERF_E_INVALID, "unknown precision mode " + std::to_string(precision));
+    m->precision = precision;
+    return SNERF_OK;
+}
+int snerf_model_precision(const snerf_model* m) { return m ? m->precision : -1; }
 
 int snerf_model_set_tensor(snerf_model* m, const char* key, const float* host_data, size_t numel) {
     if (!m || !key || (!host_data && numel)) return fail(SNERF_E_INVALID, "snerf_model_set_tensor: NULL argument");
@@ -73,15 +87,24 @@ static int pack_both(snerf_model* m) {
             return fail(err.rfind("missing", 0) == 0 ? SNERF_E_MISSING : SNERF_E_INVALID, err);
         m->host[p] = std::move(tmp);
     }
+    if (m->precision == SNERF_PREC_I8X3 && m->host_i8.stream.empty()) {
+        std::string err;
+        Packed tmp;
+        if (!pack_program_i8(m->w, PROG_FIELD, m->W, m->C, /*fold_bn=*/true, &tmp, &err))
+            return fail(err.rfind("missing", 0) == 0 ? SNERF_E_MISSING : SNERF_E_INVALID, err);
+        m->host_i8 = std::move(tmp);
+    }
     return SNERF_OK;
 }
 
 int snerf_model_pack_host(snerf_model* m, int program, uint8_t* stream_out, size_t* stream_bytes, float* bias_out,
                           size_t* bias_floats) {
-    if (!m || program < 0 || program > 1) return fail(SNERF_E_INVALID, "snerf_model_pack_host: bad argument");
+    if (!m || program < 0 || program > 2) return fail(SNERF_E_INVALID, "snerf_model_pack_host: bad argument");
+    if (program == 2 && m->precision != SNERF_PREC_I8X3)
+        return fail(SNERF_E_STATE, "program 2 (int8-digit field network) exists only under SNERF_PREC_I8X3");
     int rc = pack_both(m);
     if (rc) return rc;
-    const Packed& P = m->host[program];
+    const Packed& P = program == 2 ? m->host_i8 : m->host[program];
     if (stream_bytes) *stream_bytes = P.stream.size();
     if (bias_floats) *bias_floats = P.bias.size();
     if (stream_out) std::memcpy(stream_out, P.stream.data(), P.stream.size());
@@ -112,6 +135,15 @@ int snerf_model_finalize(snerf_model* m) {
         if ((e = hipMemcpy(m->d_bias[p], P.bias.data(), P.bias.size() * 4, hipMemcpyHostToDevice)) != hipSuccess)
             return fail_hip(e, "hipMemcpy");
     }
+    if (m->precision == SNERF_PREC_I8X3) {
+        const Packed& P = m->host_i8;
+        if ((e = hipMalloc((void**)&m->d_stream_i8, P.stream.size())) != hipSuccess) return fail_hip(e, "hipMalloc");
+        if ((e = hipMalloc((void**)&m->d_table_i8, P.bias.size() * 4)) != hipSuccess) return fail_hip(e, "hipMalloc");
+        if ((e = hipMemcpy(m->d_stream_i8, P.stream.data(), P.stream.size(), hipMemcpyHostToDevice)) != hipSuccess)
+            return fail_hip(e, "hipMemcpy");
+        if ((e = hipMemcpy(m->d_table_i8, P.bias.data(), P.bias.size() * 4, hipMemcpyHostToDevice)) != hipSuccess)
+            return fail_hip(e, "hipMemcpy");
+    }
     m->finalized = true;
     return SNERF_OK;
 }
@@ -122,6 +154,8 @@ void snerf_model_destroy(snerf_model* m) {
         if (m->d_stream[p]) (void)hipFree(m->d_stream[p]);
         if (m->d_bias[p]) (void)hipFree(m->d_bias[p]);
     }
+    if (m->d_stream_i8) (void)hipFree(m->d_stream_i8);
+    if (m->d_table_i8) (void)hipFree(m->d_table_i8);
     delete m;
 }
 
@@ -153,7 +187,7 @@ int snerf_group_forward(const snerf_model* m, int64_t n_groups, const float* d_t
     a.g_classes = d_classes;
     a.g_sky_raw = d_sky_raw;
     a.g_sky = d_sky;
-    hipError_t e = launch_mlp(PROG_GROUP, m->W, 0, a, m->n_cu, (hipStream_t)stream);
+    hipError_t e = launch_mlp(PROG_GROUP, m->W, 0, false, a, m->n_cu, (hipStream_t)stream);   // always bf16x3 (one row per ray)
     return e == hipSuccess ? SNERF_OK : fail_hip(e, "group kernel launch");
 }
 
@@ -173,7 +207,16 @@ static int field_launch(const snerf_model* m, int variant, MlpArgs& a, const sne
         a.out.points = out->d_points;
     }
     if (variant <= 1 && !a.sun) return fail(SNERF_E_INVALID, "sun directions are required for variants 0 and 1");
-    hipError_t e = launch_mlp(PROG_FIELD, m->W, variant, a, m->n_cu, (hipStream_t)stream);
+    hipError_t e;
+    if (m->precision == SNERF_PREC_I8X3) {
+        a.stream = m->d_stream_i8;
+        a.stream_bytes = (uint32_t)field_variant_chunks_i8(m->W, m->C, variant) * kChunkBytes;
+        a.bias = m->d_table_i8;
+        a.bias_floats = (int)m->host_i8.bias.size();
+        e = launch_mlp_i8(m->W, variant, a, m->n_cu, (hipStream_t)stream);
+    } else {
+        e = launch_mlp(PROG_FIELD, m->W, variant, m->precision == SNERF_PREC_BF16, a, m->n_cu, (hipStream_t)stream);
+    }
     return e == hipSuccess ? SNERF_OK : fail_hip(e, "field kernel launch");
 }
 
@@ -350,7 +393,7 @@ int snerf_field_kernel_info(const snerf_model* m, int64_t n_points, int* grid, i
     const int ncu = m->n_cu ? m->n_cu : 256;
     if (grid) *grid = (int)(tiles < ncu ? tiles : ncu);
     if (block) *block = 256;
-    if (lds_bytes) *lds_bytes = mlp_lds_bytes((int)m->host[PROG_FIELD].bias.size());
+    if (lds_bytes) *lds_bytes = mlp_lds_bytes((int)m->host[PROG_FIELD].bias.size());   // bf16 kernels
     return SNERF_OK;
 }
 

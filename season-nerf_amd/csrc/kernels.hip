@@ -11,50 +11,9 @@
 //     against its own 32 points, whose activations stay in registers from the positional encoding to the heads;
 //   * 3 bf16 MFMAs per product (hi*hi + lo*hi + hi*lo, fp32 accumulate) keep the result within ~1e-5 of fp32,
 //     the parity bar (1e-4 rel) being out of reach of plain bf16 on an omega_0 = 30 SIREN.
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-
-#include "program.h"
-#include "kernels.h"
-#if defined(SNERF_ABLATE) && !defined(ABL)
-#define ABL 0
-#endif
+#include "mlp_device.h"
 
 namespace snerf {
-
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-typedef __attribute__((ext_vector_type(4))) float f32x4;
-typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
-typedef __attribute__((address_space(3))) void lds_void;
-typedef __attribute__((address_space(3))) char lds_char;
-typedef const __attribute__((address_space(3))) float lds_cfloat;
-typedef const __attribute__((address_space(3))) u32x4 lds_cu32x4;
-typedef const __attribute__((address_space(3))) f32x4 lds_cf32x4;
-typedef const __attribute__((address_space(1))) void glb_void;
-
-#ifndef SNERF_RING_D
-#define SNERF_RING_D 7
-#endif
-constexpr int RING_D = SNERF_RING_D;            // ring slots (one chunk each)
-constexpr int DMA_PER_WAVE = kChunkBytes / kFragBytes / 4;   // 1 KiB pieces each wave moves per chunk
-constexpr int RING_BYTES = RING_D * kChunkBytes;
-constexpr int TILE_PTS = 128;                   // points per workgroup tile (4 waves x 32)
-
-struct Frag {          // B operand of one k-step: 8 bf16 hi + 8 bf16 lo of this lane's point
-    u32x4 hi, lo;
-};
-
-struct Ring {
-    uint32_t rd;       // LDS offset of the slot the NEXT ring_step hands to the consumers
-    uint32_t wr;       // LDS offset of the slot the next DMA fills
-    uint32_t cur;      // LDS offset of the chunk being consumed
-    uint32_t goff;     // byte offset in the (cyclic) global stream of the next chunk to fetch
-};
-
-__device__ __forceinline__ float sin2pi(float r) { return __builtin_amdgcn_sinf(r); }   // v_sin_f32: revolutions,
-__device__ __forceinline__ float cos2pi(float r) { return __builtin_amdgcn_cosf(r); }   // 1.25e-7 abs err (probe_hw)
 
 // two fp32 -> packed bf16 hi and packed bf16 lo (x = hi + lo to ~2^-17 relative)
 __device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t& lo) {
@@ -90,63 +49,9 @@ __device__ __forceinline__ f32x16 mfma3(const u32x4& a_hi, const u32x4& a_lo, co
     return acc;
 }
 
-// Fetch one 16 KiB chunk: 16 pieces of 1 KiB, wave w moves pieces w, w+4, w+8, w+12 (LDS-DMA: each lane's 16 bytes land
-// at M0 + lane*16).  Issued through inline asm on purpose: the __builtin_amdgcn_global_load_lds form is FLAT-encoded
-// and makes hipcc (ROCm 7.2) treat every later LDS read as dependent on a "pending flat" access, i.e. it emits
-// s_waitcnt lgkmcnt(0) in front of every MFMA instead of counted waits (measured: 685 of 685 waits).  hipcc neither
-// counts these loads nor waits for them; ring_step's hand-counted vmcnt does (cdna_hip_programming.md 5.7).
-// M0 is written and restored inside the one statement; saddr form: address = sgpr base + lane*16.
-__device__ __forceinline__ void dma_chunk(const uint8_t* stream, uint32_t goff, lds_char* lds, uint32_t wr, int wave, int lane) {
-    const uint8_t* b0 = stream + goff + wave * kFragBytes;                    // wave-uniform
-    const uint32_t dst = (uint32_t)(uintptr_t)(lds + wr + wave * kFragBytes); // wave-uniform LDS byte address
-    const uint32_t voff = lane * 16;
-    uint32_t keep;
-#pragma unroll
-    for (int part = 0; part < DMA_PER_WAVE / 4; ++part) {
-        const uint8_t* bp = b0 + part * 16 * kFragBytes;
-        asm volatile(
-            "s_mov_b32 %0, m0\n\t"
-            "s_mov_b32 m0, %2\n\t"
-            "s_nop 0\n\t"
-            "global_load_lds_dwordx4 %1, %3\n\t"
-            "s_add_u32 m0, m0, 0x1000\n\t"
-            "s_nop 0\n\t"
-            "global_load_lds_dwordx4 %1, %4\n\t"
-            "s_add_u32 m0, m0, 0x1000\n\t"
-            "s_nop 0\n\t"
-            "global_load_lds_dwordx4 %1, %5\n\t"
-            "s_add_u32 m0, m0, 0x1000\n\t"
-            "s_nop 0\n\t"
-            "global_load_lds_dwordx4 %1, %6\n\t"
-            "s_mov_b32 m0, %0"
-            : "=&s"(keep)
-            : "v"(voff), "s"(dst + part * 16 * kFragBytes), "s"(bp), "s"(bp + 4 * kFragBytes), "s"(bp + 8 * kFragBytes), "s"(bp + 12 * kFragBytes)
-            : "memory", "scc");
-    }
-}
-
-__device__ __forceinline__ uint32_t ring_next(uint32_t off) {
-    off += kChunkBytes;
-    return off == RING_BYTES ? 0u : off;
-}
-
-// Hand the next chunk to the consumers and refill the slot released TWO chunks ago.
-//  - vmcnt((D-3)*DMA_PER_WAVE): all but the (D-3) youngest chunks this wave fetched have landed => chunk `rd` is complete
-//    (counted in DMA instructions of THIS wave; extra older loads/stores only make the wait stricter);
-//  - s_barrier: every wave's pieces of chunk `rd` have landed, and every wave has issued the MFMAs that consumed the
-//    chunk two steps back (its LDS reads are therefore complete) - so the refill needs no lgkmcnt drain, and the
-//    software-pipelined fragment reads of the previous chunk stay in flight across the barrier.
-__device__ __forceinline__ void ring_step(Ring& rg, const uint8_t* stream, uint32_t stream_bytes, lds_char* lds, int wave, int lane) {
-#if defined(SNERF_ABLATE) && (ABL & 4)     // timing-only: no ring at all
-    return;
-#endif
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((RING_D - 3) * DMA_PER_WAVE) : "memory");
-    dma_chunk(stream, rg.goff, lds, rg.wr, wave, lane);
-    rg.goff += kChunkBytes;
-    if (rg.goff >= stream_bytes) rg.goff = 0;
-    rg.cur = rg.rd;
-    rg.rd = ring_next(rg.rd);
-    rg.wr = ring_next(rg.wr);
+// "bf16-fast": one MFMA per product on the rounded operands (2-3e-3 on RGB, outside the parity bar)
+__device__ __forceinline__ f32x16 mfma1(const u32x4& a_hi, const Frag& b, f32x16 acc) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_hi), __builtin_bit_cast(bf16x8, b.hi), acc, 0, 0, 0);
 }
 
 // One fused layer: out^T[n x 32 pts] = act(W[n x k] * in^T[k x 32 pts] + b), activations in registers.
@@ -215,21 +120,21 @@ __device__ __forceinline__ void epi_C(int e, const EpiTmp& t, Frag* out2) {
 #define SG_DSREAD 0x100
 #define SG_TRANS 0x400
 
-template <int NB, int KS0, int KS1, bool SIN>
+template <int NB, int KS0, int KS1, bool SIN, int TERMS = 3, bool LO_OUT = true>
 __device__ __forceinline__ void run_layer(Ring& rg, const uint8_t* stream, uint32_t stream_bytes, lds_char* lds,
                                           lds_cfloat* bias_l, const Frag* in0, const Frag* in1, Frag* out,
                                           f32x16* raw, int wave, int lane) {
     constexpr int KS = KS0 + KS1, NP = NB * KS;
     constexpr bool PIPE = KS >= 4;      // tiny layers (2 k-steps per block) run the previous epilogue in one piece
     const int h = lane >> 5;
-    u32x4 fh[PF], fl[PF];
+    u32x4 fh[PF], fl[PF] = {};
 #pragma unroll
     for (int q = 0; q < PF; ++q) {
         if (q < NP) {
             if (q % kChunkPairs == 0) ring_step(rg, stream, stream_bytes, lds, wave, lane);
             lds_char* ap = lds + rg.cur + (q % kChunkPairs) * kPairBytes + lane * 16;
             fh[q] = *(lds_cu32x4*)ap;
-            fl[q] = *(lds_cu32x4*)(ap + kFragBytes);
+            if (TERMS == 3) fl[q] = *(lds_cu32x4*)(ap + kFragBytes);
         }
     }
     f32x16 accs[2];
@@ -250,10 +155,11 @@ __device__ __forceinline__ void run_layer(Ring& rg, const uint8_t* stream, uint3
 #else
                 lds_char* ap = lds + rg.cur + (qn % kChunkPairs) * kPairBytes + lane * 16;
                 fh[q % PF] = *(lds_cu32x4*)ap;
-                fl[q % PF] = *(lds_cu32x4*)(ap + kFragBytes);
+                if (TERMS == 3) fl[q % PF] = *(lds_cu32x4*)(ap + kFragBytes);
 #endif
             }
-            acc = mfma3(a_hi, a_lo, s < KS0 ? in0[s] : in1[s - KS0], acc);
+            if (TERMS == 3) acc = mfma3(a_hi, a_lo, s < KS0 ? in0[s] : in1[s - KS0], acc);
+            else acc = mfma1(a_hi, s < KS0 ? in0[s] : in1[s - KS0], acc);
             // next block's bias -> its accumulator, issued a few k-steps early (after the previous epilogue released
             // the other accumulator buffer), so the LDS latency hides behind this block's last MFMAs
             if (b + 1 < NB && s == (KS >= 4 ? KS - 1 : 0)) next_init = load_bias(bias_l, b + 1, h);
@@ -263,13 +169,13 @@ __device__ __forceinline__ void run_layer(Ring& rg, const uint8_t* stream, uint3
                 for (int e = 0; e < 8; ++e) {
                     if (PIPE) {
                         const int sA = 1 + (e * (KS - 4)) / 8;   // starts one k-step late: the block's last MFMA has retired
-                        if (s == sA + 2) epi_C(e, et[e], out + 2 * (b - 1));
+                        if (LO_OUT && s == sA + 2) epi_C(e, et[e], out + 2 * (b - 1));
                         if (s == sA + 1) epi_B(e, et[e], out + 2 * (b - 1));
                         if (s == sA) epi_A(accs[(b - 1) & 1], e, et[e]);
                     } else if (s == 0) {
                         epi_A(accs[(b - 1) & 1], e, et[e]);
                         epi_B(e, et[e], out + 2 * (b - 1));
-                        epi_C(e, et[e], out + 2 * (b - 1));
+                        if (LO_OUT) epi_C(e, et[e], out + 2 * (b - 1));
                     }
                 }
             }
@@ -293,29 +199,13 @@ __device__ __forceinline__ void run_layer(Ring& rg, const uint8_t* stream, uint3
         for (int e = 0; e < 8; ++e) epi_A(accs[(NB - 1) & 1], e, et[e]);
 #pragma unroll
         for (int e = 0; e < 8; ++e) epi_B(e, et[e], out + 2 * (NB - 1));
+        if (LO_OUT) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) epi_C(e, et[e], out + 2 * (NB - 1));
+            for (int e = 0; e < 8; ++e) epi_C(e, et[e], out + 2 * (NB - 1));
+        }
     } else {
         *raw = accs[0];
     }
-}
-
-// sin/cos of k_j * x exactly as the reference evaluates them (misc.py:109,127-131): the fp32 argument is
-// 2^j * fl32(fl32(pi/2) * x); it is reduced in fp64 (exact power-of-two scaling, exact fract) before v_sin/v_cos.
-struct PeArg {
-    double u;   // fl32(fl32(pi/2)*x) / (2*pi), revolutions at j = 0
-};
-__device__ __forceinline__ PeArg pe_arg(float x) {
-    const float a0 = __fmul_rn(x, 1.57079637050628662109375f);
-    PeArg r;
-    r.u = (double)a0 * 0.15915494309189533576888;
-    return r;
-}
-__device__ __forceinline__ void pe_sincos(const PeArg& a, double scale, float& c, float& s) {
-    const double r = a.u * scale;                 // exact: scale = 2^j
-    const float f = (float)(r - __builtin_floor(r));
-    c = cos2pi(f);
-    s = sin2pi(f);
 }
 
 // PE(pos): 32 slots per lane-half, see slot_feature_PEPOS
@@ -372,11 +262,11 @@ __device__ __forceinline__ void make_pe_time(float t0, float t1, int h, Frag* pe
     pe[1].lo = u32x4{0, 0, 0, 0};
 }
 
-__device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }   // torch Softplus(beta 1, thr 20)
-__device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
 
 // =====================================================================================================
-template <int PROG, int W, int VARIANT>
+// FAST: every layer but the first multiplies the bf16-rounded operands once (first layer / positional encoding keep the
+// 3-term product); activations keep no low part.
+template <int PROG, int W, int VARIANT, bool FAST = false>
 __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int C_MAX = kMaxClasses;
@@ -450,8 +340,8 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpArgs A) {
             Frag hA[KW], hB[KW];
             f32x16 raw;
 #define LAYER(L, NBv, K0, K1, SINv, IN0, IN1, OUT, RAW)                                                              \
-    run_layer<NBv, K0, K1, SINv>(rg, A.stream, A.stream_bytes, lds, bias_lds + prog_bias_start(PROG_FIELD, W, C_MAX, L), \
-                                 IN0, IN1, OUT, RAW, wave, lane)
+    run_layer<NBv, K0, K1, SINv, (FAST && L != F_FC1) ? 1 : 3, !FAST>(rg, A.stream, A.stream_bytes, lds,                   \
+                                 bias_lds + prog_bias_start(PROG_FIELD, W, C_MAX, L), IN0, IN1, OUT, RAW, wave, lane)
             // trunk (G_NeRF.py:80-91)
             LAYER(F_FC1, W / 32, PEPOS_KS, 0, true, pe, nullptr, hA, nullptr);
             LAYER(F_FC2, W / 32, KW, 0, true, hA, nullptr, hB, nullptr);
@@ -492,38 +382,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpArgs A) {
             }
 #undef LAYER
             // ---- output non-linearities (T_NeRF_net_v2.py:91-98), lane-half 0 holds the head rows
-            if (h == 0 && valid) {
-                const snerf_field_out_dev& O = A.out;
-                if (O.rho) O.rho[n] = softplus_f(rho_raw);
-                if (O.points) { O.points[n * 3] = x0; O.points[n * 3 + 1] = x1; O.points[n * 3 + 2] = x2; }
-                if constexpr (VARIANT <= 1) {
-                    if (O.solar_vis) O.solar_vis[n] = sigmoid_f(sv_raw);
-                }
-                if constexpr (VARIANT == 0) {
-                    if (O.col_raw) { O.col_raw[n * 3] = col_r; O.col_raw[n * 3 + 1] = col_g; O.col_raw[n * 3 + 2] = col_b; }
-                    float ac0 = 0.f, ac1 = 0.f, ac2 = 0.f;
-#pragma unroll
-                    for (int c = 0; c < C_MAX; ++c) {
-                        if (c < C) {
-                            if (O.adjust) {
-                                O.adjust[(n * C + c) * 3] = adj[3 * c];
-                                O.adjust[(n * C + c) * 3 + 1] = adj[3 * c + 1];
-                                O.adjust[(n * C + c) * 3 + 2] = adj[3 * c + 2];
-                            }
-                            const float pc = pcls[c];
-                            ac0 = __fadd_rn(ac0, __fmul_rn(adj[3 * c], pc));
-                            ac1 = __fadd_rn(ac1, __fmul_rn(adj[3 * c + 1], pc));
-                            ac2 = __fadd_rn(ac2, __fmul_rn(adj[3 * c + 2], pc));
-                        }
-                    }
-                    if (O.adjust_col) { O.adjust_col[n * 3] = ac0; O.adjust_col[n * 3 + 1] = ac1; O.adjust_col[n * 3 + 2] = ac2; }
-                    if (O.col) {
-                        O.col[n * 3] = sigmoid_f(col_r + ac0);
-                        O.col[n * 3 + 1] = sigmoid_f(col_g + ac1);
-                        O.col[n * 3 + 2] = sigmoid_f(col_b + ac2);
-                    }
-                }
-            }
+            if (h == 0 && valid) store_field_outputs<VARIANT>(A.out, n, C, x0, x1, x2, col_r, col_g, col_b, rho_raw, sv_raw, adj, pcls);
         } else {
             // ---- group program: class softmax (T_NeRF_net_v2.py:77-78) and sky colour (G_NeRF.py:110-111)
             constexpr int KW = W / 16, W4P = pad32(W / 4), KW4 = W4P / 16;
@@ -833,23 +692,26 @@ hipError_t launch_rays_from_camera(const RayGenArgs& a, hipStream_t st) {
 
 // =====================================================================================================
 // launchers
-template <int PROG, int W, int VARIANT>
+template <int PROG, int W, int VARIANT, bool FAST = false>
 static hipError_t launch_mlp_t(const MlpArgs& a, int n_cu, hipStream_t st) {
     const int lds_bytes = RING_BYTES + a.bias_floats * 4;
     const int64_t n_tiles = (a.n + TILE_PTS - 1) / TILE_PTS;
     int grid = (int)(n_tiles < n_cu ? n_tiles : n_cu);
     if (grid < 1) grid = 1;
-    auto k = mlp_kernel<PROG, W, VARIANT>;
+    auto k = mlp_kernel<PROG, W, VARIANT, FAST>;
     hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds_bytes, st, a);
     return hipGetLastError();
 }
 
-hipError_t launch_mlp(int prog, int W, int variant, const MlpArgs& a, int n_cu, hipStream_t st) {
+hipError_t launch_mlp(int prog, int W, int variant, bool fast, const MlpArgs& a, int n_cu, hipStream_t st) {
 #define CASE(Wv)                                                                                  \
     if (W == Wv) {                                                                                \
         if (prog == PROG_GROUP) return launch_mlp_t<PROG_GROUP, Wv, 0>(a, n_cu, st);              \
+        if (fast && variant == 0) return launch_mlp_t<PROG_FIELD, Wv, 0, true>(a, n_cu, st);      \
+        if (fast && variant == 1) return launch_mlp_t<PROG_FIELD, Wv, 1, true>(a, n_cu, st);     \
+        if (fast) return launch_mlp_t<PROG_FIELD, Wv, 2, true>(a, n_cu, st);                      \
         if (variant == 0) return launch_mlp_t<PROG_FIELD, Wv, 0>(a, n_cu, st);                    \
         if (variant == 1) return launch_mlp_t<PROG_FIELD, Wv, 1>(a, n_cu, st);                    \
         return launch_mlp_t<PROG_FIELD, Wv, 2>(a, n_cu, st);                                      \

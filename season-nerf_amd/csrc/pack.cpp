@@ -119,6 +119,28 @@ static int ref_row(const LayerShape& s, int n) {
     return -1;
 }
 
+// dense folded layer l of a program in reference feature order
+static bool dense_layer(const Weights& w, int prog, int W, int C, int l, bool fold_bn, Dense* dp, std::string* err) {
+    Dense& d = *dp;
+    const LayerShape s = prog_layer(prog, W, C, l);
+    const int k_ref = kind_features(s.kind0, s.ks0) + kind_features(s.kind1, s.ks1);
+    if (prog == PROG_FIELD && l == F_HEAD) {
+        Dense c3, s1;
+        if (!dense_linear(w, "G_NeRF_net.fc10Col", 3, k_ref, &c3, err)) return false;
+        if (!dense_linear(w, "G_NeRF_net.fc10Sigma", 1, k_ref, &s1, err)) return false;
+        d.n = 4; d.k = k_ref; d.W = c3.W; d.b = c3.b;
+        d.W.insert(d.W.end(), s1.W.begin(), s1.W.end()); d.b.push_back(s1.b[0]);
+    } else {
+        const std::string pre = prog == PROG_FIELD ? field_prefix(l) : group_prefix(l);
+        // input width of the reference layer: an IN_H block narrower than its k-steps means zero-padded features
+        int kr = k_ref;
+        if (prog == PROG_GROUP && l == G_K2) kr = W / 4;          // fc_sky_color_2 reads W/4 features (padded to 32)
+        if (s.out_kind == OUT_SIN) { if (!dense_sine(w, pre, s.n_ref, kr, fold_bn, &d, err)) return false; }
+        else { if (!dense_linear(w, pre, s.n_ref, kr, &d, err)) return false; }
+    }
+    return true;
+}
+
 bool pack_program(const Weights& w, int prog, int W, int C, bool fold_bn, Packed* out, std::string* err) {
     if (W < 64 || W % 64 != 0) { *err = "layer width must be a multiple of 64 (got " + std::to_string(W) + ")"; return false; }
     if (C < 1 || C > kMaxClasses) { *err = "n_classes must be in [1," + std::to_string(kMaxClasses) + "]"; return false; }
@@ -127,23 +149,8 @@ bool pack_program(const Weights& w, int prog, int W, int C, bool fold_bn, Packed
     out->bias.assign((size_t)prog_bias_floats(prog, W, C), 0.f);
     for (int l = 0; l < L; ++l) {
         const LayerShape s = prog_layer(prog, W, C, l);
-        // ---- dense folded reference layer
         Dense d;
-        const int k_ref = kind_features(s.kind0, s.ks0) + kind_features(s.kind1, s.ks1);
-        if (prog == PROG_FIELD && l == F_HEAD) {
-            Dense c3, s1;
-            if (!dense_linear(w, "G_NeRF_net.fc10Col", 3, k_ref, &c3, err)) return false;
-            if (!dense_linear(w, "G_NeRF_net.fc10Sigma", 1, k_ref, &s1, err)) return false;
-            d.n = 4; d.k = k_ref; d.W = c3.W; d.b = c3.b;
-            d.W.insert(d.W.end(), s1.W.begin(), s1.W.end()); d.b.push_back(s1.b[0]);
-        } else {
-            const std::string pre = prog == PROG_FIELD ? field_prefix(l) : group_prefix(l);
-            // input width of the reference layer: an IN_H block narrower than its k-steps means zero-padded features
-            int kr = k_ref;
-            if (prog == PROG_GROUP && l == G_K2) kr = W / 4;          // fc_sky_color_2 reads W/4 features (padded to 32)
-            if (s.out_kind == OUT_SIN) { if (!dense_sine(w, pre, s.n_ref, kr, fold_bn, &d, err)) return false; }
-            else { if (!dense_linear(w, pre, s.n_ref, kr, &d, err)) return false; }
-        }
+        if (!dense_layer(w, prog, W, C, l, fold_bn, &d, err)) return false;
         // ---- bias table in accumulator order: [block][lane-half][reg]
         float* bias = out->bias.data() + prog_bias_start(prog, W, C, l);
         for (int b = 0; b < s.nb(); ++b)
@@ -177,6 +184,74 @@ bool pack_program(const Weights& w, int prog, int W, int C, bool fold_bn, Packed
                     }
                 }
             }
+    }
+    return true;
+}
+
+// ---- int8-digit format (program.h, FMT_I8) ----------------------------------------------------------------
+// Row n of a folded layer becomes s_n * (256 T + L): wq = round(w / s_n), s_n = max_k |w| / 32512, balanced digits
+// T = floor((wq + 128) / 256), L = wq - 256 T, both in [-128,127].  The activations arrive as q = 256 a + b + 128
+// (q = round(32767 h)), so  sum_k w_k h_k  ~  s_n / 32767 * (256 (256 M + X) + 128 sum_k wq_k),  M = sum T a,
+// X = sum (T b + L a)  (the L b term, <= 2^-16 of full scale, is dropped).  Table per row: scale 256 s_n / 32767 and
+// bias b_n + 128 s_n sum_k wq_k / 32767.
+bool pack_program_i8(const Weights& w, int prog, int W, int C, bool fold_bn, Packed* out, std::string* err) {
+    if (W < 64 || W % 64 != 0) { *err = "layer width must be a multiple of 64 (got " + std::to_string(W) + ")"; return false; }
+    if (C < 1 || C > kMaxClasses) { *err = "n_classes must be in [1," + std::to_string(kMaxClasses) + "]"; return false; }
+    const int L = prog_layers(prog);
+    out->stream.assign((size_t)prog_chunks(prog, W, C, FMT_I8) * kChunkBytes, 0);
+    out->bias.assign((size_t)prog_table_floats(prog, W, C), 0.f);
+    for (int l = 0; l < L; ++l) {
+        const LayerShape s = prog_layer(prog, W, C, l, FMT_I8);
+        Dense d;
+        if (!dense_layer(w, prog, W, C, l, fold_bn, &d, err)) return false;
+        const int f0 = kind_features(s.kind0, s.ks0, FMT_I8);
+        // column of the dense layer behind k-slot (ks, h, j), or -1
+        auto column = [&](int ks, int h, int j) {
+            int col = -1;
+            if (ks < s.ks0) { const int f = slot_feature8(s.kind0, ks, h, j); if (f >= 0) col = f; }
+            else { const int f = slot_feature8(s.kind1, ks - s.ks0, h, j); if (f >= 0) col = f0 + f; }
+            return (col >= 0 && col < d.k) ? col : -1;
+        };
+        // quantise every padded output row
+        const int n_pad = s.n_out;
+        std::vector<double> scale(n_pad, 0.0);
+        std::vector<long long> wsum(n_pad, 0);
+        std::vector<int> wq((size_t)n_pad * d.k, 0);
+        for (int n = 0; n < n_pad; ++n) {
+            const int rr = ref_row(s, n);
+            if (rr < 0) continue;
+            double mx = 0.0;
+            for (int c = 0; c < d.k; ++c) mx = std::fmax(mx, std::fabs(d.W[(size_t)rr * d.k + c]));
+            const double sn = mx > 0.0 ? mx / 32512.0 : 1.0;
+            scale[n] = sn;
+            for (int c = 0; c < d.k; ++c) wq[(size_t)n * d.k + c] = (int)std::llround(d.W[(size_t)rr * d.k + c] / sn);
+        }
+        uint8_t* base = out->stream.data() + (size_t)prog_chunk_start(prog, W, C, l, FMT_I8) * kChunkBytes;
+        for (int b = 0; b < s.nb(); ++b)
+            for (int ks = 0; ks < s.ks(); ++ks) {
+                int8_t* Tf = (int8_t*)(base + (size_t)(b * s.ks() + ks) * kPairBytes);
+                int8_t* Lf = Tf + kFragBytes;
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int r = lane & 31, h = lane >> 5, n = 32 * b + r;
+                    for (int j = 0; j < 16; ++j) {
+                        const int col = column(ks, h, j);
+                        int q = 0;
+                        if (col >= 0 && ref_row(s, n) >= 0) { q = wq[(size_t)n * d.k + col]; wsum[n] += q; }
+                        const int T = (q + 128) >> 8;                 // floor division (arithmetic shift), q in [-32512, 32512]
+                        Tf[lane * 16 + j] = (int8_t)T;
+                        Lf[lane * 16 + j] = (int8_t)(q - 256 * T);
+                    }
+                }
+            }
+        float* tab = out->bias.data() + prog_table_start(prog, W, C, l);
+        for (int b = 0; b < s.nb(); ++b)
+            for (int h = 0; h < 2; ++h)
+                for (int i = 0; i < 16; ++i) {
+                    const int n = 32 * b + acc_row(i, h), rr = ref_row(s, n);
+                    float* t = tab + (b * 2 + h) * 32;
+                    t[i] = rr >= 0 ? (float)(256.0 * scale[n] / 32767.0) : 0.f;
+                    t[16 + i] = rr >= 0 ? (float)(d.b[rr] + 128.0 * scale[n] * (double)wsum[n] / 32767.0) : 0.f;
+                }
     }
     return true;
 }

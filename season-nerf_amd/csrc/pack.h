@@ -28,5 +28,7 @@ struct Packed {
 };
 
 bool pack_program(const Weights& w, int prog, int W, int C, bool fold_bn, Packed* out, std::string* err);
+// int8-digit format (FMT_I8): stream of T/L digit fragment pairs, `bias` = per-row [scale | bias] tables
+bool pack_program_i8(const Weights& w, int prog, int W, int C, bool fold_bn, Packed* out, std::string* err);
 
 }  // namespace snerf

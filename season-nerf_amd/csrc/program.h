@@ -15,10 +15,21 @@
 //     block b (point on the lane, 16 rows in registers) becomes, after sin() and the bf16 hi/lo split, the
 //     B fragments of k-steps 2b and 2b+1 of the next layer.  The price is a fixed permutation of the k order,
 //     paid for at pack time:  k-slot (s, 8h+j)  <->  feature 32*(s>>1) + 16*(s&1) + 8*(j>>2) + 4*h + (j&3).
+//
+// Second operand format (FMT_I8, kernels_i8.hip): 16-bit fixed point in two signed int8 digits on v_mfma_i32_32x32x32_i8.
+//   * an activation h in [-1,1] is q = round(32767 h) = 256 a + u (a = signed high byte, u = unsigned low byte), carried
+//     as the digits (a, b = u - 128); the +128 is a per-row constant folded into the bias at pack time;
+//   * a weight row n is s_n (256 T + L) with balanced digits T, L in [-128,127]; a "pair" = the T fragment and the L
+//     fragment of one 32-row x 32-k tile (1 KiB each, lane l = 32h + r holds row r, 16 k-slots as 16 bytes);
+//   * per pair three MFMAs: M += T a, X += T b, X += L a (L b dropped), z = sc_n (256 M + X) + bias_n;
+//   * one k-step (32 slots) of the next layer = one 32x32 output block: lane-half h, byte j <-> row acc_row(j, h).
 #pragma once
 #include <stdint.h>
 
 namespace snerf {
+
+enum Format : int { FMT_BF16 = 0, FMT_I8 = 1 };
+__host__ __device__ constexpr int fmt_kstep(int fmt) { return fmt == FMT_I8 ? 32 : 16; }   // k-slots per MFMA step
 
 constexpr int kFragBytes = 1024;
 constexpr int kPairBytes = 2 * kFragBytes;
@@ -34,6 +45,7 @@ constexpr int PE_POS_F = 3 * (2 * PE_POS_N + 1);              // 63
 constexpr int PE_SUN_F = 3 * (2 * PE_SUN_N + 1);              // 27
 constexpr int PE_TIME_F = 2 * (2 * PE_TIME_N + 1);            // 10
 constexpr int PEPOS_KS = 4, PESUN_KS = 2, PETIME_KS = 2;      // k-steps (16 slots each) of the encodings
+constexpr int PEPOS_KS8 = 2, PESUN_KS8 = 1, PETIME_KS8 = 1;   // ... in the int8 format (32 slots each)
 
 enum InKind : int { IN_NONE = 0, IN_H = 1, IN_PEPOS = 2, IN_PESUN = 3, IN_PETIME = 4 };
 enum OutKind : int { OUT_SIN = 0, OUT_RAW = 1 };
@@ -58,47 +70,49 @@ struct LayerShape {
 
 __host__ __device__ constexpr int pad32(int x) { return (x + 31) / 32 * 32; }
 
-// W must be a multiple of 64 (so W/2 is a multiple of 32).  C = number of season classes.
-__host__ __device__ constexpr LayerShape field_layer(int W, int C, int l) {
-    const int W2 = W / 2;
+// W must be a multiple of 64 (so W/2 is a multiple of 32).  C = number of season classes.  fmt: operand format.
+__host__ __device__ constexpr LayerShape field_layer(int W, int C, int l, int fmt = FMT_BF16) {
+    const int W2 = W / 2, ks = fmt_kstep(fmt);
+    const int pp = fmt == FMT_I8 ? PEPOS_KS8 : PEPOS_KS, ps = fmt == FMT_I8 ? PESUN_KS8 : PESUN_KS;
     switch (l) {
-        case F_FC1: return {W, W, PEPOS_KS, IN_PEPOS, 0, IN_NONE, OUT_SIN, ROWS_ID};
+        case F_FC1: return {W, W, pp, IN_PEPOS, 0, IN_NONE, OUT_SIN, ROWS_ID};
         case F_FC2: case F_FC3: case F_FC4: case F_FC6: case F_FC7: case F_FC8:
-            return {W, W, W / 16, IN_H, 0, IN_NONE, OUT_SIN, ROWS_ID};
-        case F_FC5: return {W, W, W / 16, IN_H, PEPOS_KS, IN_PEPOS, OUT_SIN, ROWS_ID};
-        case F_FC9: return {W2, W2, W / 16, IN_H, 0, IN_NONE, OUT_SIN, ROWS_ID};
-        case F_HEAD: return {4, 32, W2 / 16, IN_H, 0, IN_NONE, OUT_RAW, ROWS_HEAD};
-        case F_S1: return {W2, W2, W2 / 16, IN_H, PESUN_KS, IN_PESUN, OUT_SIN, ROWS_ID};
-        case F_S2: case F_S3: return {W2, W2, W2 / 16, IN_H, 0, IN_NONE, OUT_SIN, ROWS_ID};
-        case F_S4: return {1, 32, W2 / 16, IN_H, 0, IN_NONE, OUT_RAW, ROWS_SV};
-        case F_A1: return {W, W, W2 / 16, IN_H, 0, IN_NONE, OUT_SIN, ROWS_ID};
-        case F_A2: case F_A3: return {W, W, W / 16, IN_H, 0, IN_NONE, OUT_SIN, ROWS_ID};
-        case F_AC: return {3 * C, 32, W / 16, IN_H, 0, IN_NONE, OUT_RAW, ROWS_ADJ};
+            return {W, W, W / ks, IN_H, 0, IN_NONE, OUT_SIN, ROWS_ID};
+        case F_FC5: return {W, W, W / ks, IN_H, pp, IN_PEPOS, OUT_SIN, ROWS_ID};
+        case F_FC9: return {W2, W2, W / ks, IN_H, 0, IN_NONE, OUT_SIN, ROWS_ID};
+        case F_HEAD: return {4, 32, W2 / ks, IN_H, 0, IN_NONE, OUT_RAW, ROWS_HEAD};
+        case F_S1: return {W2, W2, W2 / ks, IN_H, ps, IN_PESUN, OUT_SIN, ROWS_ID};
+        case F_S2: case F_S3: return {W2, W2, W2 / ks, IN_H, 0, IN_NONE, OUT_SIN, ROWS_ID};
+        case F_S4: return {1, 32, W2 / ks, IN_H, 0, IN_NONE, OUT_RAW, ROWS_SV};
+        case F_A1: return {W, W, W2 / ks, IN_H, 0, IN_NONE, OUT_SIN, ROWS_ID};
+        case F_A2: case F_A3: return {W, W, W / ks, IN_H, 0, IN_NONE, OUT_SIN, ROWS_ID};
+        case F_AC: return {3 * C, 32, W / ks, IN_H, 0, IN_NONE, OUT_RAW, ROWS_ADJ};
         default: return {0, 0, 0, 0, 0, 0, 0, 0};
     }
 }
 
-__host__ __device__ constexpr LayerShape group_layer(int W, int C, int l) {
-    const int W4 = W / 4;
+__host__ __device__ constexpr LayerShape group_layer(int W, int C, int l, int fmt = FMT_BF16) {
+    const int W4 = W / 4, ks = fmt_kstep(fmt);
+    const int pt = fmt == FMT_I8 ? PETIME_KS8 : PETIME_KS, ps = fmt == FMT_I8 ? PESUN_KS8 : PESUN_KS;
     switch (l) {
-        case G_T1: return {W, W, PETIME_KS, IN_PETIME, 0, IN_NONE, OUT_SIN, ROWS_ID};
-        case G_T2: return {W, W, W / 16, IN_H, 0, IN_NONE, OUT_SIN, ROWS_ID};
-        case G_CL: return {C, 32, W / 16, IN_H, 0, IN_NONE, OUT_RAW, ROWS_CLASS};
-        case G_K1: return {W4, pad32(W4), PESUN_KS, IN_PESUN, 0, IN_NONE, OUT_SIN, ROWS_ID};
-        case G_K2: return {3, 32, pad32(W4) / 16, IN_H, 0, IN_NONE, OUT_RAW, ROWS_SKY};
+        case G_T1: return {W, W, pt, IN_PETIME, 0, IN_NONE, OUT_SIN, ROWS_ID};
+        case G_T2: return {W, W, W / ks, IN_H, 0, IN_NONE, OUT_SIN, ROWS_ID};
+        case G_CL: return {C, 32, W / ks, IN_H, 0, IN_NONE, OUT_RAW, ROWS_CLASS};
+        case G_K1: return {W4, pad32(W4), ps, IN_PESUN, 0, IN_NONE, OUT_SIN, ROWS_ID};
+        case G_K2: return {3, 32, pad32(W4) / ks, IN_H, 0, IN_NONE, OUT_RAW, ROWS_SKY};
         default: return {0, 0, 0, 0, 0, 0, 0, 0};
     }
 }
 
 enum Program : int { PROG_FIELD = 0, PROG_GROUP = 1 };
 __host__ __device__ constexpr int prog_layers(int prog) { return prog == PROG_FIELD ? (int)F_NUM : (int)G_NUM; }
-__host__ __device__ constexpr LayerShape prog_layer(int prog, int W, int C, int l) {
-    return prog == PROG_FIELD ? field_layer(W, C, l) : group_layer(W, C, l);
+__host__ __device__ constexpr LayerShape prog_layer(int prog, int W, int C, int l, int fmt = FMT_BF16) {
+    return prog == PROG_FIELD ? field_layer(W, C, l, fmt) : group_layer(W, C, l, fmt);
 }
 // chunk index at which layer l starts (every layer starts on a chunk boundary), and bias-table offset (floats)
-__host__ __device__ constexpr int prog_chunk_start(int prog, int W, int C, int l) {
+__host__ __device__ constexpr int prog_chunk_start(int prog, int W, int C, int l, int fmt = FMT_BF16) {
     int c = 0;
-    for (int i = 0; i < l; ++i) c += prog_layer(prog, W, C, i).chunks();
+    for (int i = 0; i < l; ++i) c += prog_layer(prog, W, C, i, fmt).chunks();
     return c;
 }
 __host__ __device__ constexpr int prog_bias_start(int prog, int W, int C, int l) {
@@ -106,50 +120,59 @@ __host__ __device__ constexpr int prog_bias_start(int prog, int W, int C, int l)
     for (int i = 0; i < l; ++i) c += prog_layer(prog, W, C, i).n_out;
     return c;
 }
-__host__ __device__ constexpr int prog_chunks(int prog, int W, int C) { return prog_chunk_start(prog, W, C, prog_layers(prog)); }
+__host__ __device__ constexpr int prog_chunks(int prog, int W, int C, int fmt = FMT_BF16) { return prog_chunk_start(prog, W, C, prog_layers(prog), fmt); }
 __host__ __device__ constexpr int prog_bias_floats(int prog, int W, int C) { return prog_bias_start(prog, W, C, prog_layers(prog)); }
+// int8 format: per output row a scale and a bias, stored [block][lane-half][16 scales | 16 biases] = 2 floats per row
+__host__ __device__ constexpr int prog_table_start(int prog, int W, int C, int l) { return 2 * prog_bias_start(prog, W, C, l); }
+__host__ __device__ constexpr int prog_table_floats(int prog, int W, int C) { return 2 * prog_bias_floats(prog, W, C); }
 
-// ---- k-slot -> input feature maps.  kk = 16*s + 8*h + j is the K index inside a block.  -1 = zero padding.
-__host__ __device__ constexpr int slot_feature_H(int kk) {
-    const int s = kk / 16, h = (kk % 16) / 8, j = kk % 8;
-    return 32 * (s >> 1) + 16 * (s & 1) + 8 * (j >> 2) + 4 * h + (j & 3);
-}
+// accumulator register i of lane-half h  <->  row of the 32-row output block
+__host__ __device__ constexpr int acc_row(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
+
+// ---- k-slot -> input feature maps.  -1 = zero padding.
+// Encodings are produced per lane as an array v[e]; lane-half h of a point evaluates its own share:
 // PE(pos), reference feature order (misc.py:114-139): [x0 x1 x2 | per d: cos(k_0..k_9 x_d), sin(k_0..k_9 x_d)].
-// lane-half h evaluates frequencies 5h..5h+4 of all three coordinates: e = 8s + j in [0,32):
+//   lane-half h evaluates frequencies 5h..5h+4 of all three coordinates, e in [0,32):
 //   e < 30: d = e/10, r = e%10, freq = 5h + r/2, (r&1 ? sin : cos);  e = 30,31: raw x (h=0: x0,x1; h=1: x2, pad)
-__host__ __device__ constexpr int slot_feature_PEPOS(int kk) {
-    const int s = kk / 16, h = (kk % 16) / 8, j = kk % 8, e = 8 * s + j;
+__host__ __device__ constexpr int pepos_feature(int e, int h) {
     if (e < 30) { const int d = e / 10, r = e % 10; return 3 + 20 * d + 10 * (r & 1) + 5 * h + r / 2; }
     if (e == 30) return h == 0 ? 0 : 2;
     return h == 0 ? 1 : -1;
 }
-// PE(sun), n = 4: e = 8s + j in [0,16): e < 12: d = e/4, r = e%4, freq = 2h + r/2; e = 12,13 raw; 14,15 pad
-__host__ __device__ constexpr int slot_feature_PESUN(int kk) {
-    const int s = kk / 16, h = (kk % 16) / 8, j = kk % 8, e = 8 * s + j;
+// PE(sun), n = 4, e in [0,16): e < 12: d = e/4, r = e%4, freq = 2h + r/2; e = 12,13 raw; 14,15 pad
+__host__ __device__ constexpr int pesun_feature(int e, int h) {
     if (e < 12) { const int d = e / 4, r = e % 4; return 3 + 8 * d + 4 * (r & 1) + 2 * h + r / 2; }
     if (e == 12) return h == 0 ? 0 : 2;
     if (e == 13) return h == 0 ? 1 : -1;
     return -1;
 }
-// PE(time[:, 0:2]), n = 2: only k-step 0 is used; lane-half h owns coordinate d = h:
-//   j = 0 raw, 1 cos k0, 2 sin k0, 3 cos k1, 4 sin k1, 5..7 pad
-__host__ __device__ constexpr int slot_feature_PETIME(int kk) {
-    const int s = kk / 16, h = (kk % 16) / 8, j = kk % 8;
-    if (s != 0 || j > 4) return -1;
-    if (j == 0) return h;
-    const int q = j - 1;                       // 0 cos k0, 1 sin k0, 2 cos k1, 3 sin k1
+// PE(time[:, 0:2]), n = 2: lane-half h owns coordinate d = h: e = 0 raw, 1 cos k0, 2 sin k0, 3 cos k1, 4 sin k1, rest pad
+__host__ __device__ constexpr int petime_feature(int e, int h) {
+    if (e > 4) return -1;
+    if (e == 0) return h;
+    const int q = e - 1;                       // 0 cos k0, 1 sin k0, 2 cos k1, 3 sin k1
     return 2 + 4 * h + 2 * (q & 1) + (q >> 1);
 }
+// bf16 format: kk = 16*s + 8*h + j is the K index inside a block (v index e = 8 s + j).
+__host__ __device__ constexpr int slot_feature_H(int kk) {
+    const int s = kk / 16, h = (kk % 16) / 8, j = kk % 8;
+    return 32 * (s >> 1) + 16 * (s & 1) + 8 * (j >> 2) + 4 * h + (j & 3);
+}
+__host__ __device__ constexpr int slot_feature_PEPOS(int kk) { return pepos_feature(8 * (kk / 16) + kk % 8, (kk % 16) / 8); }
+__host__ __device__ constexpr int slot_feature_PESUN(int kk) { return pesun_feature(8 * (kk / 16) + kk % 8, (kk % 16) / 8); }
+__host__ __device__ constexpr int slot_feature_PETIME(int kk) { return kk / 16 != 0 ? -1 : petime_feature(kk % 8, (kk % 16) / 8); }
 __host__ __device__ constexpr int slot_feature(int kind, int kk) {
     return kind == IN_H ? slot_feature_H(kk) : kind == IN_PEPOS ? slot_feature_PEPOS(kk)
          : kind == IN_PESUN ? slot_feature_PESUN(kk) : kind == IN_PETIME ? slot_feature_PETIME(kk) : -1;
 }
-__host__ __device__ constexpr int kind_features(int kind, int ks) {
-    return kind == IN_H ? 16 * ks : kind == IN_PEPOS ? PE_POS_F : kind == IN_PESUN ? PE_SUN_F
+// int8 format: k-step s, lane-half h, byte j (v index e = 16 s + j); a hidden k-step is one output block of the producer
+__host__ __device__ constexpr int slot_feature8(int kind, int s, int h, int j) {
+    return kind == IN_H ? 32 * s + acc_row(j, h) : kind == IN_PEPOS ? pepos_feature(16 * s + j, h)
+         : kind == IN_PESUN ? (s == 0 ? pesun_feature(j, h) : -1) : kind == IN_PETIME ? (s == 0 ? petime_feature(j, h) : -1) : -1;
+}
+__host__ __device__ constexpr int kind_features(int kind, int ks, int fmt = FMT_BF16) {
+    return kind == IN_H ? fmt_kstep(fmt) * ks : kind == IN_PEPOS ? PE_POS_F : kind == IN_PESUN ? PE_SUN_F
          : kind == IN_PETIME ? PE_TIME_F : 0;
 }
-
-// accumulator register i of lane-half h  <->  row of the 32-row output block
-__host__ __device__ constexpr int acc_row(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
 
 }  // namespace snerf

@@ -78,10 +78,13 @@ class T_NeRF(nn.Module):
         self.adjust_sky_col = nn.Linear(W, n_classes * 3)
         self._handle = None
         self._sig = None
+        # arithmetic of the fused eval-mode field kernel (include/season_nerf_hip.h SNERF_PREC_*): "bf16x3" (parity
+        # default), "i8x3" (16-bit fixed point on the int8 matrix pipe: RGB ~2e-5, inputs in [-1,1]), "bf16" (fast, 2-3e-3)
+        self.precision = "bf16x3"
 
     # ------------------------------------------------------------------ device model management
     def _signature(self):
-        return tuple((k, v._version, v.data_ptr()) for k, v in self.state_dict(keep_vars=True).items())
+        return (self.precision,) + tuple((k, v._version, v.data_ptr()) for k, v in self.state_dict(keep_vars=True).items())
 
     def device_model(self):
         """Packed weights on the GPU, re-packed whenever a parameter or BN statistic changed."""
@@ -94,6 +97,9 @@ class T_NeRF(nn.Module):
         if not h:
             raise RuntimeError("season_nerf_amd: " + L.snerf_last_error().decode())
         try:
+            if self.precision not in _lib.PRECISIONS:
+                raise ValueError(f"precision must be one of {sorted(_lib.PRECISIONS)}, got {self.precision!r}")
+            _lib.check(L.snerf_model_set_precision(h, _lib.PRECISIONS[self.precision]), "set_precision")
             for k, v in self.state_dict().items():
                 if not v.is_floating_point():
                     continue

@@ -30,7 +30,7 @@ def test_exports_match_header(lib):
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
     import season_nerf_amd as sn
     assert sorted(sn._lib.EXPORTS) == declared
-    assert lib.snerf_abi_version() == 4
+    assert lib.snerf_abi_version() == 5
 
 
 def test_error_paths(lib):
@@ -218,6 +218,144 @@ def test_packed_streams_reproduce_the_network(lib, W):
     Wd, b = D.layer(W4p, 2); k1 = act(gather(pe_sun, slot_pesun, 32) @ Wd.T + b)
     Wd, b = D.layer(32, W4p // 16); sky = gather(k1, slot_H, W4p) @ Wd.T + b
     np.testing.assert_allclose(1 / (1 + np.exp(-sky[:, 0:3])), ref[3].numpy(), **tol)
+    lib.snerf_model_destroy(m)
+
+
+# ---- the int8-digit format (program.h FMT_I8): decode digits and tables, run the chain in exact integer arithmetic as the
+# kernel does (q = round(32767 h) = 256 a + u, digits (a, u - 128); M = sum T a, X = sum (T b + L a); z = sc (256 M + X) + bias)
+def slot8_H(s, h, j):
+    return 32 * s + acc_row(j, h)
+
+
+def slot8_pepos(s, h, j):
+    e = 16 * s + j
+    if e < 30:
+        d, r = divmod(e, 10)
+        return 3 + 20 * d + 10 * (r & 1) + 5 * h + r // 2
+    return (0 if h == 0 else 2) if e == 30 else (1 if h == 0 else -1)
+
+
+def slot8_pesun(s, h, j):
+    if s != 0:
+        return -1
+    if j < 12:
+        d, r = divmod(j, 4)
+        return 3 + 8 * d + 4 * (r & 1) + 2 * h + r // 2
+    if j == 12:
+        return 0 if h == 0 else 2
+    return (1 if h == 0 else -1) if j == 13 else -1
+
+
+class Decoder8:
+    def __init__(self, lib, model):
+        ns, nb = C.c_size_t(), C.c_size_t()
+        assert lib.snerf_model_pack_host(model, 2, None, C.byref(ns), None, C.byref(nb)) == 0
+        self.stream = np.zeros(ns.value, dtype=np.int8)
+        self.tab = np.zeros(nb.value, dtype=np.float32)
+        assert lib.snerf_model_pack_host(model, 2, self.stream.ctypes.data, C.byref(ns), self.tab.ctypes.data, C.byref(nb)) == 0
+        self.chunk, self.toff = 0, 0
+
+    def layer(self, n_out, ks):
+        """digit matrices T, L [n_out, 32*ks] in slot order (slot = 32 s + 16 h + j) and per-row scale / bias"""
+        nbk = n_out // 32
+        base = self.chunk * 16384
+        T = np.zeros((n_out, 32 * ks), dtype=np.int64)
+        Lo = np.zeros((n_out, 32 * ks), dtype=np.int64)
+        for b in range(nbk):
+            for s in range(ks):
+                o = base + (b * ks + s) * 2048
+                t = self.stream[o:o + 1024].reshape(64, 16)
+                l = self.stream[o + 1024:o + 2048].reshape(64, 16)
+                for lane in range(64):
+                    r, h = lane & 31, lane >> 5
+                    T[32 * b + r, 32 * s + 16 * h:32 * s + 16 * h + 16] = t[lane]
+                    Lo[32 * b + r, 32 * s + 16 * h:32 * s + 16 * h + 16] = l[lane]
+        sc, bi = np.zeros(n_out), np.zeros(n_out)
+        for b in range(nbk):
+            for h in range(2):
+                for i in range(16):
+                    sc[32 * b + acc_row(i, h)] = self.tab[self.toff + (b * 2 + h) * 32 + i]
+                    bi[32 * b + acc_row(i, h)] = self.tab[self.toff + (b * 2 + h) * 32 + 16 + i]
+        self.chunk += (nbk * ks + 7) // 8
+        self.toff += 2 * n_out
+        return T, Lo, sc, bi
+
+
+def gather8(feat, slot_fn, ks):
+    out = np.zeros((feat.shape[0], 32 * ks))
+    for s in range(ks):
+        for h in range(2):
+            for j in range(16):
+                f = slot_fn(s, h, j)
+                if 0 <= f < feat.shape[1]:
+                    out[:, 32 * s + 16 * h + j] = feat[:, f]
+    return out
+
+
+def layer8(x_slots, T, Lo, sc, bi):
+    q = np.rint(np.clip(x_slots, -1, 1) * 32767).astype(np.int64)
+    a = q >> 8
+    b = (q & 255) - 128
+    M = a @ T.T
+    X = b @ T.T + a @ Lo.T
+    acc = 256 * M + X
+    assert np.abs(acc).max() < 2 ** 31
+    return acc.astype(np.float64) * sc + bi
+
+
+@pytest.mark.parametrize("W", [64, 256])
+def test_packed_int8_stream_reproduces_the_network(lib, W):
+    Cn = 4
+    sd = orc.init_weights(W, Cn, seed=7)
+    m = lib.snerf_model_create(W, Cn)
+    ns = C.c_size_t()
+    assert lib.snerf_model_pack_host(m, 2, None, C.byref(ns), None, None) == -4       # SNERF_E_STATE without the precision mode
+    assert lib.snerf_model_set_precision(m, 7) == -1
+    assert lib.snerf_model_set_precision(m, 2) == 0 and lib.snerf_model_precision(m) == 2
+    for k, v in sd.items():
+        if v.is_floating_point():
+            arr = np.ascontiguousarray(v.numpy())
+            assert lib.snerf_model_set_tensor(m, k.encode(), arr.ctypes.data, arr.size) == 0
+    rng = np.random.Generator(np.random.PCG64(3))
+    N = 48
+    X = torch.tensor(rng.uniform(-1, 1, (N, 3)))
+    sun = rng.uniform(0, 1, (N, 3)); sun /= np.linalg.norm(sun, axis=1, keepdims=True)
+    sun = torch.tensor(sun)
+    tim = torch.tensor(rng.uniform(-1, 1, (N, 4)))
+    sd64 = orc.cast_weights(sd, torch.float64)
+    with torch.no_grad():
+        ref = orc.forward_separate(sd64, X, sun, tim)
+        pe_pos = orc.pe_encode(X, 10).numpy()
+        pe_sun = orc.pe_encode(sun, 4).numpy()
+    act = lambda z: np.sin(2 * np.pi * z)
+    W2 = W // 2
+    D = Decoder8(lib, m)
+    P = gather8(pe_pos, slot8_pepos, 2)
+    h = act(layer8(P, *D.layer(W, 2)))
+    for _ in range(3):
+        h = act(layer8(gather8(h, slot8_H, W // 32), *D.layer(W, W // 32)))
+    h = act(layer8(np.concatenate([gather8(h, slot8_H, W // 32), P], 1), *D.layer(W, W // 32 + 2)))
+    for _ in range(3):
+        h = act(layer8(gather8(h, slot8_H, W // 32), *D.layer(W, W // 32)))
+    x1 = act(layer8(gather8(h, slot8_H, W // 32), *D.layer(W2, W // 32)))
+    head = layer8(gather8(x1, slot8_H, W2 // 32), *D.layer(32, W2 // 32))
+    S_ = gather8(pe_sun, slot8_pesun, 1)
+    a = act(layer8(np.concatenate([gather8(x1, slot8_H, W2 // 32), S_], 1), *D.layer(W2, W2 // 32 + 1)))
+    for _ in range(2):
+        a = act(layer8(gather8(a, slot8_H, W2 // 32), *D.layer(W2, W2 // 32)))
+    sv = layer8(gather8(a, slot8_H, W2 // 32), *D.layer(32, W2 // 32))
+    y = act(layer8(gather8(x1, slot8_H, W2 // 32), *D.layer(W, W2 // 32)))
+    for _ in range(2):
+        y = act(layer8(gather8(y, slot8_H, W // 32), *D.layer(W, W // 32)))
+    adj = layer8(gather8(y, slot8_H, W // 32), *D.layer(32, W // 32))
+    tol = dict(rtol=5e-4, atol=2e-4)      # 16-bit fixed point on both operands, fourteen layers deep
+    np.testing.assert_allclose(head[:, 0:3], ref[1].numpy(), **tol)                                   # Col_raw
+    np.testing.assert_allclose(np.log1p(np.exp(head[:, 3:4])), ref[0].numpy(), **tol)                 # Rho
+    np.testing.assert_allclose(1 / (1 + np.exp(-sv[:, 0:1])), ref[2].numpy(), **tol)                  # Solar_Vis
+    adj_rows = np.stack([adj[:, acc_row(i, 0)] for i in range(3 * Cn)], 1).reshape(N, Cn, 3)
+    np.testing.assert_allclose(adj_rows, ref[5].numpy(), **tol)
+    err = np.abs(np.log1p(np.exp(head[:, 3:4])) - ref[0].numpy()).max() / np.abs(ref[0].numpy()).max()
+    print(f"W={W}: int8-digit chain vs fp64: density max err / max {err:.2e}")
     lib.snerf_model_destroy(m)
 
 
