@@ -14,11 +14,15 @@ REPO = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(REPO, "build", "obj")
 LIB = os.path.join(HERE, "libseason_nerf_hip.so")
-SOURCES = ["kernels.hip", "kernels_i8.hip", "api.cpp", "pack.cpp", "gemm.hip", "train_kernels.hip", "train.cpp", "dsm.hip"]
+SOURCES = ["kernels.hip", "kernels_i8.hip", "kernels_i8_w512.hip", "api.cpp", "pack.cpp", "gemm.hip", "train_kernels.hip", "train.cpp", "dsm.hip"]
 HEADERS = ["kernels.h", "mlp_device.h", "pack.h", "program.h", "train.h", os.path.join("..", "..", "include", "season_nerf_hip.h")]
 FLAGS = ["-std=c++17", "-O3", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off",
          "-mllvm", "-amdgpu-mfma-vgpr-form=1",    # MFMA accumulators in VGPRs: no v_accvgpr_read per epilogue element
          "-Wno-unused-command-line-argument"]
+
+
+EXTRA = {"kernels_i8_w512.hip": ["-mllvm", "-pragma-unroll-threshold=1000000"]}     # per-source flags
+INCLUDED = {"kernels_i8_w512.hip": ["kernels_i8.hip"]}                               # sources a source #includes
 
 
 def _hipcc():
@@ -38,7 +42,7 @@ def _stale(src, hdr_t):
     if not os.path.exists(o):
         return True
     t = os.path.getmtime(o)
-    return os.path.getmtime(os.path.join(CSRC, src)) > t or hdr_t > t
+    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in [src] + INCLUDED.get(src, [])) or hdr_t > t
 
 
 def needs_build():
@@ -50,7 +54,7 @@ def needs_build():
 
 
 def _compile(src, verbose):
-    cmd = [_hipcc()] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", _obj(src)]
+    cmd = [_hipcc()] + FLAGS + EXTRA.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", _obj(src)]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

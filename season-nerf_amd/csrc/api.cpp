@@ -31,6 +31,9 @@ struct snerf_model {
     bool finalized = false;
     Packed host[2];
     Packed host_i8;                  // field program in the int8-digit format (precision SNERF_PREC_I8X3 only)
+    Packed host_g8;                  // group program in the int8-digit format (widths without a bf16 group kernel: 512)
+    uint8_t* d_stream_g8 = nullptr;
+    float* d_table_g8 = nullptr;
     uint8_t* d_stream[2] = {nullptr, nullptr};
     float* d_bias[2] = {nullptr, nullptr};
     uint8_t* d_stream_i8 = nullptr;
@@ -44,9 +47,9 @@ const char* snerf_last_error(void) { return g_err.c_str(); }
 int snerf_abi_version(void) { return 5; }
 
 snerf_model* snerf_model_create(int layer_width, int n_classes) {
-    if (layer_width != 64 && layer_width != 256) {
+    if (layer_width != 64 && layer_width != 256 && layer_width != 512) {
         fail(SNERF_E_INVALID, "layer_width " + std::to_string(layer_width) +
-                                  " has no compiled kernel (built widths: 64, 256)");
+                                  " has no compiled kernel (built widths: 64, 256; 512 under SNERF_PREC_I8X3)");
         return nullptr;
     }
     if (n_classes < 1 || n_classes > kMaxClasses) {
@@ -78,8 +81,13 @@ int snerf_model_set_tensor(snerf_model* m, const char* key, const float* host_da
     return SNERF_OK;
 }
 
+static bool bf16_width(int W) { return W == 64 || W == 256; }     // widths the bf16 kernels (kernels.hip) are instantiated for
+
 static int pack_both(snerf_model* m) {
+    if (!bf16_width(m->W) && m->precision != SNERF_PREC_I8X3)
+        return fail(SNERF_E_INVALID, "layer_width " + std::to_string(m->W) + " has a fused kernel only under SNERF_PREC_I8X3");
     for (int p = 0; p < 2; ++p) {
+        if (!bf16_width(m->W)) break;
         if (!m->host[p].stream.empty()) continue;
         std::string err;
         Packed tmp;
@@ -93,6 +101,13 @@ static int pack_both(snerf_model* m) {
         if (!pack_program_i8(m->w, PROG_FIELD, m->W, m->C, /*fold_bn=*/true, &tmp, &err))
             return fail(err.rfind("missing", 0) == 0 ? SNERF_E_MISSING : SNERF_E_INVALID, err);
         m->host_i8 = std::move(tmp);
+    }
+    if (m->precision == SNERF_PREC_I8X3 && !bf16_width(m->W) && m->host_g8.stream.empty()) {
+        std::string err;
+        Packed tmp;
+        if (!pack_program_i8(m->w, PROG_GROUP, m->W, m->C, /*fold_bn=*/true, &tmp, &err))
+            return fail(err.rfind("missing", 0) == 0 ? SNERF_E_MISSING : SNERF_E_INVALID, err);
+        m->host_g8 = std::move(tmp);
     }
     return SNERF_OK;
 }
@@ -128,6 +143,7 @@ int snerf_model_finalize(snerf_model* m) {
     m->n_cu = prop.multiProcessorCount;
     for (int p = 0; p < 2; ++p) {
         const Packed& P = m->host[p];
+        if (P.stream.empty()) continue;
         if ((e = hipMalloc((void**)&m->d_stream[p], P.stream.size())) != hipSuccess) return fail_hip(e, "hipMalloc");
         if ((e = hipMalloc((void**)&m->d_bias[p], P.bias.size() * 4)) != hipSuccess) return fail_hip(e, "hipMalloc");
         if ((e = hipMemcpy(m->d_stream[p], P.stream.data(), P.stream.size(), hipMemcpyHostToDevice)) != hipSuccess)
@@ -143,6 +159,15 @@ int snerf_model_finalize(snerf_model* m) {
             return fail_hip(e, "hipMemcpy");
         if ((e = hipMemcpy(m->d_table_i8, P.bias.data(), P.bias.size() * 4, hipMemcpyHostToDevice)) != hipSuccess)
             return fail_hip(e, "hipMemcpy");
+        const Packed& G = m->host_g8;
+        if (!G.stream.empty()) {
+            if ((e = hipMalloc((void**)&m->d_stream_g8, G.stream.size())) != hipSuccess) return fail_hip(e, "hipMalloc");
+            if ((e = hipMalloc((void**)&m->d_table_g8, G.bias.size() * 4)) != hipSuccess) return fail_hip(e, "hipMalloc");
+            if ((e = hipMemcpy(m->d_stream_g8, G.stream.data(), G.stream.size(), hipMemcpyHostToDevice)) != hipSuccess)
+                return fail_hip(e, "hipMemcpy");
+            if ((e = hipMemcpy(m->d_table_g8, G.bias.data(), G.bias.size() * 4, hipMemcpyHostToDevice)) != hipSuccess)
+                return fail_hip(e, "hipMemcpy");
+        }
     }
     m->finalized = true;
     return SNERF_OK;
@@ -156,6 +181,8 @@ void snerf_model_destroy(snerf_model* m) {
     }
     if (m->d_stream_i8) (void)hipFree(m->d_stream_i8);
     if (m->d_table_i8) (void)hipFree(m->d_table_i8);
+    if (m->d_stream_g8) (void)hipFree(m->d_stream_g8);
+    if (m->d_table_g8) (void)hipFree(m->d_table_g8);
     delete m;
 }
 
@@ -175,10 +202,11 @@ int snerf_group_forward(const snerf_model* m, int64_t n_groups, const float* d_t
     if (n_groups == 0) return SNERF_OK;
     if (n_groups < 0 || !d_time || !d_sun) return fail(SNERF_E_INVALID, "snerf_group_forward: bad argument");
     MlpArgs a{};
-    a.stream = m->d_stream[PROG_GROUP];
-    a.stream_bytes = (uint32_t)m->host[PROG_GROUP].stream.size();
-    a.bias = m->d_bias[PROG_GROUP];
-    a.bias_floats = (int)m->host[PROG_GROUP].bias.size();
+    const bool g8 = m->d_stream_g8 != nullptr;
+    a.stream = g8 ? m->d_stream_g8 : m->d_stream[PROG_GROUP];
+    a.stream_bytes = (uint32_t)(g8 ? m->host_g8.stream.size() : m->host[PROG_GROUP].stream.size());
+    a.bias = g8 ? m->d_table_g8 : m->d_bias[PROG_GROUP];
+    a.bias_floats = (int)(g8 ? m->host_g8.bias.size() : m->host[PROG_GROUP].bias.size());
     a.n = n_groups;
     a.n_classes = m->C;
     a.group_size = 1;
@@ -187,7 +215,9 @@ int snerf_group_forward(const snerf_model* m, int64_t n_groups, const float* d_t
     a.g_classes = d_classes;
     a.g_sky_raw = d_sky_raw;
     a.g_sky = d_sky;
-    hipError_t e = launch_mlp(PROG_GROUP, m->W, 0, false, a, m->n_cu, (hipStream_t)stream);   // always bf16x3 (one row per ray)
+    // bf16x3 wherever that kernel exists (one row per ray: its cost is 1/S of the field network's)
+    hipError_t e = g8 ? launch_mlp_i8(PROG_GROUP, m->W, 0, a, m->n_cu, (hipStream_t)stream)
+                      : launch_mlp(PROG_GROUP, m->W, 0, false, a, m->n_cu, (hipStream_t)stream);
     return e == hipSuccess ? SNERF_OK : fail_hip(e, "group kernel launch");
 }
 
@@ -213,7 +243,7 @@ static int field_launch(const snerf_model* m, int variant, MlpArgs& a, const sne
         a.stream_bytes = (uint32_t)field_variant_chunks_i8(m->W, m->C, variant) * kChunkBytes;
         a.bias = m->d_table_i8;
         a.bias_floats = (int)m->host_i8.bias.size();
-        e = launch_mlp_i8(m->W, variant, a, m->n_cu, (hipStream_t)stream);
+        e = launch_mlp_i8(PROG_FIELD, m->W, variant, a, m->n_cu, (hipStream_t)stream);
     } else {
         e = launch_mlp(PROG_FIELD, m->W, variant, m->precision == SNERF_PREC_BF16, a, m->n_cu, (hipStream_t)stream);
     }

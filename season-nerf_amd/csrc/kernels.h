@@ -77,7 +77,7 @@ struct SweepArgs {
 };
 hipError_t launch_sweep(const SweepArgs& a, hipStream_t st);
 hipError_t launch_mlp(int prog, int W, int variant, bool fast, const MlpArgs& a, int n_cu, hipStream_t st);
-hipError_t launch_mlp_i8(int W, int variant, const MlpArgs& a, int n_cu, hipStream_t st);      // kernels_i8.hip
+hipError_t launch_mlp_i8(int prog, int W, int variant, const MlpArgs& a, int n_cu, hipStream_t st);      // kernels_i8.hip
 int field_variant_chunks_i8(int W, int C, int variant);
 hipError_t launch_composite(const CompArgs& a, hipStream_t st);
 // dsm.hip

@@ -1,6 +1,6 @@
 // gfx950 (MI355X / CDNA4): the fused field network on the int8 matrix pipe ("i8x3", program.h FMT_I8).
 //
-//  mlp_i8_kernel<W, VARIANT>   same register-resident chain as mlp_kernel<PROG_FIELD, W, VARIANT> (kernels.hip), but every
+//  mlp_i8_kernel<PROG, W, VARIANT>   same register-resident chain as mlp_kernel<PROG_FIELD, W, VARIANT> (kernels.hip), but every
 //                              operand is 16-bit fixed point carried as two signed int8 digits on v_mfma_i32_32x32x32_i8:
 //     * per 32-feature k-step three MFMAs (T a -> M;  T b, L a -> X; the L b term is dropped) instead of six bf16 ones
 //       (three split products for each of the two 16-slot halves): half the matrix-pipe time, exact integer accumulation;
@@ -54,6 +54,41 @@ __device__ __forceinline__ void mfma_i8x3(const i32x4& aT, const i32x4& aL, cons
     acc.X = __builtin_amdgcn_mfma_i32_32x32x32_i8(aL, b.hi, acc.X, 0, 0, 0);
 }
 
+// ---- W = 512: the hidden activations (2 x 128 registers of B operands) cannot share the 256 architectural VGPRs with
+// everything else, and hipcc neither places an MFMA B operand in an AGPR on its own nor keeps "a"-constrained values there
+// (it spills them to scratch and reloads before every MFMA: 13.7 ms per 4096 x 96 batch).  So the activations live in
+// AGPRs ADDRESSED BY NUMBER: a[base + 8 k .. base + 8 k + 7] = high / low digits of k-step k (two 4-register tuples),
+// written by v_accvgpr_write at the digit split and read by MFMAs issued through inline asm.  The compiler does not see
+// these registers: reserve_agprs() clobbers all 256 once so that it allocates none of them (the kernel uses no AGPR for
+// itself: MFMA results are in VGPRs, and nothing spills), volatile asm keeps parks and MFMAs in program order.  hipcc pads
+// no hazards around inline asm: the accumulators of an asm MFMA are read by VALU code no earlier than three MFMAs later
+// (pipelined epilogue: k-step >= 1 of the next block) or behind an explicit s_nop pad (the last block of a layer), and
+// parked digits are consumed one block (the last block: one ring step) after they were written.
+constexpr int AG_R0 = 0, AG_R1 = 128;      // two 128-register regions; who lives where: see the layer list of the kernel
+// register numbers are "i" operands: loop indices that are constants once the layer is unrolled (a number that did not fold
+// fails the build in the backend, it cannot reach the GPU)
+static __device__ __forceinline__ void park(int v, int idx) {
+    asm volatile("v_accvgpr_write_b32 a[%1], %0" ::"v"(v), "i"(idx));
+}
+template <bool FIRST>
+__device__ __forceinline__ void mfma_asm(i32x16& acc, const i32x4& a, int base) {
+    if (FIRST) asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, a[%2:%3], 0" : "=v"(acc) : "v"(a), "i"(base), "i"(base + 3));
+    else asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, a[%2:%3], %0" : "+v"(acc) : "v"(a), "i"(base), "i"(base + 3));
+}
+template <bool FIRST>      // base: first register of the k-step (4 high-digit dwords, then 4 low-digit dwords)
+__device__ __forceinline__ void mfma_i8x3_agpr(const i32x4& aT, const i32x4& aL, Acc8& acc, int base) {
+    mfma_asm<FIRST>(acc.M, aT, base);
+    mfma_asm<FIRST>(acc.X, aT, base + 4);
+    mfma_asm<false>(acc.X, aL, base);
+}
+#define A8(n) "a" #n
+#define A8x8(n) A8(n##0), A8(n##1), A8(n##2), A8(n##3), A8(n##4), A8(n##5), A8(n##6), A8(n##7), A8(n##8), A8(n##9)
+__device__ __forceinline__ void reserve_agprs() {
+    asm volatile("" ::: "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", A8x8(1), A8x8(2), A8x8(3), A8x8(4), A8x8(5), A8x8(6),
+                 A8x8(7), A8x8(8), A8x8(9), A8x8(10), A8x8(11), A8x8(12), A8x8(13), A8x8(14), A8x8(15), A8x8(16), A8x8(17), A8x8(18),
+                 A8x8(19), A8x8(20), A8x8(21), A8x8(22), A8x8(23), A8x8(24), "a250", "a251", "a252", "a253", "a254", "a255");
+}
+
 __device__ __forceinline__ Tab8 load_tab(lds_cfloat* tab_l, int b, int h) {
     lds_cf32x4* tp = (lds_cf32x4*)(tab_l + (b * 2 + h) * 32);
     Tab8 t;
@@ -73,19 +108,28 @@ __device__ __forceinline__ float preact(const Acc8& acc, const Tab8& t, int i) {
 }
 // epilogue pieces of a 32x32 block: A(e) = elements 2e, 2e+1 through the sine; Q(g) = digits of elements 4g..4g+3
 __device__ __forceinline__ void epi_A(const Acc8& acc, const Tab8& t, int e, float* ev) {
-#if defined(SNERF_ABLATE) && (ABL & 8)      // timing-only: no transcendental
-    ev[2 * e] = preact(acc, t, 2 * e) * 1e-9f;
-    ev[2 * e + 1] = preact(acc, t, 2 * e + 1) * 1e-9f;
+#if defined(SNERF_ABLATE) && (ABL & 8)      // timing-only: no transcendental; 2 fract(z) - 1 keeps the data as random as sin does
+    ev[2 * e] = __builtin_fmaf(__builtin_amdgcn_fractf(preact(acc, t, 2 * e)), 2.f, -1.f);
+    ev[2 * e + 1] = __builtin_fmaf(__builtin_amdgcn_fractf(preact(acc, t, 2 * e + 1)), 2.f, -1.f);
+#elif defined(SNERF_ABLATE) && (ABL & 16)   // timing-only: no epilogue arithmetic at all but the digit split
+    ev[2 * e] = __builtin_bit_cast(float, (acc.X[2 * e] & 0x007fffff) | 0x3f000000) - 0.75f;
+    ev[2 * e + 1] = __builtin_bit_cast(float, (acc.X[2 * e + 1] & 0x007fffff) | 0x3f000000) - 0.75f;
 #else
     ev[2 * e] = sin2pi(preact(acc, t, 2 * e));
     ev[2 * e + 1] = sin2pi(preact(acc, t, 2 * e + 1));
 #endif
 }
-__device__ __forceinline__ void epi_Q(int g, const float* ev, Frag8& o) {
+template <bool AG>       // AG: the block's 8 registers start at AGPR ago (o is not touched)
+__device__ __forceinline__ void epi_Q(int g, const float* ev, Frag8* o, int ago) {
     int h, l;
     digits4(ev[4 * g], ev[4 * g + 1], ev[4 * g + 2], ev[4 * g + 3], h, l);
-    o.hi[g] = h;
-    o.lo[g] = l;
+    if constexpr (AG) {
+        park(h, ago + g);
+        park(l, ago + 4 + g);
+    } else {
+        o->hi[g] = h;
+        o->lo[g] = l;
+    }
 }
 
 #define SG_VALU 0x002
@@ -102,11 +146,15 @@ constexpr int PF8 = SNERF_PF8;
 // run_layer (kernels.hip): weight fragments PF8 pairs ahead, ring step PF8 pairs before a chunk's first MFMA, accumulators
 // ping-pong between blocks and the epilogue of block b-1 is spread over block b's k-steps: element pair e runs its sine
 // at k-step sA(e) = 1 + e (KS-2) / 8, the digit split of quad g one step after its second pair.
-template <int NB, int KS0, int KS1, bool SIN, int D>
+//   AG_IN0 / AG_OUT >= 0: the first input block / the output live in AGPRs from that register number on (W = 512; the
+//   pointer is then unused); the second input block, where there is one, is always an encoding in VGPRs.
+template <int NB, int KS0, int KS1, bool SIN, int D, int AG_IN0 = -1, int AG_OUT = -1, bool AG = false>
 __device__ __forceinline__ void run_layer8(Ring& rg, const uint8_t* stream, uint32_t stream_bytes, lds_char* lds, lds_cfloat* tab_l,
                                            const Frag8* in0, const Frag8* in1, Frag8* out, f32x16* raw, int wave, int lane) {
     constexpr int KS = KS0 + KS1, NP = NB * KS;
     constexpr bool PIPE = KS >= 4;
+    constexpr int S_EPI = (AG && KS > 1) ? 1 : 0;      // un-pipelined epilogue: behind the block's first MFMAs (see mfma_asm)
+    static_assert(!AG || KS > 1 || NB == 1, "AGPR path: a one-step layer with several blocks would read accumulators too early");
     const int h = lane >> 5;
     i32x4 fT[PF8], fL[PF8];
 #pragma unroll
@@ -124,8 +172,10 @@ __device__ __forceinline__ void run_layer8(Ring& rg, const uint8_t* stream, uint
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         Acc8 acc;
+        if (!AG) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { acc.M[i] = 0; acc.X[i] = 0; }
+            for (int i = 0; i < 16; ++i) { acc.M[i] = 0; acc.X[i] = 0; }
+        }
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             const int q = b * KS + s;
@@ -141,7 +191,22 @@ __device__ __forceinline__ void run_layer8(Ring& rg, const uint8_t* stream, uint
                 fL[q % PF8] = *(lds_ci32x4*)(ap + kFragBytes);
 #endif
             }
-            mfma_i8x3(aT, aL, s < KS0 ? in0[s] : in1[s - KS0], acc);
+            if (AG) {
+                // encodings live in VGPRs (compiler-issued MFMA), hidden activations in AGPRs (asm MFMA)
+                if (s >= KS0 || AG_IN0 < 0) {
+                    if (s == 0) {
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) { acc.M[i] = 0; acc.X[i] = 0; }
+                    }
+                    mfma_i8x3(aT, aL, s < KS0 ? in0[s] : in1[s - KS0], acc);
+                } else if (s == 0) {
+                    mfma_i8x3_agpr<true>(aT, aL, acc, AG_IN0 + 8 * s);
+                } else {
+                    mfma_i8x3_agpr<false>(aT, aL, acc, AG_IN0 + 8 * s);
+                }
+            } else {
+                mfma_i8x3(aT, aL, s < KS0 ? in0[s] : in1[s - KS0], acc);
+            }
             if (SIN && b > 0) {
                 if (s == 0) tab = load_tab(tab_l, b - 1, h);
                 if (PIPE) {
@@ -149,13 +214,13 @@ __device__ __forceinline__ void run_layer8(Ring& rg, const uint8_t* stream, uint
                     for (int e = 0; e < 8; ++e) {
                         const int sA = 1 + (e * (KS - 2)) / 8;
                         if (s == sA) epi_A(accs[(b - 1) & 1], tab, e, ev);
-                        if ((e & 1) && s == sA + 1) epi_Q(e >> 1, ev, out[b - 1]);
+                        if ((e & 1) && s == sA + 1) epi_Q<(AG_OUT >= 0)>(e >> 1, ev, AG_OUT >= 0 ? nullptr : out + (b - 1), AG_OUT + 8 * (b - 1));
                     }
-                } else if (s == 0) {
+                } else if (s == S_EPI) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) epi_A(accs[(b - 1) & 1], tab, e, ev);
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) epi_Q(g, ev, out[b - 1]);
+                    for (int g = 0; g < 4; ++g) epi_Q<(AG_OUT >= 0)>(g, ev, AG_OUT >= 0 ? nullptr : out + (b - 1), AG_OUT + 8 * (b - 1));
                 }
             }
 #ifndef SNERF_NO_SCHED_GROUPS
@@ -173,11 +238,13 @@ __device__ __forceinline__ void run_layer8(Ring& rg, const uint8_t* stream, uint
         accs[b & 1] = acc;
     }
     tab = load_tab(tab_l, NB - 1, h);
+    if (AG) asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");   // the last asm MFMA's result: 18 wait states before a VALU read, by hand
     if (SIN) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) epi_A(accs[(NB - 1) & 1], tab, e, ev);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) epi_Q(g, ev, out[NB - 1]);
+        for (int g = 0; g < 4; ++g) epi_Q<(AG_OUT >= 0)>(g, ev, AG_OUT >= 0 ? nullptr : out + (NB - 1), AG_OUT + 8 * (NB - 1));
+        if (AG) asm volatile("s_nop 3" ::: "memory");             // parked digits -> the next layer's first MFMA
     } else {
 #pragma unroll
         for (int i = 0; i < 16; ++i) (*raw)[i] = preact(accs[(NB - 1) & 1], tab, i);
@@ -222,9 +289,22 @@ __device__ __forceinline__ void make_pe_sun8(float x0, float x1, float x2, int h
     pack16(v, pe[0]);
 }
 
+// PE(time[:,0:2]): lane-half h owns coordinate h (petime_feature), one k-step
+__device__ __forceinline__ void make_pe_time8(float t0, float t1, int h, Frag8* pe) {
+    float v[16];
+    const float x = h ? t1 : t0;
+    const PeArg a = pe_arg(x);
+    v[0] = x;
+    pe_sincos(a, 1.0, v[1], v[2]);
+    pe_sincos(a, 2.0, v[3], v[4]);
+#pragma unroll
+    for (int i = 5; i < 16; ++i) v[i] = 0.f;
+    pack16(v, pe[0]);
+}
+
 constexpr int ring_depth8(int W) { return W > 256 ? 6 : RING_D; }    // W = 512: the 54 KB table leaves room for 6 slots
 
-template <int W, int VARIANT>
+template <int PROG, int W, int VARIANT>
 __global__ __launch_bounds__(256, 1) void mlp_i8_kernel(const MlpArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int C_MAX = kMaxClasses;
@@ -264,6 +344,48 @@ __global__ __launch_bounds__(256, 1) void mlp_i8_kernel(const MlpArgs A) {
         const int64_t nc = valid ? n : A.n - 1;
         const int64_t g = nc / A.group_size;
 
+        if constexpr (PROG == PROG_GROUP) {
+            // ---- group program: class softmax (T_NeRF_net_v2.py:77-78) and sky colour (G_NeRF.py:110-111); used where the
+            // bf16 group kernel has no instance (W = 512: its activations do not fit the register file)
+            constexpr int KW = W / 32, W4P = pad32(W / 4), KW4 = W4P / 32;
+            f32x16 raw;
+#define LAYER(L, NBv, K0, K1, SINv, IN0, IN1, OUT, RAW)                                                                 \
+    run_layer8<NBv, K0, K1, SINv, D>(rg, A.stream, A.stream_bytes, lds, tab_lds + prog_table_start(PROG_GROUP, W, C_MAX, L), \
+                                     IN0, IN1, OUT, RAW, wave, lane)
+            const float t0 = A.time[nc * 4], t1 = A.time[nc * 4 + 1];
+            const float s0 = A.sun[nc * 3], s1 = A.sun[nc * 3 + 1], s2 = A.sun[nc * 3 + 2];
+            Frag8 pt[PETIME_KS8];
+            make_pe_time8(t0, t1, h, pt);
+            Frag8 hA[KW], hB[KW];
+            LAYER(G_T1, W / 32, PETIME_KS8, 0, true, pt, nullptr, hA, nullptr);
+            LAYER(G_T2, W / 32, KW, 0, true, hA, nullptr, hB, nullptr);
+            LAYER(G_CL, 1, KW, 0, false, hB, nullptr, nullptr, &raw);
+            float logit[C_MAX];
+#pragma unroll
+            for (int c = 0; c < C_MAX; ++c) logit[c] = raw[c];
+            Frag8 ps[PESUN_KS8];
+            make_pe_sun8(s0, s1, s2, h, ps);
+            Frag8 kA[KW4];
+            LAYER(G_K1, W4P / 32, PESUN_KS8, 0, true, ps, nullptr, kA, nullptr);
+            LAYER(G_K2, 1, KW4, 0, false, kA, nullptr, nullptr, &raw);
+#undef LAYER
+            if (h == 0 && valid) {
+                float m = -3.0e38f;
+#pragma unroll
+                for (int c = 0; c < C_MAX; ++c) if (c < C) m = fmaxf(m, logit[c]);
+                float e[C_MAX], sum = 0.f;
+#pragma unroll
+                for (int c = 0; c < C_MAX; ++c) { e[c] = c < C ? expf(logit[c] - m) : 0.f; sum += e[c]; }
+#pragma unroll
+                for (int c = 0; c < C_MAX; ++c) if (c < C && A.g_classes) A.g_classes[n * C + c] = e[c] / sum;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    if (A.g_sky_raw) A.g_sky_raw[n * 3 + k] = raw[k];
+                    if (A.g_sky) A.g_sky[n * 3 + k] = sigmoid_f(raw[k]);
+                }
+            }
+            continue;
+        }
         // ---- sample position (misc.py:234-247 fused): top*(1-t) + bot*t, two roundings + one add, no fma
         float x0, x1, x2;
         if (A.points) {
@@ -294,22 +416,29 @@ __global__ __launch_bounds__(256, 1) void mlp_i8_kernel(const MlpArgs A) {
         constexpr int KW = W / 32, KW2 = W2 / 32;
         Frag8 hA[KW], hB[KW];
         f32x16 raw;
-#define LAYER(L, NBv, K0, K1, SINv, IN0, IN1, OUT, RAW)                                                                 \
-    run_layer8<NBv, K0, K1, SINv, D>(rg, A.stream, A.stream_bytes, lds, tab_lds + prog_table_start(PROG_FIELD, W, C_MAX, L), \
-                                     IN0, IN1, OUT, RAW, wave, lane)
+        // AG (W = 512): hidden activations in AGPRs by number (see mfma_asm).  Two regions of 128 registers: the trunk
+        // ping-pongs R0 / R1; fc9 reads R1 and writes x1 into the first half of R0; the solar branch uses the two halves
+        // of R1; the adjust branch starts from x1 (R0) into R1, so its ping-pong is R1 / R0 / R1.  The Frag8 arrays below
+        // are the same buffers for the widths whose activations stay in compiler-allocated VGPRs.
+        constexpr bool AG = W > 256;
+        constexpr int xA = AG_R0, xB = AG_R1, xX1 = AG_R0, xSA = AG_R1, xSB = AG_R1 + 64, NOAG = -1;
+        if constexpr (AG) reserve_agprs();
+#define LAYER(L, NBv, K0, K1, SINv, IN0, IN0AG, IN1, OUT, OUTAG, RAW)                                                      \
+    run_layer8<NBv, K0, K1, SINv, D, AG ? IN0AG : -1, AG ? OUTAG : -1, AG>(rg, A.stream, A.stream_bytes, lds,                \
+        tab_lds + prog_table_start(PROG_FIELD, W, C_MAX, L), IN0, IN1, OUT, RAW, wave, lane)
         // trunk (G_NeRF.py:80-91)
-        LAYER(F_FC1, W / 32, PEPOS_KS8, 0, true, pe, nullptr, hA, nullptr);
-        LAYER(F_FC2, W / 32, KW, 0, true, hA, nullptr, hB, nullptr);
-        LAYER(F_FC3, W / 32, KW, 0, true, hB, nullptr, hA, nullptr);
-        LAYER(F_FC4, W / 32, KW, 0, true, hA, nullptr, hB, nullptr);
-        LAYER(F_FC5, W / 32, KW, PEPOS_KS8, true, hB, pe, hA, nullptr);
-        LAYER(F_FC6, W / 32, KW, 0, true, hA, nullptr, hB, nullptr);
-        LAYER(F_FC7, W / 32, KW, 0, true, hB, nullptr, hA, nullptr);
-        LAYER(F_FC8, W / 32, KW, 0, true, hA, nullptr, hB, nullptr);
+        LAYER(F_FC1, W / 32, PEPOS_KS8, 0, true, pe, NOAG, nullptr, hA, xA, nullptr);
+        LAYER(F_FC2, W / 32, KW, 0, true, hA, xA, nullptr, hB, xB, nullptr);
+        LAYER(F_FC3, W / 32, KW, 0, true, hB, xB, nullptr, hA, xA, nullptr);
+        LAYER(F_FC4, W / 32, KW, 0, true, hA, xA, nullptr, hB, xB, nullptr);
+        LAYER(F_FC5, W / 32, KW, PEPOS_KS8, true, hB, xB, pe, hA, xA, nullptr);
+        LAYER(F_FC6, W / 32, KW, 0, true, hA, xA, nullptr, hB, xB, nullptr);
+        LAYER(F_FC7, W / 32, KW, 0, true, hB, xB, nullptr, hA, xA, nullptr);
+        LAYER(F_FC8, W / 32, KW, 0, true, hA, xA, nullptr, hB, xB, nullptr);
         Frag8 x1f[KW2];
-        LAYER(F_FC9, W2 / 32, KW, 0, true, hB, nullptr, x1f, nullptr);
+        LAYER(F_FC9, W2 / 32, KW, 0, true, hB, xB, nullptr, x1f, xX1, nullptr);
         // sigma / colour head (G_NeRF.py:93-98): regs 0..2 colour, 3 density (lane-half 0)
-        LAYER(F_HEAD, 1, KW2, 0, false, x1f, nullptr, nullptr, &raw);
+        LAYER(F_HEAD, 1, KW2, 0, false, x1f, xX1, nullptr, nullptr, NOAG, &raw);
         const float col_r = raw[0], col_g = raw[1], col_b = raw[2], rho_raw = raw[3];
         float sv_raw = 0.f;
         float adj[3 * C_MAX];
@@ -320,18 +449,18 @@ __global__ __launch_bounds__(256, 1) void mlp_i8_kernel(const MlpArgs A) {
             Frag8 ps[PESUN_KS8];
             make_pe_sun8(s0, s1, s2, h, ps);
             Frag8 sA[KW2], sB[KW2];
-            LAYER(F_S1, W2 / 32, KW2, PESUN_KS8, true, x1f, ps, sA, nullptr);
-            LAYER(F_S2, W2 / 32, KW2, 0, true, sA, nullptr, sB, nullptr);
-            LAYER(F_S3, W2 / 32, KW2, 0, true, sB, nullptr, sA, nullptr);
-            LAYER(F_S4, 1, KW2, 0, false, sA, nullptr, nullptr, &raw);
+            LAYER(F_S1, W2 / 32, KW2, PESUN_KS8, true, x1f, xX1, ps, sA, xSA, nullptr);
+            LAYER(F_S2, W2 / 32, KW2, 0, true, sA, xSA, nullptr, sB, xSB, nullptr);
+            LAYER(F_S3, W2 / 32, KW2, 0, true, sB, xSB, nullptr, sA, xSA, nullptr);
+            LAYER(F_S4, 1, KW2, 0, false, sA, xSA, nullptr, nullptr, NOAG, &raw);
             sv_raw = raw[0];
         }
         if constexpr (VARIANT == 0) {
             // seasonal colour-adjust branch (T_NeRF_net_v2.py:83-87)
-            LAYER(F_A1, W / 32, KW2, 0, true, x1f, nullptr, hA, nullptr);
-            LAYER(F_A2, W / 32, KW, 0, true, hA, nullptr, hB, nullptr);
-            LAYER(F_A3, W / 32, KW, 0, true, hB, nullptr, hA, nullptr);
-            LAYER(F_AC, 1, KW, 0, false, hA, nullptr, nullptr, &raw);
+            LAYER(F_A1, W / 32, KW2, 0, true, x1f, xX1, nullptr, hB, xB, nullptr);
+            LAYER(F_A2, W / 32, KW, 0, true, hB, xB, nullptr, hA, xA, nullptr);
+            LAYER(F_A3, W / 32, KW, 0, true, hA, xA, nullptr, hB, xB, nullptr);
+            LAYER(F_AC, 1, KW, 0, false, hB, xB, nullptr, nullptr, NOAG, &raw);
 #pragma unroll
             for (int i = 0; i < 3 * C_MAX; ++i) adj[i] = raw[i];
         }
@@ -341,29 +470,45 @@ __global__ __launch_bounds__(256, 1) void mlp_i8_kernel(const MlpArgs A) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup
 }
 
-template <int W, int VARIANT>
+template <int PROG, int W, int VARIANT>
 static hipError_t launch_mlp_i8_t(const MlpArgs& a, int n_cu, hipStream_t st) {
     const int lds_bytes = ring_depth8(W) * kChunkBytes + a.bias_floats * 4;
     const int64_t n_tiles = (a.n + TILE_PTS - 1) / TILE_PTS;
     int grid = (int)(n_tiles < n_cu ? n_tiles : n_cu);
     if (grid < 1) grid = 1;
-    auto k = mlp_i8_kernel<W, VARIANT>;
+    auto k = mlp_i8_kernel<PROG, W, VARIANT>;
     hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds_bytes, st, a);
     return hipGetLastError();
 }
 
-hipError_t launch_mlp_i8(int W, int variant, const MlpArgs& a, int n_cu, hipStream_t st) {
-#define CASE(Wv)                                                             \
-    if (W == Wv) {                                                           \
-        if (variant == 0) return launch_mlp_i8_t<Wv, 0>(a, n_cu, st);        \
-        if (variant == 1) return launch_mlp_i8_t<Wv, 1>(a, n_cu, st);        \
-        return launch_mlp_i8_t<Wv, 2>(a, n_cu, st);                          \
+// The W = 512 field instances are compiled in their own translation unit (kernels_i8_w512.hip: this file again, with
+// SNERF_I8_W512_TU defined) under a larger pragma-unroll threshold: their layers (16 blocks x 16-18 k-steps) exceed
+// hipcc's default cap, and a layer loop left rolled would index the register arrays dynamically (= scratch).
+hipError_t launch_mlp_i8_w512(int variant, const MlpArgs& a, int n_cu, hipStream_t st);
+#ifdef SNERF_I8_W512_TU
+hipError_t launch_mlp_i8_w512(int variant, const MlpArgs& a, int n_cu, hipStream_t st) {
+    if (variant == 0) return launch_mlp_i8_t<PROG_FIELD, 512, 0>(a, n_cu, st);
+    if (variant == 1) return launch_mlp_i8_t<PROG_FIELD, 512, 1>(a, n_cu, st);
+    return launch_mlp_i8_t<PROG_FIELD, 512, 2>(a, n_cu, st);
+}
+#else
+hipError_t launch_mlp_i8(int prog, int W, int variant, const MlpArgs& a, int n_cu, hipStream_t st) {
+#define CASE(Wv)                                                                          \
+    if (W == Wv) {                                                                        \
+        if (prog == PROG_GROUP) return launch_mlp_i8_t<PROG_GROUP, Wv, 0>(a, n_cu, st);   \
+        if (variant == 0) return launch_mlp_i8_t<PROG_FIELD, Wv, 0>(a, n_cu, st);         \
+        if (variant == 1) return launch_mlp_i8_t<PROG_FIELD, Wv, 1>(a, n_cu, st);         \
+        return launch_mlp_i8_t<PROG_FIELD, Wv, 2>(a, n_cu, st);                           \
     }
     CASE(64)
     CASE(256)
 #undef CASE
+    if (W == 512) {
+        if (prog == PROG_GROUP) return launch_mlp_i8_t<PROG_GROUP, 512, 0>(a, n_cu, st);
+        return launch_mlp_i8_w512(variant, a, n_cu, st);
+    }
     return hipErrorInvalidValue;
 }
 
@@ -372,5 +517,6 @@ int field_variant_chunks_i8(int W, int C, int variant) {
     const int last = variant == 0 ? (int)F_NUM : variant == 1 ? (int)F_A1 : (int)F_S1;
     return prog_chunk_start(PROG_FIELD, W, C, last, FMT_I8);
 }
+#endif
 
 }  // namespace snerf

@@ -87,8 +87,7 @@ class All_in_One_Eval:
         """Eval_Tools_2.py:165-252.  Keys: Rendered_Col, PE, PV, PS, Solar_Vis, Sky_Col, Classes, Adjust, Rho, Col,
         Col_Adj, deltas, sample_pts, Albedo_Color (+ the *_Supervised / *_Merged family with use_prior)."""
         self._check(Network)
-        from .network import FUSED_WIDTHS
-        if Network.training or Network.layer_width not in FUSED_WIDTHS:
+        if Network.training or not Network.fused:
             # batch-statistics BatchNorm + autograd, or a width without a fused kernel: layer-wise fp32 engine
             from . import training
             return training.eval_train(self, data_dict, Network, train_mode, current_step)
@@ -148,8 +147,7 @@ class All_in_One_Eval:
         `Rendered_Col` [R,3], expected surface location sum(PS*pts)/(sum PS + 1e-8) [R,3] and expected surface distance
         sum(cumsum(delta)*PS)/sum(PS) [R,1], reduced inside the compositing kernel - no [R,S] tensor is written."""
         self._check(Network)
-        from .network import FUSED_WIDTHS
-        if Network.layer_width not in FUSED_WIDTHS or Network.training:
+        if not Network.fused or Network.training:
             res = self.eval(data_dict, Network, self.n_steps, False)
             ps, dl, pts = res["PS"], res["deltas"], res["sample_pts"].to(self.device)
             return (res["Rendered_Col"], (ps * pts).sum(1) / (ps.sum(1) + 1e-8), (torch.cumsum(dl, 1) * ps).sum(1) / ps.sum(1))
@@ -223,8 +221,7 @@ class All_in_One_Eval:
         """Eval_Tools_2.py:297-337 (no-prior branch): density + solar visibility along sun rays, end-point sampling.
         Keys: PE, PV_Exact, Solar_Vis, Sky_Col (raw, not sigmoided - T_NeRF_net_v2.py:154-157)."""
         self._check(Network)
-        from .network import FUSED_WIDTHS
-        if Network.training or Network.layer_width not in FUSED_WIDTHS or self.use_prior:
+        if Network.training or not Network.fused or self.use_prior:
             from . import training
             return training.eval_rho_only_train(self, data_dict, Network, train_mode, current_step)
         dev = self.device

@@ -18,7 +18,8 @@ from torch import nn
 from . import _lib
 
 OMEGA0 = 30.0
-FUSED_WIDTHS = (64, 256)      # widths with a compiled fused MFMA kernel; others run on the layer-wise fp32 engine
+FUSED_WIDTHS = (64, 256)      # widths with a compiled fused bf16 MFMA kernel; others run on the layer-wise fp32 engine
+FUSED_WIDTHS_I8 = (64, 256, 512)   # ... with a fused int8-digit kernel (precision "i8x3"): the reference's default width too
 
 
 class SineLayer(nn.Module):
@@ -81,6 +82,11 @@ class T_NeRF(nn.Module):
         # arithmetic of the fused eval-mode field kernel (include/season_nerf_hip.h SNERF_PREC_*): "bf16x3" (parity
         # default), "i8x3" (16-bit fixed point on the int8 matrix pipe: RGB ~2e-5, inputs in [-1,1]), "bf16" (fast, 2-3e-3)
         self.precision = "bf16x3"
+
+    @property
+    def fused(self):
+        """True where the eval-mode forward runs in a fused register-resident kernel (else: the layer-wise engine)."""
+        return self.layer_width in (FUSED_WIDTHS_I8 if self.precision == "i8x3" else FUSED_WIDTHS)
 
     # ------------------------------------------------------------------ device model management
     def _signature(self):
@@ -206,7 +212,7 @@ class T_NeRF(nn.Module):
         if self.training:
             rho, col, sv, sky, cls, adjc, _, _ = self._train_points(X, sun, tim)
             return rho, col, sv, sky, cls, adjc
-        if self.layer_width not in FUSED_WIDTHS:
+        if not self.fused:
             o = self._generic_points(X, sun, tim)
             return o["rho"], o["col"], o["sv"], o["sky"], o["cls"], o["adjc"]
         cls, _, sky = self._groups(tim, sun)
@@ -219,7 +225,7 @@ class T_NeRF(nn.Module):
         if self.training:
             rho, _, sv, sky, cls, _, col_raw, adj = self._train_points(X, sun, tim)
             return rho, col_raw, sv, sky, cls, adj
-        if self.layer_width not in FUSED_WIDTHS:
+        if not self.fused:
             o = self._generic_points(X, sun, tim)
             return o["rho"], o["col_raw"], o["sv"], o["sky"], o["cls"], o["adj"]
         cls, _, sky = self._groups(tim, sun)
@@ -231,7 +237,7 @@ class T_NeRF(nn.Module):
     def forward_Solar(self, X, Solar_Angle, Time):
         """-> softplus(Rho), sigmoid(Solar_Vis), Sky raw (:154-157)."""
         X, sun, tim = self._prep(X, Solar_Angle, Time)
-        if self.training or self.layer_width not in FUSED_WIDTHS:
+        if self.training or not self.fused:
             # the engine's sun-ray pass returns the raw sky head output itself (no logit round trip)
             from . import training
             if self.training:
@@ -249,7 +255,7 @@ class T_NeRF(nn.Module):
             from . import training
             with torch.no_grad():
                 return training.solar_points_forward_train(self, X, torch.ones(X.shape[0], 3, device=X.device))[0].detach()
-        if self.layer_width not in FUSED_WIDTHS:
+        if not self.fused:
             z = torch.zeros(X.shape[0], 4, device=X.device)
             return self._generic_points(X, torch.ones(X.shape[0], 3, device=X.device), z)["rho"]
         return self._field_points(2, X, None, None, ["d_rho"])["d_rho"]
@@ -258,7 +264,7 @@ class T_NeRF(nn.Module):
         (tim,) = self._prep(Time)
         self._no_train_graph("get_class_only")          # the time branch has no BatchNorm: train and eval mode agree
         sun = torch.zeros(tim.shape[0], 3, device=tim.device)
-        if self.layer_width not in FUSED_WIDTHS:
+        if not self.fused:
             return self._generic_points(torch.zeros(tim.shape[0], 3, device=tim.device), sun + 1.0, tim)["cls"]
         return self._groups(tim, sun)[0]
 

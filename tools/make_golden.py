@@ -373,6 +373,10 @@ if __name__ == "__main__":
         old.update(gen_schedule())
         np.savez_compressed(path, **old)
         sys.exit(0)
+    if "--only-w512" in sys.argv:                 # the reference's default width (main_lite.py:80): network forwards and one eval
+        gen_net(512, 3, 384, "W512_s3")
+        gen_eval(512, 2, 64, 96, "W512_R64_S96", with_prior=False)
+        sys.exit(0)
     if "--only-full-train" in sys.argv:
         # BASELINE configs[2] at its full size: ONE reference training step, 4096 rays x 96 samples + 4096 sun rays, W = 256,
         # MSE loss (43 s and ~40 GB of autograd state on the 8 CPUs of the build container).  Gradients of the big tensors are
@@ -391,6 +395,8 @@ if __name__ == "__main__":
     gen_train(256, 5, 4096, 96, "W256_R4096_S96", subsample=37)       # full-size configs[2] step (also: --only-full-train)
     gen_train(64, 3, 32, 32, "classic_W64_R32_S32", classic=True)
     gen_train(64, 4, 24, 40, "classic_prior_W64_R24_S40", prior=True, classic=True)
+    gen_net(512, 3, 384, "W512_s3")
+    gen_eval(512, 2, 64, 96, "W512_R64_S96", with_prior=False)
     gen_render(64, 2, "W64_s2")
     gen_render_by_P(64, 2, "W64_s2")
     gen_dsm()

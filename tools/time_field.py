@@ -1,0 +1,65 @@
+"""GPU: time the fused field launch (4096 rays x 96 samples, T_NeRF(W,4), variant 0) of the library SNERF_LIB points at.
+
+    [SNERF_LIB=build/variants/lib_x.so] python tools/time_field.py [--precision i8x3] [--width 256] [--reps 50]
+Prints one line: kernel ms (HIP events on the launch stream, mean of reps)."""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import season_nerf_amd as sn  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--precision", default="i8x3")
+    ap.add_argument("--width", type=int, default=256)
+    ap.add_argument("--reps", type=int, default=50)
+    ap.add_argument("--rays", type=int, default=4096)
+    ap.add_argument("--tag", default="")
+    a = ap.parse_args()
+    dev = torch.device("cuda")
+    R, S, Wd, Cc = a.rays, 96, a.width, 4
+    rng = np.random.Generator(np.random.PCG64(0))
+    t = lambda x: torch.tensor(x, dtype=torch.float32, device=dev)
+    top = t(np.concatenate([rng.uniform(-1, 1, (R, 2)), np.ones((R, 1))], 1))
+    bot = t(np.concatenate([rng.uniform(-1, 1, (R, 2)), -np.ones((R, 1))], 1))
+    sun = rng.uniform(0, 1, (R, 3)); sun = t(sun / np.linalg.norm(sun, axis=1, keepdims=True))
+    cls = torch.softmax(torch.randn(R, Cc, device=dev), 1)
+    tv = sn.sample_parameters(S, eval_mode=True).to(dev)
+    rho, sv, col = (torch.empty(R * S, device=dev), torch.empty(R * S, device=dev), torch.empty(R * S, 3, device=dev))
+    fo = sn._lib.FieldOut(d_rho=rho.data_ptr(), d_solar_vis=sv.data_ptr(), d_col=col.data_ptr())
+    L = sn._lib.lib()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    net = sn.T_NeRF(Wd, Cc)
+    net.load_state_dict(sn.synthetic_state_dict(net, 0))
+    net.precision = a.precision
+    net = net.to(dev).eval()
+    model = net.device_model()
+    run = lambda: sn._lib.check(L.snerf_field_forward_rays(model, 0, R, S, top.data_ptr(), bot.data_ptr(), tv.data_ptr(), 1,
+                                                          sun.data_ptr(), cls.data_ptr(), C.byref(fo), st), "field")
+    for _ in range(5):
+        run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    best = 1e9
+    tot = 0.0
+    for _ in range(3):
+        e0.record()
+        for _ in range(a.reps):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / a.reps
+        best = min(best, ms)
+        tot += ms
+    print(f"{a.tag or os.environ.get('SNERF_LIB', 'default'):40s} {a.precision} W={Wd}: mean {tot / 3:.4f} ms  best {best:.4f} ms  "
+          f"rho[0:3] {rho[:3].tolist()}", flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,51 @@
+"""A/B builds of one kernel source, cross-compiled HERE (the .so files travel to the GPU box), timed THERE.
+
+    python tools/variants.py build kernels_i8.hip name1="-DFOO=1" name2="-DSNERF_ABLATE -DABL=8" ...
+    python tools/variants.py run [--precision i8x3] [--width 256]        # on the GPU box: one process per library
+
+Each variant = build/variants/lib_<name>.so: the named source compiled with the extra flags, linked with the other objects of
+the regular build (build/obj, made by season-nerf_amd/build.py)."""
+import glob
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "season-nerf_amd"))
+import build as B  # noqa: E402
+
+VAR = os.path.join(REPO, "build", "variants")
+
+
+def build(src, variants):
+    B.build(verbose=False)
+    os.makedirs(VAR, exist_ok=True)
+    for f in glob.glob(os.path.join(VAR, "*")):
+        os.remove(f)
+
+    def one(nv):
+        name, flags = nv
+        o = os.path.join(VAR, name + ".o")
+        subprocess.check_call([B._hipcc()] + B.FLAGS + flags.split() + ["-c", os.path.join(B.CSRC, src), "-o", o])
+        objs = [o if s == src else B._obj(s) for s in B.SOURCES]
+        subprocess.check_call([B._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", os.path.join(VAR, f"lib_{name}.so")] + objs)
+        os.remove(o)
+        print("built", name, flush=True)
+    with ThreadPoolExecutor(max_workers=6) as ex:
+        list(ex.map(one, variants))
+
+
+def run(extra):
+    libs = sorted(glob.glob(os.path.join(VAR, "lib_*.so")))
+    for rep in range(2):
+        for lib in libs:
+            env = dict(os.environ, SNERF_LIB=lib)
+            subprocess.call([sys.executable, os.path.join(REPO, "tools", "time_field.py"), "--tag", os.path.basename(lib)[4:-3]] + extra, env=env)
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "build":
+        build(sys.argv[2], [tuple(a.split("=", 1)) for a in sys.argv[3:]])
+    else:
+        run(sys.argv[2:])
