@@ -299,12 +299,16 @@ def main():
     ap.add_argument("--workload", default="render", choices=["render", "train"],
                     help="render = headline (BASELINE configs[1]); train = configs[2]: one training step, 4096x96 + 4096 sun rays")
     ap.add_argument("--loss", default="mse", choices=["barron", "mse"], help="colour loss of --workload train (mse = reference-pinned)")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="only the headline timed region (no per-mode table, seam, sweep, training step, CPU baseline): profiler passes")
     ap.add_argument("--no-train", action="store_true", help="render workload: skip the extra training-step measurement (train_* keys)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help=argparse.SUPPRESS)   # gloo: CPU test of the launcher only
     ap.add_argument("--bn_sync", default="local", choices=["local", "global"],
                     help="--workload train, N > 1: BatchNorm statistics per rank, or over the global batch (RCCL all-reduces of the "
                          "per-layer statistics: the single-process reference's semantics)")
     a = ap.parse_args()
+    if a.headline_only:
+        a.no_sweep = a.no_train = a.no_cpu_baseline = True
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(a, sys.argv[1:]))          # child ranks; nothing here has touched the GPU
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -388,7 +392,7 @@ def main():
     field_ms = float(np.mean([ev0[i].elapsed_time(ev1[i]) for i in range(a.steps)]))
 
     extra = {}
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not a.headline_only:
         # every arithmetic mode on this same batch (outside the timed region): field-kernel time by HIP events on the launch
         # stream, and the deviation of the rendered colour from the bf16x3 mode (itself within ~3e-6 of the reference:
         # tests/test_gpu_parity.py; each mode's own error against the reference goldens: tests/test_gpu_precision.py)
@@ -441,7 +445,7 @@ def main():
         except Exception as ex:      # never let the auxiliary measurement break the headline line
             extra["image_sweep_error"] = repr(ex)
 
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not a.headline_only:
         # the same batch through the evaluator seam (All_in_One_Eval.eval: allocates its result tensors, returns the whole
         # per-sample dict) - what a reference caller pays per call on top of the raw C-ABI step above
         from types import SimpleNamespace
