@@ -244,6 +244,9 @@ int snerf_linear_wgrad(int64_t n_points, int n_in, int n_out, const float* d_gra
 int snerf_trainer_debug_read(snerf_trainer* t, const char* name, float* host_out, int64_t n_floats);
 /* torch.optim.Adam semantics (no weight decay) over the whole parameter arena in one launch; step counts from 1. */
 int snerf_trainer_adam_step(snerf_trainer* t, float lr, float beta1, float beta2, float eps, int step, void* stream);
+/* the same update (torch.optim.Adam, mg_run_NeRF.py:312-320) on caller-owned flat arenas of n floats */
+int snerf_adam_step(float* d_params, const float* d_grads, float* d_m, float* d_v, int64_t n, float lr, float beta1, float beta2,
+                    float eps, int step, void* stream);
 
 /* ---- ray table on the GPU: P_img_Pinhole.invert_P (pre_NeRF/P_Img.py:133-147) over the pixel grid of
  * mg_Pt_holder.setup_quick_loader (mg_Pt_holder.py:178-194).  P_3x4: HOST pointer to the row-major 3x4 projective

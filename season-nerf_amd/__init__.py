@@ -2,6 +2,7 @@
 call boundary: `T_NeRF` (network), `All_in_One_Eval` (ray evaluator).  All arithmetic runs in the HIP kernels of
 `csrc/` through the C ABI of `include/season_nerf_hip.h`; importing this package never falls back to a CPU path."""
 from . import _lib
+from . import ops
 from . import parallel
 from . import raytable
 from .training import FusedAdam, TrainEngine, create_solor_rays_uniform

@@ -76,6 +76,31 @@ def build(force=False, verbose=True, jobs=None):
     return LIB
 
 
+OPS_LIB = os.path.join(HERE, "libseason_nerf_ops.so")
+OPS_SRC = os.path.join(CSRC, "ops.cpp")
+
+
+def build_ops(force=False, verbose=True):
+    """The PyTorch custom-op layer (csrc/ops.cpp: TORCH_LIBRARY(season_nerf)): host C++ only, linked against the installed
+    torch and the HIP library above; lands next to it (torch.ops.load_library picks it up in season_nerf_amd/ops.py)."""
+    import torch
+    if not force and os.path.exists(OPS_LIB) and os.path.getmtime(OPS_LIB) > max(os.path.getmtime(OPS_SRC), os.path.getmtime(LIB),
+                                                                                  os.path.getmtime(os.path.join(REPO, "include", "season_nerf_hip.h"))):
+        return OPS_LIB
+    tl = os.path.dirname(torch.__file__)
+    cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+           f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}", "-I" + os.path.join(tl, "include"),
+           "-I" + os.path.join(tl, "include", "torch", "csrc", "api", "include"), "-I/opt/rocm/include", OPS_SRC, "-o", OPS_LIB,
+           "-L" + os.path.join(tl, "lib"), "-lc10", "-lc10_hip", "-ltorch_cpu", "-ltorch_hip", "-ltorch", "-L" + HERE, "-lseason_nerf_hip",
+           "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return OPS_LIB
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
+    build_ops(force="--force" in sys.argv)
     print(LIB)
+    print(OPS_LIB)

@@ -881,4 +881,14 @@ int snerf_trainer_adam_step(snerf_trainer* t, float lr, float beta1, float beta2
     return SNERF_OK;
 }
 
+/* the same update on caller-owned arenas (no trainer object): what season_nerf::fused_adam_ binds */
+int snerf_adam_step(float* d_params, const float* d_grads, float* d_m, float* d_v, int64_t n, float lr, float beta1, float beta2, float eps,
+                    int step, void* stream) {
+    if (n < 0 || (n && (!d_params || !d_grads || !d_m || !d_v))) return snerf_set_error(SNERF_E_INVALID, "snerf_adam_step: bad argument");
+    if (step < 1) return snerf_set_error(SNERF_E_INVALID, "Adam step counts from 1");
+    if (n == 0) return SNERF_OK;
+    HIPCK(launch_adam(d_params, d_grads, d_m, d_v, n, lr, beta1, beta2, eps, step, (hipStream_t)stream));
+    return SNERF_OK;
+}
+
 }  // extern "C"

@@ -10,7 +10,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from .network import T_NeRF
+from .network import T_NeRF, _ops
 
 
 def sample_parameters(n_samples, eval_mode, include_end_pt=False):
@@ -95,30 +95,16 @@ class All_in_One_Eval:
         dev = top.device
         R, S, Cn = top.shape[0], self.args.n_samples, Network.n_classes
         N = R * S
-        L = _lib.lib()
-        st = Network._stream()
         tv = sample_parameters_on(dev, S, eval_mode=not train_mode)
-        cls, _, sky = Network._groups(tim, sun)
-        e = lambda *s: torch.empty(*s, device=dev)
-        rho, sv, col, adjc, pts = e(R, S, 1), e(R, S, 1), e(R, S, 3), e(R, S, 3), e(R, S, 3)
-        fo = _lib.FieldOut(d_rho=rho.data_ptr(), d_solar_vis=sv.data_ptr(), d_col=col.data_ptr(),
-                           d_adjust_col=adjc.data_ptr(), d_points=pts.data_ptr())
-        _lib.check(L.snerf_field_forward_rays(Network.device_model(), 0, R, S, top.data_ptr(), bot.data_ptr(),
-                                              tv.data_ptr(), 1, sun.data_ptr(), cls.data_ptr(), C.byref(fo), st),
-                   "field_forward_rays")
         flags = 1 if self.use_classic_solar else 0
+        # one custom op = group network + fused field network (in-kernel ray sampling) + wave-scan compositing
+        rgb, _depth, alb, per = _ops().render_fwd(Network.op_model(), top, bot, sun, tim, tv, flags, True)
+        rho, col, sv, _adjust, adjc, _col_raw, pts, pv, pe, ps, dl, cls, sky = per
 
         def composite(rho_t, prior=None, trust=1.0):
-            rgb, alb, pv, pe, ps, dl = e(R, 3), e(R, 3), e(R, S, 1), e(R, S, 1), e(R, S, 1), e(R, S, 1)
-            co = _lib.CompositeOut(d_rgb=rgb.data_ptr(), d_albedo=alb.data_ptr(), d_pv=pv.data_ptr(),
-                                   d_pe=pe.data_ptr(), d_ps=ps.data_ptr(), d_delta=dl.data_ptr())
-            _lib.check(L.snerf_composite_rays(R, S, top.data_ptr(), bot.data_ptr(), tv.data_ptr(), rho_t.data_ptr(),
-                                              col.data_ptr(), sv.data_ptr(), sky.data_ptr(), flags,
-                                              prior.data_ptr() if prior is not None else None, float(trust),
-                                              C.byref(co), st), "composite_rays")
-            return rgb, alb, pv, pe, ps, dl
+            r = _ops().composite(top, bot, tv, rho_t, col, sv, sky, flags, prior, float(trust))
+            return r[0], r[1], r[2], r[3], r[4], r[5]
 
-        rgb, alb, pv, pe, ps, dl = composite(rho)
         res = {"Rendered_Col": rgb, "PE": pe, "PV": pv, "PS": ps, "Solar_Vis": sv,
                "Sky_Col": sky.unsqueeze(1).expand(R, S, 3), "Classes": cls.unsqueeze(1).expand(R, S, Cn),
                "Adjust": adjc, "Rho": rho, "Col": col, "Col_Adj": -1, "deltas": dl, "sample_pts": pts,

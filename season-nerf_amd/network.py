@@ -17,6 +17,13 @@ from torch import nn
 
 from . import _lib
 
+
+def _ops():
+    """torch.ops.season_nerf (csrc/ops.cpp), loaded on first use."""
+    from . import ops
+    return ops.load()
+
+
 OMEGA0 = 30.0
 FUSED_WIDTHS = (64, 256)      # widths with a compiled fused bf16 MFMA kernel; others run on the layer-wise fp32 engine
 FUSED_WIDTHS_I8 = (64, 256, 512)   # ... with a fused int8-digit kernel (precision "i8x3"): the reference's default width too
@@ -79,6 +86,7 @@ class T_NeRF(nn.Module):
         self.adjust_sky_col = nn.Linear(W, n_classes * 3)
         self._handle = None
         self._sig = None
+        self._op_model = None
         # arithmetic of the fused eval-mode field kernel (include/season_nerf_hip.h SNERF_PREC_*): "bf16x3" (parity
         # default), "i8x3" (16-bit fixed point on the int8 matrix pipe: RGB ~2e-5, inputs in [-1,1]), "bf16" (fast, 2-3e-3)
         self.precision = "bf16x3"
@@ -116,18 +124,28 @@ class T_NeRF(nn.Module):
             L.snerf_model_destroy(h)
             raise
         self._handle, self._sig = h, sig
+        self._op_model = None
         return h
+
+    def op_model(self):
+        """The packed model as the custom-op layer sees it (torch.classes.season_nerf.Model viewing the C-ABI handle)."""
+        h = self.device_model()
+        if self.__dict__.get("_op_model") is None:
+            from . import ops
+            self._op_model = ops.model_view(h)
+        return self._op_model
 
     def __getstate__(self):
         """Copies (copy.deepcopy, pickle, torch.save of the module) must not share the raw C handles: the device model, the
         training engines and the parameter store stay with the original; a copy re-packs / re-adopts lazily on first use."""
         d = self.__dict__.copy()
-        d["_handle"], d["_sig"], d["_hm_dev"] = None, None, None
+        d["_handle"], d["_sig"], d["_hm_dev"], d["_op_model"] = None, None, None, None
         for k in ("_train_engine", "_train_engines", "_param_store"):
             d.pop(k, None)
         return d
 
     def release(self):
+        self._op_model = None
         if self._handle is not None:
             _lib.lib().snerf_model_destroy(self._handle)
             self._handle = None
@@ -154,14 +172,7 @@ class T_NeRF(nn.Module):
 
     # ------------------------------------------------------------------ kernels
     def _groups(self, time, sun):
-        G = time.shape[0]
-        dev = time.device
-        cls = torch.empty(G, self.n_classes, device=dev)
-        sky_raw = torch.empty(G, 3, device=dev)
-        sky = torch.empty(G, 3, device=dev)
-        _lib.check(_lib.lib().snerf_group_forward(self.device_model(), G, time.data_ptr(), sun.data_ptr(), cls.data_ptr(),
-                                                  sky_raw.data_ptr(), sky.data_ptr(), self._stream()), "group_forward")
-        return cls, sky_raw, sky
+        return _ops().group_fwd(self.op_model(), time, sun)         # classes, sky_raw, sky
 
     def _generic_points(self, X, sun, tim):
         """Any width: the layer-wise fp32 engine in eval mode, one 'ray' of one sample per point (still all HIP)."""
@@ -182,16 +193,9 @@ class T_NeRF(nn.Module):
         return o
 
     def _field_points(self, variant, X, sun, cls, want):
-        N = X.shape[0]
-        dev = X.device
-        shapes = {"d_rho": (N, 1), "d_solar_vis": (N, 1), "d_col_raw": (N, 3), "d_adjust": (N, self.n_classes, 3),
-                  "d_col": (N, 3), "d_adjust_col": (N, 3)}
-        out = {k: torch.empty(shapes[k], device=dev) for k in want}
-        fo = _lib.FieldOut(**{k: v.data_ptr() for k, v in out.items()})
-        _lib.check(_lib.lib().snerf_field_forward_points(
-            self.device_model(), variant, N, X.data_ptr(), 1, sun.data_ptr() if sun is not None else None,
-            cls.data_ptr() if cls is not None else None, C.byref(fo), self._stream()), "field_forward_points")
-        return out
+        r = _ops().points_fwd(self.op_model(), X, sun, cls, 1, variant)
+        out = dict(zip(["d_rho", "d_solar_vis", "d_col_raw", "d_adjust", "d_col", "d_adjust_col"], r))
+        return {k: out[k] for k in want}
 
     # ------------------------------------------------------------------ reference API (T_NeRF_net_v2.py)
     def _process_time(self, Time):
