@@ -17,8 +17,8 @@
 //   season_nerf::composite_sweep(...) -> Tensor[6]                                                    mg_Img_Eval t-step sweep
 //   season_nerf::fused_adam_(param!, grad, m!, v!, lr, b1, b2, eps, step) -> ()                         mg_run_NeRF.py:312-320
 #include <ATen/ATen.h>
-#include <ATen/hip/HIPContext.h>
-#include <c10/hip/HIPGuard.h>
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>      // PyTorch-ROCm presents HIP devices under the "cuda" device type
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 #include <torch/custom_class.h>
 #include <torch/library.h>
 
@@ -47,7 +47,7 @@ void check_shape(const Tensor& t, const char* name, int64_t rows, int64_t cols) 
     TORCH_CHECK(t.dim() == 2 && (rows < 0 || t.size(0) == rows) && t.size(1) == cols, name, " must be [", rows < 0 ? std::string("N") : std::to_string(rows), ",",
                 cols, "], got ", t.sizes());
 }
-void* cur_stream(const Tensor& t) { return (void*)at::hip::getCurrentHIPStream(t.device().index()).stream(); }
+void* cur_stream(const Tensor& t) { return (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(t.device().index()).stream(); }
 
 struct Model : torch::CustomClassHolder {
     snerf_model* m = nullptr;
@@ -87,7 +87,7 @@ c10::intrusive_ptr<Model> model_from_handle(int64_t handle) {
 std::tuple<Tensor, Tensor, Tensor> group_fwd(const ModelPtr& M, const Tensor& time, const Tensor& sun) {
     check_shape(time, "time", -1, 4);
     check_shape(sun, "sun", time.size(0), 3);
-    c10::hip::HIPGuard g(time.device());
+    c10::hip::HIPGuardMasqueradingAsCUDA g(time.device());
     const int64_t G = time.size(0);
     Tensor cls = at::empty({G, M->classes()}, time.options()), sky_raw = at::empty({G, 3}, time.options()), sky = at::empty({G, 3}, time.options());
     ck(snerf_group_forward(M->m, G, fptr(time), fptr(sun), mptr(cls), mptr(sky_raw), mptr(sky), cur_stream(time)), "group_fwd");
@@ -105,7 +105,7 @@ std::vector<Tensor> points_fwd(const ModelPtr& M, const Tensor& x, const c10::op
         check_shape(*sun, "sun", G, 3);
     }
     if (classes.has_value()) check_shape(*classes, "classes", G, C);
-    c10::hip::HIPGuard g(x.device());
+    c10::hip::HIPGuardMasqueradingAsCUDA g(x.device());
     auto o = x.options();
     Tensor rho = at::empty({N, 1}, o), sv = at::empty({variant <= 1 ? N : 0, 1}, o), col_raw = at::empty({variant == 0 ? N : 0, 3}, o),
            adjust = at::empty({variant == 0 ? N : 0, C, 3}, o), col = at::empty({variant == 0 ? N : 0, 3}, o), adjc = at::empty({variant == 0 ? N : 0, 3}, o);
@@ -128,7 +128,7 @@ std::tuple<Tensor, Tensor, Tensor, std::vector<Tensor>> render_fwd(const ModelPt
     check_dev_f32(tvals, "tvals");
     TORCH_CHECK(tvals.dim() == 1 && tvals.numel() >= 1, "tvals must be [S]");
     const int64_t S = tvals.numel(), C = M->classes();
-    c10::hip::HIPGuard g(top.device());
+    c10::hip::HIPGuardMasqueradingAsCUDA g(top.device());
     auto o = top.options();
     Tensor rgb = at::empty({R, 3}, o), depth = at::empty({R, 2}, o), albedo = at::empty({R, 3}, o);
     Tensor dist = at::empty({R}, o), acc = at::empty({R}, o);
@@ -173,7 +173,7 @@ std::vector<Tensor> composite(const Tensor& top, const Tensor& bot, const Tensor
     TORCH_CHECK(rho.numel() == R * S && solar_vis.numel() == R * S && col.numel() == R * S * 3, "rho / solar_vis / col must hold R*S (x3) elements");
     check_shape(sky, "sky", R, 3);
     if (rho_prior.has_value()) { check_dev_f32(*rho_prior, "rho_prior"); TORCH_CHECK(rho_prior->numel() == R * S, "rho_prior must hold R*S elements"); }
-    c10::hip::HIPGuard g(top.device());
+    c10::hip::HIPGuardMasqueradingAsCUDA g(top.device());
     auto o = top.options();
     std::vector<Tensor> r = {at::empty({R, 3}, o), at::empty({R, 3}, o), at::empty({R, S, 1}, o), at::empty({R, S, 1}, o), at::empty({R, S, 1}, o),
                              at::empty({R, S, 1}, o), at::empty({R}, o), at::empty({R}, o), at::empty({R, 3}, o), at::empty({R}, o)};
@@ -196,7 +196,7 @@ std::vector<Tensor> composite_sweep(const Tensor& top, const Tensor& bot, const 
     check_dev_f32(rho, "rho"); check_dev_f32(col_raw, "col_raw"); check_dev_f32(adjust, "adjust"); check_dev_f32(solar_vis, "solar_vis"); check_dev_f32(sky, "sky");
     TORCH_CHECK(rho.numel() == R * S && solar_vis.numel() == R * S && col_raw.numel() == R * S * 3 && adjust.numel() == R * S * C * 3 && sky.numel() == 3,
                 "per-sample tensors must hold R*S elements (col_raw x3, adjust xC x3), sky 3");
-    c10::hip::HIPGuard g(top.device());
+    c10::hip::HIPGuardMasqueradingAsCUDA g(top.device());
     auto o = top.options();
     std::vector<Tensor> r = {at::empty({T, R, 3}, o), at::empty({T, R, 3}, o), at::empty({R, 3}, o), at::empty({R, 3}, o), at::empty({R}, o),
                              at::empty({classic ? T : 0, R, 3}, o)};
@@ -211,7 +211,7 @@ std::vector<Tensor> composite_sweep(const Tensor& top, const Tensor& bot, const 
 void fused_adam_(Tensor param, const Tensor& grad, Tensor m, Tensor v, double lr, double beta1, double beta2, double eps, int64_t step) {
     check_dev_f32(param, "param"); check_dev_f32(grad, "grad"); check_dev_f32(m, "m"); check_dev_f32(v, "v");
     TORCH_CHECK(grad.numel() == param.numel() && m.numel() == param.numel() && v.numel() == param.numel(), "param, grad, m and v must have the same size");
-    c10::hip::HIPGuard g(param.device());
+    c10::hip::HIPGuardMasqueradingAsCUDA g(param.device());
     ck(snerf_adam_step(mptr(param), fptr(grad), mptr(m), mptr(v), param.numel(), (float)lr, (float)beta1, (float)beta2, (float)eps, (int)step,
                        cur_stream(param)), "fused_adam_");
 }
