@@ -58,7 +58,7 @@ PEAK_BF16_DENSE = 2.5e15   # MI355X_MICROARCH.md: dense bf16 MFMA peak
 
 DTYPES = {"i8x3": "i8x3 (16-bit fixed point as two int8 digits on v_mfma_i32_32x32x32_i8, exact int32 accumulate, fp32 epilogue)",
           "bf16x3": "bf16x3 (3-term split bf16 MFMA, fp32 accumulate)", "bf16": "bf16 (one bf16 MFMA per product, fp32 accumulate; fast mode)"}
-KERNELS = {"i8x3": "snerf::mlp_i8_kernel<0,256,0> (fused field network, int8 digits)", "bf16x3": "snerf::mlp_kernel<0,256,0,false> (fused field network)",
+KERNELS = {"i8x3": "snerf::mlp_i8x2_kernel<256,0> (fused field network, int8 digits, two waves per SIMD)", "bf16x3": "snerf::mlp_kernel<0,256,0,false> (fused field network)",
            "bf16": "snerf::mlp_kernel<0,256,0,true> (fused field network, fast mode)"}
 # executed matrix work per 32-point wave tile, in units of 65536 ops (= one 32x32x32 int8 MFMA = two 32x32x16 bf16 MFMAs)
 MFMAS_PER_WAVE_TILE = {"i8x3": 2220, "bf16x3": 2220, "bf16": 772}

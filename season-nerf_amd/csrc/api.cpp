@@ -243,7 +243,10 @@ static int field_launch(const snerf_model* m, int variant, MlpArgs& a, const sne
         a.stream_bytes = (uint32_t)field_variant_chunks_i8(m->W, m->C, variant) * kChunkBytes;
         a.bias = m->d_table_i8;
         a.bias_floats = (int)m->host_i8.bias.size();
-        e = launch_mlp_i8(PROG_FIELD, m->W, variant, a, m->n_cu, (hipStream_t)stream);
+        // two waves per SIMD wherever the activations leave room for it (kernels_i8x2.hip); SNERF_I8_ONE_WAVE=1: A/B switch
+        static const bool one_wave = getenv("SNERF_I8_ONE_WAVE") != nullptr;
+        if (m->W <= 256 && !one_wave) e = launch_mlp_i8x2(m->W, variant, a, m->n_cu, (hipStream_t)stream);
+        else e = launch_mlp_i8(PROG_FIELD, m->W, variant, a, m->n_cu, (hipStream_t)stream);
     } else {
         e = launch_mlp(PROG_FIELD, m->W, variant, m->precision == SNERF_PREC_BF16, a, m->n_cu, (hipStream_t)stream);
     }

@@ -118,6 +118,13 @@ __device__ __forceinline__ PeArg pe_arg(float x) {
     r.u = (double)a0 * 0.15915494309189533576888;
     return r;
 }
+// the same with the power of two given as its exponent (v_ldexp_f64: exact, and no per-lane table of fp64 scales to keep live)
+__device__ __forceinline__ void pe_sincos_exp(const PeArg& a, int e, float& c, float& s) {
+    const double r = __builtin_ldexp(a.u, e);
+    const float f = (float)(r - __builtin_floor(r));
+    c = cos2pi(f);
+    s = sin2pi(f);
+}
 __device__ __forceinline__ void pe_sincos(const PeArg& a, double scale, float& c, float& s) {
     const double r = a.u * scale;                 // exact: scale = 2^j
     const float f = (float)(r - __builtin_floor(r));

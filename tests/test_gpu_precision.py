@@ -113,3 +113,36 @@ def test_width_512_needs_the_int8_mode():
     net.precision = "fp64"
     with pytest.raises(ValueError):
         net.to("cuda").eval().device_model()
+
+
+@pytest.mark.parametrize("W", [64, 256])
+def test_int8_mode_over_many_tiles(W):
+    """The goldens fit one tile per workgroup.  Here every workgroup streams the weights several times around its ring
+    (4096 rays x 96 samples = 1536 tiles of the two-wave kernel on 256 CUs): a ring or barrier mistake shows up as O(1)
+    errors in whole tiles, so compare the int8-digit kernel point by point with the bf16x3 kernel."""
+    import ctypes as C
+    s = sn()
+    R, S = 4096, 96
+    rng = np.random.Generator(np.random.PCG64(5))
+    top = T(np.concatenate([rng.uniform(-1, 1, (R, 2)), np.ones((R, 1))], 1)).cuda()
+    bot = T(np.concatenate([rng.uniform(-1, 1, (R, 2)), -np.ones((R, 1))], 1)).cuda()
+    sun = rng.uniform(0, 1, (R, 3))
+    sun = T(sun / np.linalg.norm(sun, axis=1, keepdims=True)).cuda()
+    cls = torch.softmax(torch.tensor(rng.normal(size=(R, 4)), dtype=torch.float32), 1).cuda()
+    tv = s.sample_parameters(S, eval_mode=True).cuda()
+    outs = {}
+    for prec in ["bf16x3", "i8x3"]:
+        net = make_net(W, 4, 11, prec)
+        rho, sv, col = torch.empty(R * S, device="cuda"), torch.empty(R * S, device="cuda"), torch.empty(R * S, 3, device="cuda")
+        fo = s._lib.FieldOut(d_rho=rho.data_ptr(), d_solar_vis=sv.data_ptr(), d_col=col.data_ptr())
+        for _ in range(2):       # twice: the second launch starts from whatever the first left in flight
+            s._lib.check(s._lib.lib().snerf_field_forward_rays(net.device_model(), 0, R, S, top.data_ptr(), bot.data_ptr(), tv.data_ptr(), 1,
+                                                               sun.data_ptr(), cls.data_ptr(), C.byref(fo), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                         "field")
+        torch.cuda.synchronize()
+        outs[prec] = (rho, sv, col)
+    d_rho = ((outs["i8x3"][0] - outs["bf16x3"][0]).abs() / outs["bf16x3"][0].abs().clamp_min(1e-3)).max().item()
+    d_sv = (outs["i8x3"][1] - outs["bf16x3"][1]).abs().max().item()
+    d_col = (outs["i8x3"][2] - outs["bf16x3"][2]).abs().max().item()
+    print(f"  W={W}: i8x3 vs bf16x3 over {R * S} points: rho rel {d_rho:.2e}, solar_vis abs {d_sv:.2e}, col abs {d_col:.2e}")
+    assert d_rho < 5e-4 and d_sv < 3e-4 and d_col < 3e-4, (d_rho, d_sv, d_col)
