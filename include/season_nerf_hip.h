@@ -160,8 +160,8 @@ int snerf_composite_sweep(int64_t n_rays, int n_samples, int n_classes, int n_ti
                           int flags, const snerf_sweep_out* out, void* stream);
 
 /* ---- training engine: the device side of Net_tool.train_step (mg_run_NeRF.py:288-326) = All_in_One_Eval.get_loss
- * (Eval_Tools_2.py:340-459) forward passes in .train() mode, backward, Adam.  Layer-wise fp32 (exact-fp32 MFMA GEMMs),
- * batch-statistics BatchNorm1d (momentum 0.01, misc.py:170) with running-stat EMA, activations stashed in HBM.
+ * (Eval_Tools_2.py:340-459) forward passes in .train() mode, backward, Adam.  Layer-wise, fp32 storage, 3-term split bf16 MFMA
+ * GEMMs (exact-fp32 MFMA under SNERF_TRAIN_GEMM=fp32), batch-statistics BatchNorm1d (momentum 0.01, misc.py:170) with running-stat EMA, activations stashed in HBM.
  * Two passes per step, as the reference: image rays (everything gets a gradient except the solar branch, whose output
  * is detached, Eval_Tools_2.py:214) and random sun rays (forward_Solar: trunk without gradient, :297-337).
  * The caller owns all memory: a flat parameter arena and same-sized gradient / Adam arenas (layout from

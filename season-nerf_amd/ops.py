@@ -20,8 +20,32 @@ def load():
         raise RuntimeError(f"season_nerf_amd: custom-op library not built ({OPS_PATH} missing). Run `python season-nerf_amd/build.py`.")
     ctypes.CDLL(_lib.LIB_PATH, mode=ctypes.RTLD_GLOBAL)      # the C ABI the op layer links against
     torch.ops.load_library(OPS_PATH)
+    _register_fakes()
     _loaded = True
     return torch.ops.season_nerf
+
+
+def _register_fakes():
+    """Shape / dtype propagation ("fake" kernels) for the ops whose arguments are plain tensors, so that FakeTensor tracing
+    (torch.compile, torch.library.opcheck) sees through them.  The ops that take the packed model (a torchbind object) are
+    dispatcher-visible but opaque to tracing."""
+    reg = torch.library.register_fake
+
+    @reg("season_nerf::composite")
+    def _(top, bot, tvals, rho, col, solar_vis, sky, flags, rho_prior, trust):
+        R, S = top.shape[0], tvals.numel()
+        e = top.new_empty
+        return [e(R, 3), e(R, 3), e(R, S, 1), e(R, S, 1), e(R, S, 1), e(R, S, 1), e(R), e(R), e(R, 3), e(R)]
+
+    @reg("season_nerf::composite_sweep")
+    def _(top, bot, tvals, rho, col_raw, adjust, solar_vis, sky, class_vecs, flags, classic):
+        R, T = top.shape[0], class_vecs.shape[0]
+        e = top.new_empty
+        return [e(T, R, 3), e(T, R, 3), e(R, 3), e(R, 3), e(R), e(T if classic else 0, R, 3)]
+
+    @reg("season_nerf::fused_adam_")
+    def _(param, grad, m, v, lr, beta1, beta2, eps, step):
+        return None
 
 
 def model_view(handle):

@@ -128,3 +128,19 @@ def test_seams_run_on_the_ops(golden_dir, monkeypatch):
     names = {e.key for e in prof.key_averages()}
     assert "season_nerf::render_fwd" in names and "season_nerf::points_fwd" in names and "season_nerf::group_fwd" in names, sorted(names)[:20]
     close(out["Rendered_Col"], g["eval_Rendered_Col"])
+
+
+def test_opcheck_schema_and_fake_kernels():
+    """torch.library.opcheck: the registered schemas (mutation / aliasing annotations) and the fake kernels agree with what the
+    ops really do - for the ops whose arguments are plain tensors."""
+    ops()
+    R, S = 8, 16
+    g = torch.Generator(device="cuda").manual_seed(0)
+    r = lambda *s: torch.rand(*s, device="cuda", generator=g)
+    top = torch.cat([r(R, 2) * 2 - 1, torch.ones(R, 1, device="cuda")], 1)
+    bot = torch.cat([r(R, 2) * 2 - 1, -torch.ones(R, 1, device="cuda")], 1)
+    tv = torch.linspace(0, 1, S + 1, device="cuda")[:-1].contiguous()
+    args = (top, bot, tv, r(R, S, 1), r(R, S, 3), r(R, S, 1), r(R, 3), 0, None, 1.0)
+    torch.library.opcheck(torch.ops.season_nerf.composite.default, args, test_utils=("test_schema", "test_faketensor"))
+    p, gr, m, v = r(1000), r(1000), torch.zeros(1000, device="cuda"), torch.zeros(1000, device="cuda")
+    torch.library.opcheck(torch.ops.season_nerf.fused_adam_.default, (p, gr, m, v, 1e-3, 0.9, 0.999, 1e-8, 1), test_utils=("test_schema", "test_faketensor"))
