@@ -62,7 +62,7 @@ def test_param_count():
     assert n(orc.init_weights(512, 4)) == 3195820
 
 
-@pytest.mark.parametrize("name", ["net_W64_s0.npz", "net_W256_s1.npz"])
+@pytest.mark.parametrize("name", ["net_W64_s0.npz", "net_W256_s1.npz", "net_W512_s3.npz"])
 def test_network_forwards(golden_dir, name):
     g = load(golden_dir, name)
     sd = orc.init_weights(int(g["W"]), int(g["C"]), int(g["seed"]))
@@ -84,7 +84,7 @@ def rays(g):
     return {k: T(g["in_" + k]) for k in ["Top", "Bot", "Sun_Angle", "Time_Encoded", "GT_Color"]}
 
 
-@pytest.mark.parametrize("name", ["eval_W256_R64_S96.npz", "eval_W64_R48_S64.npz"])
+@pytest.mark.parametrize("name", ["eval_W256_R64_S96.npz", "eval_W64_R48_S64.npz", "eval_W512_R64_S96.npz"])
 def test_eval_rays(golden_dir, name):
     g = load(golden_dir, name)
     sd = orc.init_weights(int(g["W"]), int(g["C"]), int(g["seed"]))
