@@ -52,7 +52,7 @@ int snerf_model_classes(const snerf_model* m);
  *   SNERF_PREC_BF16X3  3-term error-compensated bf16 MFMA products, fp32 accumulate: RGB ~3e-6, per-sample outputs ~1e-5 (default)
  *   SNERF_PREC_BF16    one bf16 MFMA per product (first layer keeps 3 terms): RGB 2-3e-3 - outside the bar, "fast" mode
  *   SNERF_PREC_I8X3    16-bit fixed point in two int8 digits on the int8 MFMA pipe, exact integer accumulation:
- *                      RGB ~2e-5, per-sample outputs ~1e-4; inputs (sample positions, sun vectors) must lie in [-1,1]
+ *                      RGB ~2e-5, per-sample outputs ~1e-4; any input range (the raw coordinates of the encodings enter in fp32)
  * The per-group network (class softmax, sky colour: one row per ray) always runs in BF16X3. */
 #define SNERF_PREC_BF16X3 0
 #define SNERF_PREC_BF16 1

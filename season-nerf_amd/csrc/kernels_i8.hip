@@ -10,8 +10,10 @@
 //       factor 30, 1/(2 pi) and the +128 digit offset, pack.cpp), v_sin_f32, then v_cvt_pknorm_i16_f32 (two elements per
 //       instruction) and two v_perm_b32 + one v_xor per four elements to split the int16 into the two digit streams.
 //  Accuracy: 16-bit fixed point on both operands: RGB within ~2e-5 relative of the fp32 reference (bf16x3: ~3e-6), density
-//  and the other per-sample outputs within ~1e-4 (tools/numerics_i8.py, tests/test_gpu_precision.py).  Inputs must lie in
-//  [-1,1] (sample positions inside the scene cube, unit sun vectors): v_cvt_pknorm saturates.
+//  and the other per-sample outputs within ~1e-4 (tools/numerics_i8.py, tests/test_gpu_precision.py).  No input range: the
+//  digit operands are sines / cosines and hidden activations, all in [-1,1] by construction; the raw coordinates the
+//  encodings carry along (x, y, z; the sun vector; the time code) enter in fp32, three FMAs per element of the layers that
+//  read them (fc1, fc5, fc_solar_1; time_layer_1, fc_sky_color_1).
 #include "mlp_i8_device.h"
 
 namespace snerf {
@@ -81,9 +83,14 @@ constexpr int PF8 = SNERF_PF8;
 // at k-step sA(e) = 1 + e (KS-2) / 8, the digit split of quad g one step after its second pair.
 //   AG_IN0 / AG_OUT >= 0: the first input block / the output live in AGPRs from that register number on (W = 512; the
 //   pointer is then unused); the second input block, where there is one, is always an encoding in VGPRs.
-template <int NB, int KS0, int KS1, bool SIN, int D, int AG_IN0 = -1, int AG_OUT = -1, bool AG = false>
+//   RAWL: the layer reads an encoding; rawx = its three raw coordinates, added in fp32 (mlp_i8_device.h add_raw).
+template <int NB, int KS0, int KS1, bool SIN, int D, int AG_IN0 = -1, int AG_OUT = -1, bool AG = false, bool RAWL = false>
 __device__ __forceinline__ void run_layer8(Ring& rg, const uint8_t* stream, uint32_t stream_bytes, lds_char* lds, lds_cfloat* tab_l,
-                                           const Frag8* in0, const Frag8* in1, Frag8* out, f32x16* raw, int wave, int lane) {
+                                           const Frag8* in0, const Frag8* in1, Frag8* out, f32x16* raw, int wave, int lane,
+                                           const float* rawx = nullptr) {
+    static_assert(!RAWL || SIN, "raw coordinates only enter sine layers");
+    lds_cfloat* raw_l = tab_l + 2 * 32 * NB;         // the layer's raw-weight table follows its scale / bias table
+    Raw8 rw;
     constexpr int KS = KS0 + KS1, NP = NB * KS;
     constexpr bool PIPE = KS >= 4;
     constexpr int S_EPI = (AG && KS > 1) ? 1 : 0;      // un-pipelined epilogue: behind the block's first MFMAs (see mfma_asm)
@@ -141,17 +148,20 @@ __device__ __forceinline__ void run_layer8(Ring& rg, const uint8_t* stream, uint
                 mfma_i8x3(aT, aL, s < KS0 ? in0[s] : in1[s - KS0], acc);
             }
             if (SIN && b > 0) {
-                if (s == 0) tab = load_tab(tab_l, b - 1, h);
+                if (s == 0) {
+                    tab = load_tab(tab_l, b - 1, h);
+                    if (RAWL) rw = load_raw(raw_l, b - 1, h);
+                }
                 if (PIPE) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         const int sA = 1 + (e * (KS - 2)) / 8;
-                        if (s == sA) epi_A(accs[(b - 1) & 1], tab, e, ev);
+                        if (s == sA) epi_A<RAWL>(accs[(b - 1) & 1], tab, e, ev, &rw, rawx);
                         if ((e & 1) && s == sA + 1) epi_Q<(AG_OUT >= 0)>(e >> 1, ev, AG_OUT >= 0 ? nullptr : out + (b - 1), AG_OUT + 8 * (b - 1));
                     }
                 } else if (s == S_EPI) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) epi_A(accs[(b - 1) & 1], tab, e, ev);
+                    for (int e = 0; e < 8; ++e) epi_A<RAWL>(accs[(b - 1) & 1], tab, e, ev, &rw, rawx);
 #pragma unroll
                     for (int g = 0; g < 4; ++g) epi_Q<(AG_OUT >= 0)>(g, ev, AG_OUT >= 0 ? nullptr : out + (b - 1), AG_OUT + 8 * (b - 1));
                 }
@@ -171,10 +181,11 @@ __device__ __forceinline__ void run_layer8(Ring& rg, const uint8_t* stream, uint
         accs[b & 1] = acc;
     }
     tab = load_tab(tab_l, NB - 1, h);
+    if (RAWL) rw = load_raw(raw_l, NB - 1, h);
     if (AG) asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");   // the last asm MFMA's result: 18 wait states before a VALU read, by hand
     if (SIN) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) epi_A(accs[(NB - 1) & 1], tab, e, ev);
+        for (int e = 0; e < 8; ++e) epi_A<RAWL>(accs[(NB - 1) & 1], tab, e, ev, &rw, rawx);
 #pragma unroll
         for (int g = 0; g < 4; ++g) epi_Q<(AG_OUT >= 0)>(g, ev, AG_OUT >= 0 ? nullptr : out + (NB - 1), AG_OUT + 8 * (NB - 1));
         if (AG) asm volatile("s_nop 3" ::: "memory");             // parked digits -> the next layer's first MFMA
@@ -185,7 +196,7 @@ __device__ __forceinline__ void run_layer8(Ring& rg, const uint8_t* stream, uint
 }
 
 
-constexpr int ring_depth8(int W) { return W > 256 ? 6 : RING_D; }    // W = 512: the 54 KB table leaves room for 6 slots
+constexpr int ring_depth8(int W) { return W > 256 ? 5 : RING_D; }    // W = 512: the 72 KB of tables leave room for 5 slots
 
 template <int PROG, int W, int VARIANT>
 __global__ __launch_bounds__(256, 1) void mlp_i8_kernel(const MlpArgs A) {
@@ -235,12 +246,16 @@ __global__ __launch_bounds__(256, 1) void mlp_i8_kernel(const MlpArgs A) {
 #define LAYER(L, NBv, K0, K1, SINv, IN0, IN1, OUT, RAW)                                                                 \
     run_layer8<NBv, K0, K1, SINv, D>(rg, A.stream, A.stream_bytes, lds, tab_lds + prog_table_start(PROG_GROUP, W, C_MAX, L), \
                                      IN0, IN1, OUT, RAW, wave, lane)
+#define LAYER_RAW(L, NBv, K0, K1, IN0, IN1, OUT, RX)                                                                    \
+    run_layer8<NBv, K0, K1, true, D, -1, -1, false, true>(rg, A.stream, A.stream_bytes, lds,                             \
+        tab_lds + prog_table_start(PROG_GROUP, W, C_MAX, L), IN0, IN1, OUT, nullptr, wave, lane, RX)
             const float t0 = A.time[nc * 4], t1 = A.time[nc * 4 + 1];
             const float s0 = A.sun[nc * 3], s1 = A.sun[nc * 3 + 1], s2 = A.sun[nc * 3 + 2];
             Frag8 pt[PETIME_KS8];
             make_pe_time8(t0, t1, h, pt);
             Frag8 hA[KW], hB[KW];
-            LAYER(G_T1, W / 32, PETIME_KS8, 0, true, pt, nullptr, hA, nullptr);
+            const float rx_t[3] = {t0, t1, 0.f}, rx_s[3] = {s0, s1, s2};
+            LAYER_RAW(G_T1, W / 32, PETIME_KS8, 0, pt, nullptr, hA, rx_t);
             LAYER(G_T2, W / 32, KW, 0, true, hA, nullptr, hB, nullptr);
             LAYER(G_CL, 1, KW, 0, false, hB, nullptr, nullptr, &raw);
             float logit[C_MAX];
@@ -249,9 +264,10 @@ __global__ __launch_bounds__(256, 1) void mlp_i8_kernel(const MlpArgs A) {
             Frag8 ps[PESUN_KS8];
             make_pe_sun8(s0, s1, s2, h, ps);
             Frag8 kA[KW4];
-            LAYER(G_K1, W4P / 32, PESUN_KS8, 0, true, ps, nullptr, kA, nullptr);
+            LAYER_RAW(G_K1, W4P / 32, PESUN_KS8, 0, ps, nullptr, kA, rx_s);
             LAYER(G_K2, 1, KW4, 0, false, kA, nullptr, nullptr, &raw);
 #undef LAYER
+#undef LAYER_RAW
             if (h == 0 && valid) {
                 float m = -3.0e38f;
 #pragma unroll
@@ -309,12 +325,16 @@ __global__ __launch_bounds__(256, 1) void mlp_i8_kernel(const MlpArgs A) {
 #define LAYER(L, NBv, K0, K1, SINv, IN0, IN0AG, IN1, OUT, OUTAG, RAW)                                                      \
     run_layer8<NBv, K0, K1, SINv, D, AG ? IN0AG : -1, AG ? OUTAG : -1, AG>(rg, A.stream, A.stream_bytes, lds,                \
         tab_lds + prog_table_start(PROG_FIELD, W, C_MAX, L), IN0, IN1, OUT, RAW, wave, lane)
+#define LAYER_RAW(L, NBv, K0, K1, IN0, IN0AG, IN1, OUT, OUTAG, RX)                                                         \
+    run_layer8<NBv, K0, K1, true, D, AG ? IN0AG : -1, AG ? OUTAG : -1, AG, true>(rg, A.stream, A.stream_bytes, lds,          \
+        tab_lds + prog_table_start(PROG_FIELD, W, C_MAX, L), IN0, IN1, OUT, nullptr, wave, lane, RX)
+        const float rx_p[3] = {x0, x1, x2}, rx_s[3] = {s0, s1, s2};      // raw coordinates: fp32, no digit range
         // trunk (G_NeRF.py:80-91)
-        LAYER(F_FC1, W / 32, PEPOS_KS8, 0, true, pe, NOAG, nullptr, hA, xA, nullptr);
+        LAYER_RAW(F_FC1, W / 32, PEPOS_KS8, 0, pe, NOAG, nullptr, hA, xA, rx_p);
         LAYER(F_FC2, W / 32, KW, 0, true, hA, xA, nullptr, hB, xB, nullptr);
         LAYER(F_FC3, W / 32, KW, 0, true, hB, xB, nullptr, hA, xA, nullptr);
         LAYER(F_FC4, W / 32, KW, 0, true, hA, xA, nullptr, hB, xB, nullptr);
-        LAYER(F_FC5, W / 32, KW, PEPOS_KS8, true, hB, xB, pe, hA, xA, nullptr);
+        LAYER_RAW(F_FC5, W / 32, KW, PEPOS_KS8, hB, xB, pe, hA, xA, rx_p);
         LAYER(F_FC6, W / 32, KW, 0, true, hA, xA, nullptr, hB, xB, nullptr);
         LAYER(F_FC7, W / 32, KW, 0, true, hB, xB, nullptr, hA, xA, nullptr);
         LAYER(F_FC8, W / 32, KW, 0, true, hA, xA, nullptr, hB, xB, nullptr);
@@ -332,7 +352,7 @@ __global__ __launch_bounds__(256, 1) void mlp_i8_kernel(const MlpArgs A) {
             Frag8 ps[PESUN_KS8];
             make_pe_sun8(s0, s1, s2, h, ps);
             Frag8 sA[KW2], sB[KW2];
-            LAYER(F_S1, W2 / 32, KW2, PESUN_KS8, true, x1f, xX1, ps, sA, xSA, nullptr);
+            LAYER_RAW(F_S1, W2 / 32, KW2, PESUN_KS8, x1f, xX1, ps, sA, xSA, rx_s);
             LAYER(F_S2, W2 / 32, KW2, 0, true, sA, xSA, nullptr, sB, xSB, nullptr);
             LAYER(F_S3, W2 / 32, KW2, 0, true, sB, xSB, nullptr, sA, xSA, nullptr);
             LAYER(F_S4, 1, KW2, 0, false, sA, xSA, nullptr, nullptr, NOAG, &raw);
@@ -348,6 +368,7 @@ __global__ __launch_bounds__(256, 1) void mlp_i8_kernel(const MlpArgs A) {
             for (int i = 0; i < 3 * C_MAX; ++i) adj[i] = raw[i];
         }
 #undef LAYER
+#undef LAYER_RAW
         if (h == 0 && valid) store_field_outputs<VARIANT>(A.out, n, C, x0, x1, x2, col_r, col_g, col_b, rho_raw, sv_raw, adj, pcls);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup

@@ -89,10 +89,15 @@ __device__ __forceinline__ TabQ load_tab_quad(lds_cfloat* tab_l, int b, int h, i
 // One fused layer (see run_layer8 in kernels_i8.hip for the arithmetic).  Chunk boundaries of the read sequence are compile-time
 // positions; every layer starts on one.  The whole layer is ONE basic block for the compiler (no branch): with branches inside
 // it hipcc sinks every block's epilogue to the end of the layer and spills the accumulators meanwhile (measured, 2.4 KB scratch).
-template <int NB, int KS0, int KS1, bool SIN>
+//   RAWL: the layer reads an encoding; rawx = its three raw coordinates, added in fp32 (table behind the scale / bias table).
+template <int NB, int KS0, int KS1, bool SIN, bool RAWL = false>
 __device__ __forceinline__ void run_layer8x2(Ring2& rg, const uint8_t* stream, uint32_t stream_bytes, lds_char* lds, lds_cfloat* tab_l,
-                                             const Frag8* in0, const Frag8* in1, Frag8* out, f32x16* raw, int wave, int lane) {
+                                             const Frag8* in0, const Frag8* in1, Frag8* out, f32x16* raw, int wave, int lane,
+                                             const float* rawx = nullptr) {
     constexpr int KS = KS0 + KS1, NP = NB * KS;
+    lds_cfloat* raw_l = tab_l + 2 * 32 * NB;
+    typedef volatile const __attribute__((address_space(3))) f32x4 lds_vf32x4;
+    f32x4 rq[4][3];        // raw-coordinate weights of the previous block's quads (RAWL), requested with the table entries
     const int h = lane >> 5;
     i32x4 fT[PFX], fL[PFX];
 #define REQUEST(QN, SLOT)                                                                              \
@@ -117,10 +122,21 @@ __device__ __forceinline__ void run_layer8x2(Ring2& rg, const uint8_t* stream, u
     Acc8 acc;
     int m[16];
     TabQ tq[4];        // table entries of the previous block's quads: requested one k-step before their slice runs
+    auto load_rq = [&](int g, int b_of) {
+        if constexpr (RAWL) {
+            lds_vf32x4* tp = (lds_vf32x4*)(raw_l + ((b_of * 2 + h) * 4 + g) * 12);
+            rq[g][0] = tp[0]; rq[g][1] = tp[1]; rq[g][2] = tp[2];
+        }
+    };
     auto quad = [&](int g, int b_of, const TabQ& t) {       // epilogue of elements 4g .. 4g+3 of block b_of from m[]
         float v[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = __builtin_fmaf((float)m[4 * g + j], t.sc[j], t.bi[j]);
+        if constexpr (RAWL) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                v[j] = __builtin_fmaf(rq[g][0][j], rawx[0], __builtin_fmaf(rq[g][1][j], rawx[1], __builtin_fmaf(rq[g][2][j], rawx[2], v[j])));
+        }
         if (SIN) {
             int hi, lo;
             digits4(sin2pi(v[0]), sin2pi(v[1]), sin2pi(v[2]), sin2pi(v[3]), hi, lo);
@@ -136,6 +152,7 @@ __device__ __forceinline__ void run_layer8x2(Ring2& rg, const uint8_t* stream, u
     for (int b = 0; b < NB; ++b) {
         if (b > 0) {
             tq[0] = load_tab_quad(tab_l, b - 1, h, 0);
+            load_rq(0, b - 1);
 #pragma unroll
             for (int i = 0; i < 16; ++i) m[i] = (int)(((uint32_t)acc.M[i] << 8) + (uint32_t)acc.X[i]);
             asm volatile("" ::: "memory");
@@ -152,7 +169,7 @@ __device__ __forceinline__ void run_layer8x2(Ring2& rg, const uint8_t* stream, u
 #pragma unroll
                 for (int g = 1; g < 4; ++g) {
                     const int sg = (g * KS) / 4, lg = sg > 0 ? sg - 1 : 0;
-                    if (lg == s) tq[g] = load_tab_quad(tab_l, b - 1, h, g);
+                    if (lg == s) { tq[g] = load_tab_quad(tab_l, b - 1, h, g); load_rq(g, b - 1); }
                 }
             }
             mfma_i8x3(aT, aL, s < KS0 ? in0[s] : in1[s - KS0], acc);
@@ -162,6 +179,17 @@ __device__ __forceinline__ void run_layer8x2(Ring2& rg, const uint8_t* stream, u
                     if ((g * KS) / 4 == s) quad(g, b - 1, tq[g]);
             }
             asm volatile("" ::: "memory");          // table loads stay in their k-step (the optimiser would gather them up front)
+#ifdef SNERF_X2_GROUPS
+            // interleave inside the k-step: each MFMA followed by its share of the epilogue slice, so that two waves running in
+            // step still alternate on the matrix pipe instead of meeting in a VALU-only stretch
+#pragma unroll
+            for (int mm = 0; mm < 3; ++mm) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // DS read
+                __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);      // transcendental
+                __builtin_amdgcn_sched_group_barrier(0x002, SNERF_X2_GROUPS, 0);      // VALU
+            }
+#endif
             __builtin_amdgcn_sched_barrier(0);      // ... and so do requests, MFMAs and epilogue slices (register pressure)
         }
     }
@@ -172,6 +200,7 @@ __device__ __forceinline__ void run_layer8x2(Ring2& rg, const uint8_t* stream, u
     for (int g = 0; g < 4; ++g) {
         asm volatile("" ::: "memory");
         const TabQ t = load_tab_quad(tab_l, NB - 1, h, g);
+        load_rq(g, NB - 1);
         quad(g, NB - 1, t);
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
@@ -251,12 +280,16 @@ __global__ __launch_bounds__(64 * NW2, 1) void mlp_i8x2_kernel(const MlpArgs A) 
 #define LAYER(L, NBv, K0, K1, SINv, IN0, IN1, OUT, RAW)                                                                       \
     run_layer8x2<NBv, K0, K1, SINv>(rg, A.stream, A.stream_bytes, lds, tab_lds + prog_table_start(PROG_FIELD, W, C_MAX, L), IN0, IN1, \
                                     OUT, RAW, wave, lane)
+#define LAYER_RAW(L, NBv, K0, K1, IN0, IN1, OUT, RX)                                                                          \
+    run_layer8x2<NBv, K0, K1, true, true>(rg, A.stream, A.stream_bytes, lds, tab_lds + prog_table_start(PROG_FIELD, W, C_MAX, L), IN0, \
+                                          IN1, OUT, nullptr, wave, lane, RX)
+        const float rx_p[3] = {x0, x1, x2}, rx_s[3] = {s0, s1, s2};      // raw coordinates: fp32, no digit range
         // trunk (G_NeRF.py:80-91)
-        LAYER(F_FC1, W / 32, PEPOS_KS8, 0, true, pe, nullptr, hA, nullptr);
+        LAYER_RAW(F_FC1, W / 32, PEPOS_KS8, 0, pe, nullptr, hA, rx_p);
         LAYER(F_FC2, W / 32, KW, 0, true, hA, nullptr, hB, nullptr);
         LAYER(F_FC3, W / 32, KW, 0, true, hB, nullptr, hA, nullptr);
         LAYER(F_FC4, W / 32, KW, 0, true, hA, nullptr, hB, nullptr);
-        LAYER(F_FC5, W / 32, KW, PEPOS_KS8, true, hB, pe, hA, nullptr);
+        LAYER_RAW(F_FC5, W / 32, KW, PEPOS_KS8, hB, pe, hA, rx_p);
         LAYER(F_FC6, W / 32, KW, 0, true, hA, nullptr, hB, nullptr);
         LAYER(F_FC7, W / 32, KW, 0, true, hB, nullptr, hA, nullptr);
         LAYER(F_FC8, W / 32, KW, 0, true, hA, nullptr, hB, nullptr);
@@ -274,7 +307,7 @@ __global__ __launch_bounds__(64 * NW2, 1) void mlp_i8x2_kernel(const MlpArgs A) 
             Frag8 ps[PESUN_KS8];
             make_pe_sun8(s0, s1, s2, h, ps);
             Frag8 sA[KW2], sB[KW2];
-            LAYER(F_S1, W2 / 32, KW2, PESUN_KS8, true, x1f, ps, sA, nullptr);
+            LAYER_RAW(F_S1, W2 / 32, KW2, PESUN_KS8, x1f, ps, sA, rx_s);
             LAYER(F_S2, W2 / 32, KW2, 0, true, sA, nullptr, sB, nullptr);
             LAYER(F_S3, W2 / 32, KW2, 0, true, sB, nullptr, sA, nullptr);
             LAYER(F_S4, 1, KW2, 0, false, sA, nullptr, nullptr, &raw);
@@ -290,6 +323,7 @@ __global__ __launch_bounds__(64 * NW2, 1) void mlp_i8x2_kernel(const MlpArgs A) 
             for (int i = 0; i < 3 * C_MAX; ++i) adj[i] = raw[i];
         }
 #undef LAYER
+#undef LAYER_RAW
         if (h == 0 && valid) store_field_outputs<VARIANT>(A.out, n, C, x0, x1, x2, col_r, col_g, col_b, rho_raw, sv_raw, adj, pcls);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup

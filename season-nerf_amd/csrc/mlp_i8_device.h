@@ -55,13 +55,40 @@ __device__ __forceinline__ Tab8 load_tab(lds_cfloat* tab_l, int b, int h) {
     return t;
 }
 
+// fp32 weights of the raw coordinates (layers that read an encoding): table [quad][dim 0..2][4 elements] behind the layer's
+// scale / bias table (program.h prog_table_start); element i = 4 g + j
+struct Raw8 {
+    f32x16 w[3];
+};
+__device__ __forceinline__ Raw8 load_raw(lds_cfloat* raw_l, int b, int h) {
+    lds_cf32x4* tp = (lds_cf32x4*)(raw_l + (b * 2 + h) * 48);
+    Raw8 r;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const f32x4 t = tp[g * 3 + d];
+            r.w[d][4 * g] = t[0]; r.w[d][4 * g + 1] = t[1]; r.w[d][4 * g + 2] = t[2]; r.w[d][4 * g + 3] = t[3];
+        }
+    return r;
+}
+__device__ __forceinline__ float add_raw(float z, const Raw8& r, int i, const float* x) {
+    return __builtin_fmaf(r.w[0][i], x[0], __builtin_fmaf(r.w[1][i], x[1], __builtin_fmaf(r.w[2][i], x[2], z)));
+}
+
 // pre-activation (revolutions for sine layers) of accumulator element i
 __device__ __forceinline__ float preact(const Acc8& acc, const Tab8& t, int i) {
     const int m = (int)(((uint32_t)acc.M[i] << 8) + (uint32_t)acc.X[i]);
     return __builtin_fmaf((float)m, t.sc[i], t.bi[i]);
 }
 // epilogue pieces of a 32x32 block: A(e) = elements 2e, 2e+1 through the sine; Q(g) = digits of elements 4g..4g+3
-__device__ __forceinline__ void epi_A(const Acc8& acc, const Tab8& t, int e, float* ev) {
+template <bool RAW = false>
+__device__ __forceinline__ void epi_A(const Acc8& acc, const Tab8& t, int e, float* ev, const Raw8* rw = nullptr, const float* rx = nullptr) {
+    if constexpr (RAW) {
+        ev[2 * e] = sin2pi(add_raw(preact(acc, t, 2 * e), *rw, 2 * e, rx));
+        ev[2 * e + 1] = sin2pi(add_raw(preact(acc, t, 2 * e + 1), *rw, 2 * e + 1, rx));
+        return;
+    }
 #if defined(SNERF_ABLATE) && (ABL & 8)      // timing-only: no transcendental; 2 fract(z) - 1 keeps the data as random as sin does
     ev[2 * e] = __builtin_fmaf(__builtin_amdgcn_fractf(preact(acc, t, 2 * e)), 2.f, -1.f);
     ev[2 * e + 1] = __builtin_fmaf(__builtin_amdgcn_fractf(preact(acc, t, 2 * e + 1)), 2.f, -1.f);

@@ -193,7 +193,8 @@ bool pack_program(const Weights& w, int prog, int W, int C, bool fold_bn, Packed
 // T = floor((wq + 128) / 256), L = wq - 256 T, both in [-128,127].  The activations arrive as q = 256 a + b + 128
 // (q = round(32767 h)), so  sum_k w_k h_k  ~  s_n / 32767 * (256 (256 M + X) + 128 sum_k wq_k),  M = sum T a,
 // X = sum (T b + L a)  (the L b term, <= 2^-16 of full scale, is dropped).  Table per row: scale 256 s_n / 32767 and
-// bias b_n + 128 s_n sum_k wq_k / 32767.
+// bias b_n + 128 s_n sum_k wq_k / 32767.  The raw coordinates of an encoding stay out of the digits (program.h): their
+// weights go to the layer's fp32 raw table and do not take part in the row scale.
 bool pack_program_i8(const Weights& w, int prog, int W, int C, bool fold_bn, Packed* out, std::string* err) {
     if (W < 64 || W % 64 != 0) { *err = "layer width must be a multiple of 64 (got " + std::to_string(W) + ")"; return false; }
     if (C < 1 || C > kMaxClasses) { *err = "n_classes must be in [1," + std::to_string(kMaxClasses) + "]"; return false; }
@@ -212,6 +213,9 @@ bool pack_program_i8(const Weights& w, int prog, int W, int C, bool fold_bn, Pac
             else { const int f = slot_feature8(s.kind1, ks - s.ks0, h, j); if (f >= 0) col = f0 + f; }
             return (col >= 0 && col < d.k) ? col : -1;
         };
+        // columns of the raw coordinates (fp32 path): none of the digit slots maps to them
+        const int rk = raw_kind(s), rdims = raw_dims(rk), rbase = (rk != IN_NONE && rk == s.kind1 && rk != s.kind0) ? f0 : 0;
+        auto is_raw_col = [&](int c) { return rk != IN_NONE && c >= rbase && c < rbase + rdims; };
         // quantise every padded output row
         const int n_pad = s.n_out;
         std::vector<double> scale(n_pad, 0.0);
@@ -221,7 +225,7 @@ bool pack_program_i8(const Weights& w, int prog, int W, int C, bool fold_bn, Pac
             const int rr = ref_row(s, n);
             if (rr < 0) continue;
             double mx = 0.0;
-            for (int c = 0; c < d.k; ++c) mx = std::fmax(mx, std::fabs(d.W[(size_t)rr * d.k + c]));
+            for (int c = 0; c < d.k; ++c) if (!is_raw_col(c)) mx = std::fmax(mx, std::fabs(d.W[(size_t)rr * d.k + c]));
             const double sn = mx > 0.0 ? mx / 32512.0 : 1.0;
             scale[n] = sn;
             for (int c = 0; c < d.k; ++c) wq[(size_t)n * d.k + c] = (int)std::llround(d.W[(size_t)rr * d.k + c] / sn);
@@ -252,6 +256,17 @@ bool pack_program_i8(const Weights& w, int prog, int W, int C, bool fold_bn, Pac
                     t[i] = rr >= 0 ? (float)(256.0 * scale[n] / 32767.0) : 0.f;
                     t[16 + i] = rr >= 0 ? (float)(d.b[rr] + 128.0 * scale[n] * (double)wsum[n] / 32767.0) : 0.f;
                 }
+        if (rk != IN_NONE) {      // fp32 weights of the raw coordinates: [block][lane-half][quad][dim][4 elements]
+            float* rt = tab + 2 * s.n_out;
+            for (int b = 0; b < s.nb(); ++b)
+                for (int h = 0; h < 2; ++h)
+                    for (int i = 0; i < 16; ++i) {
+                        const int n = 32 * b + acc_row(i, h), rr = ref_row(s, n);
+                        for (int dd = 0; dd < 3; ++dd)
+                            rt[(((b * 2 + h) * 4 + i / 4) * 3 + dd) * 4 + i % 4] =
+                                (rr >= 0 && dd < rdims && rbase + dd < d.k) ? (float)d.W[(size_t)rr * d.k + rbase + dd] : 0.f;
+                    }
+        }
     }
     return true;
 }

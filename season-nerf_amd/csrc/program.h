@@ -122,9 +122,22 @@ __host__ __device__ constexpr int prog_bias_start(int prog, int W, int C, int l)
 }
 __host__ __device__ constexpr int prog_chunks(int prog, int W, int C, int fmt = FMT_BF16) { return prog_chunk_start(prog, W, C, prog_layers(prog), fmt); }
 __host__ __device__ constexpr int prog_bias_floats(int prog, int W, int C) { return prog_bias_start(prog, W, C, prog_layers(prog)); }
-// int8 format: per output row a scale and a bias, stored [block][lane-half][16 scales | 16 biases] = 2 floats per row
-__host__ __device__ constexpr int prog_table_start(int prog, int W, int C, int l) { return 2 * prog_bias_start(prog, W, C, l); }
-__host__ __device__ constexpr int prog_table_floats(int prog, int W, int C) { return 2 * prog_bias_floats(prog, W, C); }
+// int8 format: per output row a scale and a bias, stored [block][lane-half][16 scales | 16 biases] = 2 floats per row.
+// Layers that read an encoding take its RAW coordinates (x, y, z of the point / the sun vector; t of the time code) not as
+// digits but in fp32 - three FMAs per element in the epilogue - so that the int8 mode has no input range: the digit slots of
+// the raw features carry zero weights, and a second table [block][lane-half][quad][dim 0..2][4 elements] = 3 floats per row
+// follows the layer's scale / bias table.
+__host__ __device__ constexpr int raw_kind(const LayerShape& s) {
+    return (s.kind0 == IN_PEPOS || s.kind0 == IN_PESUN || s.kind0 == IN_PETIME) ? s.kind0
+         : (s.kind1 == IN_PEPOS || s.kind1 == IN_PESUN || s.kind1 == IN_PETIME) ? s.kind1 : (int)IN_NONE;
+}
+__host__ __device__ constexpr int layer_table_floats(const LayerShape& s) { return (raw_kind(s) != IN_NONE ? 5 : 2) * s.n_out; }
+__host__ __device__ constexpr int prog_table_start(int prog, int W, int C, int l) {
+    int c = 0;
+    for (int i = 0; i < l; ++i) c += layer_table_floats(prog_layer(prog, W, C, i, FMT_I8));
+    return c;
+}
+__host__ __device__ constexpr int prog_table_floats(int prog, int W, int C) { return prog_table_start(prog, W, C, prog_layers(prog)); }
 
 // accumulator register i of lane-half h  <->  row of the 32-row output block
 __host__ __device__ constexpr int acc_row(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
@@ -165,10 +178,14 @@ __host__ __device__ constexpr int slot_feature(int kind, int kk) {
     return kind == IN_H ? slot_feature_H(kk) : kind == IN_PEPOS ? slot_feature_PEPOS(kk)
          : kind == IN_PESUN ? slot_feature_PESUN(kk) : kind == IN_PETIME ? slot_feature_PETIME(kk) : -1;
 }
-// int8 format: k-step s, lane-half h, byte j (v index e = 16 s + j); a hidden k-step is one output block of the producer
+// int8 format: k-step s, lane-half h, byte j (v index e = 16 s + j); a hidden k-step is one output block of the producer.
+// The raw coordinates of an encoding (reference features 0..2 of PE(pos) / PE(sun), 0..1 of PE(time)) have no digit slot
+// (-1: zero weight): they enter in fp32, see prog_table_start.
+__host__ __device__ constexpr int raw_dims(int kind) { return kind == IN_PETIME ? 2 : (kind == IN_PEPOS || kind == IN_PESUN) ? 3 : 0; }
 __host__ __device__ constexpr int slot_feature8(int kind, int s, int h, int j) {
-    return kind == IN_H ? 32 * s + acc_row(j, h) : kind == IN_PEPOS ? pepos_feature(16 * s + j, h)
-         : kind == IN_PESUN ? (s == 0 ? pesun_feature(j, h) : -1) : kind == IN_PETIME ? (s == 0 ? petime_feature(j, h) : -1) : -1;
+    const int f = kind == IN_H ? 32 * s + acc_row(j, h) : kind == IN_PEPOS ? pepos_feature(16 * s + j, h)
+                : kind == IN_PESUN ? (s == 0 ? pesun_feature(j, h) : -1) : kind == IN_PETIME ? (s == 0 ? petime_feature(j, h) : -1) : -1;
+    return (kind != IN_H && f >= 0 && f < raw_dims(kind)) ? -1 : f;
 }
 __host__ __device__ constexpr int kind_features(int kind, int ks, int fmt = FMT_BF16) {
     return kind == IN_H ? fmt_kstep(fmt) * ks : kind == IN_PEPOS ? PE_POS_F : kind == IN_PESUN ? PE_SUN_F

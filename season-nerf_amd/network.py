@@ -88,7 +88,7 @@ class T_NeRF(nn.Module):
         self._sig = None
         self._op_model = None
         # arithmetic of the fused eval-mode field kernel (include/season_nerf_hip.h SNERF_PREC_*): "bf16x3" (parity
-        # default), "i8x3" (16-bit fixed point on the int8 matrix pipe: RGB ~2e-5, inputs in [-1,1]), "bf16" (fast, 2-3e-3)
+        # default), "i8x3" (16-bit fixed point on the int8 matrix pipe: RGB ~2e-5), "bf16" (fast, 2-3e-3)
         self.precision = "bf16x3"
 
     @property

@@ -276,8 +276,9 @@ class Decoder8:
         assert lib.snerf_model_pack_host(model, 2, self.stream.ctypes.data, C.byref(ns), self.tab.ctypes.data, C.byref(nb)) == 0
         self.chunk, self.toff = 0, 0
 
-    def layer(self, n_out, ks):
-        """digit matrices T, L [n_out, 32*ks] in slot order (slot = 32 s + 16 h + j) and per-row scale / bias"""
+    def layer(self, n_out, ks, raw=False):
+        """digit matrices T, L [n_out, 32*ks] in slot order (slot = 32 s + 16 h + j), per-row scale / bias, and - for layers
+        that read an encoding (raw=True) - the fp32 weights [n_out, 3] of its raw coordinates"""
         nbk = n_out // 32
         base = self.chunk * 16384
         T = np.zeros((n_out, 32 * ks), dtype=np.int64)
@@ -299,7 +300,16 @@ class Decoder8:
                     bi[32 * b + acc_row(i, h)] = self.tab[self.toff + (b * 2 + h) * 32 + 16 + i]
         self.chunk += (nbk * ks + 7) // 8
         self.toff += 2 * n_out
-        return T, Lo, sc, bi
+        Wraw = None
+        if raw:                                    # [block][lane-half][quad][dim][4 elements]
+            Wraw = np.zeros((n_out, 3))
+            for b in range(nbk):
+                for h in range(2):
+                    for i in range(16):
+                        for dd in range(3):
+                            Wraw[32 * b + acc_row(i, h), dd] = self.tab[self.toff + (((b * 2 + h) * 4 + i // 4) * 3 + dd) * 4 + i % 4]
+            self.toff += 3 * n_out
+        return T, Lo, sc, bi, Wraw
 
 
 def gather8(feat, slot_fn, ks):
@@ -313,7 +323,7 @@ def gather8(feat, slot_fn, ks):
     return out
 
 
-def layer8(x_slots, T, Lo, sc, bi):
+def layer8(x_slots, T, Lo, sc, bi, Wraw=None, raw=None):
     q = np.rint(np.clip(x_slots, -1, 1) * 32767).astype(np.int64)
     a = q >> 8
     b = (q & 255) - 128
@@ -321,7 +331,11 @@ def layer8(x_slots, T, Lo, sc, bi):
     X = b @ T.T + a @ Lo.T
     acc = 256 * M + X
     assert np.abs(acc).max() < 2 ** 31
-    return acc.astype(np.float64) * sc + bi
+    z = acc.astype(np.float64) * sc + bi
+    if Wraw is not None:
+        assert raw is not None
+        z = z + raw @ Wraw.T                       # the raw coordinates enter in fp32, whatever their range
+    return z
 
 
 @pytest.mark.parametrize("W", [64, 256])
@@ -339,7 +353,7 @@ def test_packed_int8_stream_reproduces_the_network(lib, W):
             assert lib.snerf_model_set_tensor(m, k.encode(), arr.ctypes.data, arr.size) == 0
     rng = np.random.Generator(np.random.PCG64(3))
     N = 48
-    X = torch.tensor(rng.uniform(-1, 1, (N, 3)))
+    X = torch.tensor(rng.uniform(-1.7, 1.7, (N, 3)))        # beyond the cube: the raw coordinates must not saturate
     sun = rng.uniform(0, 1, (N, 3)); sun /= np.linalg.norm(sun, axis=1, keepdims=True)
     sun = torch.tensor(sun)
     tim = torch.tensor(rng.uniform(-1, 1, (N, 4)))
@@ -351,17 +365,18 @@ def test_packed_int8_stream_reproduces_the_network(lib, W):
     act = lambda z: np.sin(2 * np.pi * z)
     W2 = W // 2
     D = Decoder8(lib, m)
-    P = gather8(pe_pos, slot8_pepos, 2)
-    h = act(layer8(P, *D.layer(W, 2)))
+    Xn, Sn = X.numpy(), sun.numpy()
+    P = gather8(pe_pos, slot8_pepos, 2)                      # the raw slots gather the (possibly out-of-range) coordinates, on zero weights
+    h = act(layer8(P, *D.layer(W, 2, raw=True), raw=Xn))
     for _ in range(3):
         h = act(layer8(gather8(h, slot8_H, W // 32), *D.layer(W, W // 32)))
-    h = act(layer8(np.concatenate([gather8(h, slot8_H, W // 32), P], 1), *D.layer(W, W // 32 + 2)))
+    h = act(layer8(np.concatenate([gather8(h, slot8_H, W // 32), P], 1), *D.layer(W, W // 32 + 2, raw=True), raw=Xn))
     for _ in range(3):
         h = act(layer8(gather8(h, slot8_H, W // 32), *D.layer(W, W // 32)))
     x1 = act(layer8(gather8(h, slot8_H, W // 32), *D.layer(W2, W // 32)))
     head = layer8(gather8(x1, slot8_H, W2 // 32), *D.layer(32, W2 // 32))
     S_ = gather8(pe_sun, slot8_pesun, 1)
-    a = act(layer8(np.concatenate([gather8(x1, slot8_H, W2 // 32), S_], 1), *D.layer(W2, W2 // 32 + 1)))
+    a = act(layer8(np.concatenate([gather8(x1, slot8_H, W2 // 32), S_], 1), *D.layer(W2, W2 // 32 + 1, raw=True), raw=Sn))
     for _ in range(2):
         a = act(layer8(gather8(a, slot8_H, W2 // 32), *D.layer(W2, W2 // 32)))
     sv = layer8(gather8(a, slot8_H, W2 // 32), *D.layer(32, W2 // 32))

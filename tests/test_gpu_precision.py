@@ -146,3 +146,28 @@ def test_int8_mode_over_many_tiles(W):
     d_col = (outs["i8x3"][2] - outs["bf16x3"][2]).abs().max().item()
     print(f"  W={W}: i8x3 vs bf16x3 over {R * S} points: rho rel {d_rho:.2e}, solar_vis abs {d_sv:.2e}, col abs {d_col:.2e}")
     assert d_rho < 5e-4 and d_sv < 3e-4 and d_col < 3e-4, (d_rho, d_sv, d_col)
+
+
+@pytest.mark.parametrize("W", [256, 512])
+def test_int8_mode_has_no_input_range(W):
+    """Points outside the scene cube (the sun rays of eval_Rho_Only leave it; T_NeRF.forward takes any X): the digit operands
+    are sines / cosines and hidden activations, the raw coordinates enter in fp32 - nothing saturates."""
+    rng = np.random.Generator(np.random.PCG64(9))
+    N = 3000
+    X = T(rng.uniform(-2.5, 2.5, (N, 3))).cuda()
+    sun = T(rng.uniform(-3, 3, (N, 3))).cuda()                # not even unit vectors
+    tim = T(rng.uniform(-2, 2, (N, 4))).cuda()
+    ref = make_net(W, 4, 4, "i8x3")                            # int8 digits
+    if W <= 256:
+        hi = make_net(W, 4, 4, "bf16x3")
+        a, b = ref.forward_seperate(X, sun, tim), hi.forward_seperate(X, sun, tim)
+    else:                                                      # no bf16 kernel at 512: the layer-wise engine (fp32 storage)
+        hi = make_net(W, 4, 4, "bf16x3")
+        assert not hi.fused
+        a, b = ref.forward_seperate(X, sun, tim), hi.forward_seperate(X, sun, tim)
+    names = ["Rho", "Col_raw", "Solar_Vis", "Sky_Col", "Class", "Adjust"]
+    for k, u, v in zip(names, a, b):
+        d = (u - v).abs().max().item()
+        r = ((u - v).abs() / v.abs().clamp_min(1e-2)).max().item()
+        print(f"  W={W} {k:10s} i8x3 vs reference arithmetic on out-of-cube inputs: max abs {d:.2e} max rel {r:.2e}")
+        assert d < 5e-4 or r < 1e-3, (k, d, r)
