@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of build-time variants of the field kernel in one process-per-variant run (bench.py, same box).
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT (the repo root on the GPU box)}"
 D="season-nerf_amd"
 i=0
 for flags in "$@"; do

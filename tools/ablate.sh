@@ -1,7 +1,7 @@
 #!/bin/bash
 # Timing-only ablations of the fused field kernel (outputs of ablated builds are garbage by construction).
 # Separate libraries under /tmp selected with SNERF_LIB; the shipped .so is never touched.
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT (the repo root on the GPU box)}"
 D="season-nerf_amd"
 for abl in 0 1 2 4 3 7; do
   hipcc -std=c++17 -O3 --offload-arch=gfx950 -fPIC -shared -ffp-contract=off -DSNERF_ABLATE -DABL=$abl -Wno-unused-command-line-argument \

@@ -1,6 +1,6 @@
 #!/bin/bash
 # run the network parity test against several build variants (SNERF_LIB)
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT (the repo root on the GPU box)}"
 D="season-nerf_amd"
 i=0
 for flags in "$@"; do

@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage: tools/pmc.sh TAG "CTR1 CTR2 ..." ["CTR..." ...]   - one rocprofv3 --pmc pass per counter set (bench.py, 5 steps)
-cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT (the repo root on the GPU box)}"
 tag=$1; shift
 i=0
 for set in "$@"; do

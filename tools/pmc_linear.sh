@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage (GPU box): tools/pmc_linear.sh "COUNTERS" [plain|aol]  - SQ counters of the forward row GEMM (tools/bench_linear_fwd.py)
-cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT (the repo root on the GPU box)}"
 mode=${2:-plain}
 rocprofv3 --pmc $1 --output-format csv -d gpurun_out/pl_$mode -- python3 tools/bench_linear_fwd.py $mode > /dev/null 2>&1
 f=$(find gpurun_out/pl_$mode -name "*counter_collection.csv" | head -1)

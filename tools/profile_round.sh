@@ -3,7 +3,7 @@
 # Collects everything profiles/ needs for one build: bench lines (render + train), rocprofv3 kernel stats of the same
 # commands, and the HBM traffic PMC passes (FETCH_SIZE / WRITE_SIZE in separate runs, no tracing flags beside --pmc).
 tag=${1:-x}
-cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT (the repo root on the GPU box)}"
 out=gpurun_out/round_$tag; mkdir -p $out
 python3 bench.py > $out/bench.json 2> $out/bench.err
 python3 bench.py --workload train > $out/train_bench.json 2> $out/train_bench.err

@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage (GPU box): tools/trace_gaps.sh  - kernel trace of the training bench: busy time vs span of the timed steps, gap histogram
-cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT (the repo root on the GPU box)}"
 out=gpurun_out/gaps; rm -rf $out; mkdir -p $out
 rocprofv3 --kernel-trace --output-format csv -d $out/tr -- python3 bench.py --workload train --steps 4 --warmup 2 --no-cpu-baseline > $out/log 2>&1
 f=$(find $out/tr -name "*kernel_trace.csv" | head -1)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage (GPU box, repo root): tools/train_pmc.sh TAG "COUNTERS..."  - SQ counters of the training step's kernels (mean per launch)
 tag=${1:-x}; shift
-cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT (the repo root on the GPU box)}"
 out=gpurun_out/trainpmc_$tag; mkdir -p $out
 rocprofv3 --pmc $@ --output-format csv -d $out/pmc -- python3 bench.py --workload train --steps 2 --warmup 1 --no-cpu-baseline > $out/pmc.log 2>&1
 f=$(find $out/pmc -name "*counter_collection.csv" | head -1)

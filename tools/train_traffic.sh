@@ -3,7 +3,7 @@
 # HBM traffic of the whole training step (BASELINE configs[2]) from the PMC counters: FETCH_SIZE and WRITE_SIZE in separate
 # passes (no tracing flags beside --pmc), summed per kernel over the step, divided by the number of steps profiled.
 tag=${1:-x}
-cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT (the repo root on the GPU box)}"
 out=gpurun_out/traffic_$tag; mkdir -p $out
 STEPS=3; WARM=1
 for c in FETCH_SIZE WRITE_SIZE; do
