@@ -422,11 +422,17 @@ int snerf_field_kernel_info(const snerf_model* m, int64_t n_points, int* grid, i
     if (!m) return fail(SNERF_E_INVALID, "NULL model");
     int rc = pack_both(const_cast<snerf_model*>(m));
     if (rc) return rc;
-    const int64_t tiles = (n_points + mlp_tile_points() - 1) / mlp_tile_points();
+    const bool i8 = m->precision == SNERF_PREC_I8X3;
+    const bool two_waves = i8 && m->W <= 256;                 // kernels_i8x2.hip: 512 threads, 256 points per tile
+    const int tile = two_waves ? 256 : mlp_tile_points();
+    const int64_t tiles = (n_points + tile - 1) / tile;
     const int ncu = m->n_cu ? m->n_cu : 256;
     if (grid) *grid = (int)(tiles < ncu ? tiles : ncu);
-    if (block) *block = 256;
-    if (lds_bytes) *lds_bytes = mlp_lds_bytes((int)m->host[PROG_FIELD].bias.size());   // bf16 kernels
+    if (block) *block = two_waves ? 512 : 256;
+    if (lds_bytes) {
+        if (i8) *lds_bytes = (m->W > 256 ? 5 : 7) * kChunkBytes + (int)m->host_i8.bias.size() * 4;
+        else *lds_bytes = mlp_lds_bytes((int)m->host[PROG_FIELD].bias.size());
+    }
     return SNERF_OK;
 }
 
