@@ -3,7 +3,7 @@
 This file is a from-scratch restatement (torch-CPU, fp32 or fp64) of the algorithm the
 reference implements in PyTorch.  Only `tests/`, `__graft_entry__.smoke()` and the
 `cpu_baseline` leg of `bench.py` may import it, and only as the checker / the reported
-CPU baseline.  The product path (`season-nerf_amd/`) never imports it.
+CPU baseline.  The product path (`season_nerf_amd/`) never imports it.
 
 Parity status: PINNED.  Every function below is checked against golden vectors produced by
 importing the reference itself in the build container (`tools/make_golden.py` ->

@@ -34,7 +34,7 @@ def lib():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
-            f"season_nerf_amd: HIP library not built ({LIB_PATH} missing). Run `python season-nerf_amd/build.py` "
+            f"season_nerf_amd: HIP library not built ({LIB_PATH} missing). Run `python season_nerf_amd/build.py` "
             "(needs hipcc, gfx950). There is no CPU fallback.")
     L = C.CDLL(LIB_PATH)
     vp, i64, i32 = C.c_void_p, C.c_int64, C.c_int

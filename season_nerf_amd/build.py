@@ -1,4 +1,4 @@
-"""Build the gfx950 shared library in-tree:  python season-nerf_amd/build.py  [--force]
+"""Build the gfx950 shared library in-tree:  python season_nerf_amd/build.py  [--force]
 
 Every source is compiled to its own object (in parallel, cached under build/obj by modification time of the source
 and of the headers) and linked into libseason_nerf_hip.so next to this file (git-ignored, but it travels to the

@@ -17,7 +17,7 @@ def load():
     if _loaded:
         return torch.ops.season_nerf
     if not os.path.exists(OPS_PATH):
-        raise RuntimeError(f"season_nerf_amd: custom-op library not built ({OPS_PATH} missing). Run `python season-nerf_amd/build.py`.")
+        raise RuntimeError(f"season_nerf_amd: custom-op library not built ({OPS_PATH} missing). Run `python season_nerf_amd/build.py`.")
     ctypes.CDLL(_lib.LIB_PATH, mode=ctypes.RTLD_GLOBAL)      # the C ABI the op layer links against
     torch.ops.load_library(OPS_PATH)
     _register_fakes()

@@ -16,7 +16,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.fixture(scope="session")
 def lib():
     import importlib.util
-    spec = importlib.util.spec_from_file_location("snerf_build", os.path.join(REPO, "season-nerf_amd", "build.py"))
+    spec = importlib.util.spec_from_file_location("snerf_build", os.path.join(REPO, "season_nerf_amd", "build.py"))
     b = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(b)
     b.build()                      # no-op when the .so is up to date (__graft_entry__.build() forces a full compile);

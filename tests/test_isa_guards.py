@@ -10,7 +10,7 @@ import subprocess
 import pytest
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(REPO, "season-nerf_amd", "csrc", "gemm.hip")
+SRC = os.path.join(REPO, "season_nerf_amd", "csrc", "gemm.hip")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 

@@ -13,7 +13,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _load_parallel():
-    spec = importlib.util.spec_from_file_location("snerf_parallel", os.path.join(REPO, "season-nerf_amd", "parallel.py"))
+    spec = importlib.util.spec_from_file_location("snerf_parallel", os.path.join(REPO, "season_nerf_amd", "parallel.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     return mod
@@ -134,8 +134,8 @@ def test_bench_self_launches_ranks():
 def _ada_worker(rank, world, port):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    spec = importlib.util.spec_from_file_location("season_nerf_amd", os.path.join(REPO, "season-nerf_amd", "__init__.py"),
-                                                  submodule_search_locations=[os.path.join(REPO, "season-nerf_amd")])
+    spec = importlib.util.spec_from_file_location("season_nerf_amd", os.path.join(REPO, "season_nerf_amd", "__init__.py"),
+                                                  submodule_search_locations=[os.path.join(REPO, "season_nerf_amd")])
     import sys
     pkg = importlib.util.module_from_spec(spec)
     sys.modules["season_nerf_amd"] = pkg

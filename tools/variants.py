@@ -4,7 +4,7 @@
     python tools/variants.py run [--precision i8x3] [--width 256]        # on the GPU box: one process per library
 
 Each variant = build/variants/lib_<name>.so: the named source compiled with the extra flags, linked with the other objects of
-the regular build (build/obj, made by season-nerf_amd/build.py)."""
+the regular build (build/obj, made by season_nerf_amd/build.py)."""
 import glob
 import os
 import subprocess
@@ -12,7 +12,7 @@ import sys
 from concurrent.futures import ThreadPoolExecutor
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(REPO, "season-nerf_amd"))
+sys.path.insert(0, os.path.join(REPO, "season_nerf_amd"))
 import build as B  # noqa: E402
 
 VAR = os.path.join(REPO, "build", "variants")
