@@ -294,6 +294,7 @@ def main():
                          "i8x3 = 16-bit fixed point on the int8 MFMA pipe (RGB ~1.5e-5 of the reference: inside the 1e-4 bar), "
                          "bf16x3 = 3-term split bf16 products (RGB ~3e-6), bf16 = fast mode, OUTSIDE the bar (RGB 1-3e-3); "
                          "the other modes are timed too and reported under `modes`")
+    ap.add_argument("--gather-group", type=int, default=8, help="N > 1: rendered RGB tiles of this many steps share one asynchronous all-gather")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true", help="skip the auxiliary 512x512 sweep measurement (counter passes)")
     ap.add_argument("--workload", default="render", choices=["render", "train"],
@@ -345,7 +346,7 @@ def main():
     cls, sky_raw, sky = e(R, NC), e(R, 3), e(R, 3)
     rho, sv, col = e(R * S), e(R * S), e(R * S, 3)
     # RGB tiles of 8 consecutive steps share one asynchronous all-gather on double-buffered tile groups (parallel.TileGroupGather)
-    tg = sn.parallel.TileGroupGather((R, 3), group=8, device=dev) if use_dist else None
+    tg = sn.parallel.TileGroupGather((R, 3), group=a.gather_group, device=dev) if use_dist else None
     rgb_local = e(R, 3)
     fo = sn._lib.FieldOut(d_rho=rho.data_ptr(), d_solar_vis=sv.data_ptr(), d_col=col.data_ptr())
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -492,7 +493,7 @@ def main():
             "dtype": DTYPES[a.precision], "precision": a.precision, "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: forward render 4096 rays x 96 samples, T_NeRF(256,4) eval-mode, "
                                    "random weights (reference init law), per-ray sun/time", "rays_per_gpu": R,
-                       "samples_per_ray": S, "parallelism": f"rays sharded over {world} GPU(s), RGB tiles all-gathered (8 steps per collective, asynchronous)"},
+                       "samples_per_ray": S, "parallelism": f"rays sharded over {world} GPU(s), RGB tiles all-gathered ({a.gather_group} steps per collective, asynchronous)"},
             "per_gpu_value": value / world,
             "image_512x512x96_ms_est": 512 * 512 * S / (value / world) * 1e3, **extra,
             "roofline": {"bound": "mfma", "achieved": achieved / 1e12, "peak": PEAK_BF16_DENSE / 1e12, "unit": "TFLOP/s",
