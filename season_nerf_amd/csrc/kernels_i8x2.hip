@@ -14,7 +14,9 @@
 //  waves of a SIMD run in step (the per-chunk barrier re-aligns all eight every block), so the pipe saturates while both are
 //  in their MFMA phase and idles while both run epilogues.  Tried against that, each without gain: waves 4-7 taking every
 //  barrier half a chunk later in their own stream (a protocol in which barrier m publishes chunk m + 1), s_setprio 2 / 3 for
-//  the MFMA phase, fragment prefetch depth 1 / 3.
+//  the MFMA phase, fragment prefetch depth 1 / 3, MFMA / VALU interleave pinned inside a k-step (sched_group_barrier, the
+//  SNERF_X2_GROUPS switch below), waves 4-7 running their epilogue slices in the odd k-steps and waves 0-3 in the even ones.
+//  So the two waves running in step is not what leaves the matrix pipe 40 % idle; the chip holds 1.8 GHz in this kernel.
 //  Weight stream, tables, digit formats, accuracy: exactly those of kernels_i8.hip (same packed model, bit-identical results).
 #include "mlp_i8_device.h"
 
