@@ -32,6 +32,18 @@ constexpr int RING2_D = 7;
 constexpr int PFX = SNERF_PFX;                                // weight-fragment pairs requested ahead of their MFMAs
 static_assert(PIECES2 == 2 && kChunkPairs == 8, "the DMA below moves two pieces per wave; barrier positions assume 8-pair chunks");
 
+#ifdef SNERF_STAMP
+// Diagnostic build only (tools/variants.py ... -DSNERF_STAMP): cycle stamps of workgroup 0, second tile: per layer the s_memtime
+// at entry, and per wave the cycles spent inside ring_step2 (vmcnt wait + barrier).  Read back with snerf_debug_stamps().
+__device__ unsigned long long g_stamps[8 * 64];
+__device__ __forceinline__ void stamp(int wave, int lane, int slot, bool on) {
+    if (on && lane == 0) g_stamps[wave * 64 + slot] = __builtin_amdgcn_s_memtime();
+}
+#define STAMP(slot) stamp(wave, lane, slot, stamp_on)
+#else
+#define STAMP(slot)
+#endif
+
 struct Ring2 {
     uint32_t wr;       // LDS offset of the slot the next DMA fills
     uint32_t goff;     // byte offset in the (cyclic) global stream of the next chunk to fetch
@@ -48,7 +60,16 @@ __device__ __forceinline__ void ring_step2(Ring2& rg, const uint8_t* stream, uin
 #if defined(SNERF_ABLATE) && (ABL & 4)     // timing-only: no ring at all
     return;
 #endif
+#ifdef SNERF_STAMP
+    const unsigned long long t0_ = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RING2_D - 3) * PIECES2) : "memory");
+    const unsigned long long t1_ = __builtin_amdgcn_s_memtime();
+    asm volatile("s_barrier" ::: "memory");
+    const unsigned long long t2_ = __builtin_amdgcn_s_memtime();
+    if (blockIdx.x == 0 && lane == 0) { g_stamps[wave * 64 + 62] += t1_ - t0_; g_stamps[wave * 64 + 63] += t2_ - t1_; }
+#else
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((RING2_D - 3) * PIECES2) : "memory");
+#endif
     dma_chunk2(stream, rg.goff, lds, rg.wr, wave, lane);
     rg.goff += kChunkBytes;
     if (rg.goff >= stream_bytes) rg.goff = 0;
@@ -92,7 +113,14 @@ __device__ __forceinline__ TabQ load_tab_quad(lds_cfloat* tab_l, int b, int h, i
 // positions; every layer starts on one.  The whole layer is ONE basic block for the compiler (no branch): with branches inside
 // it hipcc sinks every block's epilogue to the end of the layer and spills the accumulators meanwhile (measured, 2.4 KB scratch).
 //   RAWL: the layer reads an encoding; rawx = its three raw coordinates, added in fp32 (table behind the scale / bias table).
-template <int NB, int KS0, int KS1, bool SIN, bool RAWL = false>
+//   PHASE (0 / 1) = the wave group (waves 0-3 / 4-7: waves w and w + 4 share a SIMD).  The matrix pipe is arbitrated by age: left
+//   alone, the older wave of a SIMD takes every MFMA slot it wants, reaches the chunk barrier early and waits there for the
+//   younger one (in-kernel stamps, -DSNERF_STAMP: wave 0 spent 30 % of the launch inside s_barrier, wave 4 3 %).  So the
+//   priority alternates per k-step (s_setprio 3 in the k-steps of one's own parity, 0 in the others): wave 0's barrier time
+//   drops to 13 %, the kernel gains 2.5 %.  Tried on top without gain: the epilogue slices in the k-steps where a wave yields,
+//   biased levels ({0,2} against {1,3}: the younger wave then takes the older one's place), alternating the tie-break per
+//   k-step pair / per block (the two waves' barrier times even out, their sum and the kernel time do not change).
+template <int NB, int KS0, int KS1, bool SIN, bool RAWL = false, int PHASE = 0>
 __device__ __forceinline__ void run_layer8x2(Ring2& rg, const uint8_t* stream, uint32_t stream_bytes, lds_char* lds, lds_cfloat* tab_l,
                                              const Frag8* in0, const Frag8* in1, Frag8* out, f32x16* raw, int wave, int lane,
                                              const float* rawx = nullptr) {
@@ -166,6 +194,10 @@ __device__ __forceinline__ void run_layer8x2(Ring2& rg, const uint8_t* stream, u
         for (int s = 0; s < KS; ++s) {
             const int q = b * KS + s;
             const i32x4 aT = fT[q % PFX], aL = fL[q % PFX];
+#ifndef SNERF_X2_NOPRIO
+            // own parity: this wave's MFMAs first (it runs no epilogue slice in this k-step); else yield to the partner
+            if (((s + PHASE) & 1) == 0) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(3);
+#endif
             if (q + PFX < NP) REQUEST(q + PFX, q % PFX);
             if (b > 0) {
 #pragma unroll
@@ -211,6 +243,10 @@ __device__ __forceinline__ void run_layer8x2(Ring2& rg, const uint8_t* stream, u
 #undef REQUEST
 }
 
+template <int W, int VARIANT, int PHASE>
+__device__ __forceinline__ void field_tiles2(const MlpArgs& A, Ring2& rg, lds_char* lds, __attribute__((address_space(3))) float* tab_lds,
+                                             int wave, int lane);
+
 template <int W, int VARIANT>
 __global__ __launch_bounds__(64 * NW2, 1) void mlp_i8x2_kernel(const MlpArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -242,6 +278,19 @@ __global__ __launch_bounds__(64 * NW2, 1) void mlp_i8x2_kernel(const MlpArgs A) 
     }
     __syncthreads();   // table visible (drains the prologue DMAs once; harmless)
 
+    if (wave < 4) field_tiles2<W, VARIANT, 0>(A, rg, lds, tab_lds, wave, lane);
+    else field_tiles2<W, VARIANT, 1>(A, rg, lds, tab_lds, wave, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup
+}
+
+// the persistent tile loop of one wave group (PHASE: see run_layer8x2); the two groups run two copies of the code
+template <int W, int VARIANT, int PHASE>
+__device__ __forceinline__ void field_tiles2(const MlpArgs& A, Ring2& rg, lds_char* lds, __attribute__((address_space(3))) float* tab_lds,
+                                             int wave, int lane) {
+    constexpr int C_MAX = kMaxClasses;
+    constexpr int W2 = W / 2;
+    const int h = lane >> 5;
+    const int C = A.n_classes;
     const int64_t n_tiles = (A.n + TILE2 - 1) / TILE2;
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int64_t n = tile * TILE2 + wave * 32 + (lane & 31);
@@ -273,32 +322,37 @@ __global__ __launch_bounds__(64 * NW2, 1) void mlp_i8x2_kernel(const MlpArgs A) 
                 for (int c = 0; c < C_MAX; ++c) if (c < C) pcls[c] = A.classes[g * C + c];
             }
         }
+#ifdef SNERF_STAMP
+        const bool stamp_on = blockIdx.x == 0 && tile == (int64_t)blockIdx.x + gridDim.x;      // the workgroup's second tile
+#endif
+        STAMP(0);
         Frag8 pe[PEPOS_KS8];
         make_pe_pos8(x0, x1, x2, h, pe);
+        STAMP(1);
 
         constexpr int KW = W / 32, KW2 = W2 / 32;
         Frag8 hA[KW], hB[KW];
         f32x16 raw;
 #define LAYER(L, NBv, K0, K1, SINv, IN0, IN1, OUT, RAW)                                                                       \
-    run_layer8x2<NBv, K0, K1, SINv>(rg, A.stream, A.stream_bytes, lds, tab_lds + prog_table_start(PROG_FIELD, W, C_MAX, L), IN0, IN1, \
-                                    OUT, RAW, wave, lane)
+    run_layer8x2<NBv, K0, K1, SINv, false, PHASE>(rg, A.stream, A.stream_bytes, lds, tab_lds + prog_table_start(PROG_FIELD, W, C_MAX, L), \
+                                                  IN0, IN1, OUT, RAW, wave, lane)
 #define LAYER_RAW(L, NBv, K0, K1, IN0, IN1, OUT, RX)                                                                          \
-    run_layer8x2<NBv, K0, K1, true, true>(rg, A.stream, A.stream_bytes, lds, tab_lds + prog_table_start(PROG_FIELD, W, C_MAX, L), IN0, \
-                                          IN1, OUT, nullptr, wave, lane, RX)
+    run_layer8x2<NBv, K0, K1, true, true, PHASE>(rg, A.stream, A.stream_bytes, lds, tab_lds + prog_table_start(PROG_FIELD, W, C_MAX, L), \
+                                                 IN0, IN1, OUT, nullptr, wave, lane, RX)
         const float rx_p[3] = {x0, x1, x2}, rx_s[3] = {s0, s1, s2};      // raw coordinates: fp32, no digit range
         // trunk (G_NeRF.py:80-91)
-        LAYER_RAW(F_FC1, W / 32, PEPOS_KS8, 0, pe, nullptr, hA, rx_p);
-        LAYER(F_FC2, W / 32, KW, 0, true, hA, nullptr, hB, nullptr);
-        LAYER(F_FC3, W / 32, KW, 0, true, hB, nullptr, hA, nullptr);
-        LAYER(F_FC4, W / 32, KW, 0, true, hA, nullptr, hB, nullptr);
-        LAYER_RAW(F_FC5, W / 32, KW, PEPOS_KS8, hB, pe, hA, rx_p);
-        LAYER(F_FC6, W / 32, KW, 0, true, hA, nullptr, hB, nullptr);
-        LAYER(F_FC7, W / 32, KW, 0, true, hB, nullptr, hA, nullptr);
-        LAYER(F_FC8, W / 32, KW, 0, true, hA, nullptr, hB, nullptr);
+        LAYER_RAW(F_FC1, W / 32, PEPOS_KS8, 0, pe, nullptr, hA, rx_p); STAMP(2);
+        LAYER(F_FC2, W / 32, KW, 0, true, hA, nullptr, hB, nullptr); STAMP(3);
+        LAYER(F_FC3, W / 32, KW, 0, true, hB, nullptr, hA, nullptr); STAMP(4);
+        LAYER(F_FC4, W / 32, KW, 0, true, hA, nullptr, hB, nullptr); STAMP(5);
+        LAYER_RAW(F_FC5, W / 32, KW, PEPOS_KS8, hB, pe, hA, rx_p); STAMP(6);
+        LAYER(F_FC6, W / 32, KW, 0, true, hA, nullptr, hB, nullptr); STAMP(7);
+        LAYER(F_FC7, W / 32, KW, 0, true, hB, nullptr, hA, nullptr); STAMP(8);
+        LAYER(F_FC8, W / 32, KW, 0, true, hA, nullptr, hB, nullptr); STAMP(9);
         Frag8 x1f[KW2];
-        LAYER(F_FC9, W2 / 32, KW, 0, true, hB, nullptr, x1f, nullptr);
+        LAYER(F_FC9, W2 / 32, KW, 0, true, hB, nullptr, x1f, nullptr); STAMP(10);
         // sigma / colour head (G_NeRF.py:93-98): regs 0..2 colour, 3 density (lane-half 0)
-        LAYER(F_HEAD, 1, KW2, 0, false, x1f, nullptr, nullptr, &raw);
+        LAYER(F_HEAD, 1, KW2, 0, false, x1f, nullptr, nullptr, &raw); STAMP(11);
         const float col_r = raw[0], col_g = raw[1], col_b = raw[2], rho_raw = raw[3];
         float sv_raw = 0.f;
         float adj[3 * C_MAX];
@@ -309,26 +363,27 @@ __global__ __launch_bounds__(64 * NW2, 1) void mlp_i8x2_kernel(const MlpArgs A) 
             Frag8 ps[PESUN_KS8];
             make_pe_sun8(s0, s1, s2, h, ps);
             Frag8 sA[KW2], sB[KW2];
-            LAYER_RAW(F_S1, W2 / 32, KW2, PESUN_KS8, x1f, ps, sA, rx_s);
-            LAYER(F_S2, W2 / 32, KW2, 0, true, sA, nullptr, sB, nullptr);
-            LAYER(F_S3, W2 / 32, KW2, 0, true, sB, nullptr, sA, nullptr);
-            LAYER(F_S4, 1, KW2, 0, false, sA, nullptr, nullptr, &raw);
+            LAYER_RAW(F_S1, W2 / 32, KW2, PESUN_KS8, x1f, ps, sA, rx_s); STAMP(12);
+            LAYER(F_S2, W2 / 32, KW2, 0, true, sA, nullptr, sB, nullptr); STAMP(13);
+            LAYER(F_S3, W2 / 32, KW2, 0, true, sB, nullptr, sA, nullptr); STAMP(14);
+            LAYER(F_S4, 1, KW2, 0, false, sA, nullptr, nullptr, &raw); STAMP(15);
             sv_raw = raw[0];
         }
         if constexpr (VARIANT == 0) {
             // seasonal colour-adjust branch (T_NeRF_net_v2.py:83-87)
-            LAYER(F_A1, W / 32, KW2, 0, true, x1f, nullptr, hA, nullptr);
-            LAYER(F_A2, W / 32, KW, 0, true, hA, nullptr, hB, nullptr);
-            LAYER(F_A3, W / 32, KW, 0, true, hB, nullptr, hA, nullptr);
-            LAYER(F_AC, 1, KW, 0, false, hA, nullptr, nullptr, &raw);
+            LAYER(F_A1, W / 32, KW2, 0, true, x1f, nullptr, hA, nullptr); STAMP(16);
+            LAYER(F_A2, W / 32, KW, 0, true, hA, nullptr, hB, nullptr); STAMP(17);
+            LAYER(F_A3, W / 32, KW, 0, true, hB, nullptr, hA, nullptr); STAMP(18);
+            LAYER(F_AC, 1, KW, 0, false, hA, nullptr, nullptr, &raw); STAMP(19);
 #pragma unroll
             for (int i = 0; i < 3 * C_MAX; ++i) adj[i] = raw[i];
         }
 #undef LAYER
 #undef LAYER_RAW
         if (h == 0 && valid) store_field_outputs<VARIANT>(A.out, n, C, x0, x1, x2, col_r, col_g, col_b, rho_raw, sv_raw, adj, pcls);
+        STAMP(20);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup
+    __builtin_amdgcn_s_setprio(0);
 }
 
 template <int W, int VARIANT>
@@ -358,3 +413,13 @@ hipError_t launch_mlp_i8x2(int W, int variant, const MlpArgs& a, int n_cu, hipSt
 }
 
 }  // namespace snerf
+
+#ifdef SNERF_STAMP
+extern "C" int snerf_debug_stamps(unsigned long long* host, int n) {
+    if (n > 8 * 64) n = 8 * 64;
+    hipError_t e = hipMemcpyFromSymbol(host, HIP_SYMBOL(snerf::g_stamps), (size_t)n * 8);
+    unsigned long long zero[8 * 64] = {};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(snerf::g_stamps), zero, sizeof(zero));
+    return e == hipSuccess ? 0 : -3;
+}
+#endif

@@ -70,6 +70,18 @@ def main():
         torch.cuda.synchronize()
         d = ((r1 - rho).abs() / rho.abs().clamp_min(1e-3))
         chk = f"  vs bf16x3: rho max rel {d.max().item():.2e} (points > 1e-3: {(d > 1e-3).sum().item()}), col max abs {(c1 - col).abs().max().item():.2e}"
+    if hasattr(L, "snerf_debug_stamps"):          # diagnostic build (-DSNERF_STAMP): cycle stamps of workgroup 0, second tile
+        import ctypes
+        L.snerf_debug_stamps((ctypes.c_ulonglong * 512)(), 512)          # clear
+        run()
+        torch.cuda.synchronize()
+        buf = (ctypes.c_ulonglong * 512)()
+        L.snerf_debug_stamps(buf, 512)
+        names = ["tile start", "PE", "fc1", "fc2", "fc3", "fc4", "fc5", "fc6", "fc7", "fc8", "fc9", "head", "s1", "s2", "s3", "s4", "a1", "a2", "a3", "ac", "stores"]
+        for w in (0, 4):
+            st = [buf[w * 64 + i] for i in range(21)]
+            print(f"  wave {w}: tile {st[20] - st[0]} cycles; " + " ".join(f"{names[i]} {st[i] - st[i - 1]}" for i in range(1, 21)))
+            print(f"          inside ring steps over the whole launch (6 tiles): vmcnt wait {buf[w * 64 + 62]}, barrier wait {buf[w * 64 + 63]}")
     print(f"{a.tag or os.environ.get('SNERF_LIB', 'default'):40s} {a.precision} W={Wd}: mean {tot / 3:.4f} ms  best {best:.4f} ms{chk}", flush=True)
 
 
