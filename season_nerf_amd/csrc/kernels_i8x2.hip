@@ -54,10 +54,27 @@ __device__ __forceinline__ uint32_t ring2_next(uint32_t off) {
     return off == RING2_D * kChunkBytes ? 0u : off;
 }
 __device__ __forceinline__ void dma_chunk2(const uint8_t* stream, uint32_t goff, lds_char* lds, uint32_t wr, int wave, int lane);
+__device__ __forceinline__ void dma_chunk4(const uint8_t* stream, uint32_t goff, lds_char* lds, uint32_t wr, int wave, int lane);
+#ifndef SNERF_X2_ALL_LOAD
+#define SNERF_X2_OLD_LOADS 1      // waves 0-3 (which reach every barrier early, see run_layer8x2) move all sixteen pieces of a chunk
+#endif
 // Hand the next chunk to the consumers and refill the slot released two chunks ago (ring_step of mlp_device.h for eight waves):
 // vmcnt((D-3)*2): all but the (D-3) youngest chunks this wave fetched have landed => the chunk about to be read is complete.
+template <int PHASE>
 __device__ __forceinline__ void ring_step2(Ring2& rg, const uint8_t* stream, uint32_t stream_bytes, lds_char* lds, int wave, int lane) {
 #if defined(SNERF_ABLATE) && (ABL & 4)     // timing-only: no ring at all
+    return;
+#endif
+#if defined(SNERF_X2_OLD_LOADS) && !defined(SNERF_STAMP)
+    if (PHASE == 0) {
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((RING2_D - 3) * 4) : "memory");
+        dma_chunk4(stream, rg.goff, lds, rg.wr, wave, lane);
+    } else {
+        asm volatile("s_barrier" ::: "memory");      // the loading waves waited for their pieces before they arrived here
+    }
+    rg.goff += kChunkBytes;
+    if (rg.goff >= stream_bytes) rg.goff = 0;
+    rg.wr = ring2_next(rg.wr);
     return;
 #endif
 #ifdef SNERF_STAMP
@@ -92,6 +109,32 @@ __device__ __forceinline__ void dma_chunk2(const uint8_t* stream, uint32_t goff,
         "s_mov_b32 m0, %0"
         : "=&s"(keep)
         : "v"(voff), "s"(dst), "s"(b0), "s"(b0 + kFragBytes)
+        : "memory", "scc");
+}
+
+// wave w (0..3) moves pieces 4w .. 4w+3
+__device__ __forceinline__ void dma_chunk4(const uint8_t* stream, uint32_t goff, lds_char* lds, uint32_t wr, int wave, int lane) {
+    const uint8_t* b0 = stream + goff + wave * (4 * kFragBytes);
+    const uint32_t dst = (uint32_t)(uintptr_t)(lds + wr + wave * (4 * kFragBytes));
+    const uint32_t voff = lane * 16;
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %3\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %4\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %5\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %6\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(dst), "s"(b0), "s"(b0 + kFragBytes), "s"(b0 + 2 * kFragBytes), "s"(b0 + 3 * kFragBytes)
         : "memory", "scc");
 }
 
@@ -130,15 +173,26 @@ __device__ __forceinline__ void run_layer8x2(Ring2& rg, const uint8_t* stream, u
     f32x4 rq[4][3];        // raw-coordinate weights of the previous block's quads (RAWL), requested with the table entries
     const int h = lane >> 5;
     i32x4 fT[PFX], fL[PFX];
+#if defined(SNERF_ABLATE) && (ABL & 2)     // timing-only: weight fragments stay in registers, no LDS reads
+    constexpr bool ABL2_ = true;
+#pragma unroll
+    for (int q = 0; q < PFX; ++q) { fT[q] = i32x4{lane, 1, 2, 3}; fL[q] = i32x4{4, lane, 6, 7}; }
+#else
+    constexpr bool ABL2_ = false;
+#endif
 #define REQUEST(QN, SLOT)                                                                              \
     do {                                                                                               \
         if ((QN) % kChunkPairs == 0) {                                                                 \
-            ring_step2(rg, stream, stream_bytes, lds, wave, lane);                                     \
+            ring_step2<PHASE>(rg, stream, stream_bytes, lds, wave, lane);                                \
             if ((QN) > 0) rg.cur = ring2_next(rg.cur);                                                 \
         }                                                                                              \
         lds_char* ap_ = lds + rg.cur + ((QN) % kChunkPairs) * kPairBytes + lane * 16;                  \
-        fT[SLOT] = *(lds_ci32x4*)ap_;                                                                  \
-        fL[SLOT] = *(lds_ci32x4*)(ap_ + kFragBytes);                                                   \
+        if (!ABL2_) {                                                                                  \
+            fT[SLOT] = *(lds_ci32x4*)ap_;                                                              \
+            fL[SLOT] = *(lds_ci32x4*)(ap_ + kFragBytes);                                               \
+        } else {                                                                                       \
+            asm volatile("" : "+v"(fT[SLOT]), "+v"(fL[SLOT]));                                         \
+        }                                                                                              \
     } while (0)
 #pragma unroll
     for (int q = 0; q < PFX; ++q) {
@@ -269,7 +323,11 @@ __global__ __launch_bounds__(64 * NW2, 1) void mlp_i8x2_kernel(const MlpArgs A) 
         uint32_t wr = 0;
 #pragma unroll
         for (int c = 0; c < RING2_D - 2; ++c) {
+#if defined(SNERF_X2_OLD_LOADS) && !defined(SNERF_STAMP)
+            if (wave < 4) dma_chunk4(A.stream, rg.goff, lds, wr, wave, lane);
+#else
             dma_chunk2(A.stream, rg.goff, lds, wr, wave, lane);
+#endif
             rg.goff += kChunkBytes;
             if (rg.goff >= A.stream_bytes) rg.goff = 0;
             wr += kChunkBytes;
