@@ -98,41 +98,35 @@ class T_NeRF(nn.Module):
 
     # ------------------------------------------------------------------ device model management
     def _signature(self):
-        return (self.precision,) + tuple((k, v._version, v.data_ptr()) for k, v in self.state_dict(keep_vars=True).items())
+        # (version, address) of every parameter and buffer: cheap enough to run on every call (the tensor list is cached;
+        # `.to()` / `load_state_dict` keep the Parameter objects and change their storage or version)
+        ts = self.__dict__.get("_sig_tensors")
+        if ts is None:
+            ts = self._sig_tensors = list(self.parameters()) + list(self.buffers())
+        return (self.precision,) + tuple((t._version, t.data_ptr()) for t in ts)
 
     def device_model(self):
-        """Packed weights on the GPU, re-packed whenever a parameter or BN statistic changed."""
+        """Packed weights on the GPU, re-packed whenever a parameter or BN statistic changed.  Returns the C-ABI handle; the
+        model is owned by the custom-op layer's object (`op_model()`, reference-counted), so a tensor op that holds it and the
+        ctypes calls that use the raw handle can never see it freed under them."""
         sig = self._signature()
         if self._handle is not None and sig == self._sig:
             return self._handle
-        L = _lib.lib()
+        if self.precision not in _lib.PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(_lib.PRECISIONS)}, got {self.precision!r}")
+        _ops()
         self.release()
-        h = L.snerf_model_create(self.layer_width, self.n_classes)
-        if not h:
-            raise RuntimeError("season_nerf_amd: " + L.snerf_last_error().decode())
-        try:
-            if self.precision not in _lib.PRECISIONS:
-                raise ValueError(f"precision must be one of {sorted(_lib.PRECISIONS)}, got {self.precision!r}")
-            _lib.check(L.snerf_model_set_precision(h, _lib.PRECISIONS[self.precision]), "set_precision")
-            for k, v in self.state_dict().items():
-                if not v.is_floating_point():
-                    continue
-                a = np.ascontiguousarray(v.detach().float().cpu().numpy())
-                _lib.check(L.snerf_model_set_tensor(h, k.encode(), a.ctypes.data, a.size), "set_tensor " + k)
-            _lib.check(L.snerf_model_finalize(h), "model_finalize")
-        except Exception:
-            L.snerf_model_destroy(h)
-            raise
-        self._handle, self._sig = h, sig
-        self._op_model = None
-        return h
+        m = torch.classes.season_nerf.Model(self.layer_width, self.n_classes, self.precision)
+        for k, v in self.state_dict().items():
+            if v.is_floating_point():
+                m.set_tensor(k, v.detach().float().cpu().contiguous())
+        m.finalize()
+        self._op_model, self._handle, self._sig = m, m.handle(), sig
+        return self._handle
 
     def op_model(self):
-        """The packed model as the custom-op layer sees it (torch.classes.season_nerf.Model viewing the C-ABI handle)."""
-        h = self.device_model()
-        if self.__dict__.get("_op_model") is None:
-            from . import ops
-            self._op_model = ops.model_view(h)
+        """The packed model as the custom ops take it (torch.classes.season_nerf.Model)."""
+        self.device_model()
         return self._op_model
 
     def __getstate__(self):
@@ -140,15 +134,14 @@ class T_NeRF(nn.Module):
         training engines and the parameter store stay with the original; a copy re-packs / re-adopts lazily on first use."""
         d = self.__dict__.copy()
         d["_handle"], d["_sig"], d["_hm_dev"], d["_op_model"] = None, None, None, None
+        d.pop("_sig_tensors", None)
         for k in ("_train_engine", "_train_engines", "_param_store"):
             d.pop(k, None)
         return d
 
     def release(self):
-        self._op_model = None
-        if self._handle is not None:
-            _lib.lib().snerf_model_destroy(self._handle)
-            self._handle = None
+        self._op_model = None          # the op layer's object owns the C model: destroyed with its last reference
+        self._handle = None
 
     def __del__(self):
         try:

@@ -49,5 +49,5 @@ def _register_fakes():
 
 
 def model_view(handle):
-    """torch.classes.season_nerf.Model viewing a C-ABI model the ctypes binding owns (network.T_NeRF.device_model())."""
+    """torch.classes.season_nerf.Model viewing (not owning) a C-ABI model created elsewhere, e.g. by a C host."""
     return load().model_from_handle(int(handle))
