@@ -425,6 +425,31 @@ def main():
                            "roofline_frac_algorithmic_of_bf16_peak": FLOP_PER_SAMPLE * R * S / (ms * 1e-3) / PEAK_BF16_DENSE,
                            "rgb_max_rel_dev_vs_bf16x3": float(((rgb - rgb_ref).abs() / rgb_ref.abs().clamp_min(1e-3)).max())}
             del netp
+        # the reference's default width (main_lite.py:80), fused on the int8 pipe only: same rays, T_NeRF(512, 4)
+        try:
+            n5 = sn.T_NeRF(512, NC)
+            n5.load_state_dict(sn.synthetic_state_dict(n5, 0))
+            n5.precision = "i8x3"
+            n5 = n5.to(dev).eval()
+            m5 = n5.device_model()
+            run5 = lambda: sn._lib.check(L.snerf_field_forward_rays(m5, 0, R, S, top.data_ptr(), bot.data_ptr(), tv.data_ptr(), 1, sun.data_ptr(),
+                                                                   cls.data_ptr(), C.byref(fo), st), "field")
+            for _ in range(2):
+                run5()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                run5()
+            e1.record()
+            torch.cuda.synchronize()
+            ms5 = e0.elapsed_time(e1) / 20
+            flop5 = 2 * (2896896 + 273152 / 96.0) * R * S        # SURVEY 8d, W = 512
+            extra["w512"] = {"field_kernel_ms": ms5, "precision": "i8x3", "ray_samples_per_s_kernel": R * S / (ms5 * 1e-3),
+                             "roofline_frac_algorithmic_of_bf16_peak": flop5 / (ms5 * 1e-3) / PEAK_BF16_DENSE,
+                             "note": "T_NeRF(512,4), the reference's default width: fused int8-digit kernel (activations parked in AGPRs)"}
+            del n5
+        except Exception as ex:
+            extra["w512_error"] = repr(ex)
         extra["modes"] = modes
         extra["modes_note"] = ("parity bar (north star): RGB / depth within 1e-4 relative of the reference; measured against the reference's "
                                "goldens in tests/: bf16x3 ~3e-6, i8x3 ~1.5e-5 (W=512: 2.5e-5), bf16 1-2e-3 (outside the bar: fast mode only)")

@@ -171,3 +171,36 @@ def test_int8_mode_has_no_input_range(W):
         r = ((u - v).abs() / v.abs().clamp_min(1e-2)).max().item()
         print(f"  W={W} {k:10s} i8x3 vs reference arithmetic on out-of-cube inputs: max abs {d:.2e} max rel {r:.2e}")
         assert d < 5e-4 or r < 1e-3, (k, d, r)
+
+
+def test_int8_mode_through_the_renderer_seams(golden_dir):
+    """Quick_Run_Net and component_render_by_dir + image assembly + seasonal sweep with the network in the int8-digit mode, against
+    the reference's images (render_W64_s2.npz): images are RGB / depth quantities, so the bar is 1e-4 (asserted at 5e-5 + 1e-5)."""
+    s = sn()
+    g = load(golden_dir, "render_W64_s2.npz")
+    net = make_net(int(g["W"]), int(g["C"]), int(g["seed"]), "i8x3")
+    args = SimpleNamespace(n_samples=96, Use_Reg=True, Solar_Type_2=False, Use_MSE_loss=True, Use_Solar=True, sc_lambda=0.03,
+                           number_low_frequency_cases=4)
+
+    def close(name, a, b, rtol=5e-5, atol=1e-5):
+        a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+        m = np.isfinite(b)
+        assert (np.isfinite(a) == m).all(), name
+        print(f"  i8x3 {name:18s} max abs {np.abs(a[m] - b[m]).max():.2e}")
+        np.testing.assert_allclose(a[m], b[m], rtol=rtol, atol=atol, err_msg=name)
+
+    qr = s.Quick_Run_Net(net, args, g["WC"], g["H"], torch.device("cuda"), use_full_solar=False)
+    imgs, mask = qr.render_img((60, 30), (45, 120), 0.25, 24)
+    assert (mask == g["qr_mask"]).all()
+    close("Col_Img", imgs["Col_Img"], g["qr_Col_Img"])
+    close("Shadow_Mask", imgs["Shadow_Mask"], g["qr_Shadow_Mask"], atol=1e-4)        # sigmoid(30 (sum PS SV - 0.2)): steep
+    close("DSM", qr.get_DSM((16, 16)), g["qr_DSM"], atol=5e-5)
+    size = (12, 12, 48)
+    d = s.component_render_by_dir(net, (80, 0), (30, 90), 0.25, size, g["WC"], g["H"], torch.device("cuda"), include_exact_solar=False)
+    assert np.array_equal(d["World_Points"], g["dir_World_Points"])
+    im = s.get_imgs_from_Img_Dict(d, size, False)
+    for k in ["Base_Img", "Season_Adj_Img", "Shadow_Adjust", "Raw_Shadow_Mask"]:
+        close("img_" + k, im[k], g["img_" + k], atol=3e-5)
+    fused = s.render_season_sweep(net, (80, 0), (30, 90), [k / 12.0 for k in range(12)], size, g["WC"], g["H"], torch.device("cuda"),
+                                  render_time_frac=0.25)
+    close("fused_sweep", fused.cpu().numpy(), g["sweep_imgs"], atol=3e-5)
