@@ -245,6 +245,20 @@ class T_NeRF(nn.Module):
         o = self._field_points(1, X, sun, None, ["d_rho", "d_solar_vis"])
         return o["d_rho"], o["d_solar_vis"], sky_raw
 
+    def approx_Solar(self, X, X_solar, Time):
+        """-> Rho(X), Rho(X_solar), Col(X), output_class, Adjust_col  (T_NeRF_net_v2.py:107-129; used by the reference's
+        Eval_Tools_3_approx_solar only).  Eval mode: the density at X_solar is a sigma-only pass, the rest one full pass at X (the
+        colour head does not depend on the sun direction).  In train mode the reference normalises both point sets with the statistics
+        of their concatenation; that variant is not built."""
+        if self.training:
+            raise NotImplementedError("season_nerf_amd.T_NeRF.approx_Solar: eval mode only (train mode needs batch statistics over the "
+                                      "concatenation of X and X_solar; the reference's main training path does not call it)")
+        X, Xs, tim = self._prep(X, X_solar, Time)
+        up = torch.zeros(X.shape[0], 3, device=X.device)
+        up[:, 2] = 1.0                                     # any direction: Rho, Col and Adjust_col do not depend on it
+        rho, col, _, _, cls, adjc = self.forward(X, up, tim)
+        return rho, self.forward_Classic_Sigma_Only(Xs), col, cls, adjc
+
     def forward_Classic_Sigma_Only(self, X):
         (X,) = self._prep(X)
         self._no_train_graph("forward_Classic_Sigma_Only")

@@ -206,3 +206,21 @@ def test_get_PV_standalone():
     assert sn.get_PV(torch.zeros(0, 8, 1).cuda(), torch.zeros(0, 8, 1).cuda()).shape == (0, 8, 1)
     with pytest.raises(ValueError):
         sn.get_PV(torch.zeros(4, 8, 1).cuda(), torch.zeros(4, 9, 1).cuda())
+
+
+def test_approx_solar_is_the_composition_of_two_passes(golden_dir):
+    """T_NeRF.approx_Solar (T_NeRF_net_v2.py:107-129), eval mode: density at X and at X_solar, colour / classes / adjustment at X -
+    pinned through the goldens of `forward` and `forward_Classic_Sigma_Only` it is composed of."""
+    g = load(golden_dir, "net_W64_s0.npz")
+    net, _ = make_net(int(g["W"]), int(g["C"]), int(g["seed"]))
+    X, sun, tim = T(g["X"]).cuda(), T(g["sun"]).cuda(), T(g["time"]).cuda()
+    Xs = X.flip(0).contiguous()
+    rho, rho_s, col, cls, adjc = net.approx_Solar(X, Xs, tim)
+    tol = dict(rtol=2e-4, atol=2e-5)
+    close("approx_Rho", rho, g["fwd_Rho"], **tol)
+    close("approx_Rho_solar", rho_s.flip(0), g["sigma_only"], **tol)
+    close("approx_Col", col, g["fwd_Col"])
+    close("approx_Class", cls, g["fwd_Class"])
+    close("approx_Adjust_col", adjc, g["fwd_Adjust"], rtol=1e-4, atol=1e-4)
+    with pytest.raises(NotImplementedError):
+        net.train().approx_Solar(X, Xs, tim)
