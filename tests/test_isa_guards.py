@@ -68,3 +68,85 @@ def test_full_tile_kernels_do_not_spill_pending_loads(tmp_path):
     src = open(SRC).read()
     k = src.index("void gemm_rows_full_kernel")
     assert re.search(r"if \(ACT\) \{[^}]*a8_wait<0>\(px\[d\], py\[d\]\);", src[k:], re.S), "the activation-backward variant must drain its prefetch before the epilogue"
+
+
+# ---- register contracts of the SHIPPED code objects (read from libseason_nerf_hip.so: no compile) ----
+def _device_code_objects(path):
+    """gfx950 ELF images inside the library's .hip_fatbin section (one clang offload bundle per translation unit)."""
+    import struct
+    data = open(path, "rb").read()
+    assert data[:4] == b"\x7fELF" and data[4] == 2
+    shoff, = struct.unpack_from("<Q", data, 0x28)
+    shentsize, shnum, shstrndx = struct.unpack_from("<HHH", data, 0x3A)
+    sec = [struct.unpack_from("<IIQQQQIIQQ", data, shoff + i * shentsize) for i in range(shnum)]
+    strtab = sec[shstrndx]
+    fat = next(s for s in sec if data[strtab[4] + s[0]:].split(b"\0", 1)[0] == b".hip_fatbin")
+    blob = data[fat[4]:fat[4] + fat[5]]
+    magic, pos, out = b"__CLANG_OFFLOAD_BUNDLE__", 0, []
+    while (i := blob.find(magic, pos)) >= 0:
+        n, = struct.unpack_from("<Q", blob, i + 24)
+        p = i + 32
+        for _ in range(n):
+            off, size, ts = struct.unpack_from("<QQQ", blob, p)
+            triple = blob[p + 24:p + 24 + ts].decode()
+            p += 24 + ts
+            if "gfx950" in triple and size:
+                out.append(blob[i + off:i + off + size])
+        pos = i + 24
+    return out
+
+
+def _kernel_metadata(elf):
+    """amdhsa.kernels of one device ELF (NT_AMDGPU_METADATA note, msgpack)."""
+    import struct
+    import msgpack
+    shoff, = struct.unpack_from("<Q", elf, 0x28)
+    shentsize, shnum, _ = struct.unpack_from("<HHH", elf, 0x3A)
+    for i in range(shnum):
+        _, typ, _, _, off, size, *_ = struct.unpack_from("<IIQQQQIIQQ", elf, shoff + i * shentsize)
+        if typ != 7:            # SHT_NOTE
+            continue
+        p = off
+        while p < off + size:
+            namesz, descsz, ntype = struct.unpack_from("<III", elf, p)
+            p += 12
+            name = elf[p:p + namesz]
+            p += (namesz + 3) & ~3
+            if ntype == 32 and name.startswith(b"AMDGPU"):
+                return msgpack.unpackb(elf[p:p + descsz], raw=False)["amdhsa.kernels"]
+            p += (descsz + 3) & ~3
+    return []
+
+
+def test_shipped_fused_kernels_hold_their_register_contracts():
+    """The fused MLP kernels are built around facts about hipcc's register allocation: none may touch scratch,
+    the two-waves-per-SIMD kernel must fit 256 registers, the W = 512 kernel owns all 256 AGPRs by number.  Checked on the library
+    the tests (and the GPU box) actually load, so a compiler or source change that breaks one shows up without a GPU."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("snerf_build", os.path.join(REPO, "season_nerf_amd", "build.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    b.build()
+    kernels = {}
+    for elf in _device_code_objects(b.LIB):
+        for k in _kernel_metadata(elf):
+            kernels[k[".name"]] = k
+    fused = {n: k for n, k in kernels.items() if re.match(r"_ZN5snerf\d+mlp_(i8x2_|i8_)?kernelI", n)}
+    assert len(fused) >= 20, sorted(fused)
+    for n, k in fused.items():
+        assert k[".private_segment_fixed_size"] == 0, (n, "uses scratch")      # (.vgpr_spill_count > 0 with no scratch = parked in AGPRs: fine)
+    x2 = {n: k for n, k in fused.items() if "mlp_i8x2_kernel" in n}
+    assert len(x2) == 6
+    for n, k in x2.items():       # two waves per SIMD: 256 registers each, nothing parked
+        assert k[".vgpr_count"] <= 256 and k[".vgpr_spill_count"] == 0 and k[".max_flat_workgroup_size"] == 512, (n, k[".vgpr_count"])
+    w512 = {n: k for n, k in fused.items() if re.search(r"mlp_i8_kernelILi0ELi512E", n)}
+    assert len(w512) == 3
+    for n, k in w512.items():     # hidden activations live in AGPRs addressed by number: the whole AGPR file is reserved
+        assert k[".agpr_count"] == 256 and k[".vgpr_count"] <= 512 and k[".vgpr_spill_count"] == 0, (n, k[".agpr_count"], k[".vgpr_count"])
+    # row GEMMs of the training engine: the variants without the activation-backward epilogue are scratch-free
+    full = {n: k for n, k in kernels.items() if "gemm_rows_full_kernel" in n}
+    assert len(full) >= 18
+    for n, k in full.items():
+        act = int(re.search(r"ILi\dELi\dELi\dELi(\d)E", n).group(1))
+        if not act:
+            assert k[".private_segment_fixed_size"] == 0, n
