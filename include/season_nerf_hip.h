@@ -49,16 +49,46 @@ int snerf_model_classes(const snerf_model* m);
 
 /* Arithmetic of the fused per-point (field) network; set before snerf_model_finalize.  The reference computes in fp32
  * (plain torch, T_NeRF_net_v2.py:75-105); the north-star bar is 1e-4 relative on RGB / depth against it.
- *   SNERF_PREC_BF16X3  3-term error-compensated bf16 MFMA products, fp32 accumulate: RGB ~3e-6, per-sample outputs ~1e-5 (default)
+ *   SNERF_PREC_BF16X3  3-term error-compensated bf16 MFMA products, fp32 accumulate: RGB ~3e-6, per-sample outputs ~1e-5 (C-ABI default)
  *   SNERF_PREC_BF16    one bf16 MFMA per product (first layer keeps 3 terms): RGB 2-3e-3 - outside the bar, "fast" mode
  *   SNERF_PREC_I8X3    16-bit fixed point in two int8 digits on the int8 MFMA pipe, exact integer accumulation:
  *                      RGB ~2e-5, per-sample outputs ~1e-4; any input range (the raw coordinates of the encodings enter in fp32)
- * The per-group network (class softmax, sky colour: one row per ray) always runs in BF16X3. */
+ *   SNERF_PREC_AUTO    SNERF_PREC_I8X3 where the packed weights clear its pack-time error bound (snerf_model_i8_estimate),
+ *                      SNERF_PREC_BF16X3 otherwise; resolved when the weights are packed (snerf_model_resolve_precision or
+ *                      snerf_model_finalize), after which snerf_model_precision reports the mode chosen
+ * The per-group network (class softmax, sky colour: one row per ray, its error is not averaged over a ray's samples) runs in
+ * BF16X3 at the widths that have that kernel (64, 256) and layer by layer in exact fp32 at 512, whatever the mode. */
 #define SNERF_PREC_BF16X3 0
 #define SNERF_PREC_BF16 1
 #define SNERF_PREC_I8X3 2
+#define SNERF_PREC_AUTO 3
 int snerf_model_set_precision(snerf_model* m, int precision);
 int snerf_model_precision(const snerf_model* m);
+
+/* What SNERF_PREC_I8X3 would add to the network's outputs for THESE weights, predicted on the host from the packed integers
+ * (no GPU): per output row the rounding of its weights to 16 bits of the row maximum, of the activations to 16 bits of
+ * [-1, 1] and the dropped low x low digit product, carried through the layers (a sine layer multiplies an error by
+ * 2 pi |cos|).  `*_rms` are absolute RMS errors of the raw (pre-softplus / pre-sigmoid) head outputs; the reference's
+ * fp32 arithmetic (T_NeRF_net_v2.py:75-105) is the zero point.  `rgb_pred` weighs them by what each head moves in the rendered
+ * colour and depth (Eval_Tools_2.py:187-215): the predicted worst relative error over a batch of rays, about twice what is
+ * observed (calibrated on weight sets with heavy tails, outliers and high gains, against fp64 and - tests/golden/stress_*.npz -
+ * against the reference itself); `budget` is the value it must stay under (the north star's 1e-4).  `acc_bound` is the exact
+ * maximum of the int32 accumulator expression (M << 8) + X over all rows and all possible activations.
+ * ok = rgb_pred <= budget && acc_bound < 2^31.  Works before or after snerf_model_finalize, under any precision setting. */
+typedef struct snerf_i8_estimate {
+    double head_rms[4];   /* density, colour, solar visibility, seasonal adjust */
+    double hidden_rms;    /* worst hidden layer: RMS error of its activations */
+    double worst;         /* max over head_rms */
+    double rgb_pred;
+    double budget;
+    int64_t acc_bound;
+    int ok;
+} snerf_i8_estimate;
+int snerf_model_i8_estimate(snerf_model* m, snerf_i8_estimate* out);
+/* Packs on the host if that has not happened yet and returns the precision the model runs in (SNERF_PREC_AUTO resolved),
+ * or a negative SNERF_E_* code.  SNERF_E_INVALID with width 512 means: the int8 bound failed and no other fused kernel
+ * exists at that width (the host falls back to the layer-wise engine). */
+int snerf_model_resolve_precision(snerf_model* m);
 
 /* Host-only packing (no GPU): sizes and bytes of the packed programs, for tests and offline tooling.
  * program 0 = per-point field network, 1 = per-group (time/sun) network (bf16 hi/lo fragment pairs + bias table);

@@ -111,6 +111,85 @@ def init_weights(W: int, C: int = 4, seed: int = 0, bn_stats: str = "random") ->
     return sd
 
 
+STRESS_KINDS = ("outlier4", "outlier8", "outlier16", "laplace", "gauss", "bn_gain", "gain2", "gain4", "trained")
+
+
+def stress_weights(W: int, C: int = 4, seed: int = 0, kind: str = "trained", calibrate_bn: bool = True) -> Dict[str, Tensor]:
+    """Weight sets shaped like trained checkpoints rather than like the init law - the cases a fixed-point kernel has to be
+    proven on (the init law is its best case: every weight of a row within the row maximum by construction).
+
+      outlierF   one weight per row of every layer multiplied by F (F = 4, 8, 16)
+      laplace    SineLayer weights redrawn Laplace-distributed with the init law's standard deviation (heavy tails)
+      gauss      ... normally distributed
+      bn_gain    BatchNorm gamma ~ log-uniform [0.5, 2], beta ~ U(-1, 1)
+      gainG      the hidden SineLayers WITHOUT BatchNorm (solar 2-3, adjust 1-3, time 2) scaled by G = 2, 4: higher frequencies
+      trained    gauss (x 1.25 on the BatchNorm-free hidden layers) + BatchNorm gamma ~ log-uniform [0.7, 1.4], beta ~ U(-1, 1)
+                 + an x3 outlier per row
+
+    calibrate_bn: the BatchNorm running statistics are set to the batch statistics of 8192 random points of the cube, layer by
+    layer (what training converges to), instead of init_weights' random values.  Deterministic (numpy PCG64)."""
+    sd = init_weights(W, C, seed)
+    rng = np.random.Generator(np.random.PCG64(1000 + seed))
+    table = layer_table(W, C)
+
+    def wkey(name, k):
+        return name + (".linear.weight" if k == "sine" else ".weight")
+
+    def redraw(dist, gain_free=1.0):
+        for name, k, n_out, n_in, has_bn, is_first in table:
+            if k != "sine":
+                continue
+            a = 1.0 / n_in if is_first else math.sqrt(6.0 / n_in) / OMEGA0
+            std = a / math.sqrt(3.0)
+            g = gain_free if not (has_bn or is_first) else 1.0
+            v = rng.laplace(0.0, std / math.sqrt(2.0), (n_out, n_in)) if dist == "laplace" else rng.normal(0.0, std, (n_out, n_in))
+            sd[wkey(name, k)] = torch.from_numpy((g * v).astype(np.float32))
+
+    def outliers(f):
+        for name, k, n_out, n_in, has_bn, is_first in table:
+            w = sd[wkey(name, k)].numpy().copy()
+            w[np.arange(n_out), rng.integers(0, n_in, n_out)] *= f
+            sd[wkey(name, k)] = torch.from_numpy(w)
+
+    def bn_gain(lo=0.5, hi=2.0):
+        for name, k, n_out, n_in, has_bn, is_first in table:
+            if has_bn:
+                sd[name + ".norm.weight"] = torch.from_numpy(np.exp(rng.uniform(math.log(lo), math.log(hi), n_out)).astype(np.float32))
+                sd[name + ".norm.bias"] = torch.from_numpy(rng.uniform(-1.0, 1.0, n_out).astype(np.float32))
+
+    if kind.startswith("outlier"):
+        outliers(float(kind[len("outlier"):]))
+    elif kind in ("laplace", "gauss"):
+        redraw(kind)
+    elif kind == "bn_gain":
+        bn_gain()
+    elif kind.startswith("gain"):
+        g = float(kind[len("gain"):])
+        for name, k, n_out, n_in, has_bn, is_first in table:
+            if k == "sine" and not has_bn and not is_first:
+                sd[wkey(name, k)] = sd[wkey(name, k)] * g
+    elif kind == "trained":
+        redraw("gauss", gain_free=1.25)
+        bn_gain(0.7, 1.4)
+        outliers(3.0)
+    elif kind != "init":
+        raise ValueError(f"unknown stress kind {kind!r}")
+    if calibrate_bn:
+        x = torch.from_numpy(rng.uniform(-1.0, 1.0, (8192, 3)).astype(np.float32))
+        g = "G_NeRF_net."
+        with torch.no_grad():
+            xe = pe_encode(x, PE_POS)
+            h = sine_layer(sd, g + "fc1", xe)
+            for i in (2, 3, 4, 5, 6, 7, 8, 9):
+                name = g + f"fc{i}"
+                inp = torch.cat([h, xe], 1) if i == 5 else h
+                z = OMEGA0 * _linear(inp.double(), sd[name + ".linear.weight"].double(), sd[name + ".linear.bias"].double())
+                sd[name + ".norm.running_mean"] = z.mean(0).float()
+                sd[name + ".norm.running_var"] = z.var(0, unbiased=True).float()
+                h = sine_layer(sd, name, inp)
+    return sd
+
+
 def width_of(sd: Dict[str, Tensor]) -> Tuple[int, int]:
     return int(sd["G_NeRF_net.fc1.linear.weight"].shape[0]), int(sd["get_class_layer.weight"].shape[0])
 

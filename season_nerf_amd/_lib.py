@@ -23,6 +23,12 @@ class SweepOut(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("d_season", "d_shaded", "d_base", "d_shadow_adjust", "d_raw_shadow", "d_classic")]
 
 
+class I8Estimate(C.Structure):
+    """snerf_i8_estimate: the pack-time error model of the int8-digit format (include/season_nerf_hip.h)."""
+    _fields_ = [("head_rms", C.c_double * 4), ("hidden_rms", C.c_double), ("worst", C.c_double),
+                ("rgb_pred", C.c_double), ("budget", C.c_double), ("acc_bound", C.c_int64), ("ok", C.c_int)]
+
+
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p)      # snerf_allreduce_fn
 
 _lib = None
@@ -50,6 +56,8 @@ def lib():
     L.snerf_model_classes.argtypes = [vp]
     L.snerf_model_set_precision.argtypes = [vp, i32]
     L.snerf_model_precision.argtypes = [vp]
+    L.snerf_model_i8_estimate.argtypes = [vp, C.POINTER(I8Estimate)]
+    L.snerf_model_resolve_precision.argtypes = [vp]
     L.snerf_model_pack_host.argtypes = [vp, i32, vp, C.POINTER(C.c_size_t), vp, C.POINTER(C.c_size_t)]
     L.snerf_group_forward.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp]
     L.snerf_field_forward_points.argtypes = [vp, i32, i64, vp, i64, vp, vp, C.POINTER(FieldOut), vp]
@@ -102,7 +110,8 @@ def lib():
     return L
 
 
-PRECISIONS = {"bf16x3": 0, "bf16": 1, "i8x3": 2}      # SNERF_PREC_* of include/season_nerf_hip.h
+PRECISIONS = {"bf16x3": 0, "bf16": 1, "i8x3": 2, "auto": 3}      # SNERF_PREC_* of include/season_nerf_hip.h
+PRECISION_NAMES = {0: "bf16x3", 1: "bf16", 2: "i8x3"}
 
 
 def check(rc, what):
@@ -112,7 +121,7 @@ def check(rc, what):
 
 EXPORTS = ["snerf_last_error", "snerf_abi_version", "snerf_model_create", "snerf_model_set_tensor",
            "snerf_model_finalize", "snerf_model_destroy", "snerf_model_width", "snerf_model_classes",
-           "snerf_model_set_precision", "snerf_model_precision",
+           "snerf_model_set_precision", "snerf_model_precision", "snerf_model_i8_estimate", "snerf_model_resolve_precision",
            "snerf_model_pack_host", "snerf_group_forward", "snerf_field_forward_points", "snerf_field_forward_rays",
            "snerf_composite_rays", "snerf_composite_sweep", "snerf_render_workspace_bytes", "snerf_render_rays", "snerf_rays_from_camera", "snerf_field_kernel_info",
            "snerf_prior_density", "snerf_surface_distance", "snerf_image_error", "snerf_transmittance",

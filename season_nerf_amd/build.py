@@ -37,11 +37,23 @@ def _obj(src):
     return os.path.join(OBJ, src + ".o")
 
 
+def _deps(src):
+    """Files the object was built from, as the compiler recorded them (-MD): the source, its #includes, the headers."""
+    d = _obj(src) + ".d"
+    if not os.path.exists(d):
+        return None
+    txt = open(d).read().replace("\\\n", " ")
+    return [f for f in txt.split(":", 1)[1].split() if f.startswith(REPO)] if ":" in txt else None
+
+
 def _stale(src, hdr_t):
     o = _obj(src)
     if not os.path.exists(o):
         return True
     t = os.path.getmtime(o)
+    deps = _deps(src)
+    if deps is not None:          # exact: only what this object really includes
+        return any((not os.path.exists(f)) or os.path.getmtime(f) > t for f in deps)
     return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in [src] + INCLUDED.get(src, [])) or hdr_t > t
 
 
@@ -54,7 +66,7 @@ def needs_build():
 
 
 def _compile(src, verbose):
-    cmd = [_hipcc()] + FLAGS + EXTRA.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", _obj(src)]
+    cmd = [_hipcc()] + FLAGS + EXTRA.get(src, []) + ["-MD", "-MF", _obj(src) + ".d", "-c", os.path.join(CSRC, src), "-o", _obj(src)]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -401,7 +401,7 @@ hipError_t launch_mlp_i8_w512(int variant, const MlpArgs& a, int n_cu, hipStream
 hipError_t launch_mlp_i8(int prog, int W, int variant, const MlpArgs& a, int n_cu, hipStream_t st) {
 #define CASE(Wv)                                                                          \
     if (W == Wv) {                                                                        \
-        if (prog == PROG_GROUP) return launch_mlp_i8_t<PROG_GROUP, Wv, 0>(a, n_cu, st);   \
+        if (prog != PROG_FIELD) return hipErrorInvalidValue;                              \
         if (variant == 0) return launch_mlp_i8_t<PROG_FIELD, Wv, 0>(a, n_cu, st);         \
         if (variant == 1) return launch_mlp_i8_t<PROG_FIELD, Wv, 1>(a, n_cu, st);         \
         return launch_mlp_i8_t<PROG_FIELD, Wv, 2>(a, n_cu, st);                           \
@@ -410,7 +410,9 @@ hipError_t launch_mlp_i8(int prog, int W, int variant, const MlpArgs& a, int n_c
     CASE(256)
 #undef CASE
     if (W == 512) {
-        if (prog == PROG_GROUP) return launch_mlp_i8_t<PROG_GROUP, 512, 0>(a, n_cu, st);
+        // the per-ray networks have no int8 instance: one row per ray, their error is not averaged over a ray's samples
+        // (api.cpp group_forward_f32 runs them in exact fp32 at this width)
+        if (prog != PROG_FIELD) return hipErrorInvalidValue;
         return launch_mlp_i8_w512(variant, a, n_cu, st);
     }
     return hipErrorInvalidValue;

@@ -7,7 +7,7 @@
 // in libseason_nerf_hip.so; nothing here computes.
 //
 //   torch.classes.season_nerf.Model(W, C, precision)      T_NeRF(layer_width, n_classes) packed weights  (T_NeRF_net_v2.py:20-60)
-//     .set_tensor(key, cpu_f32)  .finalize()  .width()  .classes()  .precision()  .handle()
+//     .set_tensor(key, cpu_f32)  .resolve()  .i8_estimate()  .finalize()  .width()  .classes()  .precision()  .handle()
 //   season_nerf::group_fwd(Model, time[G,4], sun[G,3]) -> (classes[G,C], sky_raw[G,3], sky[G,3])        get_class_only + sky head
 //   season_nerf::points_fwd(Model, x[N,3], sun[G,3]?, classes[G,C]?, group_size, variant)               T_NeRF.forward* on points
 //        -> (rho[N,1], solar_vis[N,1], col_raw[N,3], adjust[N,C,3], col[N,3], adjust_col[N,3])
@@ -55,11 +55,12 @@ struct Model : torch::CustomClassHolder {
     Model(int64_t W, int64_t C, const std::string& precision) {
         m = snerf_model_create((int)W, (int)C);
         TORCH_CHECK(m, "season_nerf::Model: ", snerf_last_error());
-        const int p = precision == "bf16x3" ? SNERF_PREC_BF16X3 : precision == "bf16" ? SNERF_PREC_BF16 : precision == "i8x3" ? SNERF_PREC_I8X3 : -1;
+        const int p = precision == "bf16x3" ? SNERF_PREC_BF16X3 : precision == "bf16" ? SNERF_PREC_BF16 : precision == "i8x3" ? SNERF_PREC_I8X3
+                    : precision == "auto" ? SNERF_PREC_AUTO : -1;
         if (p < 0 || snerf_model_set_precision(m, p) != SNERF_OK) {
             snerf_model_destroy(m);
             m = nullptr;
-            TORCH_CHECK(false, "season_nerf::Model: precision must be 'bf16x3', 'bf16' or 'i8x3' (got '", precision, "')");
+            TORCH_CHECK(false, "season_nerf::Model: precision must be 'auto', 'bf16x3', 'bf16' or 'i8x3' (got '", precision, "')");
         }
     }
     Model(int64_t handle, bool) : m((snerf_model*)handle), owner(false) {}       // view of a model the ctypes binding owns
@@ -75,6 +76,16 @@ struct Model : torch::CustomClassHolder {
     int64_t width() const { return snerf_model_width(m); }
     int64_t classes() const { return snerf_model_classes(m); }
     int64_t precision() const { return snerf_model_precision(m); }
+    // host-only: packs the weights and returns the mode the model runs in ('auto' resolved), or a negative SNERF_E_* code
+    // (SNERF_E_INVALID: no fused kernel for the resolved mode at this width)
+    int64_t resolve() { return snerf_model_resolve_precision(m); }
+    // [density, colour, solar visibility, adjust | hidden | worst | rgb_pred | budget | accumulator bound | ok]
+    std::vector<double> i8_estimate() {
+        snerf_i8_estimate e;
+        ck(snerf_model_i8_estimate(m, &e), "Model.i8_estimate");
+        return {e.head_rms[0], e.head_rms[1], e.head_rms[2], e.head_rms[3], e.hidden_rms, e.worst, e.rgb_pred, e.budget,
+                (double)e.acc_bound, (double)e.ok};
+    }
     int64_t handle() const { return (int64_t)m; }
 };
 using ModelPtr = c10::intrusive_ptr<Model>;
@@ -226,6 +237,8 @@ TORCH_LIBRARY(season_nerf, m) {
         .def("width", &Model::width)
         .def("classes", &Model::classes)
         .def("precision", &Model::precision)
+        .def("resolve", &Model::resolve)
+        .def("i8_estimate", &Model::i8_estimate)
         .def("handle", &Model::handle);
     m.def("model_from_handle(int handle) -> __torch__.torch.classes.season_nerf.Model", model_from_handle);
     m.def("group_fwd(__torch__.torch.classes.season_nerf.Model model, Tensor time, Tensor sun) -> (Tensor, Tensor, Tensor)");

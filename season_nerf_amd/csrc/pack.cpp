@@ -271,4 +271,92 @@ bool pack_program_i8(const Weights& w, int prog, int W, int C, bool fold_bn, Pac
     return true;
 }
 
+// ---- error model of the int8-digit format ------------------------------------------------------------------
+// Input of layer l of a program: index of the layer whose activations form its IN_H block, or -1 (encodings only).
+static int hidden_source(int prog, int l) {
+    if (prog == PROG_FIELD) {
+        switch (l) {
+            case F_FC1: return -1;
+            case F_HEAD: case F_S1: case F_A1: return F_FC9;
+            default: return l - 1;
+        }
+    }
+    return (l == G_T1 || l == G_K1) ? -1 : l - 1;
+}
+
+static bool estimate_program(const Weights& w, int prog, int W, int C, std::vector<std::vector<double>>* out_var, double* hidden_rms,
+                             long long* acc_bound, std::string* err) {
+    const int L = prog_layers(prog);
+    out_var->assign(L, {});
+    const double qa = 1.0 / (12.0 * 32767.0 * 32767.0);       // variance of an activation's rounding, in units of [-1,1]^2
+    const double lb = 5461.5 / (32767.0 * 32767.0);           // E[b^2] of a uniformly distributed low activation digit, same units
+    for (int l = 0; l < L; ++l) {
+        const LayerShape s = prog_layer(prog, W, C, l, FMT_I8);
+        Dense d;
+        if (!dense_layer(w, prog, W, C, l, /*fold_bn=*/true, &d, err)) return false;
+        const int f0 = kind_features(s.kind0, s.ks0, FMT_I8);
+        const int rk = raw_kind(s), rdims = raw_dims(rk), rbase = (rk != IN_NONE && rk == s.kind1 && rk != s.kind0) ? f0 : 0;
+        auto is_raw_col = [&](int c) { return rk != IN_NONE && c >= rbase && c < rbase + rdims; };
+        const int src = hidden_source(prog, l);
+        const int n_hidden = s.kind0 == IN_H ? (f0 < d.k ? f0 : d.k) : 0;          // columns [0, n_hidden) are hidden activations
+        const std::vector<double>* ein = src >= 0 ? &(*out_var)[src] : nullptr;
+        std::vector<double>& ev = (*out_var)[l];
+        ev.assign(d.n, 0.0);
+        double sum = 0.0;
+        for (int n = 0; n < d.n; ++n) {
+            const double* row = d.W.data() + (size_t)n * d.k;
+            double mx = 0.0;
+            for (int c = 0; c < d.k; ++c) if (!is_raw_col(c)) mx = std::fmax(mx, std::fabs(row[c]));
+            const double sn = mx > 0.0 ? mx / 32512.0 : 1.0;
+            double v = 0.0;
+            long long sT = 0, sL = 0;
+            for (int c = 0; c < d.k; ++c) {
+                if (is_raw_col(c)) continue;                                       // fp32 path: no digits
+                const long long q = std::llround(row[c] / sn);
+                const long long T = (q + 128) >> 8, Lq = q - 256 * T;
+                sT += T < 0 ? -T : T; sL += Lq < 0 ? -Lq : Lq;
+                const double dw = row[c] - sn * (double)q;                         // this weight's rounding error, exactly
+                v += 0.5 * dw * dw                                                 // times an activation of mean square 1/2
+                   + row[c] * row[c] * qa                                          // the activation's rounding through the weight
+                   + sn * sn * (double)(Lq * Lq) * lb;                             // the dropped L x b product
+                if (c < n_hidden && ein && c < (int)ein->size()) v += row[c] * row[c] * (*ein)[c];
+            }
+            // |M| <= 128 sum|T|, |X| <= 128 sum(|T| + |L|)   (digits in [-128, 127])
+            const long long bound = 256LL * 128LL * sT + 128LL * (sT + sL);
+            if (bound > *acc_bound) *acc_bound = bound;
+            // sine layer: d sin(2 pi z) = 2 pi cos(.) dz, mean square of the cosine 1/2
+            ev[n] = s.out_kind == OUT_SIN ? (2.0 * M_PI) * (2.0 * M_PI) * 0.5 * v : v;
+            sum += ev[n];
+        }
+        if (s.out_kind == OUT_SIN && d.n > 0) *hidden_rms = std::fmax(*hidden_rms, std::sqrt(sum / d.n));
+    }
+    return true;
+}
+
+bool estimate_i8(const Weights& w, int W, int C, I8Estimate* out, std::string* err) {
+    if (W < 64 || W % 64 != 0) { *err = "layer width must be a multiple of 64 (got " + std::to_string(W) + ")"; return false; }
+    if (C < 1 || C > kMaxClasses) { *err = "n_classes must be in [1," + std::to_string(kMaxClasses) + "]"; return false; }
+    *out = I8Estimate();
+    std::vector<std::vector<double>> ev;
+    if (!estimate_program(w, PROG_FIELD, W, C, &ev, &out->hidden_rms, &out->acc_bound, err)) return false;
+    auto rms = [](const std::vector<double>& v, int a, int b) {
+        double s = 0.0;
+        for (int i = a; i < b && i < (int)v.size(); ++i) s += v[i];
+        return b > a ? std::sqrt(s / (b - a)) : 0.0;
+    };
+    out->head_rms[0] = rms(ev[F_HEAD], 3, 4);           // fc10Sigma
+    out->head_rms[1] = rms(ev[F_HEAD], 0, 3);           // fc10Col
+    out->head_rms[2] = rms(ev[F_S4], 0, 1);
+    out->head_rms[3] = rms(ev[F_AC], 0, 3 * C);
+    for (double v : out->head_rms) out->worst = std::fmax(out->worst, v);
+    // What an error of a raw head output does to the rendered colour, relative (Eval_Tools_2.py:187-215): the density enters through
+    // the transmittance weights PS (and alone sets the depth), colour and seasonal adjustment through a sigmoid (slope <= 1/4) averaged
+    // over the samples of a ray, the solar visibility through the shading term.  (The per-ray networks - class softmax, sky colour -
+    // never run in int8 digits: their error would not average over a ray's samples.)  Weights fitted
+    // with tools/calibrate_i8_bound.py so that the sum is ~2x the worst relative colour error over a batch of rays (W = 64 ... 512,
+    // init-law, outlier, heavy-tailed and high-gain weight sets).
+    out->rgb_pred = 0.35 * out->head_rms[0] + 0.15 * out->head_rms[1] + 0.20 * out->head_rms[3] + 0.10 * out->head_rms[2];
+    return true;
+}
+
 }  // namespace snerf

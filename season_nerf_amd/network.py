@@ -26,7 +26,7 @@ def _ops():
 
 OMEGA0 = 30.0
 FUSED_WIDTHS = (64, 256)      # widths with a compiled fused bf16 MFMA kernel; others run on the layer-wise fp32 engine
-FUSED_WIDTHS_I8 = (64, 256, 512)   # ... with a fused int8-digit kernel (precision "i8x3"): the reference's default width too
+FUSED_WIDTHS_I8 = (64, 256, 512)   # ... with a fused int8-digit kernel (precision "i8x3" / "auto"): the reference's default width too
 
 
 class SineLayer(nn.Module):
@@ -85,16 +85,45 @@ class T_NeRF(nn.Module):
         self.adjust_solar_vis = nn.Linear(W, n_classes)
         self.adjust_sky_col = nn.Linear(W, n_classes * 3)
         self._handle = None
-        self._sig = None
         self._op_model = None
-        # arithmetic of the fused eval-mode field kernel (include/season_nerf_hip.h SNERF_PREC_*): "bf16x3" (parity
-        # default), "i8x3" (16-bit fixed point on the int8 matrix pipe: RGB ~2e-5), "bf16" (fast, 2-3e-3)
-        self.precision = "bf16x3"
+        self._packed = None
+        self._packed_sig = None
+        # arithmetic of the fused eval-mode field kernel (include/season_nerf_hip.h SNERF_PREC_*):
+        #   "auto"   (default) "i8x3" where the pack-time error bound of the int8-digit format clears the 1e-4 budget for THESE
+        #            weights (snerf_model_i8_estimate), else "bf16x3" - `resolved_precision` tells which
+        #   "bf16x3" 3-term split bf16 products (RGB ~3e-6), "i8x3" 16-bit fixed point on the int8 matrix pipe (RGB ~2e-5 on
+        #            well-conditioned weights), "bf16" fast mode (2-3e-3, outside the bar)
+        self.precision = "auto"
+        self._resolved = None
+
+    def _apply(self, fn, *args, **kwargs):
+        # Module._apply replaces buffers (and, by option, parameters) with new tensor objects: the cached signature list would
+        # keep tracking the dead ones
+        r = super()._apply(fn, *args, **kwargs)
+        self.__dict__.pop("_sig_tensors", None)
+        self.__dict__["_packed_sig"] = None
+        return r
+
+    @property
+    def resolved_precision(self):
+        """The arithmetic the fused kernel runs in for the current weights ("auto" resolved), or None where no fused kernel serves
+        them (the layer-wise engine then does: any width outside 64 / 256 / 512, or 512 when the int8 bound fails)."""
+        self._pack()
+        return self._resolved
 
     @property
     def fused(self):
         """True where the eval-mode forward runs in a fused register-resident kernel (else: the layer-wise engine)."""
-        return self.layer_width in (FUSED_WIDTHS_I8 if self.precision == "i8x3" else FUSED_WIDTHS)
+        return self.resolved_precision is not None
+
+    def i8_estimate(self):
+        """snerf_i8_estimate of the current weights (host only): dict with the predicted colour error `rgb_pred`, its `budget`,
+        the per-head RMS errors, the exact int32 accumulator bound and `ok`."""
+        if self.layer_width not in FUSED_WIDTHS_I8:
+            raise ValueError(f"no int8-digit kernel at width {self.layer_width}")
+        self._pack()
+        v = self._packed.i8_estimate()
+        return {"head_rms": v[0:4], "hidden_rms": v[4], "worst": v[5], "rgb_pred": v[6], "budget": v[7], "acc_bound": int(v[8]), "ok": bool(v[9])}
 
     # ------------------------------------------------------------------ device model management
     def _signature(self):
@@ -105,23 +134,45 @@ class T_NeRF(nn.Module):
             ts = self._sig_tensors = list(self.parameters()) + list(self.buffers())
         return (self.precision,) + tuple((t._version, t.data_ptr()) for t in ts)
 
+    def _pack(self):
+        """Host side of the device model: hands the weights to the C ABI and resolves the precision (no GPU work).  Cached by the
+        signature of the parameters and buffers."""
+        sig = self._signature()
+        if self.__dict__.get("_packed_sig") == sig:
+            return
+        if self.precision not in _lib.PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(_lib.PRECISIONS)}, got {self.precision!r}")
+        self.release()
+        self._packed, self._resolved, self._packed_sig = None, None, sig
+        W = self.layer_width
+        if W not in FUSED_WIDTHS_I8:
+            return
+        want = self.precision
+        if W not in FUSED_WIDTHS and want in ("bf16x3", "bf16"):
+            return                                    # no bf16 kernel at this width: layer-wise engine
+        _ops()
+        m = torch.classes.season_nerf.Model(W, self.n_classes, want)
+        for k, v in self.state_dict().items():
+            if v.is_floating_point():
+                m.set_tensor(k, v.detach().float().cpu().contiguous())
+        r = m.resolve()
+        if r == -1 and want == "auto" and W not in FUSED_WIDTHS:
+            return                                    # the int8 bound failed and there is no other fused kernel at this width
+        if r < 0:
+            raise RuntimeError(f"season_nerf_amd: packing the model failed (code {r}): {_lib.lib().snerf_last_error().decode()}")
+        self._packed, self._resolved = m, _lib.PRECISION_NAMES[r]
+
     def device_model(self):
         """Packed weights on the GPU, re-packed whenever a parameter or BN statistic changed.  Returns the C-ABI handle; the
         model is owned by the custom-op layer's object (`op_model()`, reference-counted), so a tensor op that holds it and the
         ctypes calls that use the raw handle can never see it freed under them."""
-        sig = self._signature()
-        if self._handle is not None and sig == self._sig:
+        self._pack()
+        if self._handle is not None:
             return self._handle
-        if self.precision not in _lib.PRECISIONS:
-            raise ValueError(f"precision must be one of {sorted(_lib.PRECISIONS)}, got {self.precision!r}")
-        _ops()
-        self.release()
-        m = torch.classes.season_nerf.Model(self.layer_width, self.n_classes, self.precision)
-        for k, v in self.state_dict().items():
-            if v.is_floating_point():
-                m.set_tensor(k, v.detach().float().cpu().contiguous())
-        m.finalize()
-        self._op_model, self._handle, self._sig = m, m.handle(), sig
+        if self._packed is None:
+            raise RuntimeError(f"season_nerf_amd: no fused kernel for width {self.layer_width} at precision {self.precision!r}")
+        self._packed.finalize()
+        self._op_model, self._handle = self._packed, self._packed.handle()
         return self._handle
 
     def op_model(self):
@@ -133,7 +184,8 @@ class T_NeRF(nn.Module):
         """Copies (copy.deepcopy, pickle, torch.save of the module) must not share the raw C handles: the device model, the
         training engines and the parameter store stay with the original; a copy re-packs / re-adopts lazily on first use."""
         d = self.__dict__.copy()
-        d["_handle"], d["_sig"], d["_hm_dev"], d["_op_model"] = None, None, None, None
+        d["_handle"], d["_hm_dev"], d["_op_model"] = None, None, None
+        d["_packed"], d["_resolved"], d["_packed_sig"] = None, None, None
         d.pop("_sig_tensors", None)
         for k in ("_train_engine", "_train_engines", "_param_store"):
             d.pop(k, None)

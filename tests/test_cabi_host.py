@@ -28,13 +28,13 @@ def lib():
 def test_exports_match_header(lib):
     hdr = open(os.path.join(REPO, "include", "season_nerf_hip.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    declared = sorted(set(re.findall(r"\b(snerf_[a-z_]+)\s*\(", hdr)))
+    declared = sorted(set(re.findall(r"\b(snerf_[a-z0-9_]+)\s*\(", hdr)))
     assert len(declared) >= 15
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
     import season_nerf_amd as sn
     assert sorted(sn._lib.EXPORTS) == declared
-    assert lib.snerf_abi_version() == 5
+    assert lib.snerf_abi_version() == 6
 
 
 def test_custom_op_library_registers_without_a_gpu():
@@ -438,3 +438,88 @@ def test_synthetic_state_dict_follows_the_init_law():
     assert torch.equal(sn.synthetic_state_dict(net, 3)["time_layer_2.linear.bias"], sd["time_layer_2.linear.bias"])   # deterministic
     names = [n for n, *_ in sn.per_point_layer_shapes(net)]
     assert len(names) == 19 and "time_layer_1" not in names and "G_NeRF_net.fc5" in names
+
+
+# ------------------------------------------------------------------------------------------------------------
+# Pack-time error model of the int8-digit format and SNERF_PREC_AUTO (include/season_nerf_hip.h snerf_i8_estimate): host only.
+def _host_model(lib, W, sd, precision):
+    m = lib.snerf_model_create(W, 4)
+    assert m and lib.snerf_model_set_precision(m, precision) == 0
+    for k, v in sd.items():
+        if v.is_floating_point():
+            arr = np.ascontiguousarray(v.numpy(), dtype=np.float32)
+            assert lib.snerf_model_set_tensor(m, k.encode(), arr.ctypes.data, arr.size) == 0
+    return m
+
+
+def _estimate(lib, m):
+    import season_nerf_amd as sn
+    e = sn._lib.I8Estimate()
+    assert lib.snerf_model_i8_estimate(m, C.byref(e)) == 0, lib.snerf_last_error()
+    return e
+
+
+@pytest.mark.parametrize("W", [64, 256, 512])
+def test_auto_precision_follows_the_error_bound(lib, W):
+    """Well-conditioned weights (init law, mild outliers, heavy tails) clear the bound and run in int8 digits; rows with a
+    dominant weight (x16) or a trained-like mix of gains and outliers do not and are routed to bf16x3 (512: no bf16 kernel ->
+    SNERF_E_INVALID, the host falls back to the layer-wise engine).  The thresholds are tools/calibrate_i8_bound.py's."""
+    AUTO, I8, BF3 = 3, 2, 0
+    for kind, want in [("init", I8), ("outlier4", I8), ("laplace", I8), ("outlier16", BF3), ("trained", BF3)]:
+        sd = orc.init_weights(W, 4, 0) if kind == "init" else orc.stress_weights(W, 4, 0, kind)
+        m = _host_model(lib, W, sd, AUTO)
+        e = _estimate(lib, m)
+        assert e.budget == pytest.approx(1e-4) and e.acc_bound < 2 ** 31
+        assert bool(e.ok) == (want == I8), (kind, e.rgb_pred)
+        if kind == "init":
+            assert 1e-5 < e.rgb_pred < 4e-5 and max(e.head_rms) == pytest.approx(e.worst)
+        r = lib.snerf_model_resolve_precision(m)
+        if want == BF3 and W == 512:
+            assert r == -1 and b"512" in lib.snerf_last_error()
+        else:
+            assert r == want and lib.snerf_model_precision(m) == want
+            ns = C.c_size_t()
+            assert lib.snerf_model_pack_host(m, 2, None, C.byref(ns), None, None) == (0 if want == I8 else -4)
+        lib.snerf_model_destroy(m)
+
+
+def test_int8_accumulator_bound_is_enforced(lib):
+    """(M << 8) + X is formed in int32: a row whose digits could carry it past 2^31 (K = 572 digit slots at W = 512, every weight
+    at the row maximum) is refused under an explicit SNERF_PREC_I8X3 and not chosen by SNERF_PREC_AUTO."""
+    W = 512
+    sd = orc.init_weights(W, 4, 1)
+    sd["G_NeRF_net.fc5.linear.weight"] = torch.full_like(sd["G_NeRF_net.fc5.linear.weight"], 0.004)
+    m = _host_model(lib, W, sd, 2)
+    e = _estimate(lib, m)
+    assert e.acc_bound >= 2 ** 31 and not e.ok
+    assert lib.snerf_model_resolve_precision(m) == -1 and b"int32" in lib.snerf_last_error()
+    lib.snerf_model_destroy(m)
+    m = _host_model(lib, 256, {k: (v[:256, :319] if k == "G_NeRF_net.fc5.linear.weight" else v) for k, v in
+                               {**orc.init_weights(256, 4, 1), "G_NeRF_net.fc5.linear.weight": torch.full((256, 319), 0.004)}.items()}, 2)
+    assert _estimate(lib, m).acc_bound < 2 ** 31          # 316 digit slots: cannot wrap whatever the weights
+    lib.snerf_model_destroy(m)
+
+
+def test_network_class_resolves_its_precision_on_the_host():
+    import season_nerf_amd as sn
+    net = sn.T_NeRF(256, 4)
+    net.load_state_dict(orc.init_weights(256, 4, 0))
+    assert net.precision == "auto" and net.resolved_precision == "i8x3" and net.fused
+    est = net.i8_estimate()
+    assert est["ok"] and est["rgb_pred"] < est["budget"]
+    net.load_state_dict(orc.stress_weights(256, 4, 0, "outlier16"))
+    assert net.resolved_precision == "bf16x3" and not net.i8_estimate()["ok"]
+    net512 = sn.T_NeRF(512, 4)                              # the reference's default width (main_lite.py:80)
+    net512.load_state_dict(orc.init_weights(512, 4, 0))
+    assert net512.resolved_precision == "i8x3"
+    net512.load_state_dict(orc.stress_weights(512, 4, 0, "outlier16"))
+    assert net512.resolved_precision is None and not net512.fused       # layer-wise engine
+    net512.precision = "bf16x3"
+    assert not net512.fused
+    # a buffer replaced by Module._apply (.double().float()) is still tracked
+    net.load_state_dict(orc.init_weights(256, 4, 0))
+    assert net.resolved_precision == "i8x3"
+    net.double().float()
+    with torch.no_grad():
+        net.G_NeRF_net.fc2.norm.running_var.mul_(1e-6)       # BatchNorm gain x1000: far outside the bound
+    assert net.resolved_precision == "bf16x3"

@@ -12,12 +12,14 @@ pytestmark = pytest.mark.gpu
 R, S, W, C = 4096, 96, 256, 4
 
 
-@pytest.fixture(scope="module")
-def full():
+@pytest.fixture(scope="module", params=["bf16x3", "i8x3", "auto"])
+def full(request):
+    """The whole benchmark batch in each arithmetic mode: bf16x3, the int8-digit mode the benchmark times, and the class default."""
     import season_nerf_amd as sn
     sd = orc.init_weights(W, C, 0)
     net = sn.T_NeRF(W, C)
     net.load_state_dict(sd)
+    net.precision = request.param
     net = net.to("cuda").eval()
     rng = np.random.Generator(np.random.PCG64(0))
     top = np.concatenate([rng.uniform(-1, 1, (R, 2)), np.ones((R, 1))], 1)
@@ -34,6 +36,44 @@ def full():
     return sn, sd, net, ev, data, out
 
 
+def _i8(net):
+    return net.resolved_precision == "i8x3"
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "i8x3", "auto"])
+def test_benchmark_batch_vs_reference(golden_dir, precision):
+    """BASELINE configs[1] at its full size against the REFERENCE (tests/golden/evalfull_W256_R4096_S96.npz: All_in_One_Eval.eval,
+    Eval_Tools_2.py:165-252, run on /root/reference by tools/make_golden.py): all 4096 rays - 1536 tiles of the two-wave int8
+    kernel, six per workgroup - in every mode, the one the benchmark times included.  RGB and depth asserted at 5e-5 (bar 1e-4)."""
+    import os
+    import season_nerf_amd as sn
+    g = dict(np.load(os.path.join(golden_dir, "evalfull_W256_R4096_S96.npz"), allow_pickle=False))
+    net = sn.T_NeRF(int(g["W"]), int(g["C"]))
+    net.load_state_dict(orc.init_weights(int(g["W"]), int(g["C"]), int(g["seed"])))
+    net.precision = precision
+    net = net.to("cuda").eval()
+    assert net.resolved_precision == ("i8x3" if precision == "auto" else precision)
+    args = SimpleNamespace(n_samples=int(g["S"]), Use_Reg=True, Solar_Type_2=False, Use_MSE_loss=True, Use_Solar=True, sc_lambda=0.03,
+                           number_low_frequency_cases=C)
+    ev = sn.All_in_One_Eval(args, torch.device("cuda"), 10, False, None, np.eye(4), np.zeros(3))
+    data = {k: torch.tensor(g["in_" + k]) for k in ("Top", "Bot", "Sun_Angle", "Time_Encoded")}
+    out = ev.eval(data, net, 0, False)
+    rgb2, loc, dist = ev.render_summary(data, net)
+    rel = lambda a, b: float((np.abs(a - b) / np.maximum(np.abs(b), 1e-3)).max())
+    got = {"Rendered_Col": out["Rendered_Col"], "Albedo_Color": out["Albedo_Color"], "surf_dist": dist, "surf_loc": loc}
+    for k, v in got.items():
+        a, b = v.cpu().double().numpy().reshape(g["eval_" + k].shape), g["eval_" + k].astype(np.float64)
+        r, d = rel(a, b), float(np.abs(a - b).max())
+        print(f"  {precision:7s} {k:14s} over {a.shape[0]} rays: max rel {r:.2e} max abs {d:.2e}")
+        assert (d < 5e-5) if k == "surf_loc" else (r < 5e-5), (precision, k, r, d)
+    assert rel(rgb2.cpu().double().numpy(), g["eval_Rendered_Col"].astype(np.float64)) < 5e-5
+    sel = slice(0, R, R // int(g["keep"]))
+    for k, tol in (("Rho", 4e-4), ("Solar_Vis", 3e-4), ("Col", 3e-4), ("PS", 4e-4)):
+        r = rel(out[k][sel].cpu().double().numpy(), g["sub_" + k].astype(np.float64))
+        print(f"  {precision:7s} {k:14s} per-sample, every 64th ray: max rel {r:.2e}")
+        assert r < (tol if precision != "bf16x3" else 1e-4), (precision, k, r)
+
+
 def test_subset_matches_oracle(full):
     sn, sd, net, ev, data, out = full
     idx = torch.tensor([0, 1, 127, 128, 2047, 2048, 4000, 4095] + list(range(300, 324)))
@@ -42,7 +82,7 @@ def test_subset_matches_oracle(full):
         ref = orc.eval_rays(sd, sub, S, train_mode=False)
     got = out["Rendered_Col"][idx.cuda()].cpu().numpy()
     np.testing.assert_allclose(got, ref["Rendered_Col"].numpy(), rtol=1e-4, atol=2e-6)
-    np.testing.assert_allclose(out["PS"][idx.cuda()].cpu().numpy(), ref["PS"].numpy(), rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(out["PS"][idx.cuda()].cpu().numpy(), ref["PS"].numpy(), rtol=4e-4 if _i8(net) else 1e-4, atol=2e-5)
 
 
 def test_invariants(full):
@@ -89,8 +129,8 @@ def test_config0_512x64_whole_batch_vs_oracle(full):
     np.testing.assert_allclose(rgb.cpu().numpy(), ref["Rendered_Col"].numpy(), rtol=1e-4, atol=2e-6)
     np.testing.assert_allclose(loc.cpu().numpy(), rloc.numpy(), rtol=1e-4, atol=2e-5)             # depth: 1e-4 rel (north star)
     np.testing.assert_allclose(dist.cpu().numpy(), rdist.numpy(), rtol=1e-4, atol=2e-5)
-    for k, tol in (("Rho", 2e-4), ("Col", 1e-4), ("Solar_Vis", 1e-4), ("PV", 1e-4)):
-        np.testing.assert_allclose(out[k].cpu().numpy(), ref[k].numpy(), rtol=tol, atol=2e-5, err_msg=k)
+    for k, tol in (("Rho", 2e-4), ("Col", 1e-4), ("Solar_Vis", 1e-4), ("PV", 1e-4)):       # per-sample fields: int8 digits 4e-4
+        np.testing.assert_allclose(out[k].cpu().numpy(), ref[k].numpy(), rtol=4e-4 if _i8(net) else tol, atol=4e-5 if _i8(net) else 2e-5, err_msg=k)
     assert torch.equal(out["sample_pts"].cpu(), ref["sample_pts"])                                  # bit-identical sampling
 
 

@@ -1,6 +1,7 @@
 """GPU: the arithmetic modes of the fused field kernel (include/season_nerf_hip.h SNERF_PREC_*) against the reference goldens.
 
-  bf16x3  (default)  the full parity suite of test_gpu_parity.py
+  auto    (default)  i8x3 where the pack-time error bound holds, else bf16x3: test_gpu_stress.py
+  bf16x3             the full parity suite of test_gpu_parity.py
   i8x3               16-bit fixed point on the int8 matrix pipe: RGB / depth inside the north-star bar (1e-4 relative) with
                      margin (asserted at 5e-5), per-sample network outputs inside 3e-4; also the only fused mode at the
                      reference's default width 512 (main_lite.py:80)
@@ -93,8 +94,9 @@ def test_int8_digit_network_forwards(golden_dir, name):
     r = net.forward_Solar(X, sun, tim)
     assert err(r[0], g["solar_Rho"])[1] < 5e-4 and err(r[1], g["solar_Solar_Vis"])[1] < 3e-4
     assert err(net.forward_Classic_Sigma_Only(X), g["sigma_only"])[1] < 5e-4
-    # W = 512: the per-ray group network runs on the int8 pipe too (there is no bf16 instance at that width)
-    assert err(net.get_class_only(tim), g["class_only"])[1] < (3e-4 if int(g["W"]) > 256 else 1e-4)
+    # the per-ray networks never run in int8 digits (bf16x3 kernel at 256, exact fp32 layer by layer at 512)
+    assert err(net.get_class_only(tim), g["class_only"])[1] < 2e-5
+    assert err(net.forward(X, sun, tim)[3], g["fwd_Sky_Col"])[1] < 2e-5
 
 
 def test_fast_mode_sits_in_its_band(golden_dir):
@@ -105,9 +107,13 @@ def test_fast_mode_sits_in_its_band(golden_dir):
     assert 1e-4 < r < 5e-3, r            # outside the parity bar by construction, inside its measured band
 
 
-def test_width_512_needs_the_int8_mode():
+def test_width_512_is_fused_by_default():
+    """The reference's default width (main_lite.py:80, opt2.py:79): a freshly constructed network runs the fused int8-digit kernel out
+    of the box ("auto"), bf16x3 has no fused kernel there (layer-wise engine), unknown modes raise."""
     net = sn().T_NeRF(512, 4)
-    assert not net.fused                  # default precision bf16x3: no fused kernel at this width (layer-wise engine)
+    assert net.precision == "auto" and net.fused and net.resolved_precision == "i8x3"
+    net.precision = "bf16x3"
+    assert not net.fused
     net.precision = "i8x3"
     assert net.fused
     net.precision = "fp64"
@@ -204,3 +210,57 @@ def test_int8_mode_through_the_renderer_seams(golden_dir):
     fused = s.render_season_sweep(net, (80, 0), (30, 90), [k / 12.0 for k in range(12)], size, g["WC"], g["H"], torch.device("cuda"),
                                   render_time_frac=0.25)
     close("fused_sweep", fused.cpu().numpy(), g["sweep_imgs"], atol=3e-5)
+
+
+def _many_tiles_w512():
+    """4096 rays x 96 samples at W = 512 through the one-wave int8 kernel (kernels_i8.hip: 128-point tiles, 256 workgroups ->
+    12 tiles per workgroup: ring wrap-around across tiles, the cyclic reset of the DMA offset, activations parked in AGPRs from
+    one tile to the next) against the layer-wise engine, point by point, launched twice."""
+    import ctypes as C
+    s = sn()
+    W, R, S = 512, 4096, 96
+    rng = np.random.Generator(np.random.PCG64(15))
+    top = T(np.concatenate([rng.uniform(-1, 1, (R, 2)), np.ones((R, 1))], 1)).cuda()
+    bot = T(np.concatenate([rng.uniform(-1, 1, (R, 2)), -np.ones((R, 1))], 1)).cuda()
+    sun = rng.uniform(0, 1, (R, 3))
+    sun = T(sun / np.linalg.norm(sun, axis=1, keepdims=True)).cuda()
+    tim = T(rng.uniform(-1, 1, (R, 4))).cuda()
+    tv = s.sample_parameters(S, eval_mode=True).cuda()
+    net = make_net(W, 4, 12, "i8x3")
+    cls, _, _ = net._groups(tim, sun)
+    rho, sv, col = torch.empty(R * S, device="cuda"), torch.empty(R * S, device="cuda"), torch.empty(R * S, 3, device="cuda")
+    fo = s._lib.FieldOut(d_rho=rho.data_ptr(), d_solar_vis=sv.data_ptr(), d_col=col.data_ptr())
+    for _ in range(2):
+        s._lib.check(s._lib.lib().snerf_field_forward_rays(net.device_model(), 0, R, S, top.data_ptr(), bot.data_ptr(), tv.data_ptr(), 1,
+                                                           sun.data_ptr(), cls.data_ptr(), C.byref(fo), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "field")
+    torch.cuda.synchronize()
+    ref = make_net(W, 4, 12, "bf16x3")                        # no fused bf16 kernel at 512: the layer-wise engine
+    assert not ref.fused
+    pts = (top[:, None, :] * (1 - tv[None, :, None]) + bot[:, None, :] * tv[None, :, None]).reshape(-1, 3)
+    worst = [0.0, 0.0, 0.0]
+    for lo in range(0, R, 512):                               # the engine's workspace: 512 rays at a time
+        n = slice(lo * S, (lo + 512) * S)
+        r_rho, r_col, r_sv, _, _, _ = ref.forward(pts[n], sun[lo:lo + 512].repeat_interleave(S, 0), tim[lo:lo + 512].repeat_interleave(S, 0))
+        worst[0] = max(worst[0], ((rho[n] - r_rho.reshape(-1)).abs() / r_rho.reshape(-1).abs().clamp_min(1e-3)).max().item())
+        worst[1] = max(worst[1], (sv[n] - r_sv.reshape(-1)).abs().max().item())
+        worst[2] = max(worst[2], (col[n] - r_col).abs().max().item())
+    return worst
+
+
+def test_int8_one_wave_kernel_over_many_tiles_w512():
+    d_rho, d_sv, d_col = _many_tiles_w512()
+    print(f"  W=512 one-wave int8 kernel vs layer-wise engine over 393216 points: rho rel {d_rho:.2e}, solar_vis abs {d_sv:.2e}, col abs {d_col:.2e}")
+    assert d_rho < 5e-4 and d_sv < 3e-4 and d_col < 3e-4, (d_rho, d_sv, d_col)
+
+
+def test_int8_one_wave_kernel_over_many_tiles_w256():
+    """SNERF_I8_ONE_WAVE=1 selects the one-wave kernel at W <= 256 (read once per process: a child process)."""
+    import subprocess
+    import sys
+    code = ("import os, sys; sys.path.insert(0, os.getcwd()); import tests.test_gpu_precision as t; t.test_int8_mode_over_many_tiles(256); "
+            "print('ONE_WAVE_OK')")
+    env = dict(os.environ, SNERF_I8_ONE_WAVE="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    print(r.stdout[-600:], r.stderr[-600:])
+    assert r.returncode == 0 and "ONE_WAVE_OK" in r.stdout

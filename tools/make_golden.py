@@ -154,6 +154,58 @@ def gen_eval(W, seed, R, S, tag, with_prior):
     np.savez_compressed(os.path.join(OUT, f"eval_{tag}.npz"), **out)
 
 
+STRESS_SETS = [(256, "outlier4"), (256, "outlier16"), (256, "laplace"), (256, "gain2"), (256, "trained"),
+               (512, "outlier4"), (512, "outlier16"), (512, "laplace"), (512, "trained"), (64, "outlier8")]
+
+
+def gen_stress(W, kind, R=48, S=96, seed=0):
+    """All_in_One_Eval.eval of the reference (Eval_Tools_2.py:165-252) on weight sets shaped like trained checkpoints
+    (oracle.stress_weights: per-row outliers, heavy tails, BatchNorm gains, high-frequency branches; BatchNorm statistics
+    calibrated on the cube).  The weights are regenerated from (W, kind, seed) by the tests; stored: inputs, rendered colour,
+    albedo, expected surface point / distance (mg_run_NeRF.py:188-189) and the per-sample density, visibility and colour."""
+    sd = orc.stress_weights(W, 4, seed, kind)
+    net = T_NeRF(W, 4)
+    r = net.load_state_dict(sd, strict=True)
+    assert not r.missing_keys and not r.unexpected_keys
+    net.train(False)
+    data = synth_rays(R, 500 + seed)
+    out = {"W": W, "C": 4, "seed": seed, "S": S, "kind": np.array(kind)}
+    for k, v in data.items():
+        out["in_" + k] = f32(v)
+    with torch.no_grad():
+        ev = All_in_One_Eval(args_ns(S), torch.device("cpu"), 10, False, None, H4, WC)
+        r = ev.eval(data, net, 0, False)
+        for k in ["Rendered_Col", "Albedo_Color", "Rho", "Solar_Vis", "Col", "Sky_Col", "Classes"]:
+            out["eval_" + k] = f32(r[k][:, 0] if k in ("Sky_Col", "Classes") else r[k])       # per-ray quantities: one sample
+        loc = torch.sum(r["PS"] * r["sample_pts"], 1) / (torch.sum(r["PS"], 1) + 1e-8)       # mg_run_NeRF.py:188
+        dist = torch.sum(torch.cumsum(r["deltas"], 1) * r["PS"], 1) / torch.sum(r["PS"], 1)   # mg_run_NeRF.py:189
+        out["eval_surf_loc"], out["eval_surf_dist"] = f32(loc), f32(dist)
+    np.savez_compressed(os.path.join(OUT, f"stress_W{W}_{kind}.npz"), **out)
+
+
+def gen_eval_full(W=256, seed=6, R=4096, S=96, keep=64):
+    """BASELINE configs[1] at its full size through the reference: All_in_One_Eval.eval (Eval_Tools_2.py:165-252) on 4096 rays x
+    96 samples, T_NeRF(256, 4) eval mode, init-law weights (seed 6).  Per-ray results for all rays; the per-sample fields for
+    every (R / keep)-th ray."""
+    net, _ = make_net(W, 4, seed)
+    data = synth_rays(R, 600 + seed)
+    out = {"W": W, "C": 4, "seed": seed, "S": S, "keep": keep}
+    for k, v in data.items():
+        if k != "GT_Color":
+            out["in_" + k] = f32(v)
+    with torch.no_grad():
+        ev = All_in_One_Eval(args_ns(S), torch.device("cpu"), 10, False, None, H4, WC)
+        r = ev.eval(data, net, 0, False)
+        out["eval_Rendered_Col"], out["eval_Albedo_Color"] = f32(r["Rendered_Col"]), f32(r["Albedo_Color"])
+        loc = torch.sum(r["PS"] * r["sample_pts"], 1) / (torch.sum(r["PS"], 1) + 1e-8)
+        dist = torch.sum(torch.cumsum(r["deltas"], 1) * r["PS"], 1) / torch.sum(r["PS"], 1)
+        out["eval_surf_loc"], out["eval_surf_dist"] = f32(loc), f32(dist)
+        sel = slice(0, R, R // keep)
+        for k in ["Rho", "Solar_Vis", "Col", "PS"]:
+            out["sub_" + k] = f32(r[k][sel])
+    np.savez_compressed(os.path.join(OUT, f"evalfull_W{W}_R{R}_S{S}.npz"), **out)
+
+
 def gen_train(W, seed, R, S, tag, prior=False, subsample=0, classic=False):
     """subsample > 0: tensors above 4096 elements are stored as every `subsample`-th element (flat order) plus their L2 norm
     (keeps the W=256 fixture small)."""
@@ -377,6 +429,13 @@ if __name__ == "__main__":
         gen_net(512, 3, 384, "W512_s3")
         gen_eval(512, 2, 64, 96, "W512_R64_S96", with_prior=False)
         sys.exit(0)
+    if "--only-stress" in sys.argv:               # trained-like weight sets (the int8-digit mode's hard cases) + configs[1] at full size
+        for W_, kind_ in STRESS_SETS:
+            gen_stress(W_, kind_)
+            print(f"stress_W{W_}_{kind_}.npz", os.path.getsize(os.path.join(OUT, f"stress_W{W_}_{kind_}.npz")), flush=True)
+        gen_eval_full()
+        print("evalfull_W256_R4096_S96.npz", os.path.getsize(os.path.join(OUT, "evalfull_W256_R4096_S96.npz")))
+        sys.exit(0)
     if "--only-full-train" in sys.argv:
         # BASELINE configs[2] at its full size: ONE reference training step, 4096 rays x 96 samples + 4096 sun rays, W = 256,
         # MSE loss (43 s and ~40 GB of autograd state on the 8 CPUs of the build container).  Gradients of the big tensors are
@@ -400,5 +459,8 @@ if __name__ == "__main__":
     gen_render(64, 2, "W64_s2")
     gen_render_by_P(64, 2, "W64_s2")
     gen_dsm()
+    for W_, kind_ in STRESS_SETS:
+        gen_stress(W_, kind_)
+    gen_eval_full()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

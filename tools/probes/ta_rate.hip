@@ -5,6 +5,9 @@
 //   shape 2: fully contiguous    - lane l reads 16 B at 16 l (1 KiB contiguous)
 //   shape 3: accumulator stores  - lane (c, h) stores 4 B at row 4 h, column c (two 128-B row segments per instruction)
 //   shape 4: 16-byte row stores  - lane l stores 16 B at row l / 8, byte 16 (l % 8) (eight 128-B row segments)
+//   shape 5: 16x16 accumulator stores           - lane (g, j) stores 4 B at row 4 g, column j (four 64-B row segments)
+//   shape 6: 16x16 transposed accumulator stores - lane (g, j) stores 16 B at row j, byte 16 g (sixteen 64-B row segments)
+//   shape 7: shape 6 as a pair - two such stores to the two halves of the same sixteen 128-B lines
 // Prints cycles per wave-instruction per CU (all 8 waves issuing).  build: hipcc -O3 --offload-arch=gfx950 ta_rate.hip
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -32,6 +35,9 @@ __global__ __launch_bounds__(512) void probe(float* buf, int64_t rows_total, uin
             if (SHAPE == 2) v[u] = *(const f32x4*)(buf + (base + (it % 16)) * ld + lane * 4);
             if (SHAPE == 3) buf[(base + 4 * h + (it % 4) + 8 * ((it / 4) % 4)) * ld + ((it / 16) % 8) * 32 + r] = acc[0] + it;
             if (SHAPE == 4) *(f32x4*)(buf + (base + (lane >> 3) + 8 * (it % 4)) * ld + ((it / 4) % 8) * 32 + (lane & 7) * 4) = acc + (float)it;
+            if (SHAPE == 5) buf[(base + 4 * (lane >> 4) + (it % 4) + 16 * ((it / 4) % 2)) * ld + ((it / 8) % 16) * 16 + (lane & 15)] = acc[0] + it;
+            if (SHAPE == 6) *(f32x4*)(buf + (base + (lane & 15) + 16 * (it % 2)) * ld + ((it / 2) % 16) * 16 + (lane >> 4) * 4) = acc + (float)it;
+            if (SHAPE == 7) *(f32x4*)(buf + (base + (lane & 15) + 16 * ((it / 2) % 2)) * ld + ((it / 4) % 8) * 32 + (it % 2) * 16 + (lane >> 4) * 4) = acc + (float)it;
         }
         if (SHAPE < 3) {
 #pragma unroll
@@ -65,5 +71,8 @@ int main() {
     run<2>(buf, rows, cyc, sink, "load, contiguous 1 KiB");
     run<3>(buf, rows, cyc, sink, "store dword, 2 x 128 B");
     run<4>(buf, rows, cyc, sink, "store dwordx4, 8 x 128 B");
+    run<5>(buf, rows, cyc, sink, "store dword, 4 x 64 B");
+    run<6>(buf, rows, cyc, sink, "store dwordx4, 16 x 64 B");
+    run<7>(buf, rows, cyc, sink, "store dwordx4, 16 x 64 B pairs");
     return 0;
 }
