@@ -16,6 +16,18 @@
 //   season_nerf::composite(top, bot, tvals, rho, col, solar_vis, sky, flags, rho_prior?, trust) -> Tensor[10]    get_PV + shading
 //   season_nerf::composite_sweep(...) -> Tensor[6]                                                    mg_Img_Eval t-step sweep
 //   season_nerf::fused_adam_(param!, grad, m!, v!, lr, b1, b2, eps, step) -> ()                         mg_run_NeRF.py:312-320
+// Training engine (csrc/train.cpp; `trainer` = the snerf_trainer handle a season_nerf_amd.training.TrainEngine owns and has bound to its
+// parameter / gradient / workspace tensors).  The forward ops are functional in their tensor arguments (torch.library.register_autograd
+// attaches the backward ops to them, season_nerf_amd/training.py); the engine keeps the activations of its last forward and the BatchNorm
+// running statistics behind the handle.  `params` only ties the ops into the autograd graph of the parameters.
+//   season_nerf::train_fwd_image(trainer, top, bot, tvals, sun, time, train_bn, classic, n_classes, height_map?, trust, params[])       get_loss, image rays
+//        -> [rgb, albedo, sky, pe, rgb_merged, albedo_merged | pv, ps, delta, classes, rho, solar_vis, col, pts, adjust_col | prior terms]  Eval_Tools_2.py:165-252
+//   season_nerf::train_bwd_image(trainer, grads!, g_rgb?, g_albedo?, g_sky?, g_pe?, rho_prior?, trust, g_rgb_merged?, g_albedo_merged?) -> ()
+//   season_nerf::train_fwd_points(trainer, x, sun, time, train_bn, n_classes, params[]) -> [rho, col, solar_vis, sky, classes, adjust_col, col_raw, adjust]
+//   season_nerf::train_bwd_points(trainer, grads!, g_rho?, g_col?, g_solar_vis?, g_sky?, g_classes?) -> ()                                T_NeRF.forward, train mode
+//   season_nerf::train_fwd_solar(trainer, top, bot, tvals, sun, train_bn, params[]) -> [solar_vis, pv, pe, sky_raw, rho, pts, delta]      eval_Rho_Only / forward_Solar
+//   season_nerf::train_bwd_solar(trainer, grads!, g_solar_vis) -> ()
+//   season_nerf::prior_density(pts[N,3], delta[N], height_map[h,w] f64, outside[N]?) -> rho_prior[N,1]                                    T_NeRF.Supervised_Sample
 #include <ATen/ATen.h>
 #include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>      // PyTorch-ROCm presents HIP devices under the "cuda" device type
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
@@ -227,6 +239,152 @@ void fused_adam_(Tensor param, const Tensor& grad, Tensor m, Tensor v, double lr
                        cur_stream(param)), "fused_adam_");
 }
 
+// ---- training engine ---------------------------------------------------------------------------------------------------
+snerf_trainer* trainer_of(int64_t h) {
+    TORCH_CHECK(h != 0, "season_nerf::train_*: NULL trainer handle");
+    return (snerf_trainer*)h;
+}
+const float* optptr(const c10::optional<Tensor>& t, const char* name, int64_t numel) {
+    if (!t.has_value()) return nullptr;
+    check_dev_f32(*t, name);
+    TORCH_CHECK(t->numel() == numel, name, " must hold ", numel, " elements, got ", t->sizes());
+    return fptr(*t);
+}
+
+Tensor prior_density(const Tensor& pts, const Tensor& delta, const Tensor& height_map, const c10::optional<Tensor>& outside) {
+    check_shape(pts, "pts", -1, 3);
+    check_dev_f32(delta, "delta");
+    const int64_t N = pts.size(0);
+    TORCH_CHECK(delta.numel() == N, "delta must hold one value per point");
+    TORCH_CHECK(height_map.is_cuda() && height_map.scalar_type() == at::kDouble && height_map.dim() == 2 && height_map.is_contiguous(),
+                "height_map must be a contiguous float64 [h, w] tensor on the GPU");
+    c10::hip::HIPGuardMasqueradingAsCUDA g(pts.device());
+    Tensor out = at::empty({N, 1}, pts.options());
+    ck(snerf_prior_density(N, fptr(pts), fptr(delta), height_map.data_ptr<double>(), (int)height_map.size(0), (int)height_map.size(1),
+                           optptr(outside, "outside", N), mptr(out), cur_stream(pts)), "prior_density");
+    return out;
+}
+
+std::vector<Tensor> train_fwd_image(int64_t trainer, const Tensor& top, const Tensor& bot, const Tensor& tvals, const Tensor& sun, const Tensor& time,
+                                    bool train_bn, bool classic, int64_t n_classes, const c10::optional<Tensor>& height_map, double trust,
+                                    at::TensorList /*params*/) {
+    snerf_trainer* t = trainer_of(trainer);
+    check_shape(top, "top", -1, 3);
+    const int64_t R = top.size(0);
+    check_shape(bot, "bot", R, 3); check_shape(sun, "sun", R, 3); check_shape(time, "time", R, 4);
+    check_dev_f32(tvals, "tvals");
+    TORCH_CHECK(tvals.dim() == 1 && tvals.numel() >= 1, "tvals must be [S]");
+    TORCH_CHECK(n_classes >= 1 && n_classes <= 5, "n_classes must be in [1, 5]");
+    const int64_t S = tvals.numel(), C = n_classes;
+    c10::hip::HIPGuardMasqueradingAsCUDA g(top.device());
+    auto o = top.options();
+    auto e = [&](std::initializer_list<int64_t> sz) { return at::empty(sz, o); };
+    Tensor rgb = e({R, 3}), albedo = e({R, 3}), sky = e({R, 3}), pe = e({R, S, 1}), pv = e({R, S, 1}), ps = e({R, S, 1}), delta = e({R, S, 1}),
+           cls = e({R, C}), rho = e({R, S, 1}), sv = e({R, S, 1}), col = e({R, S, 3}), pts = e({R, S, 3}), adjc = e({R, S, 3});
+    snerf_composite_out co{};
+    co.d_rgb = mptr(rgb); co.d_albedo = mptr(albedo); co.d_pv = mptr(pv); co.d_pe = mptr(pe); co.d_ps = mptr(ps); co.d_delta = mptr(delta);
+    snerf_field_out fo{};
+    fo.d_rho = mptr(rho); fo.d_solar_vis = mptr(sv); fo.d_col = mptr(col); fo.d_points = mptr(pts); fo.d_adjust_col = mptr(adjc);
+    void* st = cur_stream(top);
+    ck(snerf_trainer_forward_image(t, R, (int)S, fptr(top), fptr(bot), fptr(tvals), fptr(sun), fptr(time), train_bn ? 1 : 0, classic ? 1 : 0, &co,
+                                   mptr(sky), mptr(cls), &fo, st), "train_fwd_image");
+    Tensor rgb_m = e({0}), alb_m = e({0});
+    std::vector<Tensor> extra;
+    if (height_map.has_value()) {      // DSM-prior phase (Eval_Tools_2.py:218-248): supervised density, merged density, their composites
+        Tensor rs = prior_density(pts.reshape({-1, 3}), delta.reshape({-1}), *height_map, c10::nullopt).reshape({R, S, 1});
+        auto comp = [&](const Tensor& rho_t, const float* prior, float tr, int flags, Tensor* c_rgb, Tensor* c_alb, Tensor* c_pv, Tensor* c_pe, Tensor* c_ps) {
+            snerf_composite_out c{};
+            if (c_rgb) c.d_rgb = mptr(*c_rgb);
+            if (c_alb) c.d_albedo = mptr(*c_alb);
+            if (c_pv) c.d_pv = mptr(*c_pv);
+            if (c_pe) c.d_pe = mptr(*c_pe);
+            if (c_ps) c.d_ps = mptr(*c_ps);
+            ck(snerf_composite_rays(R, (int)S, fptr(top), fptr(bot), fptr(tvals), fptr(rho_t), fptr(col), fptr(sv), fptr(sky), flags, prior, tr, &c, st),
+               "train_fwd_image (prior composites)");
+        };
+        Tensor pv_s = e({R, S, 1}), pe_s = e({R, S, 1}), ps_s = e({R, S, 1}), pv_m = e({R, S, 1}), pe_m = e({R, S, 1}), ps_m = e({R, S, 1});
+        comp(rs, nullptr, 1.f, 0, nullptr, nullptr, &pv_s, &pe_s, &ps_s);
+        rgb_m = e({R, 3}); alb_m = e({R, 3});
+        comp(rho, fptr(rs), (float)trust, classic ? 1 : 0, &rgb_m, &alb_m, nullptr, nullptr, nullptr);
+        Tensor rho_m = rho * trust + rs * (1.0 - trust);
+        comp(rho_m, nullptr, 1.f, 0, nullptr, nullptr, &pv_m, &pe_m, &ps_m);
+        extra = {rs, pv_s, pe_s, ps_s, pv_m, pe_m, ps_m, rho_m};
+    }
+    std::vector<Tensor> r = {rgb, albedo, sky, pe, rgb_m, alb_m, pv, ps, delta, cls, rho, sv, col, pts, adjc};
+    r.insert(r.end(), extra.begin(), extra.end());
+    return r;
+}
+
+void train_bwd_image(int64_t trainer, Tensor grads, const c10::optional<Tensor>& g_rgb, const c10::optional<Tensor>& g_albedo, const c10::optional<Tensor>& g_sky,
+                     const c10::optional<Tensor>& g_pe, const c10::optional<Tensor>& rho_prior, double trust, const c10::optional<Tensor>& g_rgb_m,
+                     const c10::optional<Tensor>& g_alb_m, int64_t n_rays, int64_t n_samples) {
+    snerf_trainer* t = trainer_of(trainer);
+    check_dev_f32(grads, "grads");
+    const int64_t R = n_rays, N = n_rays * n_samples;
+    c10::hip::HIPGuardMasqueradingAsCUDA g(grads.device());
+    const float* prior = optptr(rho_prior, "rho_prior", N);
+    ck(snerf_trainer_backward_image(t, optptr(g_rgb, "g_rgb", R * 3), optptr(g_albedo, "g_albedo", R * 3), optptr(g_sky, "g_sky", R * 3), optptr(g_pe, "g_pe", N),
+                                    prior, (float)trust, prior ? optptr(g_rgb_m, "g_rgb_merged", R * 3) : nullptr,
+                                    prior ? optptr(g_alb_m, "g_albedo_merged", R * 3) : nullptr, cur_stream(grads)), "train_bwd_image");
+}
+
+std::vector<Tensor> train_fwd_points(int64_t trainer, const Tensor& x, const Tensor& sun, const Tensor& time, bool train_bn, int64_t n_classes,
+                                     at::TensorList /*params*/) {
+    snerf_trainer* t = trainer_of(trainer);
+    check_shape(x, "x", -1, 3);
+    const int64_t N = x.size(0), C = n_classes;
+    check_shape(sun, "sun", N, 3); check_shape(time, "time", N, 4);
+    TORCH_CHECK(n_classes >= 1 && n_classes <= 5, "n_classes must be in [1, 5]");
+    c10::hip::HIPGuardMasqueradingAsCUDA g(x.device());
+    auto o = x.options();
+    Tensor rho = at::empty({N, 1}, o), col = at::empty({N, 3}, o), sv = at::empty({N, 1}, o), sky = at::empty({N, 3}, o), cls = at::empty({N, C}, o),
+           adjc = at::empty({N, 3}, o), col_raw = at::empty({N, 3}, o), adj = at::empty({N, C, 3}, o), rgb = at::empty({N, 3}, o), tv = at::zeros({1}, o);
+    snerf_composite_out co{};
+    co.d_rgb = mptr(rgb);
+    snerf_field_out fo{};
+    fo.d_rho = mptr(rho); fo.d_solar_vis = mptr(sv); fo.d_col = mptr(col); fo.d_adjust_col = mptr(adjc); fo.d_col_raw = mptr(col_raw); fo.d_adjust = mptr(adj);
+    // N rays of one sample at t = 0: point = Top (per-point sun / time, as the reference's evaluator passes them, Eval_Tools_2.py:174-176)
+    ck(snerf_trainer_forward_image(t, N, 1, fptr(x), fptr(x), fptr(tv), fptr(sun), fptr(time), train_bn ? 1 : 0, 0, &co, mptr(sky), mptr(cls), &fo,
+                                   cur_stream(x)), "train_fwd_points");
+    return {rho, col, sv, sky, cls, adjc, col_raw, adj};
+}
+
+void train_bwd_points(int64_t trainer, Tensor grads, const c10::optional<Tensor>& g_rho, const c10::optional<Tensor>& g_col, const c10::optional<Tensor>& g_sv,
+                      const c10::optional<Tensor>& g_sky, const c10::optional<Tensor>& g_cls, int64_t n_points, int64_t n_classes) {
+    snerf_trainer* t = trainer_of(trainer);
+    check_dev_f32(grads, "grads");
+    const int64_t N = n_points;
+    c10::hip::HIPGuardMasqueradingAsCUDA g(grads.device());
+    ck(snerf_trainer_backward_points(t, optptr(g_rho, "g_rho", N), optptr(g_col, "g_col", N * 3), optptr(g_sv, "g_solar_vis", N), optptr(g_sky, "g_sky", N * 3),
+                                     optptr(g_cls, "g_classes", N * n_classes), cur_stream(grads)), "train_bwd_points");
+}
+
+std::vector<Tensor> train_fwd_solar(int64_t trainer, const Tensor& top, const Tensor& bot, const Tensor& tvals, const Tensor& sun, bool train_bn,
+                                    at::TensorList /*params*/) {
+    snerf_trainer* t = trainer_of(trainer);
+    check_shape(top, "top", -1, 3);
+    const int64_t R = top.size(0);
+    check_shape(bot, "bot", R, 3); check_shape(sun, "sun", R, 3);
+    check_dev_f32(tvals, "tvals");
+    TORCH_CHECK(tvals.dim() == 1 && tvals.numel() >= 1, "tvals must be [S]");
+    const int64_t S = tvals.numel();
+    c10::hip::HIPGuardMasqueradingAsCUDA g(top.device());
+    auto o = top.options();
+    Tensor sv = at::empty({R, S, 1}, o), pv = at::empty({R, S, 1}, o), pe = at::empty({R, S, 1}, o), sky_raw = at::empty({R, 3}, o), rho = at::empty({R, S, 1}, o),
+           pts = at::empty({R, S, 3}, o), dl = at::empty({R, S, 1}, o);
+    ck(snerf_trainer_forward_solar(t, R, (int)S, fptr(top), fptr(bot), fptr(tvals), fptr(sun), train_bn ? 1 : 0, mptr(sv), mptr(pv), mptr(pe), mptr(sky_raw),
+                                   mptr(rho), mptr(pts), mptr(dl), cur_stream(top)), "train_fwd_solar");
+    return {sv, pv, pe, sky_raw, rho, pts, dl};
+}
+
+void train_bwd_solar(int64_t trainer, Tensor grads, const Tensor& g_sv) {
+    snerf_trainer* t = trainer_of(trainer);
+    check_dev_f32(grads, "grads");
+    check_dev_f32(g_sv, "g_solar_vis");
+    c10::hip::HIPGuardMasqueradingAsCUDA g(grads.device());
+    ck(snerf_trainer_backward_solar(t, fptr(g_sv), cur_stream(grads)), "train_bwd_solar");
+}
+
 }  // namespace
 
 TORCH_LIBRARY(season_nerf, m) {
@@ -250,6 +408,16 @@ TORCH_LIBRARY(season_nerf, m) {
     m.def("composite_sweep(Tensor top, Tensor bot, Tensor tvals, Tensor rho, Tensor col_raw, Tensor adjust, Tensor solar_vis, Tensor sky, Tensor class_vecs, "
           "int flags, bool classic) -> Tensor[]");
     m.def("fused_adam_(Tensor(a!) param, Tensor grad, Tensor(b!) m, Tensor(c!) v, float lr, float beta1, float beta2, float eps, int step) -> ()");
+    m.def("prior_density(Tensor pts, Tensor delta, Tensor height_map, Tensor? outside) -> Tensor");
+    m.def("train_fwd_image(int trainer, Tensor top, Tensor bot, Tensor tvals, Tensor sun, Tensor time, bool train_bn, bool classic, int n_classes, "
+          "Tensor? height_map, float trust, Tensor[] params) -> Tensor[]");
+    m.def("train_bwd_image(int trainer, Tensor(a!) grads, Tensor? g_rgb, Tensor? g_albedo, Tensor? g_sky, Tensor? g_pe, Tensor? rho_prior, float trust, "
+          "Tensor? g_rgb_merged, Tensor? g_albedo_merged, int n_rays, int n_samples) -> ()");
+    m.def("train_fwd_points(int trainer, Tensor x, Tensor sun, Tensor time, bool train_bn, int n_classes, Tensor[] params) -> Tensor[]");
+    m.def("train_bwd_points(int trainer, Tensor(a!) grads, Tensor? g_rho, Tensor? g_col, Tensor? g_solar_vis, Tensor? g_sky, Tensor? g_classes, "
+          "int n_points, int n_classes) -> ()");
+    m.def("train_fwd_solar(int trainer, Tensor top, Tensor bot, Tensor tvals, Tensor sun, bool train_bn, Tensor[] params) -> Tensor[]");
+    m.def("train_bwd_solar(int trainer, Tensor(a!) grads, Tensor g_solar_vis) -> ()");
 }
 
 TORCH_LIBRARY_IMPL(season_nerf, CUDA, m) {      // "CUDA" is the dispatch key of HIP tensors in PyTorch-ROCm
@@ -259,4 +427,11 @@ TORCH_LIBRARY_IMPL(season_nerf, CUDA, m) {      // "CUDA" is the dispatch key of
     m.impl("composite", composite);
     m.impl("composite_sweep", composite_sweep);
     m.impl("fused_adam_", fused_adam_);
+    m.impl("prior_density", prior_density);
+    m.impl("train_fwd_image", train_fwd_image);
+    m.impl("train_bwd_image", train_bwd_image);
+    m.impl("train_fwd_points", train_fwd_points);
+    m.impl("train_bwd_points", train_bwd_points);
+    m.impl("train_fwd_solar", train_fwd_solar);
+    m.impl("train_bwd_solar", train_bwd_solar);
 }

@@ -191,6 +191,19 @@ class T_NeRF(nn.Module):
             d.pop(k, None)
         return d
 
+    def invalidate_packed(self):
+        """The parameters or BatchNorm statistics changed behind torch's version counters (the training engine's kernels write the
+        arenas directly): re-pack before the next fused inference."""
+        self.__dict__["_packed_sig"] = None
+
+    def height_map_on(self, dev):
+        """The DSM height map the module was built with (HM=...), float64 on `dev` (Supervised_Sample, T_NeRF_net_v2.py:175-181)."""
+        if self._hm_dev is None or self._hm_dev.device != torch.device(dev):
+            self._hm_dev = self.hm.to(device=dev, dtype=torch.float64).contiguous()
+        if self._hm_dev.dim() != 2:
+            raise ValueError("Supervised_Sample needs the 2-D height map the module was built with (HM=...)")
+        return self._hm_dev
+
     def release(self):
         self._op_model = None          # the op layer's object owns the C model: destroyed with its last reference
         self._handle = None
@@ -224,17 +237,9 @@ class T_NeRF(nn.Module):
         from . import training
         N = X.shape[0]
         eng = training._engine_for(self, N, 0, 1)
-        dev = X.device
-        e = lambda *s: torch.empty(*s, device=dev)
-        o = {"rho": e(N, 1), "sv": e(N, 1), "col": e(N, 3), "col_raw": e(N, 3), "adj": e(N, self.n_classes, 3),
-             "adjc": e(N, 3), "sky": e(N, 3), "cls": e(N, self.n_classes), "rgb": e(N, 3)}
-        tv = torch.zeros(1, device=dev)
-        co = _lib.CompositeOut(d_rgb=o["rgb"].data_ptr())
-        fo = _lib.FieldOut(d_rho=o["rho"].data_ptr(), d_solar_vis=o["sv"].data_ptr(), d_col=o["col"].data_ptr(),
-                           d_col_raw=o["col_raw"].data_ptr(), d_adjust=o["adj"].data_ptr(), d_adjust_col=o["adjc"].data_ptr())
-        _lib.check(eng.L.snerf_trainer_forward_image(eng.h, N, 1, X.data_ptr(), X.data_ptr(), tv.data_ptr(), sun.data_ptr(),
-                                                     tim.data_ptr(), 0, 0, C.byref(co), o["sky"].data_ptr(), o["cls"].data_ptr(),
-                                                     C.byref(fo), eng.stream()), "trainer_forward_image")
+        with torch.no_grad():
+            r = training._train_ops(eng, False).train_fwd_points(eng.handle, X, sun, tim, False, self.n_classes, eng.param_list)
+        o = dict(zip(["rho", "col", "sv", "sky", "cls", "adjc", "col_raw", "adj"], r))
         return o
 
     def _field_points(self, variant, X, sun, cls, want):
@@ -343,18 +348,11 @@ class T_NeRF(nn.Module):
         n = pts.shape[0]
         if pts.dim() != 2 or pts.shape[1] != 3 or dl.shape[0] != n:
             raise ValueError(f"Supervised_Sample: points {tuple(world_pts.shape)} / deltas {tuple(delta.shape)}")
-        if self._hm_dev is None or self._hm_dev.device != dev:
-            self._hm_dev = self.hm.to(device=dev, dtype=torch.float64).contiguous()
-        if self._hm_dev.dim() != 2:
-            raise ValueError("Supervised_Sample needs the 2-D height map the module was built with (HM=...)")
+        hm = self.height_map_on(dev)
         # without `outside` every point must lie in the cube, as in the reference (which indexes out of range otherwise);
         # the kernel clamps the index for memory safety instead of synchronising to check
         if outside is not None:
             outside = f(outside).reshape(-1)
             if outside.shape[0] != n:
                 raise ValueError("Supervised_Sample: `outside` must hold one value per point")
-        out = torch.empty(n, 1, device=pts.device)
-        _lib.check(_lib.lib().snerf_prior_density(n, pts.data_ptr(), dl.data_ptr(), self._hm_dev.data_ptr(), self._hm_dev.shape[0],
-                                                  self._hm_dev.shape[1], outside.data_ptr() if outside is not None else None,
-                                                  out.data_ptr(), self._stream()), "snerf_prior_density")
-        return out
+        return _ops().prior_density(pts, dl, hm, outside)

@@ -47,6 +47,29 @@ def _register_fakes():
     def _(param, grad, m, v, lr, beta1, beta2, eps, step):
         return None
 
+    @reg("season_nerf::prior_density")
+    def _(pts, delta, height_map, outside):
+        return pts.new_empty(pts.shape[0], 1)
+
+    @reg("season_nerf::train_fwd_image")
+    def _(trainer, top, bot, tvals, sun, time, train_bn, classic, n_classes, height_map, trust, params):
+        R, S, C = top.shape[0], tvals.numel(), n_classes
+        e = top.new_empty
+        m3 = (R, 3) if height_map is not None else (0,)
+        r = [e(R, 3), e(R, 3), e(R, 3), e(R, S, 1), e(*m3), e(*m3), e(R, S, 1), e(R, S, 1), e(R, S, 1), e(R, C), e(R, S, 1), e(R, S, 1), e(R, S, 3),
+             e(R, S, 3), e(R, S, 3)]
+        return r + ([e(R, S, 1) for _ in range(8)] if height_map is not None else [])
+
+    @reg("season_nerf::train_fwd_points")
+    def _(trainer, x, sun, time, train_bn, n_classes, params):
+        N, C, e = x.shape[0], n_classes, x.new_empty
+        return [e(N, 1), e(N, 3), e(N, 1), e(N, 3), e(N, C), e(N, 3), e(N, 3), e(N, C, 3)]
+
+    @reg("season_nerf::train_fwd_solar")
+    def _(trainer, top, bot, tvals, sun, train_bn, params):
+        R, S, e = top.shape[0], tvals.numel(), top.new_empty
+        return [e(R, S, 1), e(R, S, 1), e(R, S, 1), e(R, 3), e(R, S, 1), e(R, S, 3), e(R, S, 1)]
+
 
 def model_view(handle):
     """torch.classes.season_nerf.Model viewing (not owning) a C-ABI model created elsewhere, e.g. by a C host."""

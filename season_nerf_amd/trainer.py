@@ -102,7 +102,7 @@ class Net_tool:
             _allreduce_mean_grads(self._ada_params)       # ... and the loss object's alpha / scale gradients follow: every rank
             self.optim2.step()                            # must optimise the same objective (Solar_Correction weight = w / scale^2)
         if not self.fused_adam:
-            self.network._sig = None         # parameters changed under a torch optimiser: re-pack before the next inference
+            self.network.invalidate_packed()  # parameters changed under a torch optimiser: re-pack before the next inference
         self.sched.step()
         if self.sched2 is not None:
             self.sched2.step()

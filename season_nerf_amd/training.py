@@ -5,8 +5,9 @@ The heavy work (train-mode forward of both passes, backward, Adam) runs in the C
 (`snerf_trainer_*`, csrc/train.cpp).  This module only
   * owns the memory: one flat fp32 parameter arena (the module's Parameters become views into it, so `state_dict`,
     `load_state_dict` and any torch optimiser keep working), the BatchNorm running-stat arena, the workspace;
-  * plugs the engine into autograd with two `torch.autograd.Function`s (image rays, sun rays), so the reference's
-    `optim.zero_grad(); loss = get_loss(); total.backward(); optim.step()` sequence works unchanged;
+  * plugs the engine into autograd through the custom ops `torch.ops.season_nerf.train_fwd_* / train_bwd_*` (csrc/ops.cpp,
+    `torch.library.register_autograd`), so the reference's `optim.zero_grad(); loss = get_loss(); total.backward();
+    optim.step()` sequence works unchanged and the dispatcher / profiler see the passes;
   * restates the scalar loss terms on the small per-ray tensors with torch ops (R x 3 numbers).
 """
 import ctypes as C
@@ -136,6 +137,10 @@ class TrainEngine:
                                         n_rays, n_solar_rays, n_samples), "trainer_bind")
         self.classic_solar = False        # Solar_Type_2 shading in the image pass (set per call by eval_train)
         self._ar_cb = None
+        self.serial = 0                   # forwards run so far: a backward belongs to the forward whose serial it recorded
+        self.handle = int(self.h)         # as the custom ops take it
+        import weakref
+        _ENGINES[self.handle] = weakref.ref(self)
         if store.bn_sync is not None:     # global-batch BatchNorm is a property of the NETWORK: a new engine (another batch size)
             self.sync_batchnorm(True, store.bn_sync[0])       # must issue the same collectives as its siblings on the other ranks
 
@@ -225,196 +230,144 @@ class TrainEngine:
 
     def __del__(self):
         try:
+            _ENGINES.pop(self.handle, None)
             self.L.snerf_trainer_destroy(self.h)
         except Exception:
             pass
 
 
-def _composite(eng, top, bot, tv, rho, col, sv, sky, prior=None, trust=1.0, want=("pv", "pe", "ps"), classic=False):
-    """snerf_composite_rays on [R,S,*] tensors; returns dict of requested outputs."""
-    R, S, dev = rho.shape[0], rho.shape[1], rho.device
-    e = lambda *s: torch.empty(*s, device=dev)
-    shapes = {"rgb": (R, 3), "albedo": (R, 3), "pv": (R, S, 1), "pe": (R, S, 1), "ps": (R, S, 1), "delta": (R, S, 1)}
-    o = {k: e(*shapes[k]) for k in want}
-    co = _lib.CompositeOut(**{"d_" + k: v.data_ptr() for k, v in o.items()})
-    _lib.check(eng.L.snerf_composite_rays(R, S, top.data_ptr(), bot.data_ptr(), tv.data_ptr(), rho.data_ptr(), col.data_ptr(),
-                                          sv.data_ptr(), sky.data_ptr(), 1 if classic else 0, _ptr(prior), float(trust), C.byref(co), eng.stream()),
-               "composite_rays")
-    return o
+# ---------------------------------------------------------------------------------------------------------------------
+# The engine's passes as PyTorch custom ops (csrc/ops.cpp: season_nerf::train_fwd_* / train_bwd_*), tied into autograd with
+# torch.library.register_autograd: the forward op runs the HIP forward of one pass, its registered backward calls the matching
+# train_bwd_* op, which accumulates straight into the flat gradient arena behind every p.grad (attach_grads) - autograd itself
+# moves no parameter gradient (the ops return None for `params`).  One forward per engine may be outstanding: the engine
+# keeps the activations of its LAST forward, so each forward takes a serial number and a backward that finds a newer one
+# raises instead of differentiating the wrong activations.
+_ENGINES = {}           # trainer handle -> TrainEngine (weak: an engine leaves with its network)
+_AUTOGRAD_DONE = False
 
 
-class _ImagePass(torch.autograd.Function):
-    """T_NeRF.forward (train mode) + compositing on R rays; differentiable outputs: Rendered_Col, Albedo_Color,
-    Sky_Col (per ray), PE and - in the DSM-prior phase - Rendered_Col_Merged and the merged Albedo_Color."""
+def _engine_of(handle):
+    import weakref  # noqa: F401
+    ref = _ENGINES.get(int(handle))
+    eng = ref() if ref is not None else None
+    if eng is None:
+        raise RuntimeError("season_nerf_amd: the training engine of this graph no longer exists")
+    return eng
 
-    @staticmethod
-    def forward(ctx, eng, top, bot, tv, sun, tim, train_bn, prior, *params):
-        R, S, dev = eng.R, eng.S, eng.dev
-        if any(p.requires_grad for p in params):
-            eng.attach_grads()
-        e = lambda *s: torch.empty(*s, device=dev)
-        o = {"rgb": e(R, 3), "albedo": e(R, 3), "pv": e(R, S, 1), "pe": e(R, S, 1), "ps": e(R, S, 1), "delta": e(R, S, 1),
-             "sky": e(R, 3), "cls": e(R, eng.net.n_classes), "rho": e(R, S, 1), "sv": e(R, S, 1), "col": e(R, S, 3), "pts": e(R, S, 3),
-             "adjc": e(R, S, 3)}
-        co = _lib.CompositeOut(d_rgb=o["rgb"].data_ptr(), d_albedo=o["albedo"].data_ptr(), d_pv=o["pv"].data_ptr(),
-                               d_pe=o["pe"].data_ptr(), d_ps=o["ps"].data_ptr(), d_delta=o["delta"].data_ptr())
-        fo = _lib.FieldOut(d_rho=o["rho"].data_ptr(), d_solar_vis=o["sv"].data_ptr(), d_col=o["col"].data_ptr(), d_points=o["pts"].data_ptr(),
-                           d_adjust_col=o["adjc"].data_ptr())
-        _lib.check(eng.L.snerf_trainer_forward_image(eng.h, R, S, top.data_ptr(), bot.data_ptr(), tv.data_ptr(), sun.data_ptr(),
-                                                     tim.data_ptr(), 1 if train_bn else 0, 1 if eng.classic_solar else 0, C.byref(co), o["sky"].data_ptr(),
-                                                     o["cls"].data_ptr(), C.byref(fo), eng.stream()), "trainer_forward_image")
-        ctx.eng, ctx.prior = eng, None
-        extra = {}
-        rgb_m, alb_m = e(0), e(0)
-        if prior is not None:                                    # Eval_Tools_2.py:218-248
-            net, trust = prior
-            rs = net.Supervised_Sample(o["pts"].reshape(-1, 3), o["delta"].reshape(-1, 1)).reshape(R, S, 1).float().contiguous()
-            sup = _composite(eng, top, bot, tv, rs, o["col"], o["sv"], o["sky"])
-            mer = _composite(eng, top, bot, tv, o["rho"], o["col"], o["sv"], o["sky"], prior=rs, trust=trust, want=("rgb", "albedo"),
-                             classic=eng.classic_solar)
-            rgb_m, alb_m = mer["rgb"], mer["albedo"]
-            rho_m = o["rho"] * trust + rs * (1 - trust)
-            mm = _composite(eng, top, bot, tv, rho_m, o["col"], o["sv"], o["sky"])
-            extra = {"PV_Supervised": sup["pv"], "PE_Supervised": sup["pe"], "PS_Supervised": sup["ps"], "PV_Merged": mm["pv"],
-                     "PE_Merged": mm["pe"], "PS_Merged": mm["ps"], "Rho_Merged": rho_m}
-            ctx.prior = (rs, float(trust))
-        ctx.extra_keys = list(extra.keys())
-        outs = (o["rgb"], o["albedo"], o["sky"], o["pe"], rgb_m, alb_m, o["pv"], o["ps"], o["delta"], o["cls"], o["rho"], o["sv"],
-                o["col"], o["pts"], o["adjc"]) + tuple(extra.values())
-        ctx.mark_non_differentiable(*outs[6:])
-        return outs
 
-    @staticmethod
-    def backward(ctx, g_rgb, g_albedo, g_sky, g_pe, g_rgb_m, g_alb_m, *_):
-        eng = ctx.eng
-        c = lambda g: g.contiguous() if g is not None else None
-        g_rgb, g_albedo, g_sky, g_pe, g_rgb_m, g_alb_m = c(g_rgb), c(g_albedo), c(g_sky), c(g_pe), c(g_rgb_m), c(g_alb_m)
-        rs, trust = ctx.prior if ctx.prior is not None else (None, 1.0)
-        if rs is None:
-            g_rgb_m = g_alb_m = None
-        # parameter gradients accumulate straight into the arena behind every p.grad (attach_grads): autograd gets None
+def _check_serial(ctx, what):
+    eng = _engine_of(ctx.trainer)
+    if eng.serial != ctx.serial:
+        raise RuntimeError(f"season_nerf_amd: backward of a {what} pass whose engine has run another forward since (serial {ctx.serial} -> "
+                           f"{eng.serial}): the engine keeps the activations of its last forward only - one forward per batch size may be "
+                           "outstanding; call backward() before the next forward of the same size")
+    return eng
+
+
+def _grad_list(grads):
+    g = grads[0] if (len(grads) == 1 and isinstance(grads[0], (list, tuple))) else grads
+    return [None if x is None else x.contiguous() for x in g]
+
+
+def _register_autograd():
+    global _AUTOGRAD_DONE
+    if _AUTOGRAD_DONE:
+        return
+    from .network import _ops
+    ops = _ops()
+
+    def setup(ctx, inputs, output):
+        ctx.trainer = int(inputs[0])
+        ctx.serial = _engine_of(ctx.trainer).serial
+        # no gradient travels through autograd: one None per input, a list of Nones for the parameter list (the last input)
+        ctx.no_grads = (None,) * (len(inputs) - 1) + ([None] * len(inputs[-1]),)
+
+    def setup_image(ctx, inputs, output):
+        setup(ctx, inputs, output)
+        ctx.trust = float(inputs[10])
+        ctx.rs = output[15] if len(output) > 15 else None          # the DSM-prior density of this forward
+        ctx.R, ctx.S = inputs[1].shape[0], inputs[3].numel()
+
+    def bwd_image(ctx, *grads):
+        eng = _check_serial(ctx, "image-ray")
+        g = _grad_list(grads)
         eng.attach_grads()
-        _lib.check(eng.L.snerf_trainer_backward_image(eng.h, _ptr(g_rgb), _ptr(g_albedo), _ptr(g_sky), _ptr(g_pe), _ptr(rs), trust,
-                                                      _ptr(g_rgb_m), _ptr(g_alb_m), eng.stream()), "trainer_backward_image")
-        return (None,) * (8 + len(eng.param_list))
+        merged = ctx.rs is not None
+        ops.train_bwd_image(ctx.trainer, eng.grads, g[0], g[1], g[2], g[3], ctx.rs, ctx.trust if merged else 1.0, g[4] if merged else None,
+                            g[5] if merged else None, ctx.R, ctx.S)
+        return ctx.no_grads
+
+    def setup_points(ctx, inputs, output):
+        setup(ctx, inputs, output)
+        ctx.N, ctx.C = inputs[1].shape[0], int(inputs[5])
+
+    def bwd_points(ctx, *grads):
+        eng = _check_serial(ctx, "per-point")
+        g = _grad_list(grads)
+        eng.attach_grads()
+        ops.train_bwd_points(ctx.trainer, eng.grads, g[0], g[1], g[2], g[3], g[4], ctx.N, ctx.C)
+        return ctx.no_grads
+
+    def bwd_solar(ctx, *grads):
+        eng = _check_serial(ctx, "sun-ray")
+        g = _grad_list(grads)
+        if g[0] is not None:
+            eng.attach_grads()
+            ops.train_bwd_solar(ctx.trainer, eng.grads, g[0])
+        return ctx.no_grads
+
+    torch.library.register_autograd("season_nerf::train_fwd_image", bwd_image, setup_context=setup_image)
+    torch.library.register_autograd("season_nerf::train_fwd_points", bwd_points, setup_context=setup_points)
+    torch.library.register_autograd("season_nerf::train_fwd_solar", bwd_solar, setup_context=setup)
+    _AUTOGRAD_DONE = True
 
 
-class _SolarPass(torch.autograd.Function):
+def _train_ops(eng, params_need_grad=True):
+    """torch.ops.season_nerf with the autograd formulas registered; a new forward of `eng` starts here (serial, .grad views)."""
+    from .network import _ops
+    _register_autograd()
+    eng.serial += 1
+    if params_need_grad and any(p.requires_grad for p in eng.param_list):
+        eng.attach_grads()
+    return _ops()
+
+
+def _image_pass(eng, top, bot, tv, sun, tim, train_bn, height_map, trust):
+    """T_NeRF.forward (train mode) + compositing on R rays.  Differentiable: Rendered_Col, Albedo_Color, Sky_Col (per ray), PE and -
+    in the DSM-prior phase - Rendered_Col_Merged and the merged Albedo_Color; everything else comes back detached."""
+    r = _train_ops(eng).train_fwd_image(eng.handle, top, bot, tv, sun, tim, bool(train_bn), bool(eng.classic_solar), eng.net.n_classes,
+                                        height_map, float(trust), eng.param_list)
+    return list(r[:6]) + [t.detach() for t in r[6:]]
+
+
+def _solar_pass(eng, top, bot, tv, sun, train_bn):
     """T_NeRF.forward_Solar (train mode) along sun rays; differentiable output: Solar_Vis (the trunk carries no gradient,
     G_NeRF.py:141-145)."""
-
-    @staticmethod
-    def forward(ctx, eng, top, bot, tv, sun, train_bn, *params):
-        R, S, dev = eng.Rs, eng.S, eng.dev
-        e = lambda *s: torch.empty(*s, device=dev)
-        sv, pv, pe, sky_raw, rho, pts, dl = e(R, S, 1), e(R, S, 1), e(R, S, 1), e(R, 3), e(R, S, 1), e(R, S, 3), e(R, S, 1)
-        _lib.check(eng.L.snerf_trainer_forward_solar(eng.h, R, S, top.data_ptr(), bot.data_ptr(), tv.data_ptr(), sun.data_ptr(),
-                                                     1 if train_bn else 0, sv.data_ptr(), pv.data_ptr(), pe.data_ptr(),
-                                                     sky_raw.data_ptr(), rho.data_ptr(), pts.data_ptr(), dl.data_ptr(), eng.stream()),
-                   "trainer_forward_solar")
-        ctx.eng = eng
-        ctx.mark_non_differentiable(pv, pe, sky_raw, rho, pts, dl)
-        return sv, pv, pe, sky_raw, rho, pts, dl
-
-    @staticmethod
-    def backward(ctx, g_sv, *_):
-        eng = ctx.eng
-        if g_sv is not None:
-            eng.attach_grads()
-            g = g_sv.contiguous()
-            _lib.check(eng.L.snerf_trainer_backward_solar(eng.h, g.data_ptr(), eng.stream()), "trainer_backward_solar")
-        return (None,) * (6 + len(eng.param_list))
-
-
-_ZERO_TV = {}
-
-
-def _zero_tv(dev):
-    """The one sample parameter of a 'ray' that is a single explicit point: t = 0, i.e. point = Top * 1 + Bot * 0 = Top."""
-    key = torch.device(dev)
-    if key not in _ZERO_TV:
-        _ZERO_TV[key] = torch.zeros(1, device=dev)
-    return _ZERO_TV[key]
-
-
-class _PointsPass(torch.autograd.Function):
-    """Seam B1 in train mode: `T_NeRF.forward(X, Solar_Angle, Time)` on N explicit points with batch-statistics BatchNorm and an
-    autograd graph (T_NeRF_net_v2.py:75-105; the reference's evaluator calls it so, Eval_Tools_2.py:174-176).  The engine runs
-    the points as N rays of one sample (per-point sun / time, as the reference computes them).  Differentiable outputs:
-    Rho, Col, Solar_Vis, Sky_Col, output_class; Adjust_col / Col_raw / Adjust are returned without a graph."""
-
-    @staticmethod
-    def forward(ctx, eng, X, sun, tim, train_bn, *params):
-        N, dev, Cn = eng.R, eng.dev, eng.net.n_classes
-        if any(p.requires_grad for p in params):
-            eng.attach_grads()
-        e = lambda *s: torch.empty(*s, device=dev)
-        rho, col, sv, sky, cls, adjc, col_raw, adj, rgb = e(N, 1), e(N, 3), e(N, 1), e(N, 3), e(N, Cn), e(N, 3), e(N, 3), e(N, Cn, 3), e(N, 3)
-        co = _lib.CompositeOut(d_rgb=rgb.data_ptr())
-        fo = _lib.FieldOut(d_rho=rho.data_ptr(), d_solar_vis=sv.data_ptr(), d_col=col.data_ptr(), d_adjust_col=adjc.data_ptr(),
-                           d_col_raw=col_raw.data_ptr(), d_adjust=adj.data_ptr())
-        tv = _zero_tv(dev)
-        _lib.check(eng.L.snerf_trainer_forward_image(eng.h, N, 1, X.data_ptr(), X.data_ptr(), tv.data_ptr(), sun.data_ptr(), tim.data_ptr(),
-                                                     1 if train_bn else 0, 0, C.byref(co), sky.data_ptr(), cls.data_ptr(), C.byref(fo),
-                                                     eng.stream()), "trainer_forward_image")
-        ctx.eng = eng
-        ctx.mark_non_differentiable(adjc, col_raw, adj)
-        return rho, col, sv, sky, cls, adjc, col_raw, adj
-
-    @staticmethod
-    def backward(ctx, g_rho, g_col, g_sv, g_sky, g_cls, *_):
-        eng = ctx.eng
-        c = lambda g: g.contiguous() if g is not None else None
-        g_rho, g_col, g_sv, g_sky, g_cls = c(g_rho), c(g_col), c(g_sv), c(g_sky), c(g_cls)
-        eng.attach_grads()
-        _lib.check(eng.L.snerf_trainer_backward_points(eng.h, _ptr(g_rho), _ptr(g_col), _ptr(g_sv), _ptr(g_sky), _ptr(g_cls), eng.stream()),
-                   "trainer_backward_points")
-        return (None,) * (5 + len(eng.param_list))
-
-
-class _SolarPointsPass(torch.autograd.Function):
-    """`T_NeRF.forward_Solar` in train mode on explicit points (T_NeRF_net_v2.py:154-157, G_NeRF.py:141-145: the trunk runs
-    without gradient, only the solar-visibility branch is differentiated).  Sky raw is returned without a graph."""
-
-    @staticmethod
-    def forward(ctx, eng, X, sun, train_bn, *params):
-        N, dev = eng.Rs, eng.dev
-        e = lambda *s: torch.empty(*s, device=dev)
-        sv, pv, pe, sky_raw, rho, pts, dl = e(N, 1), e(N, 1), e(N, 1), e(N, 3), e(N, 1), e(N, 3), e(N, 1)
-        tv = _zero_tv(dev)
-        _lib.check(eng.L.snerf_trainer_forward_solar(eng.h, N, 1, X.data_ptr(), X.data_ptr(), tv.data_ptr(), sun.data_ptr(),
-                                                     1 if train_bn else 0, sv.data_ptr(), pv.data_ptr(), pe.data_ptr(), sky_raw.data_ptr(),
-                                                     rho.data_ptr(), pts.data_ptr(), dl.data_ptr(), eng.stream()), "trainer_forward_solar")
-        ctx.eng = eng
-        ctx.mark_non_differentiable(rho, sky_raw)
-        return rho, sv, sky_raw
-
-    @staticmethod
-    def backward(ctx, _g_rho, g_sv, _g_sky):
-        eng = ctx.eng
-        if g_sv is not None:
-            eng.attach_grads()
-            g = g_sv.contiguous()
-            _lib.check(eng.L.snerf_trainer_backward_solar(eng.h, g.data_ptr(), eng.stream()), "trainer_backward_solar")
-        return (None,) * (4 + len(eng.param_list))
+    r = _train_ops(eng, params_need_grad=False).train_fwd_solar(eng.handle, top, bot, tv, sun, bool(train_bn), eng.param_list)
+    return [r[0]] + [t.detach() for t in r[1:]]
 
 
 def points_forward_train(net, X, sun, tim):
-    """(Rho, Col, Solar_Vis, Sky_Col, output_class, Adjust_col, Col_raw, Adjust) of a train-mode network on N points."""
+    """Seam B1 in train mode: `T_NeRF.forward(X, Solar_Angle, Time)` on N explicit points with batch-statistics BatchNorm and an
+    autograd graph (T_NeRF_net_v2.py:75-105; the reference's evaluator calls it so, Eval_Tools_2.py:174-176) ->
+    (Rho, Col, Solar_Vis, Sky_Col, output_class | Adjust_col, Col_raw, Adjust without a graph)."""
     N = X.shape[0]
     eng = _engine_for(net, N, N, 1)
-    out = _PointsPass.apply(eng, X, sun, tim, net.training, *eng.param_list)
+    r = _train_ops(eng).train_fwd_points(eng.handle, X, sun, tim, bool(net.training), net.n_classes, eng.param_list)
     _after_train_forward(net)
-    return out
+    return tuple(r[:5]) + tuple(t.detach() for t in r[5:])
 
 
 def solar_points_forward_train(net, X, sun):
-    """(softplus Rho, sigmoid Solar_Vis, Sky raw) of `forward_Solar` on a train-mode network."""
+    """`T_NeRF.forward_Solar` in train mode on explicit points (T_NeRF_net_v2.py:154-157, G_NeRF.py:141-145: the trunk runs without
+    gradient, only the solar-visibility branch is differentiated) -> (softplus Rho, sigmoid Solar_Vis, Sky raw)."""
     N = X.shape[0]
     eng = _engine_for(net, N, N, 1)
-    out = _SolarPointsPass.apply(eng, X, sun, net.training, *eng.param_list)
+    tv = torch.zeros(1, device=X.device)          # N rays of one sample at t = 0: point = Top
+    sv, pv, pe, sky_raw, rho, pts, dl = _solar_pass(eng, X, X, tv, sun, net.training)
     _after_train_forward(net)
-    return out
+    return rho, sv, sky_raw
 
 
 def _angles_to_local_vecs(el_deg, az_deg, world_center, W2L_H):
@@ -469,7 +422,7 @@ def _after_train_forward(net):
         nbt = [m.num_batches_tracked for m in net.modules() if isinstance(m, torch.nn.BatchNorm1d)]
         if nbt:
             torch._foreach_add_(nbt, 1)
-        net._sig = None
+        net.invalidate_packed()
 
 
 _ENGINE_CACHE = 2          # engines (workspaces) kept per network: e.g. the training batch and a validation batch
@@ -502,9 +455,9 @@ def eval_train(ev, data_dict, net, train_mode, current_step=0):
     n_solar = R if ev.args.Use_Solar else 0
     eng = _engine_for(net, R, n_solar, S)
     tv = _to_dev(sample_parameters(S, eval_mode=not train_mode), dev)
-    prior = (net, current_step / ev.n_steps) if ev.use_prior else None
     eng.classic_solar = bool(ev.use_classic_solar)            # Solar_Type_2: per-sample shading, Solar_Vis carries gradient
-    res = _ImagePass.apply(eng, top, bot, tv, sun, tim, net.training, prior, *eng.param_list)
+    res = _image_pass(eng, top, bot, tv, sun, tim, net.training, net.height_map_on(dev) if ev.use_prior else None,
+                      current_step / ev.n_steps if ev.use_prior else 1.0)
     rgb, alb, sky, pe, rgb_m, alb_m, pv, ps, dl, cls, rho, sv, col, pts, adjc = res[:15]
     _after_train_forward(net)
     Cn = net.n_classes
@@ -514,7 +467,7 @@ def eval_train(ev, data_dict, net, train_mode, current_step=0):
            "sample_pts": pts, "Albedo_Color": alb}
     if ev.use_prior:
         keys = ["PV_Supervised", "PE_Supervised", "PS_Supervised", "PV_Merged", "PE_Merged", "PS_Merged", "Rho_Merged"]
-        out.update(dict(zip(keys, res[15:])))
+        out.update(dict(zip(keys, res[16:])))                    # res[15] = the DSM-prior density itself
         if ev.use_classic_solar:                                  # Eval_Tools_2.py:228-229
             out["Rendered_Col_Supervised"] = (out["PS_Supervised"] * col * (sv + (1 - sv) * sky_e)).sum(1).detach()
         else:
@@ -536,7 +489,7 @@ def eval_rho_only_train(ev, data_dict, net, train_mode, current_step=0):
             raise RuntimeError("season_nerf_amd: the sun-ray pass must follow an image pass of the same step with as many rays")
         eng = _engine_for(net, R, R, S)
     tv = _to_dev(sample_parameters(S, eval_mode=not train_mode, include_end_pt=True), dev)
-    sv, pv, pe, sky_raw, rho, pts, dl = _SolarPass.apply(eng, top, bot, tv, sun, net.training, *eng.param_list)
+    sv, pv, pe, sky_raw, rho, pts, dl = _solar_pass(eng, top, bot, tv, sun, net.training)
     _after_train_forward(net)
     if ev.use_prior:                                              # Eval_Tools_2.py:319-334
         trust = current_step / ev.n_steps
@@ -544,8 +497,9 @@ def eval_rho_only_train(ev, data_dict, net, train_mode, current_step=0):
         rs = net.Supervised_Sample(p2, d2, outside=rho.detach().reshape(-1))      # outside the cube: the network's own density
         rho_m = (rho * trust + rs.reshape(R, S, 1) * (1 - trust)).contiguous()
         z3 = torch.zeros(R, S, 3, device=dev)
-        m = _composite(eng, top, bot, tv, rho_m, z3, sv.detach().contiguous(), torch.zeros(R, 3, device=dev), want=("pv", "pe"))
-        pv, pe = m["pv"], m["pe"]
+        from .network import _ops
+        m = _ops().composite(top, bot, tv, rho_m, z3, sv.detach().contiguous(), torch.zeros(R, 3, device=dev), 0, None, 1.0)
+        pv, pe = m[2], m[3]
     return {"PE": pe, "PV_Exact": pv, "Solar_Vis": sv, "Sky_Col": sky_raw.unsqueeze(1).expand(R, S, 3)}
 
 
@@ -660,4 +614,4 @@ class FusedAdam(torch.optim.Optimizer):
             torch.distributed.all_reduce(eng.grads)
             eng.grads /= torch.distributed.get_world_size()
         eng.adam_step(g["lr"], g["betas"], g["eps"])
-        self.net._sig = None          # parameters changed outside torch's version counters: re-pack before inference
+        self.net.invalidate_packed()  # parameters changed outside torch's version counters: re-pack before inference

@@ -144,3 +144,86 @@ def test_opcheck_schema_and_fake_kernels():
     torch.library.opcheck(torch.ops.season_nerf.composite.default, args, test_utils=("test_schema", "test_faketensor"))
     p, gr, m, v = r(1000), r(1000), torch.zeros(1000, device="cuda"), torch.zeros(1000, device="cuda")
     torch.library.opcheck(torch.ops.season_nerf.fused_adam_.default, (p, gr, m, v, 1e-3, 0.9, 0.999, 1e-8, 1), test_utils=("test_schema", "test_faketensor"))
+
+
+def _train_setup(R=24, S=16, W=64, hm=None):
+    import season_nerf_amd as sn
+    from types import SimpleNamespace
+    net = sn.T_NeRF(W, 4) if hm is None else sn.T_NeRF(W, 4, HM=hm)
+    net.load_state_dict(orc.init_weights(W, 4, 2, bn_stats="identity"))
+    net = net.cuda().train()
+    args = SimpleNamespace(n_samples=S, Use_Reg=True, Solar_Type_2=False, Use_MSE_loss=True, Use_Solar=True, sc_lambda=0.03, number_low_frequency_cases=4)
+    ev = sn.All_in_One_Eval(args, torch.device("cuda"), 10, hm is not None, None, np.eye(4), np.zeros(3))
+    rng = np.random.Generator(np.random.PCG64(3))
+    t = lambda a: torch.tensor(a, dtype=torch.float32)
+    top = np.concatenate([rng.uniform(-1, 1, (R, 2)), np.ones((R, 1))], 1)
+    bot = np.concatenate([rng.uniform(-1, 1, (R, 2)), -np.ones((R, 1))], 1)
+    sun = rng.uniform(0.1, 1, (R, 3)); sun /= np.linalg.norm(sun, axis=1, keepdims=True)
+    data = {"Top": t(top), "Bot": t(bot), "Sun_Angle": t(sun), "Time_Encoded": t(rng.uniform(-1, 1, (R, 4))), "GT_Color": t(rng.uniform(0, 1, (R, 3)))}
+    return sn, net, ev, data
+
+
+def test_training_seam_runs_on_the_ops():
+    """get_loss + backward (Eval_Tools_2.py:340-459, mg_run_NeRF.py:288-326) through torch.ops.season_nerf.train_*: the profiler sees
+    the forward ops and the backward ops autograd reaches through torch.library.register_autograd; gradients land in p.grad."""
+    sn, net, ev, data = _train_setup()
+    with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CPU]) as prof:
+        loss = ev.get_loss(data, net, 0, True)
+        total = sum(v * w for v, w in loss.values())
+        total.backward()
+    names = {e.key for e in prof.key_averages()}
+    for op in ["train_fwd_image", "train_fwd_solar", "train_bwd_image", "train_bwd_solar"]:
+        assert "season_nerf::" + op in names, (op, sorted(n for n in names if "season" in n))
+    g = net.G_NeRF_net.fc2.linear.weight.grad
+    assert g is not None and torch.isfinite(g).all() and float(g.abs().max()) > 0
+    assert g.data_ptr() == net._train_engine.store.grad_views[net._train_engine.param_keys.index("G_NeRF_net.fc2.linear.weight")].data_ptr()
+    # the per-point seam (T_NeRF.forward in train mode) likewise
+    X = torch.rand(64, 3, device="cuda") * 2 - 1
+    with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CPU]) as prof:
+        rho, col, sv, sky, cls, adjc = net.forward(X, torch.ones(64, 3, device="cuda"), torch.ones(64, 4, device="cuda"))
+        (rho.sum() + col.sum()).backward()
+    names = {e.key for e in prof.key_averages()}
+    assert "season_nerf::train_fwd_points" in names and "season_nerf::train_bwd_points" in names
+
+
+def test_one_forward_per_engine_may_be_outstanding():
+    """The engine keeps the activations of its LAST forward: a backward through an older forward of the same size raises instead of
+    silently differentiating the newer activations (two forwards, then (l1 + l2).backward())."""
+    sn, net, ev, data = _train_setup()
+    X1, X2 = torch.rand(32, 3, device="cuda") * 2 - 1, torch.rand(32, 3, device="cuda") * 2 - 1
+    sun, tim = torch.ones(32, 3, device="cuda"), torch.ones(32, 4, device="cuda")
+    r1 = net.forward(X1, sun, tim)
+    r2 = net.forward(X2, sun, tim)
+    with pytest.raises(RuntimeError, match="one forward"):
+        (r1[0].sum() + r2[0].sum()).backward()
+    r3 = net.forward(X1, sun, tim)                     # a fresh forward differentiates fine
+    r3[0].sum().backward()
+    # different sizes use different engines: both graphs stay valid
+    ra = net.forward(X1[:16], sun[:16], tim[:16])
+    rb = net.forward(X2, sun, tim)
+    (ra[0].sum() + rb[0].sum()).backward()
+
+
+def test_training_ops_validate_and_fake():
+    sn, net, ev, data = _train_setup()
+    ev.get_loss(data, net, 0, True)                     # builds the engine
+    eng = net._train_engine
+    o = sn.ops.load()
+    R, S = eng.R, eng.S
+    d = {k: v.cuda() for k, v in data.items()}
+    tv = sn.sample_parameters(S, eval_mode=True).cuda()
+    with pytest.raises(RuntimeError, match="NULL trainer"):
+        o.train_fwd_image(0, d["Top"], d["Bot"], tv, d["Sun_Angle"], d["Time_Encoded"], True, False, 4, None, 1.0, eng.param_list)
+    with pytest.raises(RuntimeError, match="float32"):
+        o.train_fwd_image(eng.handle, d["Top"].double(), d["Bot"], tv, d["Sun_Angle"], d["Time_Encoded"], True, False, 4, None, 1.0, eng.param_list)
+    with pytest.raises(RuntimeError, match=r"\[24,3\]|sun"):
+        o.train_fwd_solar(eng.handle, d["Top"], d["Bot"], tv, d["Sun_Angle"][:5], True, eng.param_list)
+    with pytest.raises(RuntimeError, match="g_rgb"):
+        o.train_bwd_image(eng.handle, eng.grads, torch.zeros(5, 3, device="cuda"), None, None, None, None, 1.0, None, None, R, S)
+    args = (eng.handle, d["Top"], d["Bot"], tv, d["Sun_Angle"], d["Time_Encoded"], True, False, 4, None, 1.0, eng.param_list)
+    torch.library.opcheck(o.train_fwd_image.default, args, test_utils=("test_schema", "test_faketensor"))
+    torch.library.opcheck(o.train_fwd_solar.default, (eng.handle, d["Top"], d["Bot"], tv, d["Sun_Angle"], True, eng.param_list),
+                          test_utils=("test_schema", "test_faketensor"))
+    hm = torch.rand(9, 7, dtype=torch.float64, device="cuda")
+    pts, dl = torch.rand(50, 3, device="cuda") * 2 - 1, torch.rand(50, device="cuda") * 0.05
+    torch.library.opcheck(o.prior_density.default, (pts, dl, hm, None), test_utils=("test_schema", "test_faketensor"))

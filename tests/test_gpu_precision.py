@@ -95,8 +95,8 @@ def test_int8_digit_network_forwards(golden_dir, name):
     assert err(r[0], g["solar_Rho"])[1] < 5e-4 and err(r[1], g["solar_Solar_Vis"])[1] < 3e-4
     assert err(net.forward_Classic_Sigma_Only(X), g["sigma_only"])[1] < 5e-4
     # the per-ray networks never run in int8 digits (bf16x3 kernel at 256, exact fp32 layer by layer at 512)
-    assert err(net.get_class_only(tim), g["class_only"])[1] < 2e-5
-    assert err(net.forward(X, sun, tim)[3], g["fwd_Sky_Col"])[1] < 2e-5
+    assert err(net.get_class_only(tim), g["class_only"])[1] < 5e-5
+    assert err(net.forward(X, sun, tim)[3], g["fwd_Sky_Col"])[1] < 5e-5
 
 
 def test_fast_mode_sits_in_its_band(golden_dir):
