@@ -220,8 +220,7 @@ static hipError_t linear_fwd(snerf_trainer* t, const LayerP& L, Act InA, int64_t
     if (rows_ok(t, M, L.n_in, L.n_out)) {
         GemmX x{};
         x.n_tiles = (L.n_out + 31) / 32; x.ksteps = (L.n_in + 15) / 16;
-        hipError_t e = launch_split_weights(t->params + L.w, L.n_out, L.n_in, false, t->w_frag, x.n_tiles, x.ksteps, st);
-        if (e != hipSuccess) return e;
+        x.W = t->params + L.w; x.w_rows = L.n_out; x.w_cols = L.n_in; x.w_transpose = 0;      // split by the launcher, in its kernel's fragment order
         x.A = In; x.frag = t->w_frag; x.C = Z; x.M = M; x.N = L.n_out; x.K = L.n_in; x.lda = ld_in; x.ldc = ldz;
         x.alpha = alpha; x.bias = t->params + L.b; x.stats = stats; x.accumulate = 0;
         x.act_tab = InA.tab; x.act_cols = InA.tab ? InA.cols : 0;
@@ -253,8 +252,7 @@ static hipError_t linear_dgrad(snerf_trainer* t, const LayerP& L, const float* d
         GemmX x{};
         x.n_tiles = (n_cols + 31) / 32; x.ksteps = (L.n_out + 15) / 16;
         // Bt[n = input feature][k = output feature] = W[k][n]: transposed split
-        hipError_t e = launch_split_weights(t->params + L.w, L.n_out, L.n_in, true, t->w_frag, x.n_tiles, x.ksteps, st);
-        if (e != hipSuccess) return e;
+        x.W = t->params + L.w; x.w_rows = L.n_out; x.w_cols = L.n_in; x.w_transpose = 1;
         x.A = dZ; x.frag = t->w_frag; x.C = dIn; x.M = M; x.N = n_cols; x.K = L.n_out; x.lda = ldz; x.ldc = ld_in;
         x.alpha = alpha; x.bias = nullptr; x.stats = nullptr; x.accumulate = accumulate ? 1 : 0;
         if (below && below->tab && below->L->n_out == n_cols) {      // with `accumulate` the caller guarantees this is the last producer
@@ -787,7 +785,7 @@ int snerf_linear_forward(int64_t n_points, int n_in, int n_out, const float* d_i
         if (!d_scratch || scratch_bytes < snerf_linear_scratch_bytes(n_out, n_in)) return snerf_set_error(SNERF_E_INVALID, "snerf_linear_forward: scratch too small");
         GemmX x{};
         x.n_tiles = (n_out + 31) / 32; x.ksteps = (n_in + 15) / 16;
-        HIPCK(launch_split_weights(d_weight, n_out, n_in, false, (uint16_t*)d_scratch, x.n_tiles, x.ksteps, st));
+        x.W = d_weight; x.w_rows = n_out; x.w_cols = n_in; x.w_transpose = 0;
         x.A = d_in; x.frag = (const uint16_t*)d_scratch; x.C = d_out; x.M = n_points; x.N = n_out; x.K = n_in; x.lda = ld_in; x.ldc = ld_out;
         x.alpha = alpha; x.bias = d_bias; x.stats = d_stats; x.accumulate = 0;
         if (d_act_tab) {
@@ -818,7 +816,7 @@ int snerf_linear_dgrad(int64_t n_points, int n_in, int n_out, const float* d_gra
         if (!d_scratch || scratch_bytes < snerf_linear_scratch_bytes(n_out, n_in)) return snerf_set_error(SNERF_E_INVALID, "snerf_linear_dgrad: scratch too small");
         GemmX x{};
         x.n_tiles = (n_cols + 31) / 32; x.ksteps = (n_out + 15) / 16;
-        HIPCK(launch_split_weights(d_weight, n_out, n_in, true, (uint16_t*)d_scratch, x.n_tiles, x.ksteps, st));
+        x.W = d_weight; x.w_rows = n_out; x.w_cols = n_in; x.w_transpose = 1;
         x.A = d_grad_out; x.frag = (const uint16_t*)d_scratch; x.C = d_grad_in; x.M = n_points; x.N = n_cols; x.K = n_out; x.lda = ld_go; x.ldc = ld_gi;
         x.alpha = alpha; x.bias = nullptr; x.stats = nullptr; x.accumulate = accumulate ? 1 : 0;
         if (d_below_z) {

@@ -25,7 +25,11 @@ hipError_t launch_gemm(const GemmArgs& g, hipStream_t st);
 // fragment order by launch_split_weights (n_tiles x ksteps fragments of 2 KiB: bf16 hi, bf16 lo)
 struct GemmX {
     const float* A;            // [M, lda] fp32, k contiguous
-    const uint16_t* frag;      // [n_tiles][ksteps][2][512] bf16
+    // weights: either already split (frag, 32x32x16 fragment order: [n_tiles][ksteps][2][512] bf16) or raw fp32 (W != NULL): the
+    // launcher then splits them into `frag` (scratch of n_tiles * ksteps * 2 KiB, any of the two fragment orders) for the kernel it picks
+    const uint16_t* frag;
+    const float* W;            // optional raw weights [w_rows, w_cols]; Bt[n][k] = W[n][k] (w_transpose = 0) or W[k][n] (1)
+    int w_rows, w_cols, w_transpose;
     float* C;
     int64_t M, N, K, lda, ldc;
     int n_tiles, ksteps;       // ceil(N/32), ceil(K/16)

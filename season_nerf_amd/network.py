@@ -122,8 +122,7 @@ class T_NeRF(nn.Module):
         if self.layer_width not in FUSED_WIDTHS_I8:
             raise ValueError(f"no int8-digit kernel at width {self.layer_width}")
         self._pack()
-        v = self._packed.i8_estimate()
-        return {"head_rms": v[0:4], "hidden_rms": v[4], "worst": v[5], "rgb_pred": v[6], "budget": v[7], "acc_bound": int(v[8]), "ok": bool(v[9])}
+        return dict(self._estimate)
 
     # ------------------------------------------------------------------ device model management
     def _signature(self):
@@ -143,21 +142,21 @@ class T_NeRF(nn.Module):
         if self.precision not in _lib.PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(_lib.PRECISIONS)}, got {self.precision!r}")
         self.release()
-        self._packed, self._resolved, self._packed_sig = None, None, sig
+        self._packed, self._resolved, self._packed_sig, self._estimate = None, None, sig, None
         W = self.layer_width
         if W not in FUSED_WIDTHS_I8:
             return
         want = self.precision
-        if W not in FUSED_WIDTHS and want in ("bf16x3", "bf16"):
-            return                                    # no bf16 kernel at this width: layer-wise engine
         _ops()
         m = torch.classes.season_nerf.Model(W, self.n_classes, want)
         for k, v in self.state_dict().items():
             if v.is_floating_point():
                 m.set_tensor(k, v.detach().float().cpu().contiguous())
+        v = m.i8_estimate()
+        self._estimate = {"head_rms": v[0:4], "hidden_rms": v[4], "worst": v[5], "rgb_pred": v[6], "budget": v[7], "acc_bound": int(v[8]), "ok": bool(v[9])}
         r = m.resolve()
-        if r == -1 and want == "auto" and W not in FUSED_WIDTHS:
-            return                                    # the int8 bound failed and there is no other fused kernel at this width
+        if r == -1 and W not in FUSED_WIDTHS and (want != "i8x3" or self._estimate["acc_bound"] < 2 ** 31):
+            return                                    # bf16 modes, or "auto" whose int8 bound failed: no such fused kernel at this width
         if r < 0:
             raise RuntimeError(f"season_nerf_amd: packing the model failed (code {r}): {_lib.lib().snerf_last_error().decode()}")
         self._packed, self._resolved = m, _lib.PRECISION_NAMES[r]

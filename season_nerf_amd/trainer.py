@@ -22,22 +22,29 @@ import torch
 from .training import FusedAdam
 
 
-def get_output_loc(n_steps, n_outputs):
-    """misc.py:35-42: power-law spaced save points, the last one at n_steps."""
-    if n_outputs > 0:
-        alpha = np.log(n_steps) / np.log(n_outputs)
-        ans = (np.arange(1, n_outputs + 1) ** alpha).astype(int)
-        ans[-1] = n_steps
-    else:
-        ans = np.array([n_steps])
-    return ans
+def save_points(total_steps, count):
+    """Step numbers at which a run of `total_steps` steps is evaluated / saved `count` times: the k-th lands on k ** e, truncated,
+    with e = log(total_steps) / log(count) (so that the count-th falls on the last step, which is then forced exactly) - early
+    checkpoints dense, late ones sparse.  Behaviour of the reference's misc.get_output_loc (misc.py:35-42); pinned by the
+    reference-generated save points in tests/golden/micro.npz."""
+    if count <= 0:
+        return np.array([total_steps])
+    ks = np.arange(1, count + 1)
+    pts = np.power(ks, np.log(total_steps) / np.log(count)).astype(int)
+    pts[-1] = total_steps
+    return pts
 
 
-def get_output_loc_lin_first(n_steps, n_outputs, min_gap):
-    """misc.py:45-53."""
-    if n_outputs * min_gap >= n_steps:
-        return np.linspace(1, n_steps, n_outputs + 1, dtype=int)[1::]
-    return np.maximum(get_output_loc(n_steps, n_outputs), np.arange(1, n_outputs + 1) * min_gap)
+def save_points_spaced(total_steps, count, min_gap):
+    """`save_points` with at least `min_gap` steps between consecutive points (the k-th not before k * min_gap); when even that many
+    gaps do not fit, `count` evenly spaced points (misc.get_output_loc_lin_first, misc.py:45-53)."""
+    if count * min_gap >= total_steps:
+        return np.linspace(1, total_steps, count + 1, dtype=int)[1:]
+    floor = min_gap * np.arange(1, count + 1)
+    return np.maximum(save_points(total_steps, count), floor)
+
+
+get_output_loc, get_output_loc_lin_first = save_points, save_points_spaced      # the reference's names (misc.py:35,45)
 
 
 def _allreduce_mean_grads(params):
@@ -148,18 +155,18 @@ class T_NeRF_Net_Tool(Net_tool):
         self.training_DSM, self.GT_DSM = training_DSM, GT_DSM
         self._step_count = 0
         self._get_data, self._eval_img, self.solar_vecs = get_data, eval_img, solar_vecs
-        ps = [0.2, 0.0, 0.0]                                                   # Net_Tool_2.py:23-24
-        ps.append(1 - np.sum(ps))
-        p1, p2, p3 = int(ps[0] * n_steps), int(ps[1] * n_steps), int(ps[2] * n_steps)
-        p4 = n_steps - p3 - p2 - p1
-        pi = [p1, p2, p3, p4]
-        self.section_starts = np.array([0, p1, p1 + p2, p1 + p2 + p3])
-        self.section_Ends = np.array([p1, p1 + p2, p1 + p2 + p3, n_steps])
-        self.Section_Steps = [int(self.section_starts[i + 1] - self.section_starts[i]) for i in range(3)]
-        self.Section_Steps.append(int(n_steps - self.section_starts[-1]))
-        self.sub_section_outputs = []
-        for i in range(4):
-            self.sub_section_outputs.append(self.section_starts[i] + get_output_loc_lin_first(pi[i], int(args.n_saves * ps[i]), min_gap=1000))
+        # Learning phases (Net_Tool_2.py:23-54): fractions of the run spent in phase 1 (DSM-prior "jump start"), 2, 3 and - the
+        # remainder - 4 (free learning); phases 2 and 3 are empty in the reference's schedule.  Attribute names are the reference's
+        # (step() and outside code read them).
+        fractions = np.array([0.2, 0.0, 0.0])
+        fractions = np.append(fractions, 1 - fractions.sum())
+        lengths = [int(f * n_steps) for f in fractions[:3]]
+        lengths.append(n_steps - sum(lengths))
+        bounds = np.concatenate([[0], np.cumsum(lengths)])                     # phase i runs over steps [bounds[i], bounds[i + 1])
+        self.section_starts, self.section_Ends = bounds[:4].copy(), bounds[1:].copy()
+        self.Section_Steps = [int(n) for n in np.diff(bounds)]
+        # save points of every phase: its share of args.n_saves, power-law spaced from the phase's first step, >= 1000 steps apart
+        self.sub_section_outputs = [bounds[i] + save_points_spaced(lengths[i], int(args.n_saves * fractions[i]), min_gap=1000) for i in range(4)]
         self.sub_section_outputs[-1][-1] = n_steps
         self.learning_mode = -1
         self.network = T_NeRF(args.fc_units, n_classes=args.number_low_frequency_cases, HM=training_DSM).to(self.device)

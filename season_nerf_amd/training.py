@@ -137,7 +137,7 @@ class TrainEngine:
                                         n_rays, n_solar_rays, n_samples), "trainer_bind")
         self.classic_solar = False        # Solar_Type_2 shading in the image pass (set per call by eval_train)
         self._ar_cb = None
-        self.serial = 0                   # forwards run so far: a backward belongs to the forward whose serial it recorded
+        self.serial = {"image": 0, "solar": 0}      # forwards run so far, per stash: a backward belongs to the forward whose serial it recorded
         self.handle = int(self.h)         # as the custom ops take it
         import weakref
         _ENGINES[self.handle] = weakref.ref(self)
@@ -258,10 +258,10 @@ def _engine_of(handle):
 
 def _check_serial(ctx, what):
     eng = _engine_of(ctx.trainer)
-    if eng.serial != ctx.serial:
-        raise RuntimeError(f"season_nerf_amd: backward of a {what} pass whose engine has run another forward since (serial {ctx.serial} -> "
-                           f"{eng.serial}): the engine keeps the activations of its last forward only - one forward per batch size may be "
-                           "outstanding; call backward() before the next forward of the same size")
+    if eng.serial[ctx.kind] != ctx.serial:
+        raise RuntimeError(f"season_nerf_amd: backward of {what} pass whose engine has run another such forward since (serial {ctx.serial} -> "
+                           f"{eng.serial[ctx.kind]}): the engine keeps the activations of its last forward of each kind only - one forward per "
+                           "batch size may be outstanding; call backward() before the next forward of the same size")
     return eng
 
 
@@ -277,20 +277,21 @@ def _register_autograd():
     from .network import _ops
     ops = _ops()
 
-    def setup(ctx, inputs, output):
-        ctx.trainer = int(inputs[0])
-        ctx.serial = _engine_of(ctx.trainer).serial
+    def setup(ctx, inputs, output, kind="solar"):
+        # the engine holds two stashes: the image-ray (or per-point) pass and the sun-ray pass - a training step runs one of each
+        ctx.trainer, ctx.kind = int(inputs[0]), kind
+        ctx.serial = _engine_of(ctx.trainer).serial[kind]
         # no gradient travels through autograd: one None per input, a list of Nones for the parameter list (the last input)
         ctx.no_grads = (None,) * (len(inputs) - 1) + ([None] * len(inputs[-1]),)
 
     def setup_image(ctx, inputs, output):
-        setup(ctx, inputs, output)
+        setup(ctx, inputs, output, "image")
         ctx.trust = float(inputs[10])
         ctx.rs = output[15] if len(output) > 15 else None          # the DSM-prior density of this forward
         ctx.R, ctx.S = inputs[1].shape[0], inputs[3].numel()
 
     def bwd_image(ctx, *grads):
-        eng = _check_serial(ctx, "image-ray")
+        eng = _check_serial(ctx, "an image-ray")
         g = _grad_list(grads)
         eng.attach_grads()
         merged = ctx.rs is not None
@@ -299,18 +300,18 @@ def _register_autograd():
         return ctx.no_grads
 
     def setup_points(ctx, inputs, output):
-        setup(ctx, inputs, output)
+        setup(ctx, inputs, output, "image")
         ctx.N, ctx.C = inputs[1].shape[0], int(inputs[5])
 
     def bwd_points(ctx, *grads):
-        eng = _check_serial(ctx, "per-point")
+        eng = _check_serial(ctx, "a per-point")
         g = _grad_list(grads)
         eng.attach_grads()
         ops.train_bwd_points(ctx.trainer, eng.grads, g[0], g[1], g[2], g[3], g[4], ctx.N, ctx.C)
         return ctx.no_grads
 
     def bwd_solar(ctx, *grads):
-        eng = _check_serial(ctx, "sun-ray")
+        eng = _check_serial(ctx, "a sun-ray")
         g = _grad_list(grads)
         if g[0] is not None:
             eng.attach_grads()
@@ -323,11 +324,11 @@ def _register_autograd():
     _AUTOGRAD_DONE = True
 
 
-def _train_ops(eng, params_need_grad=True):
+def _train_ops(eng, params_need_grad=True, kind="image"):
     """torch.ops.season_nerf with the autograd formulas registered; a new forward of `eng` starts here (serial, .grad views)."""
     from .network import _ops
     _register_autograd()
-    eng.serial += 1
+    eng.serial[kind] += 1
     if params_need_grad and any(p.requires_grad for p in eng.param_list):
         eng.attach_grads()
     return _ops()
@@ -344,7 +345,7 @@ def _image_pass(eng, top, bot, tv, sun, tim, train_bn, height_map, trust):
 def _solar_pass(eng, top, bot, tv, sun, train_bn):
     """T_NeRF.forward_Solar (train mode) along sun rays; differentiable output: Solar_Vis (the trunk carries no gradient,
     G_NeRF.py:141-145)."""
-    r = _train_ops(eng, params_need_grad=False).train_fwd_solar(eng.handle, top, bot, tv, sun, bool(train_bn), eng.param_list)
+    r = _train_ops(eng, params_need_grad=False, kind="solar").train_fwd_solar(eng.handle, top, bot, tv, sun, bool(train_bn), eng.param_list)
     return [r[0]] + [t.detach() for t in r[1:]]
 
 

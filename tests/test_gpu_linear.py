@@ -194,7 +194,9 @@ def test_dgrad_activation_backward_epilogue(shape):
 
 
 def test_full_tile_kernel_bit_identical_to_general_kernel():
-    """gemm_rows_full_kernel (hand-issued A stream, cross-tile prefetch, buffer-addressed epilogue) against gemm_rows_kernel on
+    """(Also: gemm_rows16_kernel, the 16x16x32 form the wide layers run on, against the same outputs to 4e-6 of the output scale -
+    it sums the k terms of a 32-k step in another order - with identical untouched cells and column sums.)
+    gemm_rows_full_kernel (hand-issued A stream, cross-tile prefetch, buffer-addressed epilogue) against gemm_rows_kernel on
     the same inputs: same fragments, same summation order -> identical bits in every output (forward with and without activation
     on load, thin heads, zero-padded K, dgrad with the activation-backward epilogue); column sums agree to fp32 partial-sum
     rounding.  The path is chosen per process (SNERF_GEMM_FULL), so the two runs are child processes."""
@@ -203,3 +205,4 @@ def test_full_tile_kernel_bit_identical_to_general_kernel():
     r = subprocess.run([sys.executable, tool], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "mismatches: 0" in r.stdout
+    print(r.stdout[-400:])

@@ -1,4 +1,4 @@
-"""Build-time guard for the hand-issued A stream of gemm_rows_full_kernel (csrc/gemm.hip): between `a8_issue` and `a8_wait` the
+"""Build-time guard for the hand-issued A stream of gemm_rows_full_kernel and gemm_rows16_kernel (csrc/gemm.hip): between `a8_issue` and `a8_wait` the
 destination registers hold nothing, so the compiler must never spill them.  The instantiations without the activation-backward
 epilogue must therefore compile without scratch traffic at all; the activation-backward ones do spill in their epilogue and are
 protected in the source by `a8_wait<0>` on every slot before it (checked here as text).  Cross-compiles for gfx950; no GPU."""
@@ -32,20 +32,22 @@ def test_full_tile_kernels_do_not_spill_pending_loads(tmp_path):
     lines = out.read_text().split("\n")
     seen, i = 0, 0
     while i < len(lines):
-        m = re.match(r"^_ZN5snerf21gemm_rows_full_kernelILi(\d)ELi(\d)ELi(\d)ELi(\d)EEEvNS_5GemmXE:", lines[i])
+        m = re.match(r"^_ZN5snerf(?:21gemm_rows_full_kernel|18gemm_rows16_kernel)ILi(\d)ELi(\d)ELi(\d)ELi(\d)EEEvNS_5GemmXE:", lines[i])
         if not m:
             i += 1
             continue
+        kname = "gemm_rows16_kernel" if "rows16" in lines[i] else "gemm_rows_full_kernel"
+        wait = "a16_wait" if "rows16" in lines[i] else "a8_wait"
         j = i
         while "s_endpgm" not in lines[j]:
             j += 1
         body = lines[i:j]
         nt, pf, aol, act = (int(x) for x in m.groups())
         scratch = sum("scratch_" in l for l in body)
-        waits = sum("a8_wait" in l for l in body)
-        assert waits >= pf, (nt, pf, aol, act, waits)
+        waits = sum(wait in l for l in body)
+        assert waits >= pf, (kname, nt, pf, aol, act, waits)
         if not act:
-            assert scratch == 0, f"gemm_rows_full_kernel<{nt},{pf},{aol},{act}> spills ({scratch} scratch ops) while A loads are pending"
+            assert scratch == 0, f"{kname}<{nt},{pf},{aol},{act}> spills ({scratch} scratch ops) while A loads are pending"
         # every variant: no spill and no register move may touch a register with a hand-issued load in flight (program-order scan)
         pending, in_asm = set(), False
         for l in body:
@@ -57,15 +59,17 @@ def test_full_tile_kernels_do_not_spill_pending_loads(tmp_path):
                 in_asm = False
             elif in_asm and t.startswith("global_load_dwordx4"):
                 pending |= _vregs(t.split(",")[0])
-            elif in_asm and "a8_wait" in t:
-                pending -= _vregs(t.split("a8_wait")[1])
+            elif in_asm and wait in t:
+                pending -= _vregs(t.split(wait)[1])
             elif "scratch_" in code or code.startswith("v_mov") or code.startswith("v_accvgpr"):
                 hit = _vregs(code) & pending
-                assert not hit, f"gemm_rows_full_kernel<{nt},{pf},{aol},{act}> moves / spills v{sorted(hit)} while its load is in flight: {t}"
+                assert not hit, f"{kname}<{nt},{pf},{aol},{act}> moves / spills v{sorted(hit)} while its load is in flight: {t}"
         seen += 1
         i = j
-    assert seen >= 18
+    assert seen >= 18 + 7
     src = open(SRC).read()
+    k16 = src.index("void gemm_rows16_kernel")
+    assert re.search(r"if \(ACT\) \{[^}]*a16_wait<0>\(", src[k16:], re.S), "the activation-backward variant of the 16x16x32 kernel must drain its prefetch before the epilogue"
     k = src.index("void gemm_rows_full_kernel")
     assert re.search(r"if \(ACT\) \{[^}]*a8_wait<0>\(px\[d\], py\[d\]\);", src[k:], re.S), "the activation-backward variant must drain its prefetch before the epilogue"
 
