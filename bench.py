@@ -142,7 +142,8 @@ def bench_train(a, standalone=True):
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
     steps, warm = (min(a.steps, 20), min(a.warmup, 3)) if standalone else (12, 3)
-    net = sn.T_NeRF(W, NC)
+    Wt = getattr(a, "width", W)
+    net = sn.T_NeRF(Wt, NC)
     net.load_state_dict(sn.synthetic_state_dict(net, 0, bn_stats="identity"))        # reference init law, fresh BatchNorm
     net = net.to(dev).train()
     barron = a.loss == "barron"
@@ -191,7 +192,7 @@ def bench_train(a, standalone=True):
     per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))     # stream time of each step (diagnostic)
     gemm = os.environ.get("SNERF_TRAIN_GEMM", "bf16x3")
     # algorithmic FLOPs: image rays 3 x forward; sun rays: trunk+heads+solar forward + 3 x solar/sky heads
-    flop = R * S * (3 * FLOP_PER_SAMPLE + 2 * (524800 + 3 * 54656))
+    flop = R * S * (3 * FLOP_PER_SAMPLE + 2 * (524800 + 3 * 54656)) if Wt == 256 else float("nan")
     # HBM bytes the layer-wise design moves per step (every per-point layer is a pass over [points x width] fp32
     # arrays; per-ray branches are negligible).  Forward of a layer: one GEMM (read the pre-activation of the layer below -
     # the activation is applied on load - write Z); backward: activation backward (see bwd_bytes), then wgrad (read dZ, in)
@@ -237,10 +238,12 @@ def bench_train(a, standalone=True):
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "f32 storage; " + ("bf16x3 split MFMA GEMMs (forward with activation on load, dgrad, wgrad)" if gemm != "fp32" else "fp32 MFMA GEMMs"),
                "data": "synthetic",
-               "config": {"workload": f"BASELINE configs[2]: training step 4096x96, T_NeRF(256,4) train-mode BatchNorm, solar branch on, {lname}",
+               "config": {"workload": f"BASELINE configs[2]: training step 4096x96, T_NeRF({Wt},4) train-mode BatchNorm, solar branch on, {lname}"
+                                      + ("" if Wt == 256 else " - at the reference's default width (main_lite.py:80), not the BASELINE config"),
                           "parallelism": f"rays sharded over {world} GPU(s), one all-reduce of the flat gradient arena, BatchNorm statistics "
                                          + ("over the global batch (all-reduced)" if a.bn_sync == "global" and use_dist else "per rank")},
                "final_loss": float(tot.detach()), "step_ms_median": per_step[len(per_step) // 2], "step_ms_min": per_step[0],
+               "collectives": dict(sn.parallel.COLLECTIVES) if use_dist else None,
                "roofline": {"bound": "hbm", "achieved": hbm_bytes / dt / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": hbm_bytes / dt / 8e12,
                             "traffic": traffic, "bytes_per_step": hbm_bytes, "algorithmic_tflops": flop / dt / 1e12,
                             "note": "whole step, not one kernel: train-mode BatchNorm forces a layer-wise design in which every layer is "
@@ -250,7 +253,7 @@ def bench_train(a, standalone=True):
         if not a.no_cpu_baseline and world == 1:      # reported at N = 1 only (rank 0)
             from oracle import season_nerf_oracle as orc          # CPU-baseline leg only
             torch.set_num_threads(min(host_cpus(), 32))
-            sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in orc.init_weights(W, NC, 0, bn_stats="identity").items()}
+            sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in orc.init_weights(Wt, NC, 0, bn_stats="identity").items()}
             n = 256
             dc = {k: v[:n].cpu() for k, v in d.items()}
             rng = np.random.Generator(np.random.PCG64(1))
@@ -326,6 +329,7 @@ def main():
     ap.add_argument("--workload", default="render", choices=["render", "train"],
                     help="render = headline (BASELINE configs[1]); train = configs[2]: one training step, 4096x96 + 4096 sun rays")
     ap.add_argument("--loss", default="mse", choices=["barron", "mse"], help="colour loss of --workload train (mse = reference-pinned)")
+    ap.add_argument("--width", type=int, default=256, choices=[256, 512], help="--workload train: fc_units (256 = BASELINE configs[2]; 512 = the reference's default)")
     ap.add_argument("--headline-only", action="store_true",
                     help="only the headline timed region (no per-mode table, seam, sweep, training step, CPU baseline): profiler passes")
     ap.add_argument("--no-train", action="store_true", help="render workload: skip the extra training-step measurement (train_* keys)")
@@ -563,7 +567,7 @@ def main():
             "config": {"workload": "BASELINE configs[1]: forward render 4096 rays x 96 samples, T_NeRF(256,4) eval-mode, "
                                    "random weights (reference init law), per-ray sun/time", "rays_per_gpu": R,
                        "samples_per_ray": S, "parallelism": f"rays sharded over {world} GPU(s), RGB tiles all-gathered ({a.gather_group} steps per collective, asynchronous)"},
-            "per_gpu_value": value / world,
+            "per_gpu_value": value / world, "collectives": dict(sn.parallel.COLLECTIVES) if use_dist else None,
             "image_512x512x96_ms_est": 512 * 512 * S / (value / world) * 1e3, "repeat": blocks,
             "i8_estimate": ({k: v for k, v in net.i8_estimate().items() if k in ("rgb_pred", "budget", "acc_bound", "ok")} if W in (64, 256, 512) else None), **extra,
             "roofline": {"bound": "mfma", "achieved": achieved / 1e12, "peak": PEAK_BF16_DENSE / 1e12, "unit": "TFLOP/s",

@@ -528,7 +528,8 @@ int snerf_field_kernel_info(const snerf_model* m, int64_t n_points, int* grid, i
     int rc = pack_both(const_cast<snerf_model*>(m));
     if (rc) return rc;
     const bool i8 = m->precision == SNERF_PREC_I8X3;
-    const bool two_waves = i8 && m->W <= 256;                 // kernels_i8x2.hip: 512 threads, 256 points per tile
+    static const bool one_wave = getenv("SNERF_I8_ONE_WAVE") != nullptr;         // the A/B switch field_launch honours
+    const bool two_waves = i8 && m->W <= 256 && !one_wave;    // kernels_i8x2.hip: 512 threads, 256 points per tile
     const int tile = two_waves ? 256 : mlp_tile_points();
     const int64_t tiles = (n_points + tile - 1) / tile;
     const int ncu = m->n_cu ? m->n_cu : 256;

@@ -11,7 +11,7 @@
 //   season_nerf::group_fwd(Model, time[G,4], sun[G,3]) -> (classes[G,C], sky_raw[G,3], sky[G,3])        get_class_only + sky head
 //   season_nerf::points_fwd(Model, x[N,3], sun[G,3]?, classes[G,C]?, group_size, variant)               T_NeRF.forward* on points
 //        -> (rho[N,1], solar_vis[N,1], col_raw[N,3], adjust[N,C,3], col[N,3], adjust_col[N,3])
-//   season_nerf::render_fwd(Model, top[R,3], bot[R,3], sun[R,3], time[R,4], tvals[S], flags, want_per_sample)
+//   season_nerf::render_fwd(Model, top[R,3], bot[R,3], sun[R,3], time[R,4], tvals[S], flags, want_per_sample, want_unmixed=False)
 //        -> (rgb[R,3], depth[R,2] = (surface distance, accumulated weight), albedo[R,3], per_sample[])  All_in_One_Eval.eval
 //   season_nerf::composite(top, bot, tvals, rho, col, solar_vis, sky, flags, rho_prior?, trust) -> Tensor[10]    get_PV + shading
 //   season_nerf::composite_sweep(...) -> Tensor[6]                                                    mg_Img_Eval t-step sweep
@@ -142,7 +142,7 @@ std::vector<Tensor> points_fwd(const ModelPtr& M, const Tensor& x, const c10::op
 }
 
 std::tuple<Tensor, Tensor, Tensor, std::vector<Tensor>> render_fwd(const ModelPtr& M, const Tensor& top, const Tensor& bot, const Tensor& sun,
-                                                                   const Tensor& time, const Tensor& tvals, int64_t flags, bool want_per_sample) {
+                                                                   const Tensor& time, const Tensor& tvals, int64_t flags, bool want_per_sample, bool want_unmixed) {
     check_shape(top, "top", -1, 3);
     const int64_t R = top.size(0);
     check_shape(bot, "bot", R, 3);
@@ -165,11 +165,15 @@ std::tuple<Tensor, Tensor, Tensor, std::vector<Tensor>> render_fwd(const ModelPt
     if (want_per_sample) {
         // Rho, Col, Solar_Vis, Adjust, Adjust_col, Col_raw, sample_pts, PV, PE, PS, deltas (the per-sample keys of eval's result
         // dict), then the per-ray Classes [R,C] and Sky_Col [R,3]
-        per = {at::empty({R, S, 1}, o), at::empty({R, S, 3}, o), at::empty({R, S, 1}, o), at::empty({R, S, C, 3}, o), at::empty({R, S, 3}, o),
-               at::empty({R, S, 3}, o), at::empty({R, S, 3}, o), at::empty({R, S, 1}, o), at::empty({R, S, 1}, o), at::empty({R, S, 1}, o),
+        // Adjust [R,S,C,3] and Col_raw (the unmixed seasonal terms: forward_seperate, the seasonal sweep) only on request: eval's result
+        // dict does not carry them, and at 4096 x 96, C = 4 they are 23.6 MB of HBM writes - as much as everything else the kernel moves
+        const int64_t U = want_unmixed ? R : 0;
+        per = {at::empty({R, S, 1}, o), at::empty({R, S, 3}, o), at::empty({R, S, 1}, o), at::empty({U, S, C, 3}, o), at::empty({R, S, 3}, o),
+               at::empty({U, S, 3}, o), at::empty({R, S, 3}, o), at::empty({R, S, 1}, o), at::empty({R, S, 1}, o), at::empty({R, S, 1}, o),
                at::empty({R, S, 1}, o)};
-        fo.d_rho = mptr(per[0]); fo.d_col = mptr(per[1]); fo.d_solar_vis = mptr(per[2]); fo.d_adjust = mptr(per[3]); fo.d_adjust_col = mptr(per[4]);
-        fo.d_col_raw = mptr(per[5]); fo.d_points = mptr(per[6]);
+        fo.d_rho = mptr(per[0]); fo.d_col = mptr(per[1]); fo.d_solar_vis = mptr(per[2]); fo.d_adjust_col = mptr(per[4]);
+        if (want_unmixed) { fo.d_adjust = mptr(per[3]); fo.d_col_raw = mptr(per[5]); }
+        fo.d_points = mptr(per[6]);
         co.d_pv = mptr(per[7]); co.d_pe = mptr(per[8]); co.d_ps = mptr(per[9]); co.d_delta = mptr(per[10]);
     }
     ck(snerf_render_rays(M->m, R, (int)S, fptr(top), fptr(bot), fptr(tvals), fptr(sun), fptr(time), (int)flags, mptr(rgb), &fo, &co, ws.data_ptr(),
@@ -402,7 +406,7 @@ TORCH_LIBRARY(season_nerf, m) {
     m.def("group_fwd(__torch__.torch.classes.season_nerf.Model model, Tensor time, Tensor sun) -> (Tensor, Tensor, Tensor)");
     m.def("points_fwd(__torch__.torch.classes.season_nerf.Model model, Tensor x, Tensor? sun, Tensor? classes, int group_size, int variant) -> Tensor[]");
     m.def("render_fwd(__torch__.torch.classes.season_nerf.Model model, Tensor top, Tensor bot, Tensor sun, Tensor time, Tensor tvals, int flags, "
-          "bool want_per_sample) -> (Tensor, Tensor, Tensor, Tensor[])");
+          "bool want_per_sample, bool want_unmixed=False) -> (Tensor, Tensor, Tensor, Tensor[])");
     m.def("composite(Tensor top, Tensor bot, Tensor tvals, Tensor rho, Tensor col, Tensor solar_vis, Tensor sky, int flags, Tensor? rho_prior, float trust) "
           "-> Tensor[]");
     m.def("composite_sweep(Tensor top, Tensor bot, Tensor tvals, Tensor rho, Tensor col_raw, Tensor adjust, Tensor solar_vis, Tensor sky, Tensor class_vecs, "

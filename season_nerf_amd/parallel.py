@@ -5,8 +5,20 @@ Rays are independent given the weights, so the path shards with NO c
 every rank holds a replica of the 3.3 MB weights, renders a contiguous block of rays, and the only exchange is one
 all-gather of the rendered rows (RGB tiles: 12 B/ray) - latency-bound, a few tens of microseconds over xGMI.
 """
+import collections
+
 import torch
 import torch.distributed as dist
+
+# Collectives this process has issued on the hot path, by kind - so that a run under torch.distributed (also with ONE rank: RCCL
+# initialised, stream-ordered, timed, proving nothing about scaling) can show which exchanges really executed (bench.py `collectives`).
+COLLECTIVES = collections.Counter()
+
+
+def data_parallel(group=None):
+    """True where the data-parallel exchanges run: an initialised process group - a world of ONE rank included, so that the RCCL
+    code path can be exercised on a single GPU."""
+    return dist.is_available() and dist.is_initialized()
 
 
 def shard_bounds(n, world):
@@ -37,6 +49,7 @@ def gather_rows(local, n_total, group=None):
     pad[: local.shape[0]] = local
     buf = torch.empty((world * mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(buf, pad, group=group)
+    COLLECTIVES["rows_all_gather"] += 1
     return torch.cat([buf[k * mx: k * mx + (hi - lo)] for k, (lo, hi) in enumerate(bounds)], 0)
 
 
@@ -73,6 +86,7 @@ class TileGroupGather:
         if dist.is_initialized():
             flat = self.full[b].view((self.world * self.G,) + tuple(self.tiles[b].shape[1:]))      # concatenation form: every backend takes it
             self.pending[b] = dist.all_gather_into_tensor(flat, self.tiles[b], group=self.pg, async_op=True)
+            COLLECTIVES["tile_group_all_gather"] += 1
         else:
             self.full[b][0].copy_(self.tiles[b])
 
@@ -121,17 +135,19 @@ def allreduce_gradients(module_or_params, group=None, average=True):
     global-batch mean when shards are equal.  Note: train-mode BatchNorm statistics stay per rank."""
     params = list(module_or_params.parameters()) if hasattr(module_or_params, "parameters") else list(module_or_params)
     params = [p for p in params if p.requires_grad]
-    if not params or not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not params or not data_parallel(group):
         return
     store = getattr(module_or_params, "_param_store", None)
     if store is not None and all(p.grad is not None and p.grad.data_ptr() == v.data_ptr() for p, v in zip(store.param_list, store.grad_views)):
         # a season_nerf_amd.T_NeRF after a training backward: every .grad is a view of one flat arena - reduce it in place
         dist.all_reduce(store.grads, op=dist.ReduceOp.SUM, group=group)
+        COLLECTIVES["grad_arena_all_reduce"] += 1
         if average:
             store.grads /= dist.get_world_size(group)
         return
     flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    COLLECTIVES["grad_bucket_all_reduce"] += 1
     if average:
         flat /= dist.get_world_size(group)
     off = 0

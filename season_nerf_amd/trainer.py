@@ -49,15 +49,17 @@ get_output_loc, get_output_loc_lin_first = save_points, save_points_spaced      
 
 def _allreduce_mean_grads(params):
     """Data parallel: average the gradients of a few small tensors (the adaptive-loss parameters) over all ranks as ONE
-    message.  No-op without an initialised process group or with a single rank."""
+    message.  No-op without an initialised process group (a group of one rank still issues the collective)."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() < 2:
+    from . import parallel
+    if not parallel.data_parallel():
         return
     ps = [p for p in params if p.grad is not None]
     if not ps:
         return
     flat = torch.cat([p.grad.reshape(-1) for p in ps])
     dist.all_reduce(flat)
+    parallel.COLLECTIVES["ada_loss_all_reduce"] += 1
     flat /= dist.get_world_size()
     o = 0
     for p in ps:

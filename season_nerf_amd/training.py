@@ -207,6 +207,8 @@ class TrainEngine:
                     return 1
                 view = self.ws[off:off + size].view(torch.float64 if is_double else torch.float32)
                 dist.all_reduce(view, op=dist.ReduceOp.SUM, group=group)      # stream-ordered: torch inserts the event waits
+                from . import parallel
+                parallel.COLLECTIVES["bn_stats_all_reduce"] += 1
                 return 0
             except Exception:                                                  # never unwind through the C frames
                 import traceback
@@ -610,9 +612,13 @@ class FusedAdam(torch.optim.Optimizer):
             raise RuntimeError("FusedAdam.step before any training forward/backward")
         g = self.param_groups[0]
         eng.attach_grads()            # every p.grad is a view of the flat arena the backward kernels accumulated into
-        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+        from . import parallel
+        if parallel.data_parallel():
             # data parallel: ONE all-reduce of the flat gradient arena over RCCL/xGMI, then identical Adam on every rank
+            # (issued for a world of one rank too: the collective path runs wherever a process group exists)
             torch.distributed.all_reduce(eng.grads)
-            eng.grads /= torch.distributed.get_world_size()
+            parallel.COLLECTIVES["grad_arena_all_reduce"] += 1
+            if torch.distributed.get_world_size() > 1:
+                eng.grads /= torch.distributed.get_world_size()
         eng.adam_step(g["lr"], g["betas"], g["eps"])
         self.net.invalidate_packed()  # parameters changed outside torch's version counters: re-pack before inference

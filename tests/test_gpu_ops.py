@@ -44,7 +44,7 @@ def test_render_fwd_matches_the_reference(golden_dir, precision):
     S = int(g["S"])
     import season_nerf_amd as sn
     tv = sn.sample_parameters(S, eval_mode=True).cuda()
-    rgb, depth, albedo, per = torch.ops.season_nerf.render_fwd(m, top, bot, sun, tim, tv, 0, True)
+    rgb, depth, albedo, per = torch.ops.season_nerf.render_fwd(m, top, bot, sun, tim, tv, 0, True, True)
     tol = dict(rtol=1e-4, atol=2e-6) if precision == "bf16x3" else dict(rtol=5e-5, atol=2e-6)
     close(rgb, g["eval_Rendered_Col"], **tol)
     close(albedo, g["eval_Albedo_Color"], **tol)
@@ -54,6 +54,10 @@ def test_render_fwd_matches_the_reference(golden_dir, precision):
     close(per[9], g["eval_PS"], rtol=3e-4, atol=2e-5)
     close(per[11].unsqueeze(1).expand(-1, S, -1), g["eval_Classes"], rtol=1e-4, atol=2e-5)
     close(per[12].unsqueeze(1).expand(-1, S, -1), g["eval_Sky_Col"], rtol=1e-4, atol=2e-5)
+    assert per[3].shape == (top.shape[0], S, 4, 3) and per[5].shape == (top.shape[0], S, 3)
+    # the unmixed seasonal terms (Adjust, Col_raw) only on request: eval()'s dict does not carry them
+    _, _, _, per1 = torch.ops.season_nerf.render_fwd(m, top, bot, sun, tim, tv, 0, True)
+    assert per1[3].numel() == 0 and per1[5].numel() == 0 and torch.equal(per1[1], per[1]) and torch.equal(per1[4], per[4])
     # per-ray only: no per-sample tensors are allocated
     rgb2, _, _, per2 = torch.ops.season_nerf.render_fwd(m, top, bot, sun, tim, tv, 0, False)
     assert per2 == [] and torch.equal(rgb, rgb2)

@@ -51,9 +51,9 @@ def _ref_grads(g):
 
 
 @pytest.mark.parametrize("name", ["train_W64_R32_S32.npz", "train_prior_W64_R24_S40.npz", "train_W256_R32_S40.npz",
-                                  "train_classic_W64_R32_S32.npz", "train_classic_prior_W64_R24_S40.npz"])
+                                  "train_classic_W64_R32_S32.npz", "train_classic_prior_W64_R24_S40.npz", "train_W512_R32_S40.npz"])
 def test_train_step_vs_reference(golden_dir, name):
-    """name 2: the DSM-prior phase (use_prior=True: supervised + merged composites, Alpha_Adjust loss); name 3: the benchmark
+    """name 6: the reference's default width (fc_units = 512, main_lite.py:80): K = 575 / 512 layers in 64-column groups.  name 2: the DSM-prior phase (use_prior=True: supervised + merged composites, Alpha_Adjust loss); name 3: the benchmark
     width (W=256: 64-column-group GEMM for fc5, several column groups per row tile, full 256x256 wgrad blocks, 1280 points =
     not a multiple of the 512-row tile); name 4: Solar_Type_2 (per-sample shading, the solar branch differentiated from the image); name 5: Solar_Type_2 in the
     DSM-prior phase."""

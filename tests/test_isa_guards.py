@@ -154,3 +154,50 @@ def test_shipped_fused_kernels_hold_their_register_contracts():
         act = int(re.search(r"ILi\dELi\dELi\dELi(\d)E", n).group(1))
         if not act:
             assert k[".private_segment_fixed_size"] == 0, n
+
+
+def test_w512_kernel_agprs_are_touched_only_by_the_hand_written_instructions(tmp_path):
+    """mlp_i8_kernel<FIELD, 512, *> parks its hidden activations in AGPRs addressed BY NUMBER (v_accvgpr_write a[n] at the digit
+    split, v_mfma_i32_32x32x32_i8 reading a[n:n+3] as its B operand, all through inline asm).  The one asm clobber that reserves
+    a0..a255 does not stop the register allocator from placing its own values there afterwards (AV-class operands, copies,
+    rematerialisation) - which would silently corrupt the parked activations.  So: disassemble the shipped code objects and allow
+    an AGPR operand nowhere but in those two instruction forms."""
+    import importlib.util
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not available")
+    spec = importlib.util.spec_from_file_location("snerf_build", os.path.join(REPO, "season_nerf_amd", "build.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    b.build()
+    seen = 0
+    for n, elf in enumerate(_device_code_objects(b.LIB)):
+        names = [k[".name"] for k in _kernel_metadata(elf) if re.search(r"mlp_i8_kernelILi0ELi512E", k[".name"])]
+        if not names:
+            continue
+        f = tmp_path / f"co{n}.elf"
+        f.write_bytes(elf)
+        dis = subprocess.run([objdump, "-d", "--mcpu=gfx950", str(f)], capture_output=True, text=True, timeout=600).stdout
+        for name in names:
+            m = re.search(r"^[0-9a-f]+ <" + re.escape(name) + r">:\n(.*?)(?=^[0-9a-f]+ <|\Z)", dis, re.S | re.M)
+            assert m, name
+            writes = mfma_b = 0
+            for line in m.group(1).split("\n"):
+                code = line.split("//")[0].strip()
+                if not code or not re.search(r"\ba(\d+|\[\d+:\d+\])", code):
+                    continue
+                op = code.split()[0]
+                args = code[len(op):]
+                if op == "v_accvgpr_write_b32":
+                    assert re.match(r"\s*a\d+, v\d+\s*$", args), (name, code)        # park: AGPR <- VGPR
+                    writes += 1
+                elif op == "v_mfma_i32_32x32x32_i8":
+                    d, a_, b_, c_ = [x.strip() for x in args.split(",")[:4]]
+                    # weights (A) and accumulators in VGPRs, the parked activations (B) in AGPRs; C = 0 starts an accumulation
+                    assert d.startswith("v[") and a_.startswith("v[") and b_.startswith("a[") and (c_.startswith("v[") or c_ == "0"), (name, code)
+                    mfma_b += 1
+                else:
+                    raise AssertionError(f"{name}: AGPR operand outside the hand-written forms: {code}")
+            assert writes > 100 and mfma_b > 100, (name, writes, mfma_b)
+            seen += 1
+    assert seen == 3

@@ -123,7 +123,7 @@ def _ref_grads(g):
     return out
 
 
-@pytest.mark.parametrize("name", ["train_W64_R32_S32.npz", "train_W256_R32_S40.npz", "train_classic_W64_R32_S32.npz"])
+@pytest.mark.parametrize("name", ["train_W64_R32_S32.npz", "train_W256_R32_S40.npz", "train_classic_W64_R32_S32.npz", "train_W512_R32_S40.npz"])
 def test_train_step_mse(golden_dir, name):
     """get_loss (MSE) + backward + BN running stats + one Adam step, train-mode BatchNorm; third file: Solar_Type_2."""
     g = load(golden_dir, name)

@@ -436,6 +436,10 @@ if __name__ == "__main__":
         gen_eval_full()
         print("evalfull_W256_R4096_S96.npz", os.path.getsize(os.path.join(OUT, "evalfull_W256_R4096_S96.npz")))
         sys.exit(0)
+    if "--only-w512-train" in sys.argv:           # one reference training step at the reference's default width (main_lite.py:80)
+        gen_train(512, 6, 32, 40, "W512_R32_S40", subsample=149)
+        print("train_W512_R32_S40.npz", os.path.getsize(os.path.join(OUT, "train_W512_R32_S40.npz")))
+        sys.exit(0)
     if "--only-full-train" in sys.argv:
         # BASELINE configs[2] at its full size: ONE reference training step, 4096 rays x 96 samples + 4096 sun rays, W = 256,
         # MSE loss (43 s and ~40 GB of autograd state on the 8 CPUs of the build container).  Gradients of the big tensors are
@@ -452,6 +456,7 @@ if __name__ == "__main__":
     gen_train(64, 1, 24, 40, "prior_W64_R24_S40", prior=True)
     gen_train(256, 2, 32, 40, "W256_R32_S40", subsample=37)
     gen_train(256, 5, 4096, 96, "W256_R4096_S96", subsample=37)       # full-size configs[2] step (also: --only-full-train)
+    gen_train(512, 6, 32, 40, "W512_R32_S40", subsample=149)          # the reference's default width (also: --only-w512-train)
     gen_train(64, 3, 32, 32, "classic_W64_R32_S32", classic=True)
     gen_train(64, 4, 24, 40, "classic_prior_W64_R24_S40", prior=True, classic=True)
     gen_net(512, 3, 384, "W512_s3")
