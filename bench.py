@@ -112,8 +112,12 @@ def cpu_baseline():
     sub = lambda n: {k: v[:n] for k, v in data.items()}
     with torch.no_grad():
         orc.eval_rays(sd, sub(128), S, False)              # warm-up
-        n, reps, ts = 2048, 3, []                   # ~4 s per repetition on 16 cores: 10-15 s of CPU work in total
-        for _ in range(reps):
+        n, ts = R, []                                      # the whole 4096-ray batch per repetition
+        t0 = time.perf_counter()
+        orc.eval_rays(sd, sub(n), S, False)
+        ts.append(time.perf_counter() - t0)
+        reps = int(min(max(3, np.ceil(12.0 / ts[0])), 12))  # >= 12 s of CPU work in all (hosts differ 6x), at most 12 repetitions
+        for _ in range(reps - 1):
             t0 = time.perf_counter()
             orc.eval_rays(sd, sub(n), S, False)
             ts.append(time.perf_counter() - t0)
@@ -122,6 +126,47 @@ def cpu_baseline():
             "sample": f"{n} rays x {S} samples of the same workload (eval-mode forward render, fp32 torch-CPU oracle), "
                       f"median of {reps} after warm-up", "seconds_per_repetition": ts, "torch_threads": torch.get_num_threads(),
             "torch_interop_threads": torch.get_num_interop_threads(), **host_info()}
+
+
+TRAIN_KERNEL = "snerf::gemm_rows16_kernel<8,4,1,0>"
+
+
+def train_dominant_kernel(dev, launches=20):
+    """The training step's dominant kernel on its own, live: the forward row GEMM of a 256 -> 256 SineLayer at M = 393 216 points
+    (activation on load from the stored pre-activation of the layer below, BatchNorm column sums in the epilogue) - 21 of the
+    step's launches, ~23 % of its time.  Algorithmic bytes: read Z_in, write Z_out = 4 M (K + N).  HIP events on the stream the
+    C ABI launches on (torch's current stream)."""
+    import season_nerf_amd as sn
+    L = sn._lib.lib()
+    M, K, N = R * S, 256, 256
+    A = torch.randn(M, K, device=dev) * 4
+    Wt = torch.randn(N, K, device=dev) / 16
+    b = torch.randn(N, device=dev)
+    out = torch.empty(M, N, device=dev)
+    tab = torch.rand(2 * K, device=dev)
+    stats = torch.zeros(2 * N, dtype=torch.float64, device=dev)
+    sc = torch.empty(L.snerf_linear_scratch_bytes(N, K), dtype=torch.uint8, device=dev)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    run = lambda: sn._lib.check(L.snerf_linear_forward(M, K, N, A.data_ptr(), K, Wt.data_ptr(), b.data_ptr(), 30.0, out.data_ptr(), N, stats.data_ptr(), 1,
+                                                      sc.data_ptr(), sc.numel(), tab.data_ptr(), K, st), "linear_forward")
+    for _ in range(3):
+        run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(launches):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / launches * 1e3 - 5.0          # each call also runs the 5 us weight-split kernel (own launch, in the trace)
+    nbytes = 4.0 * M * (K + N)
+    traffic = None
+    try:
+        traffic = json.load(open(_profile_file("train_kernel_traffic.json")))["bytes_per_launch"]
+    except Exception:
+        pass
+    return {"bound": "hbm", "kernel": TRAIN_KERNEL + " (forward 256->256 SineLayer, activation on load + BatchNorm sums in the epilogue, M = 393216)",
+            "achieved": nbytes / (us * 1e-6) / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": nbytes / (us * 1e-6) / 8e12, "traffic": traffic,
+            "kernel_us": us, "algorithmic_bytes": nbytes, "launches_per_step": 21}
 
 
 def bench_train(a, standalone=True):
@@ -244,17 +289,20 @@ def bench_train(a, standalone=True):
                                          + ("over the global batch (all-reduced)" if a.bn_sync == "global" and use_dist else "per rank")},
                "final_loss": float(tot.detach()), "step_ms_median": per_step[len(per_step) // 2], "step_ms_min": per_step[0],
                "collectives": dict(sn.parallel.COLLECTIVES) if use_dist else None,
-               "roofline": {"bound": "hbm", "achieved": hbm_bytes / dt / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": hbm_bytes / dt / 8e12,
-                            "traffic": traffic, "bytes_per_step": hbm_bytes, "algorithmic_tflops": flop / dt / 1e12,
-                            "note": "whole step, not one kernel: train-mode BatchNorm forces a layer-wise design in which every layer is "
-                                    "a pass over [393216 x width] fp32 arrays; achieved = bytes that design moves per step (counted from "
-                                    "the layer table, DESIGN 5.4) / step time, peak = HBM3E 8 TB/s (MI355X_MICROARCH.md); "
-                                    "per-kernel times in profiles/*/train_kernel_stats.csv"}}
+               "roofline": None,
+               "step_roofline": {"bound": "hbm", "achieved": hbm_bytes / dt / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": hbm_bytes / dt / 8e12,
+                                 "traffic": traffic, "bytes_per_step": hbm_bytes, "algorithmic_tflops": flop / dt / 1e12,
+                                 "note": "whole step, not one kernel: train-mode BatchNorm forces a layer-wise design in which every layer is "
+                                         "a pass over [393216 x width] fp32 arrays; achieved = bytes that design moves per step (counted from "
+                                         "the layer table, DESIGN 5.4) / step time, traffic = HBM bytes per step by the PMC counters, "
+                                         "peak = HBM3E 8 TB/s (MI355X_MICROARCH.md); per-kernel times in profiles/*/train_kernel_stats.csv"}}
+        if Wt == 256 and world == 1:
+            out["roofline"] = train_dominant_kernel(dev)
         if not a.no_cpu_baseline and world == 1:      # reported at N = 1 only (rank 0)
             from oracle import season_nerf_oracle as orc          # CPU-baseline leg only
             torch.set_num_threads(min(host_cpus(), 32))
             sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in orc.init_weights(Wt, NC, 0, bn_stats="identity").items()}
-            n = 256
+            n = 512
             dc = {k: v[:n].cpu() for k, v in d.items()}
             rng = np.random.Generator(np.random.PCG64(1))
             st = torch.tensor(np.concatenate([rng.uniform(-1, 1, (n, 2)), np.ones((n, 1))], 1), dtype=torch.float32)
@@ -333,6 +381,7 @@ def main():
     ap.add_argument("--headline-only", action="store_true",
                     help="only the headline timed region (no per-mode table, seam, sweep, training step, CPU baseline): profiler passes")
     ap.add_argument("--no-train", action="store_true", help="render workload: skip the extra training-step measurement (train_* keys)")
+    ap.add_argument("--train-kernel-only", action="store_true", help="--workload train: only the dominant training kernel (`--steps` launches), for profiler passes")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help=argparse.SUPPRESS)   # gloo: CPU test of the launcher only
     ap.add_argument("--bn_sync", default="local", choices=["local", "global"],
                     help="--workload train, N > 1: BatchNorm statistics per rank, or over the global batch (RCCL all-reduces of the "
@@ -349,6 +398,10 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but the launcher started {world} ranks")
     if a.backend == "gloo":
         return launcher_selftest(a, world, rank)
+    if a.workload == "train" and a.train_kernel_only:        # profiler passes over the dominant training kernel alone
+        torch.cuda.set_device(local)
+        print(json.dumps(train_dominant_kernel(torch.device("cuda", local), launches=max(a.steps, 1))))
+        return
     if a.workload == "train":
         out = bench_train(a)
         if out is not None:
@@ -543,7 +596,8 @@ def main():
                 tr = bench_train(argparse.Namespace(**{**vars(a), "loss": "mse"}), standalone=False)
                 extra.update({"train_ms_per_step": tr["ms_per_step"], "train_value": tr["value"], "train_unit": tr["unit"],
                               "train_metric": tr["metric"], "train_steps": tr["steps"], "train_final_loss": tr["final_loss"],
-                              "train_dtype": tr["dtype"], "train_roofline": tr["roofline"], "train_config": tr["config"]})
+                              "train_dtype": tr["dtype"], "train_roofline": tr["roofline"], "train_step_roofline": tr["step_roofline"],
+                              "train_config": tr["config"]})
                 if "cpu_baseline" in tr:
                     extra["train_cpu_baseline"] = tr["cpu_baseline"]
             except Exception as ex:      # never let the auxiliary measurement break the headline line

@@ -47,11 +47,11 @@ def pmc(out, name, counters, bench_args):
 
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "x"
-    prec = sys.argv[sys.argv.index("--precision") + 1] if "--precision" in sys.argv else "i8x3"
+    prec = sys.argv[sys.argv.index("--precision") + 1] if "--precision" in sys.argv else "auto"
     out = os.path.join(REPO, "gpurun_out", "round_" + tag)
     os.makedirs(out, exist_ok=True)
     with open(os.path.join(out, "bench.json"), "w") as f:
-        subprocess.call(["python3", "bench.py", "--precision", prec], stdout=f, stderr=open(os.path.join(out, "bench.err"), "w"), cwd=REPO)
+        subprocess.call(["python3", "bench.py"] + (["--precision", prec] if "--precision" in sys.argv else []), stdout=f, stderr=open(os.path.join(out, "bench.err"), "w"), cwd=REPO)
     bench = json.load(open(os.path.join(out, "bench.json")))
     kname = bench["roofline"]["kernel"].split(" ")[0]                      # e.g. snerf::mlp_i8_kernel<0,256,0>
     key = kname.split("::")[-1].split("<")[0]                               # mlp_i8_kernel
@@ -122,6 +122,24 @@ def main():
                             "write_MB_per_step": ps(v["WRITE_SIZE"]) / 1e6} for k, v in rows[:24]]}
         res["bytes_per_step"] = 2 * res["fetch_bytes_per_step_raw"] + res["write_bytes_per_step"]
         json.dump(res, open(os.path.join(out, "train_traffic.json"), "w"), indent=1)
+        # the dominant training kernel on its own (bench.py --workload train --train-kernel-only: what train_roofline is measured on)
+        kargs = ["--workload", "train", "--train-kernel-only", "--steps", "8"]
+        d = os.path.join(out, "prof_tk")
+        sh(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "--", "python3", "bench.py"] + kargs, os.path.join(out, "prof_tk.log"))
+        st = find(d, "*kernel_stats.csv")
+        if st:
+            shutil.copy(st, os.path.join(out, "train_kernel_kernel_stats.csv"))
+        shutil.rmtree(d, ignore_errors=True)
+        tk = {}
+        for c in ("FETCH_SIZE", "WRITE_SIZE"):
+            acc = pmc(out, "tk_" + c, [c], kargs)
+            for k, v in acc.items():
+                if "gemm_rows16_kernel" in k:
+                    tk[c] = sum(v[c]) / len(v[c])
+        if len(tk) == 2:
+            json.dump({"kernel": "snerf::gemm_rows16_kernel<8,4,1,0>, forward 256->256, M = 393216", "command": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE -- python3 bench.py " + " ".join(kargs),
+                       "FETCH_SIZE_KB": tk["FETCH_SIZE"], "WRITE_SIZE_KB": tk["WRITE_SIZE"], "correction": "gfx950: FETCH_SIZE x2 (16 B/lane streaming reads)",
+                       "bytes_per_launch": (2 * tk["FETCH_SIZE"] + tk["WRITE_SIZE"]) * 1024.0}, open(os.path.join(out, "train_kernel_traffic.json"), "w"), indent=1)
     print(open(os.path.join(out, "recompute.txt")).read())
     print({k: v for k, v in tot.items()})
 
