@@ -3,8 +3,9 @@ HIP C-ABI.  Same constructor, same `state_dict` keys/shapes (SURVEY App. C - `Fi
 forward variants and return conventions; the arithmetic runs in the gfx950 kernels, never in PyTorch.
 
 Eval mode (`.eval()`, BatchNorm running statistics): the fused register-resident MFMA kernels (widths 64 / 256), no autograd.
-Train mode (`.train()`, batch-statistics BatchNorm): `forward`, `forward_seperate`, `forward_full_eval` and `forward_Solar`
-run on the layer-wise training engine and return tensors with an autograd graph whose backward is the engine's HIP backward
+Train mode (`.train()`, batch-statistics BatchNorm): every forward variant (`forward`, `forward_seperate`, `forward_full_eval`,
+`forward_Solar`, `forward_Classic_Sigma_Only`, `get_class_only`, `approx_Solar`)
+runs on the layer-wise training engine and returns tensors with an autograd graph whose backward is the engine's HIP backward
 (gradients land in the parameters' `.grad`) - so the reference's own evaluator trains through this class unchanged.
 Not differentiable (returned without a graph): `Adjust_col`, and `Col_raw` / `Adjust` of the `forward_seperate` family.
 """
@@ -254,11 +255,6 @@ class T_NeRF(nn.Module):
         from . import training
         return training.points_forward_train(self, X, sun, tim)
 
-    def _no_train_graph(self, what):
-        if self.training and torch.is_grad_enabled():
-            raise NotImplementedError(f"season_nerf_amd.T_NeRF.{what}: no autograd graph in train mode (the reference's training "
-                                      "step does not differentiate it); call it under torch.no_grad() or in .eval() mode")
-
     def forward(self, X, Solar_Angle, Time):
         """-> Rho[N,1], Col[N,3], Solar_Vis[N,1], Sky_Col[N,3], output_class[N,C], Adjust_col[N,3]  (:75-105)"""
         X, sun, tim = self._prep(X, Solar_Angle, Time)
@@ -304,35 +300,52 @@ class T_NeRF(nn.Module):
     def approx_Solar(self, X, X_solar, Time):
         """-> Rho(X), Rho(X_solar), Col(X), output_class, Adjust_col  (T_NeRF_net_v2.py:107-129; used by the reference's
         Eval_Tools_3_approx_solar only).  Eval mode: the density at X_solar is a sigma-only pass, the rest one full pass at X (the
-        colour head does not depend on the sun direction).  In train mode the reference normalises both point sets with the statistics
-        of their concatenation; that variant is not built."""
-        if self.training:
-            raise NotImplementedError("season_nerf_amd.T_NeRF.approx_Solar: eval mode only (train mode needs batch statistics over the "
-                                      "concatenation of X and X_solar; the reference's main training path does not call it)")
+        colour head does not depend on the sun direction).  Train mode: one pass over the concatenation [X; X_solar] - the reference
+        normalises both point sets with the BatchNorm statistics of their concatenation - with an autograd graph."""
         X, Xs, tim = self._prep(X, X_solar, Time)
-        up = torch.zeros(X.shape[0], 3, device=X.device)
-        up[:, 2] = 1.0                                     # any direction: Rho, Col and Adjust_col do not depend on it
+        N = X.shape[0]
+        if self.training:
+            both = torch.cat([X, Xs], 0).contiguous()
+            up = torch.zeros(both.shape[0], 3, device=X.device)
+            up[:, 2] = 1.0                                 # any direction: Rho, Col and Adjust_col do not depend on it
+            t2 = torch.cat([tim, tim[:1].expand(Xs.shape[0], 4)], 0).contiguous()      # classes are used for the first N points only
+            rho, col, _, _, cls, adjc, _, _ = self._train_points(both, up, t2)
+            return rho[:N], rho[N:], col[:N], cls[:N], adjc[:N]
+        up = torch.zeros(N, 3, device=X.device)
+        up[:, 2] = 1.0
         rho, col, _, _, cls, adjc = self.forward(X, up, tim)
         return rho, self.forward_Classic_Sigma_Only(Xs), col, cls, adjc
 
     def forward_Classic_Sigma_Only(self, X):
+        """softplus(fc10Sigma(trunk(X))) (T_NeRF_net_v2.py:169-170, G_NeRF.py:74-77).  Train mode: batch-statistics BatchNorm over X and
+        an autograd graph through the trunk (a full per-point pass of the engine; the other heads' outputs are dropped)."""
         (X,) = self._prep(X)
-        self._no_train_graph("forward_Classic_Sigma_Only")
-        if self.training:        # batch-statistics BatchNorm: the trunk + density head of the engine's sun-ray pass
+        if self.training:
+            up = torch.ones(X.shape[0], 3, device=X.device)
+            if torch.is_grad_enabled():
+                return self._train_points(X, up, torch.zeros(X.shape[0], 4, device=X.device))[0]
             from . import training
-            with torch.no_grad():
-                return training.solar_points_forward_train(self, X, torch.ones(X.shape[0], 3, device=X.device))[0].detach()
+            with torch.no_grad():      # trunk + density head of the engine's sun-ray pass (no seasonal branch)
+                return training.solar_points_forward_train(self, X, up)[0].detach()
         if not self.fused:
             z = torch.zeros(X.shape[0], 4, device=X.device)
             return self._generic_points(X, torch.ones(X.shape[0], 3, device=X.device), z)["rho"]
         return self._field_points(2, X, None, None, ["d_rho"])["d_rho"]
 
     def get_class_only(self, Time):
+        """softmax(get_class_layer(time_layer_2(time_layer_1(PE(Time[:, 0:2]))))) (T_NeRF_net_v2.py:160-163).  The time branch has no
+        BatchNorm: train and eval mode agree.  Train mode with gradients enabled: through the engine's per-point pass with the running
+        BatchNorm statistics (nothing of the trunk is updated), differentiable in the time-branch parameters."""
         (tim,) = self._prep(Time)
-        self._no_train_graph("get_class_only")          # the time branch has no BatchNorm: train and eval mode agree
-        sun = torch.zeros(tim.shape[0], 3, device=tim.device)
+        n = tim.shape[0]
+        sun = torch.zeros(n, 3, device=tim.device)
+        if self.training and torch.is_grad_enabled():
+            from . import training
+            eng = training._engine_for(self, n, n, 1)
+            r = training._train_ops(eng).train_fwd_points(eng.handle, torch.zeros(n, 3, device=tim.device), sun + 1.0, tim, False, self.n_classes, eng.param_list)
+            return r[4]
         if not self.fused:
-            return self._generic_points(torch.zeros(tim.shape[0], 3, device=tim.device), sun + 1.0, tim)["cls"]
+            return self._generic_points(torch.zeros(n, 3, device=tim.device), sun + 1.0, tim)["cls"]
         return self._groups(tim, sun)[0]
 
     def Supervised_Sample(self, world_pts, delta, outside=None):

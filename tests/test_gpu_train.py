@@ -365,8 +365,8 @@ def test_train_mode_forward_variants_and_guards(golden_dir):
     # Col = sigmoid(Col_raw + sum_c class_c Adjust_c) ties the two variants together (T_NeRF_net_v2.py:89-98)
     col = torch.sigmoid(b[1] + (b[5] * b[4].unsqueeze(2)).sum(1))
     np.testing.assert_allclose(a[1].detach().cpu().numpy(), col.detach().cpu().numpy(), rtol=0, atol=2e-6)
-    with pytest.raises(NotImplementedError):
-        net.forward_Classic_Sigma_Only(X)
+    r0 = net.forward_Classic_Sigma_Only(X)          # train mode with gradients: a graph through the trunk (test_sibling_forwards_...)
+    assert r0.requires_grad
     with torch.no_grad():
         r1 = net.forward_Classic_Sigma_Only(X)
         r2 = net.forward_Solar(X, sun, tim)[0]
@@ -416,3 +416,62 @@ def test_full_size_training_step_vs_reference(golden_dir):
     for k in g:
         if k.startswith("bn_"):
             np.testing.assert_allclose(sd[k[3:]].cpu().numpy(), g[k], rtol=1e-4, atol=1e-5, err_msg=k)
+
+
+def test_sibling_forwards_train_mode_gradients_vs_oracle():
+    """`forward_Classic_Sigma_Only`, `get_class_only` and `approx_Solar` in .train() with gradients enabled (T_NeRF_net_v2.py:107-129,
+    160-172; the reference differentiates all three through plain autograd): values and parameter gradients against the oracle's
+    autograd on the CPU - batch-statistics BatchNorm over X (sigma only) / over the concatenation [X; X_solar] (approx_Solar)."""
+    import season_nerf_amd as sn
+    W, C, N = 64, 4, 1300
+    sd = orc.init_weights(W, C, 5, bn_stats="identity")
+    rng = np.random.Generator(np.random.PCG64(21))
+    X, Xs = T(rng.uniform(-1, 1, (N, 3))), T(rng.uniform(-1, 1, (N // 2, 3)))
+    tim = T(rng.uniform(-1, 1, (N, 4)))
+    wr, ws, wc, wk = T(rng.normal(size=(N, 1))), T(rng.normal(size=(N // 2, 1))), T(rng.normal(size=(N, 3))), T(rng.normal(size=(N, C)))
+
+    def oracle(case):
+        p = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v) for k, v in sd.items()}
+        if case == "sigma":
+            loss = (orc.forward_sigma_only(p, X, train_bn=True) * wr).sum()
+        elif case == "class":
+            loss = (orc.class_probs(p, tim) * wk).sum()
+        else:
+            x1 = orc.trunk(p, torch.cat([X, Xs], 0), train_bn=True)
+            rho_raw, col_raw = orc.position_heads(p, x1)
+            rho = orc.softplus(rho_raw)
+            cls = orc.class_probs(p, tim)
+            adj = orc.adjust_branch(p, x1[:N], C)
+            col = torch.sigmoid(col_raw[:N] + (adj * cls.unsqueeze(2)).sum(1))
+            loss = (rho[:N] * wr).sum() + (rho[N:] * ws).sum() + (col * wc).sum() + (cls * wk).sum()
+        loss.backward()
+        return float(loss), {k: v.grad for k, v in p.items() if torch.is_tensor(v) and v.requires_grad and v.grad is not None}
+
+    for case in ("sigma", "class", "approx"):
+        net = sn.T_NeRF(W, C)
+        net.load_state_dict(sd)
+        net = net.cuda().train()
+        d = lambda t: t.cuda()
+        if case == "sigma":
+            loss = (net.forward_Classic_Sigma_Only(d(X)) * d(wr)).sum()
+        elif case == "class":
+            before = net.G_NeRF_net.fc2.norm.running_var.clone()
+            loss = (net.get_class_only(d(tim)) * d(wk)).sum()
+            assert torch.equal(before, net.G_NeRF_net.fc2.norm.running_var)          # no BatchNorm statistic is touched by the time branch
+        else:
+            rho, rho_s, col, cls, adjc = net.approx_Solar(d(X), d(Xs), d(tim))
+            loss = (rho * d(wr)).sum() + (rho_s * d(ws)).sum() + (col * d(wc)).sum() + (cls * d(wk)).sum()
+        loss.backward()
+        ref_loss, ref = oracle(case)
+        assert abs(float(loss) - ref_loss) <= 2e-5 * max(1.0, abs(ref_loss)), (case, float(loss), ref_loss)
+        params = dict(net.named_parameters())
+        gmax = max(float(v.abs().max()) for v in ref.values())
+        worst = 0.0
+        for k, gr in ref.items():
+            if float(gr.abs().max()) == 0.0:
+                assert params[k].grad is None or float(params[k].grad.abs().max()) <= 1e-6 * gmax, (case, k)
+                continue
+            got = params[k].grad.cpu()
+            worst = max(worst, float((got - gr).abs().max()) / max(float(gr.abs().max()), 1e-3 * gmax))
+        print(f"  {case}: loss {float(loss):.6f} (oracle {ref_loss:.6f}), worst relative gradient error {worst:.2e}")
+        assert worst < 5e-4, (case, worst)
