@@ -589,6 +589,18 @@ def main():
             extra["eval_seam_ms"] = (time.perf_counter() - t1) / n_seam * 1e3
             extra["eval_seam_note"] = "All_in_One_Eval.eval(data_dict on the GPU, net, 0, False): full 14-key result dict, wall clock per call"
             del res
+            # what a parameter change costs the next inference call (an in-loop validation render during training pays it once per
+            # save point): state_dict D2H, host-side BatchNorm fold + error model + fragment packing, H2D upload
+            tp = []
+            for _ in range(3):
+                net.invalidate_packed()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                net.device_model()
+                torch.cuda.synchronize()
+                tp.append((time.perf_counter() - t1) * 1e3)
+            extra["repack_ms"] = min(tp)
+            extra["repack_note"] = "T_NeRF.device_model() after a parameter change: D2H of the state_dict + host pack (fold, int8 error model, digits) + upload"
         if not a.no_train:
             del rho, sv, col
             torch.cuda.empty_cache()

@@ -17,15 +17,14 @@
 
 #include <type_traits>
 
+#include "gemm_common.h"
 #include "train.h"
 
 namespace snerf {
 
-typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 constexpr int GBM = 128, GBN = 128, GBK = 16, GPAD = 4;
 
-typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 // A [rows x GBK] (K_CONTIG) or [GBK x rows] tile is moved in two phases (register staging, T14): `fetch` issues the
 // global loads of the NEXT tile before the MFMA block, `stash` writes them to the k-major LDS image dst[k][r] after it,
@@ -183,26 +182,8 @@ hipError_t launch_gemm(const GemmArgs& g, hipStream_t st) {
 // which makes these GEMMs HBM-bound (403 MB in + 403 MB out per layer at 4096 x 96).
 namespace snerf {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
-typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 
-constexpr int RO_WAVES = 8, RO_MT = 1;                       // 8 waves x 32 rows = 256 rows per workgroup tile (64 accumulators per lane)
-constexpr int RO_ROWS = RO_WAVES * RO_MT * 32;
 constexpr int RO_PF = 4;                                     // k-steps of A loads in flight ahead of the MFMAs
-
-__device__ __forceinline__ void split2_bf16(float a, float b, uint32_t& hi, uint32_t& lo) {
-    bf16x2_t hv;
-    hv[0] = (__bf16)a;
-    hv[1] = (__bf16)b;
-    hi = __builtin_bit_cast(uint32_t, hv);
-    const float ha = __builtin_bit_cast(float, hi << 16);
-    const float hb = __builtin_bit_cast(float, hi & 0xffff0000u);
-    bf16x2_t lv;
-    lv[0] = (__bf16)(a - ha);
-    lv[1] = (__bf16)(b - hb);
-    lo = __builtin_bit_cast(uint32_t, lv);
-}
 
 // Fragment-order split: tile T (32 output columns), k-step ks (16 k): 1 KiB hi then 1 KiB lo; inside, lane (r,h) owns 16 bytes =
 // bf16 of Bt[T*32 + r][ks*16 + h*8 + 0..7].  Bt[n][k] = W[n][k] (transpose = 0, W is [rows x cols]) or W[k][n] (transpose = 1).
@@ -678,283 +659,6 @@ __global__ __launch_bounds__(512) void gemm_rows_full_kernel(const GemmX g) {
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// The same full-tile row GEMM on v_mfma_f32_16x16x32_bf16.  Why a second MFMA shape: the vector-memory path, not HBM or the
-// matrix pipe, bounds the 32x32x16 form.  Its A operand puts one ROW on every lane of a half-wave - a 1 KiB load
-// instruction touches 64 different 128-B lines (147 cycles per instruction and CU, tools/probes/ta_rate.hip) - and every A
-// byte is loaded by two column groups.  The 16x16x32 A operand has 16 rows x 4 lanes: with the k order chosen below the four
-// lanes of a row read 64 contiguous bytes per instruction (quad-coalesced: 67 cycles), from the SAME row-major activations.
-// The accumulator of a 16x16 tile (lane (g, j): column j, rows 4g .. 4g+3) stores as four 64-B row segments per instruction,
-// at the per-byte rate of the 32x32 form's two 128-B segments (17 against 16 cycles per 256 B).  Arithmetic, summation order
-// inside a product (hi*hi last) and results differ from the 32x32x16 kernel only by the order of the k terms inside a 32-k step.
-//   fragment order (split_weights16_kernel): n-tile T (16 columns), k-step ks (32 k): 1 KiB hi then 1 KiB lo; lane (g, j) owns
-//   16 bytes = bf16 of Bt[16 T + j][32 ks + kmap(g, e)], e = 0..7, kmap(g, e) = 4 g + e (e < 4), 16 + 4 g + (e - 4) (e >= 4) -
-//   so a lane's A values are two 16-byte loads, at byte 16 g and byte 64 + 16 g of the 128-B k-step of its row.
-// A wave owns 32 rows = two 16-row tiles (each weight fragment read from LDS serves both); 8 waves = 256 rows per workgroup tile.
-__global__ void split_weights16_kernel(const float* W, int rows, int cols, int transpose, uint16_t* frag, int n_tiles16, int ksteps32) {
-    const int64_t total = (int64_t)n_tiles16 * ksteps32 * 512;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int e = (int)(i & 7), lane = (int)((i >> 3) & 63);
-        const int64_t tk = i >> 9;
-        const int ks = (int)(tk % ksteps32), T = (int)(tk / ksteps32);
-        const int g = lane >> 4, n = T * 16 + (lane & 15), k = ks * 32 + (e < 4 ? 4 * g + e : 16 + 4 * g + (e - 4));
-        float v = 0.f;
-        if (!transpose) { if (n < rows && k < cols) v = W[(int64_t)n * cols + k]; }
-        else { if (k < rows && n < cols) v = W[(int64_t)k * cols + n]; }
-        const __bf16 h = (__bf16)v;
-        const __bf16 l = (__bf16)(v - (float)h);
-        uint16_t* dst = frag + tk * 1024 + lane * 8 + e;
-        dst[0] = __builtin_bit_cast(uint16_t, h);
-        dst[512] = __builtin_bit_cast(uint16_t, l);
-    }
-}
-
-__device__ __forceinline__ void a16_issue(const float* p, f32x4& x, f32x4& y) {       // k = 4g .. 4g+3 and 16+4g .. 16+4g+3 of a 32-k step
-    asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:64" : "=&v"(x), "=&v"(y) : "v"(p));
-}
-template <int N>
-__device__ __forceinline__ void a16_wait(f32x4& x0, f32x4& y0, f32x4& x1, f32x4& y1) {
-    asm volatile("s_waitcnt vmcnt(%4) ; a16_wait %0 %1 %2 %3" : "+v"(x0), "+v"(y0), "+v"(x1), "+v"(y1) : "n"(N));
-}
-
-// NT: 16-column n-tiles per group (8 = 128 columns).  PF: 32-k steps of A in flight.  AOL / ACT as in gemm_rows_full_kernel.
-template <int NT, int PF, int AOL, int ACT>
-__global__ __launch_bounds__(512) void gemm_rows16_kernel(const GemmX g) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds_w[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int jj = lane & 15, gq = lane >> 4;
-    const int KS = g.ksteps >> 1;                                   // 32-k steps (multiple of PF)
-    const int n_groups = (2 * g.n_tiles) / NT;
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
-    const int workers_per_xcd = slots / n_groups;
-    if (slot >= workers_per_xcd * n_groups) return;
-    const int grp = slot % n_groups, worker = (slot / n_groups) * 8 + xcd, n_workers = workers_per_xcd * 8;
-
-    {
-        const u32x4* src = (const u32x4*)(g.frag + (int64_t)grp * NT * KS * 1024);
-        u32x4* dst = (u32x4*)lds_w;
-        const int n16 = NT * KS * 128;
-        int i0 = tid;
-        for (; i0 + 7 * 512 < n16; i0 += 512 * 8) {
-            u32x4 v[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = src[i0 + q * 512];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) dst[i0 + q * 512] = v[q];
-        }
-        for (; i0 < n16; i0 += 512) dst[i0] = src[i0];
-    }
-    const uint8_t* lds_tab = lds_w + (size_t)NT * KS * 2048;
-    if (AOL == 1) {
-        float* dst = (float*)lds_tab;
-        for (int i = tid; i < 2 * g.act_cols; i += 512) dst[i] = g.act_tab[i];
-    }
-    const int col0 = grp * NT * 16 + jj;                            // this lane's column of n-tile 0
-    __syncthreads();
-
-    const int64_t n_row_tiles = (g.M + RO_ROWS - 1) / RO_ROWS;
-    float st1[NT], st2[NT];
-#pragma unroll
-    for (int j = 0; j < NT; ++j) st1[j] = st2[j] = 0.f;
-
-    auto a_ptr = [&](int64_t rt, int half) {
-        int64_t m = rt * RO_ROWS + wave * 32 + half * 16 + jj;
-        m = m < g.M ? m : g.M - 1;                                  // loads stay in bounds, stores are masked
-        return g.A + m * g.lda + gq * 4;
-    };
-    // epilogue addressing through buffer instructions (see gemm_rows_full_kernel): lane offset + scalar row offset + immediate
-    const bool nok0 = NT > 1 || col0 < g.N;                       // thin head (N < 16): out-of-range lanes store nowhere
-    const int lc = nok0 ? (int)(4 * gq * g.ldc + col0) * 4 : (int)0x80000000;
-    const int lz = ACT ? (int)(4 * gq * g.eld + col0) * 4 : 0;
-    const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc((void*)g.C, 0, (int)(g.M * g.ldc * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_z = __builtin_amdgcn_make_buffer_rsrc((void*)(ACT ? g.ez : g.A), 0, -1, 0x00020000);
-    int64_t rt = worker;
-    const float* arow0 = a_ptr(rt < n_row_tiles ? rt : n_row_tiles - 1, 0);
-    const float* arow1 = a_ptr(rt < n_row_tiles ? rt : n_row_tiles - 1, 1);
-    f32x4 px[PF][2], py[PF][2];
-#pragma unroll
-    for (int d = 0; d < PF; ++d) {
-        a16_issue(arow0 + d * 32, px[d][0], py[d][0]);
-        a16_issue(arow1 + d * 32, px[d][1], py[d][1]);
-    }
-
-    for (; rt < n_row_tiles; rt += n_workers) {
-        const int64_t rn = rt + n_workers;
-        const float* anext0 = a_ptr(rn < n_row_tiles ? rn : rt, 0);
-        const float* anext1 = a_ptr(rn < n_row_tiles ? rn : rt, 1);
-        f32x4 acc[2][NT];
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[h][j][e] = 0.f;
-        for (int ks0 = 0; ks0 < KS; ks0 += PF) {
-            const bool last = ks0 + PF >= KS;
-            const float* src0 = last ? anext0 : arow0 + (ks0 + PF) * 32;
-            const float* src1 = last ? anext1 : arow1 + (ks0 + PF) * 32;
-#pragma unroll
-            for (int d = 0; d < PF; ++d) {
-                const int ks = ks0 + d;
-                f32x4 ta[2], tb[2];                                  // AOL: [a | b] of this lane's 8 k values (shared by both row tiles)
-                if (AOL) {
-                    int k0 = ks * 32 + gq * 4;
-                    k0 = k0 + 20 <= g.act_cols ? k0 : 0;           // clamped: the loads are unconditional (act_cols is a multiple of 32 here)
-                    const float* tp = (const float*)lds_tab + k0;
-                    ta[0] = *(const f32x4*)tp; ta[1] = *(const f32x4*)(tp + 16);
-                    tb[0] = *(const f32x4*)(tp + g.act_cols); tb[1] = *(const f32x4*)(tp + g.act_cols + 16);
-                }
-                a16_wait<4 * (PF - 1)>(px[d][0], py[d][0], px[d][1], py[d][1]);      // the PF-1 younger k-steps stay in flight
-                u32x4 ahi[2], alo[2];
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    float a8[8] = {px[d][h][0], px[d][h][1], px[d][h][2], px[d][h][3], py[d][h][0], py[d][h][1], py[d][h][2], py[d][h][3]};
-                    if (AOL) {
-                        if (ks * 32 < g.act_cols) {                 // uniform
-#pragma unroll
-                            for (int e = 0; e < 8; ++e)
-                                a8[e] = __builtin_amdgcn_sinf(__builtin_fmaf(ta[e >> 2][e & 3], a8[e], tb[e >> 2][e & 3]));
-                        }
-                    }
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        uint32_t hh, ll;
-                        split2_bf16(a8[2 * q], a8[2 * q + 1], hh, ll);
-                        ahi[h][q] = hh;
-                        alo[h][q] = ll;
-                    }
-                }
-                a16_issue(src0 + d * 32, px[d][0], py[d][0]);        // refill the slot just consumed (next tile's on the last round)
-                a16_issue(src1 + d * 32, px[d][1], py[d][1]);
-                __builtin_amdgcn_sched_barrier(0);
-                const bf16x8 Ahi0 = __builtin_bit_cast(bf16x8, ahi[0]), Alo0 = __builtin_bit_cast(bf16x8, alo[0]);
-                const bf16x8 Ahi1 = __builtin_bit_cast(bf16x8, ahi[1]), Alo1 = __builtin_bit_cast(bf16x8, alo[1]);
-                const uint32_t base = (uint32_t)ks * 2048u + (uint32_t)lane * 16u;
-                constexpr int JB = NT < 4 ? NT : 4;                  // weight fragments of four n-tiles in registers at a time
-#pragma unroll
-                for (int j0 = 0; j0 < NT; j0 += JB) {
-                    bf16x8 Bhi[JB], Blo[JB];
-#pragma unroll
-                    for (int j = 0; j < JB; ++j) {
-                        Bhi[j] = __builtin_bit_cast(bf16x8, *(const u32x4*)(lds_w + base + (uint32_t)(j0 + j) * KS * 2048u));
-                        Blo[j] = __builtin_bit_cast(bf16x8, *(const u32x4*)(lds_w + base + (uint32_t)(j0 + j) * KS * 2048u + 1024u));
-                    }
-#pragma unroll
-                    for (int j = 0; j < JB; ++j) {
-                        acc[0][j0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Alo0, Bhi[j], acc[0][j0 + j], 0, 0, 0);
-                        acc[1][j0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Alo1, Bhi[j], acc[1][j0 + j], 0, 0, 0);
-                    }
-#pragma unroll
-                    for (int j = 0; j < JB; ++j) {
-                        acc[0][j0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ahi0, Blo[j], acc[0][j0 + j], 0, 0, 0);
-                        acc[1][j0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ahi1, Blo[j], acc[1][j0 + j], 0, 0, 0);
-                    }
-#pragma unroll
-                    for (int j = 0; j < JB; ++j) {
-                        acc[0][j0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ahi0, Bhi[j], acc[0][j0 + j], 0, 0, 0);
-                        acc[1][j0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ahi1, Bhi[j], acc[1][j0 + j], 0, 0, 0);
-                    }
-                }
-            }
-        }
-        // epilogue: D[row = 16 h + 4 gq + e, col = 16 j + jj]
-        const int64_t rowu = rt * RO_ROWS + wave * 32;
-        auto epilogue = [&](auto interior_tag) {
-            constexpr bool INTERIOR = decltype(interior_tag)::value;      // no row of the workgroup tile is masked: branch-free
-            float zt[2][8], ec[2][4];
-            auto fetch = [&](int j, float (&z_)[8], float (&c_)[4]) {     // ACT: pre-activations and [a, b, mu, istd] of column j
-                const int64_t n = col0 + 16 * j;
-#pragma unroll
-                for (int h = 0; h < 2; ++h)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int64_t ro = 16 * h + e;
-                        if (INTERIOR) {
-                            z_[4 * h + e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_z, lz + j * 64, (int)((rowu + ro) * g.eld * 4), 0));
-                        } else {
-                            int64_t m = rowu + ro + 4 * gq;
-                            m = m < g.M ? m : g.M - 1;
-                            z_[4 * h + e] = g.ez[m * g.eld + n];
-                        }
-                    }
-                c_[0] = g.etab[n]; c_[1] = g.etab[g.N + n];
-                c_[2] = g.emu[n]; c_[3] = g.eistd[n];                     // the launcher substitutes zeros for a layer without BatchNorm
-            };
-            if (ACT) fetch(0, zt[0], ec[0]);
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const int64_t n = col0 + 16 * j;
-                // bias of this lane's column: fetched here (L1-resident), not held in registers across the k-loop
-                const float biasj = (!ACT && g.bias && n < g.N) ? g.bias[n] : 0.f;
-                const float shiftj = (!ACT && g.stats) ? g.alpha * biasj : 0.f;
-                if (ACT) {
-                    if (j + 1 < NT) fetch(j + 1, zt[(j + 1) & 1], ec[(j + 1) & 1]);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-#pragma unroll
-                for (int h = 0; h < 2; ++h)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int64_t ro = 16 * h + e;
-                        float v = g.alpha * (acc[h][j][e] + biasj);
-                        const float z = ACT ? zt[j & 1][4 * h + e] : 0.f;
-                        if (ACT) v *= __builtin_amdgcn_cosf(__builtin_fmaf(ec[j & 1][0], z, ec[j & 1][1]));
-                        const bool ok = INTERIOR || rowu + ro + 4 * gq < g.M;
-                        if (INTERIOR) {
-                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rs_c, lc + j * 64, (int)((rowu + ro) * g.ldc * 4), 0);
-                        } else if (ok && nok0) {
-                            g.C[(rowu + ro + 4 * gq) * g.ldc + n] = v;
-                        }
-                        if (ACT) {
-                            const float s1 = v, s2 = v * ((z - ec[j & 1][2]) * ec[j & 1][3]);
-                            st1[j] += ok ? s1 : 0.f;
-                            st2[j] += ok ? s2 : 0.f;
-                        } else {
-                            const float dd = v - shiftj;
-                            st1[j] += ok ? dd : 0.f;
-                            st2[j] += ok ? dd * dd : 0.f;
-                        }
-                    }
-                if (ACT) __builtin_amdgcn_sched_barrier(0);
-            }
-        };
-        if (ACT) {      // this variant's epilogue may spill registers: the prefetched operands must have landed before it may touch them
-#pragma unroll
-            for (int d = 0; d < PF; ++d) a16_wait<0>(px[d][0], py[d][0], px[d][1], py[d][1]);
-        }
-        if (rt * RO_ROWS + RO_ROWS <= g.M) epilogue(std::true_type{});
-        else epilogue(std::false_type{});
-        arow0 = anext0;
-        arow1 = anext1;
-    }
-    // the never-consumed refills of the last round must land before their registers are reused (see gemm_rows_full_kernel)
-#pragma unroll
-    for (int d = 0; d < PF; ++d) a16_wait<0>(px[d][0], py[d][0], px[d][1], py[d][1]);
-    if (g.stats) {
-        __syncthreads();
-        float* red = (float*)lds_w;                        // [8 waves][NT][2][16]
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            float a = st1[j], b = st2[j];
-            a += __shfl_xor(a, 16, 64); b += __shfl_xor(b, 16, 64);
-            a += __shfl_xor(a, 32, 64); b += __shfl_xor(b, 32, 64);
-            if (gq == 0) {
-                red[((wave * NT + j) * 2 + 0) * 16 + jj] = a;
-                red[((wave * NT + j) * 2 + 1) * 16 + jj] = b;
-            }
-        }
-        __syncthreads();
-        if (tid < NT * 32) {
-            const int j = tid >> 5, which = (tid >> 4) & 1, c = tid & 15;
-            double s = 0.0;
-#pragma unroll
-            for (int w = 0; w < RO_WAVES; ++w) s += (double)red[((w * NT + j) * 2 + which) * 16 + c];
-            const int64_t n = (int64_t)(grp * NT + j) * 16 + c;
-            if (n < g.N) atomicAdd(g.stats + which * g.N + n, s);
-        }
-    }
-}
-
 // =====================================================================================================
 // bf16x3 weight-gradient GEMM:   dW[o, i] += alpha * sum_m dZ[m, o] * In[m, i]           (K = #points, split over workgroups)
 // Both operands are point-major, so the 8 consecutive-k values an MFMA lane needs are 8 rows of one column: each lane gathers
@@ -1246,40 +950,6 @@ static hipError_t launch_full(const GemmX& gx, int aol_mode, int act_mode, dim3 
     return hipGetLastError();
 }
 
-template <int NT, int PF>
-static hipError_t launch_rows16(const GemmX& gx, int aol_mode, int act_mode, dim3 grid, size_t lds, hipStream_t st) {
-#define SNERF_GO16(A_, C_)                                                                                            \
-    do {                                                                                                              \
-        static bool done = false;                                                                                     \
-        auto k = gemm_rows16_kernel<NT, PF, A_, C_>;                                                                  \
-        if (!done) {                                                                                                  \
-            hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-            if (e != hipSuccess) return e;                                                                            \
-            done = true;                                                                                              \
-        }                                                                                                             \
-        hipLaunchKernelGGL(k, grid, dim3(512), lds, st, gx);                                                          \
-    } while (0)
-    if constexpr (PF == 4) {          // only the activation-on-load form fits four k-steps of prefetch without scratch
-        if (act_mode == 1 || aol_mode != 1) return hipErrorInvalidValue;
-        SNERF_GO16(1, 0);
-    } else {
-        if (act_mode == 1) SNERF_GO16(0, 1);
-        else if (aol_mode == 1) SNERF_GO16(1, 0);
-        else SNERF_GO16(0, 0);
-    }
-#undef SNERF_GO16
-    return hipGetLastError();
-}
-
-hipError_t launch_split_weights16(const float* W, int rows, int cols, bool transpose, uint16_t* frag, int n_tiles16, int ksteps32, hipStream_t st) {
-    const int64_t total = (int64_t)n_tiles16 * ksteps32 * 512;
-    if (total <= 0) return hipSuccess;
-    int64_t b = (total + 255) / 256;
-    if (b > 4096) b = 4096;
-    hipLaunchKernelGGL(split_weights16_kernel, dim3((unsigned)b), dim3(256), 0, st, W, rows, cols, transpose ? 1 : 0, frag, n_tiles16, ksteps32);
-    return hipGetLastError();
-}
-
 int gemm_rows_group_tiles(int ksteps) { return ksteps <= 20 ? 4 : (ksteps <= 32 ? 2 : 0); }     // n-tiles whose weights fit the 160 KiB LDS
 
 hipError_t launch_gemm_bf16x3(const GemmX& g, hipStream_t st) {
@@ -1352,15 +1022,7 @@ hipError_t launch_gemm_bf16x3(const GemmX& g, hipStream_t st) {
             // heads and the 64-column groups of the K = 320 layer keep the 32x32x16 form)
             const bool k32 = KS % 2 == 0 && (g.K % 32 == 0 || (g.a_padded && g.lda >= (int64_t)KS * 16));
             if (mode16 && g.W && k32 && ntf == 4 && (!aol || g.act_cols % 32 == 0)) {
-                hipError_t e = launch_split_weights16(g.W, g.w_rows, g.w_cols, g.w_transpose != 0, const_cast<uint16_t*>(g.frag), 2 * g.n_tiles, KS / 2, st);
-                if (e != hipSuccess) return e;
-                const int KS32 = KS / 2;
-                // 32-k steps of A in flight: 4 with activation on load (244 registers, no scratch), 2 otherwise (the plain form spills at 4,
-                // the activation-backward epilogue needs the registers); must divide the k-step count
-                int pf16 = (aol && !act && KS32 % 4 == 0) ? 4 : (KS32 % 2 == 0 ? 2 : 1);
-                if (pf16 == 4) return launch_rows16<8, 4>(gx, 1, 0, grid_f, lds_f, st);
-                return pf16 == 2 ? launch_rows16<8, 2>(gx, aol_mode, act_mode, grid_f, lds_f, st)
-                                 : launch_rows16<8, 1>(gx, aol_mode, act_mode, grid_f, lds_f, st);
+                return launch_gemm_rows16(gx, aol_mode, act_mode, grid_f, lds_f, st);
             }
             {
                 hipError_t e = split32();

@@ -11,6 +11,7 @@ import pytest
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(REPO, "season_nerf_amd", "csrc", "gemm.hip")
+SRC16 = os.path.join(REPO, "season_nerf_amd", "csrc", "gemm16.hip")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 
@@ -25,19 +26,21 @@ def _vregs(text):
 
 @pytest.mark.skipif(not (os.path.exists(HIPCC) or shutil.which("hipcc")), reason="hipcc not available")
 def test_full_tile_kernels_do_not_spill_pending_loads(tmp_path):
-    out = tmp_path / "gemm.s"
-    subprocess.check_call([HIPCC if os.path.exists(HIPCC) else "hipcc", "-std=c++17", "-O3", "--offload-arch=gfx950", "-ffp-contract=off",
-                           "-mllvm", "-amdgpu-mfma-vgpr-form=1", "-Wno-unused-command-line-argument", "-S", "--cuda-device-only", "-o", str(out), SRC],
-                          timeout=900)
-    lines = out.read_text().split("\n")
+    lines = []
+    for n, src_file in enumerate((SRC, SRC16)):
+        out = tmp_path / f"gemm{n}.s"
+        subprocess.check_call([HIPCC if os.path.exists(HIPCC) else "hipcc", "-std=c++17", "-O3", "--offload-arch=gfx950", "-ffp-contract=off",
+                               "-mllvm", "-amdgpu-mfma-vgpr-form=1", "-Wno-unused-command-line-argument", "-S", "--cuda-device-only", "-o", str(out), src_file],
+                              timeout=900)
+        lines += out.read_text().split("\n")
     seen, i = 0, 0
     while i < len(lines):
         m = re.match(r"^_ZN5snerf(?:21gemm_rows_full_kernel|18gemm_rows16_kernel)ILi(\d)ELi(\d)ELi(\d)ELi(\d)EEEvNS_5GemmXE:", lines[i])
         if not m:
             i += 1
             continue
-        kname = "gemm_rows16_kernel" if "rows16" in lines[i] else "gemm_rows_full_kernel"
-        wait = "a16_wait" if "rows16" in lines[i] else "a8_wait"
+        kname = "gemm_rows16_kernel" if "rows16" in lines[i] else "gemm_rows_full_kernel"      # (gemm_wreg_kernel loads by LDS-DMA: no register holds a load in flight)
+        wait = "a8_wait" if kname == "gemm_rows_full_kernel" else "a16_wait"
         j = i
         while "s_endpgm" not in lines[j]:
             j += 1
@@ -68,8 +71,9 @@ def test_full_tile_kernels_do_not_spill_pending_loads(tmp_path):
         i = j
     assert seen >= 18 + 7
     src = open(SRC).read()
-    k16 = src.index("void gemm_rows16_kernel")
-    assert re.search(r"if \(ACT\) \{[^}]*a16_wait<0>\(", src[k16:], re.S), "the activation-backward variant of the 16x16x32 kernel must drain its prefetch before the epilogue"
+    src16 = open(SRC16).read()
+    k16 = src16.index("void gemm_rows16_kernel")
+    assert re.search(r"if \(ACT\) \{[^}]*a16_wait<0>\(", src16[k16:], re.S), "the activation-backward variant of the 16x16x32 kernel must drain its prefetch before the epilogue"
     k = src.index("void gemm_rows_full_kernel")
     assert re.search(r"if \(ACT\) \{[^}]*a8_wait<0>\(px\[d\], py\[d\]\);", src[k:], re.S), "the activation-backward variant must drain its prefetch before the epilogue"
 

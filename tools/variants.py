@@ -28,6 +28,18 @@ def build(src, variants):
         name, flags = nv
         o = os.path.join(VAR, name + ".o")
         subprocess.check_call([B._hipcc()] + B.FLAGS + flags.split() + ["-c", os.path.join(B.CSRC, src), "-o", o])
+        # A kernel that keeps hand-issued loads in flight (gemm_rows*: a8_issue / a16_issue) must not touch scratch: a spilled register
+        # with a load still landing in it corrupts whatever it was reallocated to - addresses included (GPU memory faults).  Refuse.
+        meta = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", o], capture_output=True, text=True).stdout
+        asm = subprocess.run([B._hipcc()] + B.FLAGS + flags.split() + ["-S", "--cuda-device-only", "-o", "-", os.path.join(B.CSRC, src)],
+                             capture_output=True, text=True).stdout
+        import re
+        bad = [m.group(1) for m in re.finditer(r"\.amdhsa_kernel (\S*gemm_rows\S*)(?:.*?)\.amdhsa_private_segment_fixed_size (\d+)", asm, re.S)
+               if int(m.group(2)) > 0 and "ELi1EEEv" not in m.group(1)]       # (the activation-backward forms drain their loads before they spill)
+        if bad:
+            os.remove(o)
+            print(f"REFUSED {name}: scratch in {bad} while hand-issued loads are pending", flush=True)
+            return
         objs = [o if s == src else B._obj(s) for s in B.SOURCES]
         subprocess.check_call([B._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", os.path.join(VAR, f"lib_{name}.so")] + objs)
         os.remove(o)
@@ -38,10 +50,17 @@ def build(src, variants):
 
 def run(extra):
     libs = sorted(glob.glob(os.path.join(VAR, "lib_*.so")))
-    for rep in range(2):
+    script = None
+    if extra and extra[0] == "--script":      # e.g. --script tools/bench_rows.py 30   (prints its own lines; the variant name is printed first)
+        script, extra = extra[1], extra[2:]
+    for rep in range(2 if script is None else 1):
         for lib in libs:
             env = dict(os.environ, SNERF_LIB=lib)
-            subprocess.call([sys.executable, os.path.join(REPO, "tools", "time_field.py"), "--tag", os.path.basename(lib)[4:-3]] + extra, env=env)
+            if script:
+                print("==", os.path.basename(lib)[4:-3], flush=True)
+                subprocess.call([sys.executable, os.path.join(REPO, script)] + extra, env=env)
+            else:
+                subprocess.call([sys.executable, os.path.join(REPO, "tools", "time_field.py"), "--tag", os.path.basename(lib)[4:-3]] + extra, env=env)
 
 
 if __name__ == "__main__":
