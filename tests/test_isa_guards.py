@@ -73,7 +73,7 @@ def test_full_tile_kernels_do_not_spill_pending_loads(tmp_path):
     src = open(SRC).read()
     src16 = open(SRC16).read()
     k16 = src16.index("void gemm_rows16_kernel")
-    assert re.search(r"if \(ACT\) \{[^}]*a16_wait<0>\(", src16[k16:], re.S), "the activation-backward variant of the 16x16x32 kernel must drain its prefetch before the epilogue"
+    assert re.search(r"if \(ACT\) \{[^}]*a16_wait(?:_slot)?<0>\(", src16[k16:], re.S), "the activation-backward variant of the 16x16x32 kernel must drain its prefetch before the epilogue"
     k = src.index("void gemm_rows_full_kernel")
     assert re.search(r"if \(ACT\) \{[^}]*a8_wait<0>\(px\[d\], py\[d\]\);", src[k:], re.S), "the activation-backward variant must drain its prefetch before the epilogue"
 
