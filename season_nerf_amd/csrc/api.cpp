@@ -121,7 +121,7 @@ int snerf_model_set_tensor(snerf_model* m, const char* key, const float* host_da
 
 static bool bf16_width(int W) { return W == 64 || W == 256; }     // widths the bf16 kernels (kernels.hip) are instantiated for
 
-static int pack_both(snerf_model* m) {
+static int pack_both(snerf_model* m, bool want_bf16_field = false) {
     if (!m->resolved) {          // SNERF_PREC_AUTO: int8 digits where their error bound holds for these weights
         snerf_i8_estimate e;
         int rc = i8_estimate(m, &e);
@@ -142,6 +142,8 @@ static int pack_both(snerf_model* m) {
     for (int p = 0; p < 2; ++p) {
         if (!bf16_width(m->W)) break;
         if (!m->host[p].stream.empty()) continue;
+        // under int8 digits the bf16 form of the FIELD program is never launched: packed only on request (snerf_model_pack_host)
+        if (p == PROG_FIELD && m->precision == SNERF_PREC_I8X3 && !want_bf16_field) continue;
         std::string err;
         Packed tmp;
         if (!pack_program(m->w, p, m->W, m->C, /*fold_bn=*/true, &tmp, &err))
@@ -169,7 +171,7 @@ int snerf_model_pack_host(snerf_model* m, int program, uint8_t* stream_out, size
     if (!m || program < 0 || program > 2) return fail(SNERF_E_INVALID, "snerf_model_pack_host: bad argument");
     if (program == 2 && m->precision != SNERF_PREC_I8X3)
         return fail(SNERF_E_STATE, "program 2 (int8-digit field network) exists only under SNERF_PREC_I8X3");
-    int rc = pack_both(m);
+    int rc = pack_both(m, program == PROG_FIELD);
     if (rc) return rc;
     const Packed& P = program == 2 ? m->host_i8 : m->host[program];
     if (stream_bytes) *stream_bytes = P.stream.size();
