@@ -1021,8 +1021,8 @@ hipError_t launch_gemm_bf16x3(const GemmX& g, hipStream_t st) {
             // the 16x16x32 form (quad-coalesced A loads): raw weights at hand, K in whole 32-k steps, wide layers only (the thin
             // heads and the 64-column groups of the K = 320 layer keep the 32x32x16 form)
             const bool k32 = KS % 2 == 0 && (g.K % 32 == 0 || (g.a_padded && g.lda >= (int64_t)KS * 16));
-            if (mode16 && g.W && k32 && ntf == 4 && (!aol || g.act_cols % 32 == 0)) {
-                return launch_gemm_rows16(gx, aol_mode, act_mode, grid_f, lds_f, st);
+            if (mode16 && g.W && k32 && ntf == 4 && (!aol || g.act_cols % 32 == 0) && lds_f + 128 * 4 * 5 <= 160 * 1024) {
+                return launch_gemm_rows16(gx, aol_mode, act_mode, grid_f, lds_f + 128 * 4 * (act_mode ? 5 : 1), st);      // + per-column constants
             }
             {
                 hipError_t e = split32();

@@ -19,6 +19,9 @@ static int ro_blocks16() {
     return n;
 }
 
+#ifndef SNERF_ABLW
+#define SNERF_ABLW 0       // the same for gemm_wreg_kernel: 1 no MFMAs, 2 no stores, 4 no LDS-DMA, 8 no produce step
+#endif
 #ifndef SNERF_ABL16
 #define SNERF_ABL16 0      // timing-only ablations of scratch builds (tools/variants.py): 1 no MFMAs, 2 no stores, 4 no A refills, 8 no sin / split, 16 no LDS weight reads
 #endif
@@ -109,6 +112,20 @@ __global__ __launch_bounds__(64 * R16_WAVES) void gemm_rows16_kernel(const GemmX
     if (AOL == 1) {
         float* dst = (float*)lds_tab;
         for (int i = tid; i < 2 * g.act_cols; i += 64 * R16_WAVES) dst[i] = g.act_tab[i];
+    }
+    // per-column constants of this group's NT * 16 columns, behind the table: the epilogue reads them from LDS - a global load there
+    // would make hipcc wait for vmcnt(0), i.e. for the previous tile's stores and every prefetched operand of the next one
+    float* lds_col = (float*)(lds_tab + (AOL ? (size_t)g.act_cols * 8 : 0));      // [bias | etab a | etab b | mu | istd][NT * 16]
+    for (int i = tid; i < NT * 16; i += 64 * R16_WAVES) {
+        const int64_t n = (int64_t)grp * NT * 16 + i;
+        const bool in = n < g.N;
+        lds_col[i] = (!ACT && g.bias && in) ? g.bias[n] : 0.f;
+        if (ACT) {
+            lds_col[NT * 16 + i] = in ? g.etab[n] : 0.f;
+            lds_col[2 * NT * 16 + i] = in ? g.etab[g.N + n] : 0.f;
+            lds_col[3 * NT * 16 + i] = in ? g.emu[n] : 0.f;
+            lds_col[4 * NT * 16 + i] = in ? g.eistd[n] : 0.f;
+        }
     }
     const int col0 = grp * NT * 16 + jj;                            // this lane's column of n-tile 0
     __syncthreads();
@@ -262,15 +279,15 @@ __global__ __launch_bounds__(64 * R16_WAVES) void gemm_rows16_kernel(const GemmX
                             z_[4 * h + e] = g.ez[m * g.eld + n];
                         }
                     }
-                c_[0] = g.etab[n]; c_[1] = g.etab[g.N + n];
-                c_[2] = g.emu[n]; c_[3] = g.eistd[n];                     // the launcher substitutes zeros for a layer without BatchNorm
+                c_[0] = lds_col[NT * 16 + 16 * j + jj]; c_[1] = lds_col[2 * NT * 16 + 16 * j + jj];
+                c_[2] = lds_col[3 * NT * 16 + 16 * j + jj]; c_[3] = lds_col[4 * NT * 16 + 16 * j + jj];      // (zeros for a layer without BatchNorm)
             };
             if (ACT) fetch(0, zt[0], ec[0]);
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 const int64_t n = col0 + 16 * j;
                 // bias of this lane's column: fetched here (L1-resident), not held in registers across the k-loop
-                const float biasj = (!ACT && g.bias && n < g.N) ? g.bias[n] : 0.f;
+                const float biasj = ACT ? 0.f : lds_col[16 * j + jj];
                 const float shiftj = (!ACT && g.stats) ? g.alpha * biasj : 0.f;
                 if (ACT) {
                     if (j + 1 < NT) fetch(j + 1, zt[(j + 1) & 1], ec[(j + 1) & 1]);
@@ -386,22 +403,23 @@ hipError_t launch_split_weights16(const float* W, int rows, int cols, bool trans
 // their weight fragments, all of K, in its own registers (2 n-tiles x 8 k-steps x hi / lo x 4 registers = 128); the workgroup
 // covers all 256 columns, so an activation row is loaded once per layer chip-wide, activated and split once, published to LDS as
 // finished MFMA fragments and read from there by all eight waves (LDS has the bandwidth: 85 B / clock against 16 of the memory path).
-//   stage = 64 rows x 64 k = 8 fragments (4 row tiles x 2 k-steps): wave w produces fragment (row tile w & 3, k-step w >> 2) - two
-//           16-byte loads per lane in the operand layout of gemm_rows16_kernel, sin, split, two ds_write_b128 - all waves consume all 8;
+//   stage = 64 rows x 128 k = 16 fragments (4 row tiles x 4 k-steps): wave w produces fragments (row tile w & 3, k-steps w >> 2 and
+//           (w >> 2) + 2) - 16-byte pieces in the operand layout of gemm_rows16_kernel, sin, split, ds_write_b128 - all waves consume all 16;
 //   two LDS slots, one barrier per stage: slot (s + 1) & 1 is written in the interval in which every wave consumes slot s & 1
 //           (its last readers finished before barrier s);
-//   the raw fp32 activations reach LDS by LDS-DMA (global_load_lds_dwordx4: no registers hold a load in flight), RAW_D = 6 stages =
-//           96 KiB per CU ahead of their use - with the weights in registers the LDS is free for it; each wave fetches and later
+//   the raw fp32 activations reach LDS by LDS-DMA (global_load_lds_dwordx4: no registers hold a load in flight), two stages =
+//           64 KiB per CU ahead of their use - with the weights in registers the LDS is free for it; each wave fetches and later
 //           reads only its own fragment's bytes (hand-counted vmcnt, no barrier), the stream runs across tile boundaries.
 // Same products and fragment order as gemm_rows16_kernel; per output the k-steps are summed in the same order: bit-identical results.
 template <int NTW, int KS, int AOL, int ACT>      // NTW: 16-column n-tiles per wave (2: N = 256, 1: N = 128); KS: 32-k steps (K = 32 KS)
 __global__ __launch_bounds__(512) void gemm_wreg_kernel(const GemmX g) {
-    constexpr int NST = KS / 2, RAW_D = 6, TM = 64;
-    // [2 slots][4 row tiles][2 k-steps][hi | lo][1 KiB] = 32 KiB of finished fragments | [RAW_D][8 waves][x | y][1 KiB] raw fp32 | table
+    constexpr int NST = KS / 4, RAW_D = 2, TM = 64;                         // stage = 64 rows x 128 k = 16 fragments (4 row tiles x 4 k-steps)
+    constexpr int SLOT = 32768;
+    // [2 slots][4 row tiles][4 k-steps][hi | lo][1 KiB] = 64 KiB of finished fragments | [RAW_D][8 waves][2 units][x | y][1 KiB] raw fp32 | table
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_a[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int jj = lane & 15, gq = lane >> 4;
-    const int my_rt = wave & 3, my_ks = wave >> 2;                          // the fragment of every stage this wave produces
+    const int my_rt = wave & 3, my_kq = wave >> 2;                          // this wave produces fragments (my_rt, my_kq) and (my_rt, my_kq + 2) of every stage
     // this wave's weights: n-tiles NTW * wave + j, every k-step, hi and lo, as MFMA B operands
     bf16x8 Wh[NTW][KS], Wl[NTW][KS];
 #pragma unroll
@@ -416,11 +434,23 @@ __global__ __launch_bounds__(512) void gemm_wreg_kernel(const GemmX g) {
             Wh[j][ks] = __builtin_bit_cast(bf16x8, wh);
             Wl[j][ks] = __builtin_bit_cast(bf16x8, wl);
         }
-    uint8_t* lds_raw = lds_a + 2 * 16384;
-    const uint8_t* lds_tab = lds_raw + RAW_D * 16384;
+    uint8_t* lds_raw = lds_a + 2 * SLOT;
+    const uint8_t* lds_tab = lds_raw + RAW_D * SLOT;
     if (AOL) {
         float* dst = (float*)lds_tab;
         for (int i = tid; i < 2 * g.act_cols; i += 512) dst[i] = g.act_tab[i];
+    }
+    // per-column constants behind the table (the epilogue must not load from global memory: hipcc would wait for vmcnt(0) there -
+    // for the previous tile's stores and for every DMA in flight)
+    float* lds_col = (float*)(lds_tab + (AOL ? (size_t)g.act_cols * 8 : 0));      // [bias | etab a | etab b | mu | istd][N]
+    for (int i = tid; i < (int)g.N; i += 512) {
+        lds_col[i] = (!ACT && g.bias) ? g.bias[i] : 0.f;
+        if (ACT) {
+            lds_col[g.N + i] = g.etab[i];
+            lds_col[2 * g.N + i] = g.etab[g.N + i];
+            lds_col[3 * g.N + i] = g.emu[i];
+            lds_col[4 * g.N + i] = g.eistd[i];
+        }
     }
     __syncthreads();
     const int col0 = NTW * wave * 16 + jj;                                  // this lane's column of the wave's n-tile 0
@@ -434,13 +464,13 @@ __global__ __launch_bounds__(512) void gemm_wreg_kernel(const GemmX g) {
     const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc((void*)g.C, 0, (int)(g.M * g.ldc * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_z = __builtin_amdgcn_make_buffer_rsrc((void*)(ACT ? g.ez : g.A), 0, -1, 0x00020000);
 
-    // the A stream of this wave: stage st of tile t -> rows t * 64 + 16 my_rt + (0..15), k = 64 st + 32 my_ks + {4 gq .., 16 + 4 gq ..};
-    // LDS-DMA, saddr form: wave-uniform base (row clamped so that every lane's row offset is >= 0) + per-lane byte offset
-    int64_t t_load = worker;                                                // tile / stage of the next DMA to issue
+    // the A stream of this wave: stage st of tile t -> rows t * 64 + 16 my_rt + (0..15), k = 128 st + 32 (my_kq + 2 u) + {4 gq .., 16 + 4 gq ..},
+    // u = 0, 1; LDS-DMA, saddr form: wave-uniform base (row clamped so that every lane's row offset is >= 0) + per-lane byte offset
+    int64_t t_load = worker;                                                // tile / stage of the next DMA group to issue
     int st_load = 0;
     typedef __attribute__((address_space(3))) uint8_t lds_u8;
-    const uint32_t raw_lds = (uint32_t)(uintptr_t)((lds_u8*)lds_raw + wave * 2048);      // this wave's 2 KiB of every raw slot (LDS byte address)
-    auto dma_issue = [&](int q) {                                           // next stage of the stream -> raw slot q
+    const uint32_t raw_lds = (uint32_t)(uintptr_t)((lds_u8*)lds_raw + wave * 4096);      // this wave's 4 KiB of every raw slot (LDS byte address)
+    auto dma_issue = [&](int q) {                                           // next stage of the stream -> raw slot q (4 x 1 KiB per wave)
         const int64_t t = t_load < n_tiles_m ? t_load : (n_tiles_m - 1);    // past the end: harmless re-reads of the last tile
         int64_t r0 = t * TM + 16 * my_rt;                                   // first row of this wave's row tile
         int64_t rb = r0 < g.M - 16 ? r0 : g.M - 16;
@@ -448,10 +478,11 @@ __global__ __launch_bounds__(512) void gemm_wreg_kernel(const GemmX g) {
         int64_t m = r0 + jj;
         m = m < g.M ? m : g.M - 1;
         const uint32_t voff = (uint32_t)((m - rb) * g.lda * 4 + gq * 16);
-        const float* base = g.A + rb * g.lda + st_load * 64 + my_ks * 32;
+        const float* base = g.A + rb * g.lda + st_load * 128 + my_kq * 32;
         if (++st_load == NST) { st_load = 0; t_load += n_workers; }
         uint32_t keep;
-        asm volatile(
+        if (SNERF_ABLW & 4) return;
+        asm volatile(      // (no instruction offsets: they would move the LDS side too)
             "s_mov_b32 %0, m0\n\t"
             "s_mov_b32 m0, %2\n\t"
             "s_nop 0\n\t"
@@ -459,9 +490,15 @@ __global__ __launch_bounds__(512) void gemm_wreg_kernel(const GemmX g) {
             "s_add_u32 m0, m0, 0x400\n\t"
             "s_nop 0\n\t"
             "global_load_lds_dwordx4 %1, %4\n\t"
+            "s_add_u32 m0, m0, 0x400\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %1, %5\n\t"
+            "s_add_u32 m0, m0, 0x400\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %1, %6\n\t"
             "s_mov_b32 m0, %0"
             : "=&s"(keep)
-            : "v"(voff), "s"(raw_lds + (uint32_t)q * 16384u), "s"(base), "s"(base + 16)      // (no instruction offset: it would move the LDS side too)
+            : "v"(voff), "s"(raw_lds + (uint32_t)q * (uint32_t)SLOT), "s"(base), "s"(base + 16), "s"(base + 64), "s"(base + 80)
             : "memory", "scc");
     };
 #pragma unroll
@@ -469,37 +506,41 @@ __global__ __launch_bounds__(512) void gemm_wreg_kernel(const GemmX g) {
     int rq = 0;                                                             // raw slot of the next stage to finish
 
     auto produce = [&](int st, int slot) {                                  // finish stage `st` of the current stream position into frag slot
-        f32x4 ta[2], tb[2];
-        const int k0 = st * 64 + my_ks * 32 + gq * 4;
-        if (AOL) {
-            const int kc = k0 + 20 <= g.act_cols ? k0 : 0;
-            const float* tp = (const float*)lds_tab + kc;
-            ta[0] = *(const f32x4*)tp; ta[1] = *(const f32x4*)(tp + 16);
-            tb[0] = *(const f32x4*)(tp + g.act_cols); tb[1] = *(const f32x4*)(tp + g.act_cols + 16);
-        }
-        // all but the 2 (RAW_D - 1) youngest vector-memory operations of this wave have completed: this stage's two DMAs have
+        // all but the 4 (RAW_D - 1) youngest vector-memory operations of this wave have completed: this stage's four DMAs have
         // (operations issued since - epilogue stores - only make the wait stricter)
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (RAW_D - 1)) : "memory");
-        const uint8_t* rp = lds_raw + rq * 16384 + wave * 2048 + lane * 16;
-        const f32x4 x = *(const f32x4*)rp, y = *(const f32x4*)(rp + 1024);
-        float a8[8] = {x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};
-        if (AOL) {
-            if (st * 64 + my_ks * 32 < g.act_cols) {                        // wave-uniform (act_cols is a multiple of 32)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (RAW_D - 1)) : "memory");
 #pragma unroll
-                for (int e = 0; e < 8; ++e) a8[e] = __builtin_amdgcn_sinf(__builtin_fmaf(ta[e >> 2][e & 3], a8[e], tb[e >> 2][e & 3]));
+        for (int u = 0; u < 2; ++u) {
+            const int kq = my_kq + 2 * u;
+            const int k0 = st * 128 + kq * 32 + gq * 4;
+            f32x4 ta[2], tb[2];
+            if (AOL) {
+                const int kc = k0 + 20 <= g.act_cols ? k0 : 0;
+                const float* tp = (const float*)lds_tab + kc;
+                ta[0] = *(const f32x4*)tp; ta[1] = *(const f32x4*)(tp + 16);
+                tb[0] = *(const f32x4*)(tp + g.act_cols); tb[1] = *(const f32x4*)(tp + g.act_cols + 16);
             }
-        }
-        u32x4 hi, lo;
+            const uint8_t* rp = lds_raw + rq * SLOT + wave * 4096 + u * 2048 + lane * 16;
+            const f32x4 x = *(const f32x4*)rp, y = *(const f32x4*)(rp + 1024);
+            float a8[8] = {x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};
+            if (AOL) {
+                if (st * 128 + kq * 32 < g.act_cols) {                      // wave-uniform (act_cols is a multiple of 32)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            uint32_t hh, ll;
-            split2_bf16(a8[2 * q], a8[2 * q + 1], hh, ll);
-            hi[q] = hh;
-            lo[q] = ll;
+                    for (int e = 0; e < 8; ++e) a8[e] = __builtin_amdgcn_sinf(__builtin_fmaf(ta[e >> 2][e & 3], a8[e], tb[e >> 2][e & 3]));
+                }
+            }
+            u32x4 hi, lo;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                uint32_t hh, ll;
+                split2_bf16(a8[2 * q], a8[2 * q + 1], hh, ll);
+                hi[q] = hh;
+                lo[q] = ll;
+            }
+            uint8_t* f = lds_a + slot * SLOT + (my_rt * 4 + kq) * 2048 + lane * 16;
+            *(u32x4*)f = hi;
+            *(u32x4*)(f + 1024) = lo;
         }
-        uint8_t* f = lds_a + slot * 16384 + (my_rt * 2 + my_ks) * 2048 + lane * 16;
-        *(u32x4*)f = hi;
-        *(u32x4*)(f + 1024) = lo;
         dma_issue(rq);                                                      // refill the raw slot just read (its values are in registers)
         rq = rq + 1 == RAW_D ? 0 : rq + 1;
     };
@@ -515,48 +556,55 @@ __global__ __launch_bounds__(512) void gemm_wreg_kernel(const GemmX g) {
             for (int j = 0; j < NTW; ++j)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[r][j][e] = 0.f;
-        auto stage = [&](int st) {
-            // the next stage (this tile's st + 1, or stage 0 of the wave's next tile) goes into the other slot while this one is consumed
+#pragma unroll
+        for (int st = 0; st < NST; ++st) {
             const bool more = st + 1 < NST || t + n_workers < n_tiles_m;
-            if (more) produce(st + 1 < NST ? st + 1 : 0, slot ^ 1);
-            const uint8_t* base = lds_a + slot * 16384 + lane * 16;
+            const uint8_t* base = lds_a + slot * SLOT + lane * 16;
+            // 16 fragment pairs (k-step kq, row tile r), read two pairs ahead of their MFMAs (LDS latency behind 12 MFMAs of the
+            // pairs before); the scheduling barriers keep hipcc from sinking the reads next to their use, where each would expose it
+            bf16x8 fh[3], fl[3];
+            auto rd = [&](int gi, int b) {
+                const int kq = gi >> 2, r = gi & 3;
+                fh[b] = __builtin_bit_cast(bf16x8, *(const u32x4*)(base + (r * 4 + kq) * 2048));
+                fl[b] = __builtin_bit_cast(bf16x8, *(const u32x4*)(base + (r * 4 + kq) * 2048 + 1024));
+            };
+            rd(0, 0);
+            rd(1, 1);
 #pragma unroll
-            for (int k2 = 0; k2 < 2; ++k2) {
-                // the eight fragments of this k-step in one batch (their LDS latency is paid once, not per row tile), then 24 MFMAs
-                bf16x8 Ahi[4], Alo[4];
+            for (int gi = 0; gi < 16; ++gi) {
+                const int kq = gi >> 2, r = gi & 3, b = gi % 3;
+                if (gi + 2 < 16) rd(gi + 2, (gi + 2) % 3);
+                // the next stage (this tile's st + 1, or stage 0 of the wave's next tile) is finished into the other slot in the middle
+                // of this one's matrix work (its last readers passed the previous barrier)
+                if (gi == 6 && more && !(SNERF_ABLW & 8)) produce(st + 1 < NST ? st + 1 : 0, slot ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+#if SNERF_ABLW & 1
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    Ahi[r] = __builtin_bit_cast(bf16x8, *(const u32x4*)(base + (r * 2 + k2) * 2048));
-                    Alo[r] = __builtin_bit_cast(bf16x8, *(const u32x4*)(base + (r * 2 + k2) * 2048 + 1024));
-                }
+                for (int j = 0; j < NTW; ++j) acc[r][j][0] += __builtin_bit_cast(float, __builtin_bit_cast(u32x4, fl[b])[0] ^ __builtin_bit_cast(u32x4, fh[b])[1] ^ __builtin_bit_cast(u32x4, Wh[j][4 * st + kq])[0]);
+                __builtin_amdgcn_sched_barrier(0);
+                continue;
+#endif
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
+                for (int j = 0; j < NTW; ++j) acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fl[b], Wh[j][4 * st + kq], acc[r][j], 0, 0, 0);
 #pragma unroll
-                    for (int j = 0; j < NTW; ++j) acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Alo[r], Wh[j][2 * st + k2], acc[r][j], 0, 0, 0);
+                for (int j = 0; j < NTW; ++j) acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh[b], Wl[j][4 * st + kq], acc[r][j], 0, 0, 0);
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int j = 0; j < NTW; ++j) acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ahi[r], Wl[j][2 * st + k2], acc[r][j], 0, 0, 0);
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int j = 0; j < NTW; ++j) acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ahi[r], Wh[j][2 * st + k2], acc[r][j], 0, 0, 0);
+                for (int j = 0; j < NTW; ++j) acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh[b], Wh[j][4 * st + kq], acc[r][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
             __syncthreads();
             slot ^= 1;
-        };
-#pragma unroll
-        for (int st = 0; st < NST; ++st) stage(st);
+        }
         // epilogue: D[row = 16 r + 4 gq + e, col = 16 j + jj] of this wave's NTW n-tiles
         const int64_t rowu = t * TM;
         const bool interior = rowu + TM <= g.M;
 #pragma unroll
         for (int j = 0; j < NTW; ++j) {
             const int64_t n = col0 + 16 * j;
-            const float biasj = (!ACT && g.bias) ? g.bias[n] : 0.f;
+            const float biasj = ACT ? 0.f : lds_col[n];
             const float shiftj = (!ACT && g.stats) ? g.alpha * biasj : 0.f;
             float e_a = 0.f, e_b = 0.f, e_mu = 0.f, e_is = 0.f;
-            if (ACT) { e_a = g.etab[n]; e_b = g.etab[g.N + n]; e_mu = g.emu[n]; e_is = g.eistd[n]; }
+            if (ACT) { e_a = lds_col[g.N + n]; e_b = lds_col[2 * g.N + n]; e_mu = lds_col[3 * g.N + n]; e_is = lds_col[4 * g.N + n]; }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float z[4];
@@ -575,7 +623,8 @@ __global__ __launch_bounds__(512) void gemm_wreg_kernel(const GemmX g) {
                     float v = g.alpha * (acc[r][j][e] + biasj);
                     if (ACT) v *= __builtin_amdgcn_cosf(__builtin_fmaf(e_a, z[e], e_b));
                     const bool ok = interior || rowu + ro + 4 * gq < g.M;
-                    if (interior) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rs_c, lc + j * 64, (int)((rowu + ro) * g.ldc * 4), 0);
+                    if (SNERF_ABLW & 2) { if (v == 123.456f) g.C[0] = v; }
+                    else if (interior) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rs_c, lc + j * 64, (int)((rowu + ro) * g.ldc * 4), 0);
                     else if (ok) g.C[(rowu + ro + 4 * gq) * g.ldc + n] = v;
                     if (ACT) {
                         st1[j] += ok ? v : 0.f;
@@ -606,7 +655,7 @@ __global__ __launch_bounds__(512) void gemm_wreg_kernel(const GemmX g) {
 
 template <int NTW, int KS>
 static hipError_t launch_wreg(const GemmX& gx, int aol_mode, int act_mode, hipStream_t st) {
-    const size_t lds = (2 + 6) * 16384 + (aol_mode ? (size_t)gx.act_cols * 8 : 0);
+    const size_t lds = (2 + 2) * 32768 + (aol_mode ? (size_t)gx.act_cols * 8 : 0) + (size_t)gx.N * 4 * (act_mode ? 5 : 1);
     const dim3 grid(ro_blocks16());
 #define SNERF_GOW(A_, C_)                                                                                              \
     do {                                                                                                              \
@@ -631,7 +680,7 @@ bool gemm_wreg_ok(const GemmX& gx) {
     static int mode = -1;
     // opt-in (SNERF_GEMM_WREG=1): measured equal to gemm_rows16_kernel in the forward (213 against 200-224 us per 256 -> 256 layer) and
     // slower with the activation-backward epilogue (282 against 236 us) - see DESIGN 5.4 for what the per-stage barrier costs
-    if (mode < 0) { const char* e = getenv("SNERF_GEMM_WREG"); mode = (e && e[0] == '1') ? 1 : 0; }
+    if (mode < 0) { const char* e = getenv("SNERF_GEMM_WREG"); mode = (e && e[0] == '1') ? 1 : 0; if (SNERF_ABLW) mode = 1; }
     const int KS32 = gx.ksteps / 2;
     return mode && gx.W && gx.ksteps % 4 == 0 && (KS32 == 8 || KS32 == 4) && (gx.N == 256 || gx.N == 128) && gx.N == (int64_t)gx.n_tiles * 32;
 }

@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 template <int SHAPE>
@@ -61,8 +62,9 @@ static void run(float* buf, int64_t rows, uint64_t* cyc, float* sink, const char
     printf("%-28s %7.1f cycles per wave-instruction per CU (8 waves issuing; %.1f per instruction and wave)\n", name, (double)(e1 - s0) / iters / 8.0, (double)(e1 - s0) / iters);
 }
 
-int main() {
-    const int64_t rows = 131072;                                // 128 MiB: Infinity Cache resident
+int main(int argc, char** argv) {
+    // default 128 MiB: Infinity Cache resident (the cost of the access SHAPE); `./ta_rate 2097152` = 2 GiB: every pass misses it (HBM)
+    const int64_t rows = argc > 1 ? atoll(argv[1]) : 131072;
     float* buf; uint64_t* cyc; float* sink;
     (void)hipMalloc(&buf, rows * 256 * 4); (void)hipMemset(buf, 0, rows * 256 * 4);
     (void)hipMalloc(&cyc, 256); (void)hipMalloc(&sink, 256 * 512 * 4);
