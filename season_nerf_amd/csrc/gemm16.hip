@@ -19,6 +19,9 @@ static int ro_blocks16() {
     return n;
 }
 
+#ifndef SNERF_STORE_AUX
+#define SNERF_STORE_AUX 0  // cache policy of the epilogue stores (buffer instruction aux bits: 1 sc0, 2 nt, 16 sc1)
+#endif
 #ifndef SNERF_ABLW
 #define SNERF_ABLW 0       // the same for gemm_wreg_kernel: 1 no MFMAs, 2 no stores, 4 no LDS-DMA, 8 no produce step
 #endif
@@ -84,6 +87,9 @@ __device__ __forceinline__ void a16_wait_slot(f32x4 (&x)[R16_RT], f32x4 (&y)[R16
 template <int NT, int PF, int AOL, int ACT>
 __global__ __launch_bounds__(64 * R16_WAVES) void gemm_rows16_kernel(const GemmX g) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_w[];
+#ifdef SNERF_STAMP16
+    const uint64_t stamp_entry = __builtin_amdgcn_s_memrealtime();
+#endif
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int jj = lane & 15, gq = lane >> 4;
     const int KS = g.ksteps >> 1;                                   // 32-k steps (multiple of PF)
@@ -134,6 +140,9 @@ __global__ __launch_bounds__(64 * R16_WAVES) void gemm_rows16_kernel(const GemmX
     float st1[NT], st2[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) st1[j] = st2[j] = 0.f;
+#ifdef SNERF_STAMP16      // diagnostic build: shader clock held inside the tile loop = d(s_memtime) / d(s_memrealtime) x 100 MHz
+    const uint64_t stamp_c0 = __builtin_amdgcn_s_memtime(), stamp_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
 
     auto a_ptr = [&](int64_t rt, int half) {
         int64_t m = rt * RO_ROWS + wave * (16 * R16_RT) + half * 16 + jj;
@@ -305,7 +314,7 @@ __global__ __launch_bounds__(64 * R16_WAVES) void gemm_rows16_kernel(const GemmX
                         if (SNERF_ABL16 & 2) {
                             if (v == 123.456f) g.C[0] = v;
                         } else if (INTERIOR) {
-                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rs_c, lc + j * 64, (int)((rowu + ro) * g.ldc * 4), 0);
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rs_c, lc + j * 64, (int)((rowu + ro) * g.ldc * 4), SNERF_STORE_AUX);
                         } else if (ok && nok0) {
                             g.C[(rowu + ro + 4 * gq) * g.ldc + n] = v;
                         }
@@ -334,6 +343,13 @@ __global__ __launch_bounds__(64 * R16_WAVES) void gemm_rows16_kernel(const GemmX
     // the never-consumed refills of the last round must land before their registers are reused (see gemm_rows_full_kernel)
 #pragma unroll
     for (int d = 0; d < PF; ++d) a16_wait_slot<0>(px[d], py[d]);
+#ifdef SNERF_STAMP16
+    if (g.stats && tid == 0 && blockIdx.x < 256) {     // per workgroup, behind the column sums: cycles of the tile loop, its start and end in 100 MHz ticks
+        g.stats[2 * g.N + 3 * blockIdx.x] = (double)stamp_entry;
+        g.stats[2 * g.N + 3 * blockIdx.x + 1] = (double)stamp_r0;
+        g.stats[2 * g.N + 3 * blockIdx.x + 2] = (double)__builtin_amdgcn_s_memrealtime();
+    }
+#endif
     if (g.stats) {
         __syncthreads();
         float* red = (float*)lds_w;                        // [waves][NT][2][16]
@@ -357,6 +373,11 @@ __global__ __launch_bounds__(64 * R16_WAVES) void gemm_rows16_kernel(const GemmX
             if (n < g.N) atomicAdd(g.stats + which * g.N + n, s);
         }
     }
+#ifdef SNERF_STAMP16
+    __syncthreads();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every store and atomic of this wave acknowledged
+    if (g.stats && tid == 0 && blockIdx.x < 256) g.stats[2 * g.N + 768 + blockIdx.x] = (double)__builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 template <int NT, int PF>
@@ -624,7 +645,7 @@ __global__ __launch_bounds__(512) void gemm_wreg_kernel(const GemmX g) {
                     if (ACT) v *= __builtin_amdgcn_cosf(__builtin_fmaf(e_a, z[e], e_b));
                     const bool ok = interior || rowu + ro + 4 * gq < g.M;
                     if (SNERF_ABLW & 2) { if (v == 123.456f) g.C[0] = v; }
-                    else if (interior) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rs_c, lc + j * 64, (int)((rowu + ro) * g.ldc * 4), 0);
+                    else if (interior) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rs_c, lc + j * 64, (int)((rowu + ro) * g.ldc * 4), SNERF_STORE_AUX);
                     else if (ok) g.C[(rowu + ro + 4 * gq) * g.ldc + n] = v;
                     if (ACT) {
                         st1[j] += ok ? v : 0.f;
@@ -675,14 +696,14 @@ static hipError_t launch_wreg(const GemmX& gx, int aol_mode, int act_mode, hipSt
     return hipGetLastError();
 }
 
-// shapes the register-resident-weight kernel takes: N = 256 or 128 output columns, K = 256 or 128
+// shapes the (experimental) register-resident-weight kernel takes: N = 256 or 128 output columns, K = 256
 bool gemm_wreg_ok(const GemmX& gx) {
     static int mode = -1;
     // opt-in (SNERF_GEMM_WREG=1): measured equal to gemm_rows16_kernel in the forward (213 against 200-224 us per 256 -> 256 layer) and
     // slower with the activation-backward epilogue (282 against 236 us) - see DESIGN 5.4 for what the per-stage barrier costs
     if (mode < 0) { const char* e = getenv("SNERF_GEMM_WREG"); mode = (e && e[0] == '1') ? 1 : 0; if (SNERF_ABLW) mode = 1; }
     const int KS32 = gx.ksteps / 2;
-    return mode && gx.W && gx.ksteps % 4 == 0 && (KS32 == 8 || KS32 == 4) && (gx.N == 256 || gx.N == 128) && gx.N == (int64_t)gx.n_tiles * 32;
+    return mode && gx.W && KS32 == 8 && gx.ksteps == 16 && (gx.N == 256 || gx.N == 128) && gx.N == (int64_t)gx.n_tiles * 32;
 }
 
 // gx: as launch_gemm_bf16x3 prepared it for the full-tile path (raw weights in gx.W, K in whole 32-k steps, N = 32 n_tiles)
@@ -691,8 +712,7 @@ hipError_t launch_gemm_rows16(const GemmX& gx, int aol_mode, int act_mode, dim3 
     hipError_t e = launch_split_weights16(gx.W, gx.w_rows, gx.w_cols, gx.w_transpose != 0, const_cast<uint16_t*>(gx.frag), 2 * gx.n_tiles, KS32, st);
     if (e != hipSuccess) return e;
     if (gemm_wreg_ok(gx)) {      // weights in registers, activations through LDS: each A byte crosses the memory path once
-        if (gx.N == 256) return KS32 == 8 ? launch_wreg<2, 8>(gx, aol_mode, act_mode, st) : launch_wreg<2, 4>(gx, aol_mode, act_mode, st);
-        return KS32 == 8 ? launch_wreg<1, 8>(gx, aol_mode, act_mode, st) : launch_wreg<1, 4>(gx, aol_mode, act_mode, st);
+        return gx.N == 256 ? launch_wreg<2, 8>(gx, aol_mode, act_mode, st) : launch_wreg<1, 8>(gx, aol_mode, act_mode, st);
     }
     // 32-k steps of A in flight: 4 with activation on load (244 registers, no scratch), 2 otherwise (the plain form spills at 4,
     // the activation-backward epilogue needs the registers); must divide the k-step count

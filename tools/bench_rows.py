@@ -14,7 +14,7 @@ W_ = torch.randn(N, K, device="cuda") / 16
 b = torch.randn(N, device="cuda")
 out = torch.empty(M, N, device="cuda")
 tab = torch.rand(2 * K, device="cuda")
-stats = torch.zeros(2 * N, dtype=torch.float64, device="cuda")
+stats = torch.zeros(2 * N + 1024, dtype=torch.float64, device="cuda")      # (+ 64 stamp pairs of the -DSNERF_STAMP16 diagnostic build)
 sc = torch.empty(L.snerf_linear_scratch_bytes(N, K), dtype=torch.uint8, device="cuda")
 mu, istd = torch.randn(N, device="cuda"), torch.rand(N, device="cuda") + 0.5
 cases = {
@@ -38,3 +38,15 @@ for name, f in list(cases.items()) * int(os.environ.get("ROWS_ROUNDS", "2")):
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / reps * 1e3
     print(f"{name:16s} {us:7.1f} us  (incl. ~5 us weight split)", flush=True)
+    if os.environ.get("ROWS_STAMPS") and "stats" in name:
+        fin = stats[2 * N + 768:].cpu().numpy() * 0.01
+        s_ = stats[2 * N:2 * N + 768].cpu().numpy().reshape(-1, 3)
+        s_ = s_[s_[:, 1] > 0]
+        if len(s_):
+            import numpy as np
+            te, t0, t1 = s_[:, 0] * 0.01, s_[:, 1] * 0.01, s_[:, 2] * 0.01                  # us: kernel entry, tile loop start, tile loop end
+            dur = t1 - t0
+            print(f"    {len(s_)} workgroups: entry -> loop start min / median / max {(t0 - te).min():.1f} / {np.median(t0 - te):.1f} / {(t0 - te).max():.1f} us; "
+                  f"tile loop {dur.min():.1f} / {np.median(dur):.1f} / {dur.max():.1f} us; first entry -> last entry {te.max() - te.min():.1f}, "
+                  f"first entry -> last loop end {t1.max() - te.min():.1f} us; -> last wave's stores and atomics acknowledged {fin.max() - te.min():.1f} us")
+        stats.zero_()
