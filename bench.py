@@ -237,7 +237,7 @@ def bench_train(a, standalone=True):
     per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))     # stream time of each step (diagnostic)
     gemm = os.environ.get("SNERF_TRAIN_GEMM", "bf16x3")
     # algorithmic FLOPs: image rays 3 x forward; sun rays: trunk+heads+solar forward + 3 x solar/sky heads
-    flop = R * S * (3 * FLOP_PER_SAMPLE + 2 * (524800 + 3 * 54656)) if Wt == 256 else float("nan")
+    flop = R * S * (3 * FLOP_PER_SAMPLE + 2 * (524800 + 3 * 54656)) if Wt == 256 else None      # SURVEY 8d counts W = 256 only
     # HBM bytes the layer-wise design moves per step (every per-point layer is a pass over [points x width] fp32
     # arrays; per-ray branches are negligible).  Forward of a layer: one GEMM (read the pre-activation of the layer below -
     # the activation is applied on load - write Z); backward: activation backward (see bwd_bytes), then wgrad (read dZ, in)
@@ -291,7 +291,7 @@ def bench_train(a, standalone=True):
                "collectives": dict(sn.parallel.COLLECTIVES) if use_dist else None,
                "roofline": None,
                "step_roofline": {"bound": "hbm", "achieved": hbm_bytes / dt / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": hbm_bytes / dt / 8e12,
-                                 "traffic": traffic, "bytes_per_step": hbm_bytes, "algorithmic_tflops": flop / dt / 1e12,
+                                 "traffic": traffic if Wt == 256 else None, "bytes_per_step": hbm_bytes, "algorithmic_tflops": (flop / dt / 1e12) if flop else None,
                                  "note": "whole step, not one kernel: train-mode BatchNorm forces a layer-wise design in which every layer is "
                                          "a pass over [393216 x width] fp32 arrays; achieved = bytes that design moves per step (counted from "
                                          "the layer table, DESIGN 5.4) / step time, traffic = HBM bytes per step by the PMC counters, "
