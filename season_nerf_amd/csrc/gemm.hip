@@ -12,6 +12,8 @@
 // Tile 128x128x16, 4 waves as 2x2, each wave 64x64 = 2x2 MFMA tiles; LDS tiles are k-major ([k][m], [k][n]) so the
 // one-float-per-lane operands (A[i=l&31][k=l>>5], B[k=l>>5][j=l&31]) are conflict-free ds_read_b32.
 #include <hip/hip_runtime.h>
+#include <map>
+#include <mutex>
 #include <stdint.h>
 #include <stdlib.h>
 
@@ -697,6 +699,11 @@ struct WgradX {
     int n_out, n_in;
     float alpha;
     int64_t rows_per_block;      // multiple of 32
+    // two-stage reduction over the row blocks (optional): every workgroup stores its 256 x 256 block of partial sums here in
+    // register order, [block x][block y][block z][wave][a][b][e][lane], and wgrad_reduce_kernel adds them up into dW.  The other
+    // way - 64 Ki atomic adds per workgroup - is bound by the atomic rate of a CU (one 256-byte wave instruction per ~50 ns,
+    // MI355X_MICROARCH.md): ~50 us at the tail of EVERY launch, whatever its size
+    float* partial;
 };
 
 constexpr int WG_STAGE = 32;
@@ -849,6 +856,16 @@ __global__ __launch_bounds__(512) void wgrad_bf16x3_kernel(const WgradX g) {
         const float tot = z_sum + __shfl_xor(z_sum, 32, 64);
         if (h == 0 && ok_o) atomicAdd(g.dbias + col_o, g.bias_alpha * tot);
     }
+    if (g.partial) {
+        float* out = g.partial + ((((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * gridDim.z + blockIdx.z) * 8 + wave) * 8192 + lane;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) out[((a * 4 + b) * 16 + e) * 64] = acc[a][b][e];      // 256 contiguous bytes per instruction
+        return;
+    }
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -862,6 +879,48 @@ __global__ __launch_bounds__(512) void wgrad_bf16x3_kernel(const WgradX g) {
                 }
             }
         }
+}
+
+// dW[o, i] += alpha * sum over the row blocks of their partial sums (one thread per element of a 256 x 256 block, in register order)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int n_row_blocks, float* dW, int64_t ldw,
+                                                           int n_out, int n_in, float alpha) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;                       // [wave][a][b][e][lane]
+    const int lane = idx & 63, e = (idx >> 6) & 15, b = (idx >> 10) & 3, a = (idx >> 12) & 1, wave = idx >> 13;
+    const int64_t blocks_yz = (int64_t)gridDim.y * gridDim.z, yz = (int64_t)blockIdx.y * gridDim.z + blockIdx.z;
+    const float* p = partial + yz * 65536 + idx;
+    constexpr int U = 16;                                                  // loads in flight per thread (16 KiB per CU: enough for the full rate)
+    const int64_t stride = blocks_yz * 65536;
+    float s[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) s[u] = 0.f;
+    int x = 0;
+    for (; x + U <= n_row_blocks; x += U) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) s[u] += p[(int64_t)(x + u) * stride];
+    }
+    for (; x < n_row_blocks; ++x) s[0] += p[(int64_t)x * stride];
+#pragma unroll
+    for (int w = U / 2; w > 0; w >>= 1)
+#pragma unroll
+        for (int u = 0; u < w; ++u) s[u] += s[u + w];
+    const int o = blockIdx.y * 256 + (2 * (wave >> 1) + a) * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+    const int i = blockIdx.z * 256 + (4 * (wave & 1) + b) * 32 + (lane & 31);
+    if (o < n_out && i < n_in) dW[(int64_t)o * ldw + i] += alpha * s[0];
+}
+
+// partial-sum scratch of the two-stage reduction, one per stream (grown on demand, never freed: 64 MiB for a 256 x 256 layer on 256 CUs)
+static float* wgrad_scratch(hipStream_t st, size_t floats) {
+    struct Buf { float* p; size_t cap; };
+    static std::mutex mu;
+    static std::map<hipStream_t, Buf> bufs;
+    std::lock_guard<std::mutex> lock(mu);
+    Buf& b = bufs[st];
+    if (floats > b.cap) {
+        float* q = nullptr;
+        if (hipMalloc(&q, floats * sizeof(float)) != hipSuccess) return nullptr;
+        b.p = q; b.cap = floats;                                       // the old block stays alive for launches already queued
+    }
+    return b.p;
 }
 
 hipError_t launch_wgrad_bf16x3(float* dZ, int64_t ldz, const float* In, int64_t ldi, int64_t M, int n_out, int n_in, float alpha,
@@ -891,6 +950,17 @@ hipError_t launch_wgrad_bf16x3(float* dZ, int64_t ldz, const float* In, int64_t 
     g.rows_per_block = rows;
     const bool full = n_out % 256 == 0 && n_in % 256 == 0;
     const dim3 grid((unsigned)bx, by, bz), block(512);
+    static int two_stage = -1;
+    if (two_stage < 0) { const char* e = getenv("SNERF_WGRAD_ATOMIC"); two_stage = (e && e[0] == '1') ? 0 : 1; }
+    // (a few row blocks, or a thin layer whose blocks are mostly empty: the atomics are cheap enough)
+    if (two_stage && bx >= 8 && (int64_t)(n_out < 256 ? n_out : 256) * (n_in < 256 ? n_in : 256) >= 32768) {
+        g.partial = wgrad_scratch(st, (size_t)bx * by * bz * 65536);
+        if (!g.partial) return hipErrorOutOfMemory;
+    }
+    auto finish = [&]() -> hipError_t {
+        if (g.partial) hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(256, by, bz), dim3(256), 0, st, g.partial, (int)bx, dW, ldw, n_out, n_in, alpha);
+        return hipGetLastError();
+    };
     if (bn) {
         if (bz != 1) return hipErrorInvalidValue;            // in-place dZ: every element must be gathered exactly once
         g.z = bn->z; g.ldzz = bn->ldz; g.bn_gamma = bn->gamma; g.bn_mu = bn->mu; g.bn_istd = bn->istd; g.bn_sdy = bn->sdy; g.bn_sdyx = bn->sdyx;
@@ -901,7 +971,7 @@ hipError_t launch_wgrad_bf16x3(float* dZ, int64_t ldz, const float* In, int64_t 
         if (full) hipLaunchKernelGGL((wgrad_bf16x3_kernel<true, false>), grid, block, 131072, st, g);
         else hipLaunchKernelGGL((wgrad_bf16x3_kernel<false, false>), grid, block, 131072, st, g);
     }
-    return hipGetLastError();
+    return finish();
 }
 
 hipError_t launch_split_weights(const float* W, int rows, int cols, bool transpose, uint16_t* frag, int n_tiles, int ksteps, hipStream_t st) {

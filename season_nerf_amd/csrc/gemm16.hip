@@ -165,6 +165,13 @@ __global__ __launch_bounds__(64 * R16_WAVES) void gemm_rows16_kernel(const GemmX
 #pragma unroll
         for (int h = 0; h < R16_RT; ++h) a16_issue(arow[h] + d * 32, px[d][h], py[d][h]);
 
+#ifdef SNERF_PHASE16       // diagnostic build: where one wave's time goes (shader cycles: load wait | convert + refill | LDS + MFMA issue | epilogue)
+#define SNERF_PH(x) __builtin_amdgcn_sched_barrier(0); const uint64_t x = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0)
+    uint64_t ph_wait = 0, ph_conv = 0, ph_mfma = 0, ph_epi = 0, ph_steps = 0;
+    const uint64_t ph_t0 = __builtin_amdgcn_s_memtime();
+#else
+#define SNERF_PH(x)
+#endif
     for (; rt < n_row_tiles; rt += n_workers) {
         const int64_t rn = rt + n_workers;
         const float* anext[R16_RT];
@@ -193,9 +200,11 @@ __global__ __launch_bounds__(64 * R16_WAVES) void gemm_rows16_kernel(const GemmX
                     ta[0] = *(const f32x4*)tp; ta[1] = *(const f32x4*)(tp + 16);
                     tb[0] = *(const f32x4*)(tp + g.act_cols); tb[1] = *(const f32x4*)(tp + g.act_cols + 16);
                 }
+                SNERF_PH(q0);
 #if !(SNERF_ABL16 & 4)
                 a16_wait_slot<2 * R16_RT * (PF - 1)>(px[d], py[d]);                  // the PF-1 younger k-steps stay in flight
 #endif
+                SNERF_PH(q1);
                 u32x4 ahi[R16_RT], alo[R16_RT];
 #pragma unroll
                 for (int h = 0; h < R16_RT; ++h) {
@@ -224,6 +233,7 @@ __global__ __launch_bounds__(64 * R16_WAVES) void gemm_rows16_kernel(const GemmX
                 for (int h = 0; h < R16_RT; ++h) a16_issue(srcs[h] + d * 32, px[d][h], py[d][h]);      // refill the slot just consumed (next tile's on the last round)
 #endif
                 __builtin_amdgcn_sched_barrier(0);
+                SNERF_PH(q2);
                 bf16x8 Ahi[R16_RT], Alo[R16_RT];
 #pragma unroll
                 for (int h = 0; h < R16_RT; ++h) { Ahi[h] = __builtin_bit_cast(bf16x8, ahi[h]); Alo[h] = __builtin_bit_cast(bf16x8, alo[h]); }
@@ -266,6 +276,10 @@ __global__ __launch_bounds__(64 * R16_WAVES) void gemm_rows16_kernel(const GemmX
                         if constexpr (R16_RT == 2) acc[R16_RT - 1][j0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ahi[R16_RT - 1], Bhi[j], acc[R16_RT - 1][j0 + j], 0, 0, 0);
                     }
                 }
+#ifdef SNERF_PHASE16
+                SNERF_PH(q3);
+                ph_wait += q1 - q0; ph_conv += q2 - q1; ph_mfma += q3 - q2; ++ph_steps;
+#endif
             }
         }
         // epilogue: D[row = 16 h + 4 gq + e, col = 16 j + jj]
@@ -335,14 +349,26 @@ __global__ __launch_bounds__(64 * R16_WAVES) void gemm_rows16_kernel(const GemmX
 #pragma unroll
             for (int d = 0; d < PF; ++d) a16_wait_slot<0>(px[d], py[d]);
         }
+        SNERF_PH(q4);
         if (rt * RO_ROWS + RO_ROWS <= g.M) epilogue(std::true_type{});
         else epilogue(std::false_type{});
+#ifdef SNERF_PHASE16
+        SNERF_PH(q5);
+        ph_epi += q5 - q4;
+#endif
 #pragma unroll
         for (int h = 0; h < R16_RT; ++h) arow[h] = anext[h];
     }
     // the never-consumed refills of the last round must land before their registers are reused (see gemm_rows_full_kernel)
 #pragma unroll
     for (int d = 0; d < PF; ++d) a16_wait_slot<0>(px[d], py[d]);
+#ifdef SNERF_PHASE16
+    if (g.stats && lane == 0 && (wave == 0 || wave == R16_WAVES / 2) && blockIdx.x < 256) {
+        double* o = g.stats + 2 * g.N + 1024 + (blockIdx.x * 2 + (wave != 0)) * 6;
+        o[0] = (double)ph_wait; o[1] = (double)ph_conv; o[2] = (double)ph_mfma; o[3] = (double)ph_epi;
+        o[4] = (double)(__builtin_amdgcn_s_memtime() - ph_t0); o[5] = (double)ph_steps;
+    }
+#endif
 #ifdef SNERF_STAMP16
     if (g.stats && tid == 0 && blockIdx.x < 256) {     // per workgroup, behind the column sums: cycles of the tile loop, its start and end in 100 MHz ticks
         g.stats[2 * g.N + 3 * blockIdx.x] = (double)stamp_entry;

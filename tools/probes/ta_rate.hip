@@ -50,10 +50,11 @@ __global__ __launch_bounds__(512) void probe(float* buf, int64_t rows_total, uin
     if (blockIdx.x == 0 && lane == 0) { cyc[2 * wave] = t0; cyc[2 * wave + 1] = t1; }
 }
 
+static int g_grid = 256;
 template <int SHAPE>
 static void run(float* buf, int64_t rows, uint64_t* cyc, float* sink, const char* name) {
     const int iters = 4096;
-    for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL(probe<SHAPE>, dim3(256), dim3(512), 0, 0, buf, rows, cyc, sink, iters);
+    for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL(probe<SHAPE>, dim3(g_grid), dim3(512), 0, 0, buf, rows, cyc, sink, iters);
     (void)hipDeviceSynchronize();
     uint64_t c[16];
     (void)hipMemcpy(c, cyc, sizeof(c), hipMemcpyDeviceToHost);
@@ -63,8 +64,11 @@ static void run(float* buf, int64_t rows, uint64_t* cyc, float* sink, const char
 }
 
 int main(int argc, char** argv) {
-    // default 128 MiB: Infinity Cache resident (the cost of the access SHAPE); `./ta_rate 2097152` = 2 GiB: every pass misses it (HBM)
+    // default 128 MiB: Infinity Cache resident (the cost of the access SHAPE); `./ta_rate 2097152` = 2 GiB: every pass misses it (HBM);
+    // `./ta_rate 2048` = 2 MiB: L2 resident.  Second argument: workgroups (= CUs) issuing, default 256 - fewer tell a per-CU limit from a shared one.
     const int64_t rows = argc > 1 ? atoll(argv[1]) : 131072;
+    if (argc > 2) g_grid = atoi(argv[2]);
+    printf("rows %lld (%.0f MiB), %d workgroups\n", (long long)rows, rows / 1024.0, g_grid);
     float* buf; uint64_t* cyc; float* sink;
     (void)hipMalloc(&buf, rows * 256 * 4); (void)hipMemset(buf, 0, rows * 256 * 4);
     (void)hipMalloc(&cyc, 256); (void)hipMalloc(&sink, 256 * 512 * 4);

@@ -28,13 +28,13 @@ def build(src, variants):
         name, flags = nv
         o = os.path.join(VAR, name + ".o")
         subprocess.check_call([B._hipcc()] + B.FLAGS + flags.split() + ["-c", os.path.join(B.CSRC, src), "-o", o])
-        # A kernel that keeps hand-issued loads in flight (gemm_rows*: a8_issue / a16_issue) must not touch scratch: a spilled register
+        # A kernel that keeps hand-issued loads in flight (gemm_rows_full / gemm_rows16 / gemm_wreg: a8_issue / a16_issue) must not touch scratch: a spilled register
         # with a load still landing in it corrupts whatever it was reallocated to - addresses included (GPU memory faults).  Refuse.
         meta = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", o], capture_output=True, text=True).stdout
         asm = subprocess.run([B._hipcc()] + B.FLAGS + flags.split() + ["-S", "--cuda-device-only", "-o", "-", os.path.join(B.CSRC, src)],
                              capture_output=True, text=True).stdout
         import re
-        bad = [m.group(1) for m in re.finditer(r"\.amdhsa_kernel (\S*gemm_rows\S*)(?:.*?)\.amdhsa_private_segment_fixed_size (\d+)", asm, re.S)
+        bad = [m.group(1) for m in re.finditer(r"\.amdhsa_kernel (\S*gemm_(?:rows_full|rows16|wreg)\S*)(?:.*?)\.amdhsa_private_segment_fixed_size (\d+)", asm, re.S)
                if int(m.group(2)) > 0 and "ELi1EEEv" not in m.group(1)]       # (the activation-backward forms drain their loads before they spill)
         if bad:
             os.remove(o)
