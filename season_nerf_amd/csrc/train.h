@@ -37,6 +37,7 @@ struct GemmX {
     const float* bias;
     double* stats;             // optional [2][N]: += sum_m (v - alpha*bias), += sum_m (v - alpha*bias)^2   (train-mode BatchNorm)
     int accumulate;
+    int reverse;               // row tiles from the last to the first (set by the launcher, see launch_gemm_rows16)
     const float* act_tab;      // optional activation-on-load table [a | b] x act_cols for the leading columns of A: sin(2 pi (a z + b))
     int act_cols;              // multiple of 8, <= K
     int tab_lds;               // set by the launcher: the table fits in LDS behind the weights

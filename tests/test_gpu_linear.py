@@ -206,3 +206,31 @@ def test_full_tile_kernel_bit_identical_to_general_kernel():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "mismatches: 0" in r.stdout
     print(r.stdout[-400:])
+
+
+@pytest.mark.parametrize("shape", [(5000 + 77, 256, 256), (2311, 128, 256)])
+def test_row_tiles_in_both_orders(shape):
+    """gemm_rows16_kernel walks its row tiles forwards on one launch and backwards on the next (launch_gemm_rows16: the rows the producer
+    wrote last first).  Four consecutive launches on a ragged row count cover both orders: every one must give the same product, the same
+    BatchNorm sums, and leave the rows past M alone."""
+    sn, L, st = _env()
+    M, K, N = shape
+    g = torch.Generator(device="cpu").manual_seed(M)
+    A = torch.randn(M, K, generator=g).cuda()
+    Wt = (torch.randn(N, K, generator=g) / np.sqrt(K)).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    sc = _scratch(L, N, K)
+    ref = 30.0 * (A.double() @ Wt.double().T + b.double())
+    d = ref - 30.0 * b.double()
+    outs = []
+    for _ in range(4):
+        out = torch.full((M + 300, N), 7.0, device="cuda")
+        stats = torch.zeros(2, N, dtype=torch.float64, device="cuda")
+        sn._lib.check(L.snerf_linear_forward(M, K, N, A.data_ptr(), K, Wt.data_ptr(), b.data_ptr(), 30.0, out.data_ptr(), N,
+                                             stats.data_ptr(), 1, sc.data_ptr(), sc.numel(), None, 0, st), "linear_forward")
+        assert _rel(out[:M], ref) < TOL[1]
+        assert bool((out[M:] == 7.0).all())
+        np.testing.assert_allclose(stats[0].cpu().numpy(), d.sum(0).cpu().numpy(), rtol=0, atol=2e-4 * float(d.abs().sum(0).max()))
+        outs.append(out[:M].clone())
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])          # a row's product does not depend on the order of the tiles
