@@ -225,6 +225,7 @@ def bench_train(a, standalone=True):
         marks[i].record()
         tot = step()
     marks[steps].record()
+    host_ms = (time.perf_counter() - t0) / steps * 1e3       # what the host needs to ENQUEUE a step (diagnostic: below ms_per_step = the GPU is never waiting for it)
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
@@ -287,7 +288,7 @@ def bench_train(a, standalone=True):
                                       + ("" if Wt == 256 else " - at the reference's default width (main_lite.py:80), not the BASELINE config"),
                           "parallelism": f"rays sharded over {world} GPU(s), one all-reduce of the flat gradient arena, BatchNorm statistics "
                                          + ("over the global batch (all-reduced)" if a.bn_sync == "global" and use_dist else "per rank")},
-               "final_loss": float(tot.detach()), "step_ms_median": per_step[len(per_step) // 2], "step_ms_min": per_step[0],
+               "final_loss": float(tot.detach()), "step_ms_median": per_step[len(per_step) // 2], "step_ms_min": per_step[0], "host_enqueue_ms_per_step": host_ms,
                "collectives": dict(sn.parallel.COLLECTIVES) if use_dist else None,
                "roofline": None,
                "step_roofline": {"bound": "hbm", "achieved": hbm_bytes / dt / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": hbm_bytes / dt / 8e12,

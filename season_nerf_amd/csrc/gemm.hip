@@ -708,23 +708,29 @@ struct WgradX {
 
 constexpr int WG_STAGE = 32;
 
-template <bool FULL, bool BNZ>  // FULL: every 256 x 256 block of dW is complete (no tile or column masks in the hot loop)
+// FULL: every 256 x 256 block of dW is complete (no tile or column masks in the hot loop).  TA x TB: 32 x 32 tiles of dW per wave - the
+// workgroup's block is 4 TA tiles of n_out by 2 TB tiles of n_in (2 x 4: 256 x 256; 1 x 2: 128 x 128, so that a 128-wide layer keeps all
+// eight waves multiplying instead of two)
+template <bool FULL, bool BNZ, int TA = 2, int TB = 4>
 __global__ __launch_bounds__(512) void wgrad_bf16x3_kernel(const WgradX g) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_f[];          // [2 buffers][2 operands][8 tiles][2 ksteps][hi,lo][1 KiB]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const int o_base = blockIdx.y * 256, i_base = blockIdx.z * 256;
-    const int to_n = FULL ? 8 : ((g.n_out - o_base + 31) / 32 < 8 ? (g.n_out - o_base + 31) / 32 : 8);      // valid 32-column tiles of each operand
-    const int ti_n = FULL ? 8 : ((g.n_in - i_base + 31) / 32 < 8 ? (g.n_in - i_base + 31) / 32 : 8);
-    const int wo = wave >> 1, wi = wave & 1;                 // this wave's dW piece: n_out tiles {2wo, 2wo+1} x n_in tiles {4wi .. 4wi+3}
+    constexpr int NTO = 4 * TA, NTI = 2 * TB;              // 32-column tiles of each operand in this workgroup's block
+    const int o_base = blockIdx.y * (32 * NTO), i_base = blockIdx.z * (32 * NTI);
+    const int to_n = FULL ? NTO : ((g.n_out - o_base + 31) / 32 < NTO ? (g.n_out - o_base + 31) / 32 : NTO);      // valid tiles of each operand
+    const int ti_n = FULL ? NTI : ((g.n_in - i_base + 31) / 32 < NTI ? (g.n_in - i_base + 31) / 32 : NTI);
+    const int wo = wave >> 1, wi = wave & 1;                 // this wave's dW piece: n_out tiles {TA wo + a} x n_in tiles {TB wi + b}
     const int64_t m_begin = (int64_t)blockIdx.x * g.rows_per_block;
     const int64_t m_end = m_begin + g.rows_per_block < g.M ? m_begin + g.rows_per_block : g.M;
     if (m_begin >= m_end) return;
     const int n_stages = (int)((m_end - m_begin + WG_STAGE - 1) / WG_STAGE);
 
-    // producer role: wave w gathers tile w of dZ and tile w of In (both k-steps of the stage)
-    const bool make_o = FULL || wave < to_n, make_i = FULL || wave < ti_n;
-    const int col_o = o_base + wave * 32 + r, col_i = i_base + wave * 32 + r;
+    // producer role: wave w gathers tile w of dZ and one tile of In (both k-steps of the stage) - In tile w, or, where dZ has only four
+    // tiles, In tile 7 - w, so that the waves without a dZ tile take the In tiles first
+    const int tile_i = TA == 1 ? 7 - wave : wave;
+    const bool make_o = FULL || wave < to_n, make_i = FULL || tile_i < ti_n;
+    const int col_o = o_base + wave * 32 + r, col_i = i_base + tile_i * 32 + r;
     const bool ok_o = FULL || (make_o && col_o < g.n_out), ok_i = FULL || (make_i && col_i < g.n_in);
     // branch-free gathers: a wave-uniform 64-bit stage base plus a 32-bit lane offset (row clamped to the last valid row of this
     // workgroup's range); out-of-range values are zeroed at publish time so that nothing depends on the loads before then
@@ -755,9 +761,9 @@ __global__ __launch_bounds__(512) void wgrad_bf16x3_kernel(const WgradX g) {
             for (int e = 0; e < 8; ++e) {
                 const int k = h * 8 + ks * 16 + e;
                 const uint32_t kr = (uint32_t)(k < last_rel ? k : last_rel);
-                vo[ks][e] = bo[kr * ldz + co];          // raw: masking waits for publish, so nothing here depends on the
-                vi[ks][e] = bi[kr * ldi + ci];          // loads and they stay in flight across the MFMA block
-                if (BNZ) vz[ks][e] = bz[kr * ldzz + co];
+                if (FULL || make_o) vo[ks][e] = bo[kr * ldz + co];          // raw: masking waits for publish, so nothing here depends on the
+                if (FULL || make_i) vi[ks][e] = bi[kr * ldi + ci];          // loads and they stay in flight across the MFMA block
+                if (BNZ && (FULL || make_o)) vz[ks][e] = bz[kr * ldzz + co];      // (wave-uniform conditions: a wave without a tile loads nothing)
             }
         gathered_last = last_rel;
         gathered_ms = ms;
@@ -802,17 +808,17 @@ __global__ __launch_bounds__(512) void wgrad_bf16x3_kernel(const WgradX g) {
                 split2_bf16((ok_i && k0) ? i0 : 0.f, (ok_i && k1) ? i1 : 0.f, a, b);
                 ih[q] = a; il[q] = b;
             }
-            const uint32_t f = (uint32_t)((wave * 2 + ks) * 2048 + lane * 16);
+            const uint32_t f = (uint32_t)((wave * 2 + ks) * 2048 + lane * 16), fi = (uint32_t)((tile_i * 2 + ks) * 2048 + lane * 16);
             if (make_o) { *(u32x4*)(base + f) = oh; *(u32x4*)(base + f + 1024) = ol; }
-            if (make_i) { *(u32x4*)(base + 32768 + f) = ih; *(u32x4*)(base + 32768 + f + 1024) = il; }
+            if (make_i) { *(u32x4*)(base + 32768 + fi) = ih; *(u32x4*)(base + 32768 + fi + 1024) = il; }
         }
     };
 
-    f32x16 acc[2][4];
+    f32x16 acc[TA][TB];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < TA; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
+        for (int b = 0; b < TB; ++b)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
@@ -824,22 +830,22 @@ __global__ __launch_bounds__(512) void wgrad_bf16x3_kernel(const WgradX g) {
         const uint8_t* base = lds_f + (s & 1) * 65536 + lane * 16;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            u32x4 ah[2], al[2];
+            u32x4 ah[TA], al[TA];
 #pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                const uint32_t f = (uint32_t)(((2 * wo + a) * 2 + ks) * 2048);
+            for (int a = 0; a < TA; ++a) {
+                const uint32_t f = (uint32_t)(((TA * wo + a) * 2 + ks) * 2048);
                 ah[a] = *(const u32x4*)(base + f);
                 al[a] = *(const u32x4*)(base + f + 1024);
             }
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                if (FULL || 4 * wi + b < ti_n) {
-                    const uint32_t f = (uint32_t)(32768 + ((4 * wi + b) * 2 + ks) * 2048);
+            for (int b = 0; b < TB; ++b) {
+                if (FULL || TB * wi + b < ti_n) {
+                    const uint32_t f = (uint32_t)(32768 + ((TB * wi + b) * 2 + ks) * 2048);
                     const bf16x8 Bhi = __builtin_bit_cast(bf16x8, *(const u32x4*)(base + f));
                     const bf16x8 Blo = __builtin_bit_cast(bf16x8, *(const u32x4*)(base + f + 1024));
 #pragma unroll
-                    for (int a = 0; a < 2; ++a) {
-                        if (FULL || 2 * wo + a < to_n) {
+                    for (int a = 0; a < TA; ++a) {
+                        if (FULL || TA * wo + a < to_n) {
                             const bf16x8 Ahi = __builtin_bit_cast(bf16x8, ah[a]), Alo = __builtin_bit_cast(bf16x8, al[a]);
                             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Alo, Bhi, acc[a][b], 0, 0, 0);
                             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ahi, Blo, acc[a][b], 0, 0, 0);
@@ -857,39 +863,41 @@ __global__ __launch_bounds__(512) void wgrad_bf16x3_kernel(const WgradX g) {
         if (h == 0 && ok_o) atomicAdd(g.dbias + col_o, g.bias_alpha * tot);
     }
     if (g.partial) {
-        float* out = g.partial + ((((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * gridDim.z + blockIdx.z) * 8 + wave) * 8192 + lane;
+        float* out = g.partial + ((((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * gridDim.z + blockIdx.z) * 8 + wave) * (TA * TB * 1024) + lane;
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < TA; ++a)
 #pragma unroll
-            for (int b = 0; b < 4; ++b)
+            for (int b = 0; b < TB; ++b)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) out[((a * 4 + b) * 16 + e) * 64] = acc[a][b][e];      // 256 contiguous bytes per instruction
+                for (int e = 0; e < 16; ++e) out[((a * TB + b) * 16 + e) * 64] = acc[a][b][e];      // 256 contiguous bytes per instruction
         return;
     }
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < TA; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            if (FULL || (2 * wo + a < to_n && 4 * wi + b < ti_n)) {
-                const int i = i_base + (4 * wi + b) * 32 + r;
+        for (int b = 0; b < TB; ++b) {
+            if (FULL || (TA * wo + a < to_n && TB * wi + b < ti_n)) {
+                const int i = i_base + (TB * wi + b) * 32 + r;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const int o = o_base + (2 * wo + a) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    const int o = o_base + (TA * wo + a) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                     if (FULL || (o < g.n_out && i < g.n_in)) atomicAdd(g.dW + (int64_t)o * g.ldw + i, g.alpha * acc[a][b][e]);
                 }
             }
         }
 }
 
-// dW[o, i] += alpha * sum over the row blocks of their partial sums (one thread per element of a 256 x 256 block, in register order)
+// dW[o, i] += alpha * sum over the row blocks of their partial sums (one thread per element of a workgroup's block of dW, in register
+// order: [wave][a < ta][b < tb][e][lane])
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int n_row_blocks, float* dW, int64_t ldw,
-                                                           int n_out, int n_in, float alpha) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;                       // [wave][a][b][e][lane]
-    const int lane = idx & 63, e = (idx >> 6) & 15, b = (idx >> 10) & 3, a = (idx >> 12) & 1, wave = idx >> 13;
+                                                           int n_out, int n_in, float alpha, int ta, int tb) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int lane = idx & 63, e = (idx >> 6) & 15, ab = (idx >> 10) % (ta * tb), wave = (idx >> 10) / (ta * tb), a = ab / tb, b = ab % tb;
+    const int block = 8 * ta * tb * 1024;
     const int64_t blocks_yz = (int64_t)gridDim.y * gridDim.z, yz = (int64_t)blockIdx.y * gridDim.z + blockIdx.z;
-    const float* p = partial + yz * 65536 + idx;
+    const float* p = partial + yz * block + idx;
     constexpr int U = 16;                                                  // loads in flight per thread (16 KiB per CU: enough for the full rate)
-    const int64_t stride = blocks_yz * 65536;
+    const int64_t stride = blocks_yz * block;
     float s[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) s[u] = 0.f;
@@ -903,8 +911,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     for (int w = U / 2; w > 0; w >>= 1)
 #pragma unroll
         for (int u = 0; u < w; ++u) s[u] += s[u + w];
-    const int o = blockIdx.y * 256 + (2 * (wave >> 1) + a) * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-    const int i = blockIdx.z * 256 + (4 * (wave & 1) + b) * 32 + (lane & 31);
+    const int o = blockIdx.y * 128 * ta + (ta * (wave >> 1) + a) * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+    const int i = blockIdx.z * 64 * tb + (tb * (wave & 1) + b) * 32 + (lane & 31);
     if (o < n_out && i < n_in) dW[(int64_t)o * ldw + i] += alpha * s[0];
 }
 
@@ -923,24 +931,32 @@ static float* wgrad_scratch(hipStream_t st, size_t floats) {
     return b.p;
 }
 
+template <bool FULL, bool BNZ, int TA, int TB>
+static hipError_t launch_wgrad_as(const WgradX& g, dim3 grid, hipStream_t st) {
+    static bool done = false;
+    auto k = wgrad_bf16x3_kernel<FULL, BNZ, TA, TB>;
+    if (!done) {
+        hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        if (e != hipSuccess) return e;
+        done = true;
+    }
+    hipLaunchKernelGGL(k, grid, dim3(512), 131072, st, g);
+    return hipGetLastError();
+}
+
 hipError_t launch_wgrad_bf16x3(float* dZ, int64_t ldz, const float* In, int64_t ldi, int64_t M, int n_out, int n_in, float alpha,
                                float* dW, int64_t ldw, hipStream_t st, const float* in_tab, int in_cols, const WgradBN* bn) {
     if (M <= 0 || n_out <= 0 || n_in <= 0) return hipSuccess;
     if (ldz >= (1 << 24) || ldi >= (1 << 24)) return hipErrorInvalidValue;      // 32-bit lane offsets: 64 rows x ld
-    static bool attr_done = false;
-    if (!attr_done) {
-        const void* fns[4] = {(const void*)wgrad_bf16x3_kernel<true, false>, (const void*)wgrad_bf16x3_kernel<false, false>,
-                              (const void*)wgrad_bf16x3_kernel<true, true>, (const void*)wgrad_bf16x3_kernel<false, true>};
-        for (const void* f : fns) {
-            hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-            if (e != hipSuccess) return e;
-        }
-        attr_done = true;
-    }
     WgradX g{};
     g.in_tab = in_tab; g.in_cols = in_tab ? in_cols : 0;
     g.dZ = dZ; g.In = In; g.dW = dW; g.M = M; g.ldz = ldz; g.ldi = ldi; g.ldw = ldw; g.n_out = n_out; g.n_in = n_in; g.alpha = alpha;
-    const int by = (n_out + 255) / 256, bz = (n_in + 255) / 256;
+    // the workgroup's block of dW: 128 TA x 64 TB - the 128-wide layers get blocks of their own size (SNERF_WGRAD_SMALL=0: always 256 x 256)
+    static int small_blocks = -1;
+    if (small_blocks < 0) { const char* e = getenv("SNERF_WGRAD_SMALL"); small_blocks = (e && e[0] == '0') ? 0 : 1; }
+    const int ta = (small_blocks && n_out <= 128) ? 1 : 2, tb = (small_blocks && n_in <= 128) ? 2 : 4;
+    const int bo = 128 * ta, bi = 64 * tb;
+    const int by = (n_out + bo - 1) / bo, bz = (n_in + bi - 1) / bi;
     int64_t bx = ro_grid_blocks() / (by * bz);
     if (bx < 1) bx = 1;
     int64_t rows = (M + bx - 1) / bx;
@@ -949,29 +965,29 @@ hipError_t launch_wgrad_bf16x3(float* dZ, int64_t ldz, const float* In, int64_t 
     bx = (M + rows - 1) / rows;
     g.rows_per_block = rows;
     const bool full = n_out % 256 == 0 && n_in % 256 == 0;
-    const dim3 grid((unsigned)bx, by, bz), block(512);
+    const dim3 grid((unsigned)bx, by, bz);
     static int two_stage = -1;
     if (two_stage < 0) { const char* e = getenv("SNERF_WGRAD_ATOMIC"); two_stage = (e && e[0] == '1') ? 0 : 1; }
     // (a few row blocks, or a thin layer whose blocks are mostly empty: the atomics are cheap enough)
-    if (two_stage && bx >= 8 && (int64_t)(n_out < 256 ? n_out : 256) * (n_in < 256 ? n_in : 256) >= 32768) {
-        g.partial = wgrad_scratch(st, (size_t)bx * by * bz * 65536);
+    if (two_stage && bx >= 8 && 2 * (int64_t)(n_out < bo ? n_out : bo) * (n_in < bi ? n_in : bi) >= (int64_t)bo * bi) {
+        g.partial = wgrad_scratch(st, (size_t)bx * by * bz * 8 * ta * tb * 1024);
         if (!g.partial) return hipErrorOutOfMemory;
     }
-    auto finish = [&]() -> hipError_t {
-        if (g.partial) hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(256, by, bz), dim3(256), 0, st, g.partial, (int)bx, dW, ldw, n_out, n_in, alpha);
-        return hipGetLastError();
-    };
     if (bn) {
         if (bz != 1) return hipErrorInvalidValue;            // in-place dZ: every element must be gathered exactly once
         g.z = bn->z; g.ldzz = bn->ldz; g.bn_gamma = bn->gamma; g.bn_mu = bn->mu; g.bn_istd = bn->istd; g.bn_sdy = bn->sdy; g.bn_sdyx = bn->sdyx;
         g.bn_inv_m = bn->inv_m; g.bias_alpha = bn->bias_alpha; g.dbias = bn->dbias;
-        if (full) hipLaunchKernelGGL((wgrad_bf16x3_kernel<true, true>), grid, block, 131072, st, g);
-        else hipLaunchKernelGGL((wgrad_bf16x3_kernel<false, true>), grid, block, 131072, st, g);
-    } else {
-        if (full) hipLaunchKernelGGL((wgrad_bf16x3_kernel<true, false>), grid, block, 131072, st, g);
-        else hipLaunchKernelGGL((wgrad_bf16x3_kernel<false, false>), grid, block, 131072, st, g);
     }
-    return finish();
+    hipError_t e;
+    if (full) e = bn ? launch_wgrad_as<true, true, 2, 4>(g, grid, st) : launch_wgrad_as<true, false, 2, 4>(g, grid, st);
+    else if (ta == 2 && tb == 4) e = bn ? launch_wgrad_as<false, true, 2, 4>(g, grid, st) : launch_wgrad_as<false, false, 2, 4>(g, grid, st);
+    else if (ta == 1 && tb == 4) e = bn ? launch_wgrad_as<false, true, 1, 4>(g, grid, st) : launch_wgrad_as<false, false, 1, 4>(g, grid, st);
+    else if (ta == 2 && tb == 2) e = bn ? launch_wgrad_as<false, true, 2, 2>(g, grid, st) : launch_wgrad_as<false, false, 2, 2>(g, grid, st);
+    else e = bn ? launch_wgrad_as<false, true, 1, 2>(g, grid, st) : launch_wgrad_as<false, false, 1, 2>(g, grid, st);
+    if (e != hipSuccess) return e;
+    if (g.partial)
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(8 * ta * tb * 4, by, bz), dim3(256), 0, st, g.partial, (int)bx, dW, ldw, n_out, n_in, alpha, ta, tb);
+    return hipGetLastError();
 }
 
 hipError_t launch_split_weights(const float* W, int rows, int cols, bool transpose, uint16_t* frag, int n_tiles, int ksteps, hipStream_t st) {
