@@ -1,6 +1,5 @@
 // Full-tile row GEMM on v_mfma_f32_16x16x32_bf16 (its own translation unit: see the comment at the kernel).
 #include <hip/hip_runtime.h>
-#include <atomic>
 #include <stdint.h>
 #include <stdlib.h>
 
@@ -737,13 +736,7 @@ bool gemm_wreg_ok(const GemmX& gx) {
 // gx: as launch_gemm_bf16x3 prepared it for the full-tile path (raw weights in gx.W, K in whole 32-k steps, N = 32 n_tiles)
 hipError_t launch_gemm_rows16(const GemmX& gx_in, int aol_mode, int act_mode, dim3 grid, size_t lds, hipStream_t st) {
     GemmX gx = gx_in;
-    {   // every other launch walks its row tiles backwards: a layer then starts with the rows its producer wrote last, some of which are still in
-        // the Infinity Cache (forward 256 -> 256: 182 -> 177 us, the training step -1.3 %; SNERF_SNAKE=0 turns it off)
-        static int snake = -1;
-        static std::atomic<unsigned> launches{0};
-        if (snake < 0) { const char* e = getenv("SNERF_SNAKE"); snake = (e && e[0] == '0') ? 0 : 1; }
-        gx.reverse = snake ? (int)(launches.fetch_add(1, std::memory_order_relaxed) & 1u) : 0;
-    }
+    gx.reverse = stream_direction();      // every other streaming launch walks its row tiles backwards (gemm.hip)
     const int KS32 = gx.ksteps / 2;
     hipError_t e = launch_split_weights16(gx.W, gx.w_rows, gx.w_cols, gx.w_transpose != 0, const_cast<uint16_t*>(gx.frag), 2 * gx.n_tiles, KS32, st);
     if (e != hipSuccess) return e;

@@ -55,6 +55,40 @@ __global__ __launch_bounds__(512) void copyd(const float* __restrict__ A, float*
     }
 }
 
+// D KiB in flight per wave as in copyd, but the workgroup stays on a tile of 8 x TR rows (TR / D batches) before it moves on: the chip-wide
+// window of rows in work is 256 x 8 x TR KiB instead of 256 x 8 x D - which of the two (in flight, window) does the rate follow?
+template <int D, int TR>
+__global__ __launch_bounds__(512) void copyw(const float* __restrict__ A, float* __restrict__ C, int64_t M) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t n_tiles = M / (8 * TR);
+    for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        for (int b = 0; b < TR / D; ++b) {
+            const int64_t row0 = (t * 8 + wave) * TR + b * D;
+            f32x4 v[D];
+#pragma unroll
+            for (int r = 0; r < D; ++r) v[r] = *(const f32x4*)(A + (row0 + r) * 256 + lane * 4);
+#pragma unroll
+            for (int r = 0; r < D; ++r) *(f32x4*)(C + (row0 + r) * 256 + lane * 4) = v[r];
+        }
+    }
+}
+
+template <int D, int TR>
+static void runw(const float* A, float* C, int64_t M) {
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((copyw<D, TR>), dim3(256), dim3(512), 0, 0, A, C, M);
+    (void)hipEventRecord(e0);
+    const int reps = 20;
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((copyw<D, TR>), dim3(256), dim3(512), 0, 0, A, C, M);
+    (void)hipEventRecord(e1);
+    (void)hipEventSynchronize(e1);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    const double us = ms / reps * 1e3, bytes = (double)M * 256 * 4 * 2;
+    printf("copy, %2d KiB in flight per wave, tiles of %3d rows per wave (window %3d MiB)  %7.1f us per launch  %.2f TB/s\n", D, TR, 2 * TR, us, bytes / (us * 1e-6) / 1e12);
+}
+
 template <int D>
 static void rund(const float* A, float* C, int64_t M) {
     hipEvent_t e0, e1;
@@ -97,5 +131,6 @@ int main() {
     run<2>(A, C, M, "dword stores, 4 x 64 B, whole rows per workgroup");
     run<0>(A, C, M, "copy, 16 B per lane, 1 KiB contiguous stores");
     rund<2>(A, C, M); rund<4>(A, C, M); rund<8>(A, C, M); rund<16>(A, C, M); rund<32>(A, C, M); rund<64>(A, C, M);
+    runw<2, 32>(A, C, M); runw<4, 32>(A, C, M); runw<2, 8>(A, C, M); runw<8, 32>(A, C, M); runw<2, 128>(A, C, M); runw<32, 128>(A, C, M);
     return 0;
 }
