@@ -311,8 +311,9 @@ __global__ __launch_bounds__(64 * R16_WAVES) void gemm_rows16_kernel(const GemmX
             for (int j = 0; j < NT; ++j) {
                 const int64_t n = col0 + 16 * j;
                 // bias of this lane's column: fetched here (L1-resident), not held in registers across the k-loop
-                const float biasj = ACT ? 0.f : lds_col[16 * j + jj];
-                const float shiftj = (!ACT && g.stats) ? g.alpha * biasj : 0.f;
+                // plain form: v = alpha acc + (alpha bias) in one fma, and the BatchNorm sums of v - alpha bias = alpha acc are taken from the
+                // accumulator itself (sum acc, sum acc^2; scaled by alpha, alpha^2 once, after the tile loop): 3 vector instructions per element
+                const float abj = ACT ? 0.f : g.alpha * lds_col[16 * j + jj];
                 if (ACT) {
                     if (j + 1 < NT) fetch(j + 1, zt[(j + 1) & 1], ec[(j + 1) & 1]);
                     __builtin_amdgcn_sched_barrier(0);
@@ -322,7 +323,7 @@ __global__ __launch_bounds__(64 * R16_WAVES) void gemm_rows16_kernel(const GemmX
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int64_t ro = 16 * h + e;
-                        float v = g.alpha * (acc[h][j][e] + biasj);
+                        float v = ACT ? g.alpha * acc[h][j][e] : __builtin_fmaf(g.alpha, acc[h][j][e], abj);
                         const float z = ACT ? zt[j & 1][4 * h + e] : 0.f;
                         if (ACT) v *= __builtin_amdgcn_cosf(__builtin_fmaf(ec[j & 1][0], z, ec[j & 1][1]));
                         const bool ok = INTERIOR || rowu + ro + 4 * gq < g.M;
@@ -338,7 +339,7 @@ __global__ __launch_bounds__(64 * R16_WAVES) void gemm_rows16_kernel(const GemmX
                             st1[j] += ok ? s1 : 0.f;
                             st2[j] += ok ? s2 : 0.f;
                         } else {
-                            const float dd = v - shiftj;
+                            const float dd = acc[h][j][e];
                             st1[j] += ok ? dd : 0.f;
                             st2[j] += ok ? dd * dd : 0.f;
                         }
@@ -382,7 +383,7 @@ __global__ __launch_bounds__(64 * R16_WAVES) void gemm_rows16_kernel(const GemmX
         float* red = (float*)lds_w;                        // [waves][NT][2][16]
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-            float a = st1[j], b = st2[j];
+            float a = ACT ? st1[j] : g.alpha * st1[j], b = ACT ? st2[j] : (g.alpha * g.alpha) * st2[j];
             a += __shfl_xor(a, 16, 64); b += __shfl_xor(b, 16, 64);
             a += __shfl_xor(a, 32, 64); b += __shfl_xor(b, 32, 64);
             if (gq == 0) {

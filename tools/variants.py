@@ -35,7 +35,8 @@ def build(src, variants):
                              capture_output=True, text=True).stdout
         import re
         bad = [m.group(1) for m in re.finditer(r"\.amdhsa_kernel (\S*gemm_(?:rows_full|rows16|wreg)\S*)(?:.*?)\.amdhsa_private_segment_fixed_size (\d+)", asm, re.S)
-               if int(m.group(2)) > 0 and "ELi1EEEv" not in m.group(1)]       # (the activation-backward forms drain their loads before they spill)
+               if int(m.group(2)) > 0 and "ELi1EEEv" not in m.group(1)       # (the activation-backward forms drain their loads before they spill)
+               and not any(x and x in m.group(1) for x in os.environ.get("VARIANTS_UNUSED", "").split(","))]      # kernels the run will not launch
         if bad:
             os.remove(o)
             print(f"REFUSED {name}: scratch in {bad} while hand-issued loads are pending", flush=True)
