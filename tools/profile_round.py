@@ -122,6 +122,9 @@ def main():
                             "write_MB_per_step": ps(v["WRITE_SIZE"]) / 1e6} for k, v in rows[:24]]}
         res["bytes_per_step"] = 2 * res["fetch_bytes_per_step_raw"] + res["write_bytes_per_step"]
         json.dump(res, open(os.path.join(out, "train_traffic.json"), "w"), indent=1)
+        with open(os.path.join(out, "train_copy_rate.txt"), "w") as f:      # the step priced against the rate of a read + write stream
+            subprocess.call([sys.executable, os.path.join(REPO, "tools", "train_table.py"), os.path.join(out, "train_traffic.json"),
+                             os.path.join(out, "train_kernel_stats.csv")], stdout=f, stderr=subprocess.STDOUT)
         # the dominant training kernel on its own (bench.py --workload train --train-kernel-only: what train_roofline is measured on)
         kargs = ["--workload", "train", "--train-kernel-only", "--steps", "8"]
         d = os.path.join(out, "prof_tk")
