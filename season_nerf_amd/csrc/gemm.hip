@@ -1050,7 +1050,9 @@ static hipError_t launch_full(const GemmX& gx, int aol_mode, int act_mode, dim3 
     return hipGetLastError();
 }
 
-int gemm_rows_group_tiles(int ksteps) { return ksteps <= 20 ? 4 : (ksteps <= 32 ? 2 : 0); }     // n-tiles whose weights fit the 160 KiB LDS
+// n-tiles whose weights (2 KiB per tile and 16-k step) fit the 160 KiB LDS beside an activation-on-load table (8 bytes per input column):
+// four up to K = 320, two up to K = 608 (W = 512's [fc4 | PE] layer has 36 k-steps)
+int gemm_rows_group_tiles(int ksteps) { return ksteps <= 20 ? 4 : (ksteps <= 38 ? 2 : 0); }
 
 hipError_t launch_gemm_bf16x3(const GemmX& g, hipStream_t st) {
     if (g.M <= 0 || g.N <= 0) return hipSuccess;
