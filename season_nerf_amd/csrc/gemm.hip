@@ -693,6 +693,7 @@ static int ro_grid_blocks() {
 struct WgradX {
     const float* in_tab;         // optional activation-on-load table for the first in_cols columns of In ([a | b], see gemm_rows_kernel)
     int in_cols;
+    int in_tab_stride;           // distance between an input column's a and b in the table (>= in_cols: a column window of a wider table)
     // BNZ (optional): dZ holds dL/dY of a BatchNorm SineLayer on entry; the BatchNorm backward
     //   dZ = gamma*istd*(dY - mean(dY) - xhat*mean(dY*xhat)),  xhat = (z - mu)*istd
     // is applied to each gathered value, written back IN PLACE (every element is gathered by exactly one lane when the grid has
@@ -761,7 +762,7 @@ __global__ __launch_bounds__(512) void wgrad_bf16x3_kernel(const WgradX g) {
     float z_sum = 0.f;
     // activation on load: this lane's In column is a stored pre-activation -> sin(2 pi (a z + b)) at publish time
     const bool in_act = g.in_tab != nullptr && ok_i && col_i < g.in_cols;
-    const float c_a = in_act ? g.in_tab[col_i] : 0.f, c_b = in_act ? g.in_tab[g.in_cols + col_i] : 0.f;
+    const float c_a = in_act ? g.in_tab[col_i] : 0.f, c_b = in_act ? g.in_tab[g.in_tab_stride + col_i] : 0.f;
     auto gather = [&](int stage) {
         const int64_t ms = ((int64_t)(g.reverse ? n_stages - 1 - stage : stage) * gridDim.x + blockIdx.x) * WG_STAGE;      // uniform
         const int last_rel = (int)(m_last - ms < 63 ? m_last - ms : 63);         // >= 0: the stage exists
@@ -958,11 +959,11 @@ static hipError_t launch_wgrad_as(const WgradX& g, dim3 grid, hipStream_t st) {
 }
 
 hipError_t launch_wgrad_bf16x3(float* dZ, int64_t ldz, const float* In, int64_t ldi, int64_t M, int n_out, int n_in, float alpha,
-                               float* dW, int64_t ldw, hipStream_t st, const float* in_tab, int in_cols, const WgradBN* bn) {
+                               float* dW, int64_t ldw, hipStream_t st, const float* in_tab, int in_cols, const WgradBN* bn, int in_tab_stride) {
     if (M <= 0 || n_out <= 0 || n_in <= 0) return hipSuccess;
     if (ldz >= (1 << 24) || ldi >= (1 << 24)) return hipErrorInvalidValue;      // 32-bit lane offsets: 64 rows x ld
     WgradX g{};
-    g.in_tab = in_tab; g.in_cols = in_tab ? in_cols : 0;
+    g.in_tab = in_tab; g.in_cols = in_tab ? in_cols : 0; g.in_tab_stride = in_tab_stride > 0 ? in_tab_stride : g.in_cols;
     g.dZ = dZ; g.In = In; g.dW = dW; g.M = M; g.ldz = ldz; g.ldi = ldi; g.ldw = ldw; g.n_out = n_out; g.n_in = n_in; g.alpha = alpha;
     // the workgroup's block of dW: 128 TA x 64 TB - the 128-wide layers get blocks of their own size (SNERF_WGRAD_SMALL=0: always 256 x 256)
     static int small_blocks = -1;

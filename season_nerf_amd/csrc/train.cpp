@@ -274,7 +274,8 @@ static hipError_t linear_dgrad(snerf_trainer* t, const LayerP& L, const float* d
 // A layer with more than 256 inputs (fc5: [fc4 | PE]) goes as two launches: the first 256 input columns with the dZ pass, then the
 // rest on the finished dZ.
 static bool wgrad_bn_ok(const snerf_trainer* t, const LayerP& L, int64_t M, const Act& In) {
-    return t->gemm_mode == 1 && M >= 1024 && (L.n_in <= 256 || !In.tab || In.cols <= 256);
+    (void)L; (void)In;
+    return t->gemm_mode == 1 && M >= 1024;
 }
 static hipError_t linear_wgrad(snerf_trainer* t, const LayerP& L, float* dZ, int64_t ldz, Act InA, int64_t M, float alpha, hipStream_t st,
                                const WgradBN* bn = nullptr) {
@@ -282,11 +283,13 @@ static hipError_t linear_wgrad(snerf_trainer* t, const LayerP& L, float* dZ, int
     const int64_t ld_in = InA.ld;
     if (t->gemm_mode == 1 && M >= 1024) {
         if (bn && L.n_in > 256) {
+            // the activation-on-load table covers the first tc input columns: each launch gets its window of it ([a | b], b at distance tc)
             const int n0 = 256, tc = InA.tab ? InA.cols : 0;
-            if (tc > n0) return hipErrorInvalidValue;
-            hipError_t e = launch_wgrad_bf16x3(dZ, ldz, In, ld_in, M, L.n_out, n0, alpha, t->grads + L.w, L.n_in, st, InA.tab, tc, bn);
+            hipError_t e = launch_wgrad_bf16x3(dZ, ldz, In, ld_in, M, L.n_out, n0, alpha, t->grads + L.w, L.n_in, st, InA.tab, tc < n0 ? tc : n0, bn, tc);
             if (e != hipSuccess) return e;
-            return launch_wgrad_bf16x3(dZ, ldz, In + n0, ld_in, M, L.n_out, L.n_in - n0, alpha, t->grads + L.w + n0, L.n_in, st, nullptr, 0, nullptr);
+            const int rest = tc > n0 ? tc - n0 : 0;
+            return launch_wgrad_bf16x3(dZ, ldz, In + n0, ld_in, M, L.n_out, L.n_in - n0, alpha, t->grads + L.w + n0, L.n_in, st,
+                                       rest ? InA.tab + n0 : nullptr, rest, nullptr, tc);
         }
         return launch_wgrad_bf16x3(dZ, ldz, In, ld_in, M, L.n_out, L.n_in, alpha, t->grads + L.w, L.n_in, st, InA.tab, InA.tab ? InA.cols : 0, bn);
     }

@@ -66,7 +66,7 @@ struct WgradBN {
 int stream_direction();      // 0 / 1, alternating per streaming launch (gemm.hip)
 hipError_t launch_wgrad_bf16x3(float* dZ, int64_t ldz, const float* In, int64_t ldi, int64_t M, int n_out, int n_in, float alpha,
                                float* dW, int64_t ldw, hipStream_t st, const float* in_tab = nullptr, int in_cols = 0,
-                               const WgradBN* bn = nullptr);
+                               const WgradBN* bn = nullptr, int in_tab_stride = 0);      // in_tab_stride: see WgradX (0 = in_cols)
 
 // ---- elementwise / reduction kernels of the training path (train_kernels.hip)
 struct PeArgs {            // positions (from rays or explicit) -> PE(pos) [N,64] (63 features + zero pad) and points [N,3]
