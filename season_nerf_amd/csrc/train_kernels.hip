@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const ColArgs A) {
 //   MODE 3  BatchNorm dZ: D <- gamma*istd*(dY - mean(dY) - xhat*mean(dY*xhat)), out0 += alpha0 * sum, dY = dH*cos(.) recomputed
 //   MODE 4  the same with D already holding dY (a dgrad epilogue applied the cosine)
 template <int MODE>
-__global__ __launch_bounds__(256) void colpass_vec_kernel(const ColArgs A, int C4, int cpt, const float* sdy, const float* sdyx) {
+__global__ __launch_bounds__(256) void colpass_vec_kernel(const ColArgs A, int C4, int cpt, const float* sdy, const float* sdyx, int rows_per_block) {
     __shared__ float red[2][256][4];
     const int tc = threadIdx.x % cpt, tr = threadIdx.x / cpt, rows_pass = 256 / cpt;
     const bool live = tc < C4;
@@ -170,8 +170,8 @@ __global__ __launch_bounds__(256) void colpass_vec_kernel(const ColArgs A, int C
         }
     }
     float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
-    const int64_t r0 = (int64_t)blockIdx.x * ROWS_PER_BLOCK;
-    const int64_t r1 = r0 + ROWS_PER_BLOCK < A.M ? r0 + ROWS_PER_BLOCK : A.M;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = r0 + rows_per_block < A.M ? r0 + rows_per_block : A.M;
     if (live) {
         for (int64_t r = r0 + tr; r < r1; r += rows_pass) {
             const f32x4_t z = *(const f32x4_t*)(A.Z + r * A.ld + tc * 4);
@@ -218,8 +218,11 @@ static hipError_t launch_colpass_vec(const ColArgs& a, const float* sdy, const f
     const int C4 = a.C / 4;
     int cpt = 1;
     while (cpt < C4) cpt <<= 1;
-    const int64_t blocks = (a.M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
-    hipLaunchKernelGGL(colpass_vec_kernel<MODE>, dim3((unsigned)blocks), dim3(256), 0, st, a, C4, cpt, sdy, sdyx);
+    // 512 rows per block for the per-point arrays; the per-ray branches (a few thousand rows) get shorter blocks so that they still fill the chip
+    int rpb = ROWS_PER_BLOCK;
+    while (rpb > 32 && rpb > 256 / cpt && (a.M + rpb - 1) / rpb < 512) rpb >>= 1;
+    const int64_t blocks = (a.M + rpb - 1) / rpb;
+    hipLaunchKernelGGL(colpass_vec_kernel<MODE>, dim3((unsigned)blocks), dim3(256), 0, st, a, C4, cpt, sdy, sdyx, rpb);
     return hipGetLastError();
 }
 
@@ -443,8 +446,23 @@ __global__ void point_out_fwd_kernel(const PointOutArgs A) {
         }
     }
 }
-__global__ void point_out_bwd_kernel(const PointOutArgs A) {
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < A.n; i += (int64_t)gridDim.x * blockDim.x) {
+__global__ __launch_bounds__(256) void point_out_bwd_kernel(const PointOutArgs A) {
+    // d_cls[ray, c] collects one term per sample: the samples of a ray sit next to each other, so a block first adds them up in LDS (the
+    // 256 points of one pass cover at most 256 / n_samples + 2 rays) and sends one atomic per ray and class to memory - 96 samples of a
+    // ray hammering one address cost 160 us at 4096 x 96
+    constexpr int CMAX = 8;
+    __shared__ float bins[258 * CMAX];
+    const bool binned = A.d_cls && A.d_head && A.C <= CMAX;
+    for (int64_t i0 = blockIdx.x * (int64_t)blockDim.x; i0 < A.n; i0 += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = i0 + threadIdx.x;
+        const int64_t g0 = i0 / A.n_samples;
+        const int64_t i_last = i0 + 255 < A.n ? i0 + 255 : A.n - 1;
+        const int n_bins = (int)(i_last / A.n_samples - g0 + 1) * A.C;
+        if (binned) {
+            for (int b = threadIdx.x; b < n_bins; b += 256) bins[b] = 0.f;
+            __syncthreads();
+        }
+        if (i < A.n) {
         const int64_t g = i / A.n_samples;
         if (A.d_head) {
             const float raw = A.head[i * 4 + 3];
@@ -464,10 +482,17 @@ __global__ void point_out_bwd_kernel(const PointOutArgs A) {
                     if (A.d_adj) A.d_adj[i * 3 * A.C + 3 * c + k] = dpre[k] * p;
                     dc += dpre[k] * A.adj[i * 3 * A.C + 3 * c + k];
                 }
-                if (A.d_cls) atomicAdd(A.d_cls + g * A.C + c, dc);
+                if (binned) atomicAdd(bins + (g - g0) * A.C + c, dc);
+                else if (A.d_cls) atomicAdd(A.d_cls + g * A.C + c, dc);
             }
         }
         if (A.d_sv_raw && A.d_sv) { const float y = A.sv[i]; A.d_sv_raw[i] = A.d_sv[i] * y * (1.f - y); }
+        }
+        if (binned) {
+            __syncthreads();
+            for (int b = threadIdx.x; b < n_bins; b += 256) atomicAdd(A.d_cls + g0 * A.C + b, bins[b]);
+            __syncthreads();
+        }
     }
 }
 hipError_t launch_point_out(const PointOutArgs& a, bool backward, hipStream_t st) {
