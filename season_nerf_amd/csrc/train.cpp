@@ -248,6 +248,22 @@ static hipError_t linear_dgrad(snerf_trainer* t, const LayerP& L, const float* d
                                int n_cols, float alpha, bool accumulate, hipStream_t st, const ActBelow* below = nullptr,
                                bool* fused = nullptr) {
     if (fused) *fused = false;
+    static int thin = -1;
+    if (thin < 0) { const char* e = getenv("SNERF_THIN_DGRAD"); thin = (e && e[0] == '0') ? 0 : 1; }
+    if (thin && t->gemm_mode == 1 && M >= 1024 && L.n_out <= 4) {      // a thin head: a rank-K update of dIn, streamed (exact fp32)
+        ThinDgradArgs a{};
+        a.D = dZ; a.ldd = ldz; a.W = t->params + L.w; a.ldw = L.n_in; a.C = dIn; a.ldc = ld_in; a.M = M; a.K = L.n_out; a.N = n_cols;
+        a.accumulate = accumulate ? 1 : 0; a.alpha = alpha;
+        const bool act = below && below->tab && below->L->n_out == n_cols;
+        if (act) {
+            a.ez = below->Z.p; a.eld = below->Z.ld; a.etab = below->tab; a.stats = t->bn_stats;
+            if (below->L->bn) { a.emu = below->bnslot + 2 * t->W; a.eistd = below->bnslot + 3 * t->W; }
+        }
+        if (thin_dgrad_ok(a)) {
+            if (act && fused) *fused = true;
+            return launch_thin_dgrad(a, st);
+        }
+    }
     if (rows_ok(t, M, L.n_out, n_cols)) {
         GemmX x{};
         x.n_tiles = (n_cols + 31) / 32; x.ksteps = (L.n_out + 15) / 16;

@@ -99,6 +99,22 @@ struct ColArgs {
     int64_t M_global;      // mode 3: rows of the global batch the BatchNorm means were taken over (>= M)
 };
 hipError_t launch_colreduce(const ColArgs& a, hipStream_t st);
+struct ThinDgradArgs {     // input gradient of a head with K <= 4 outputs as a stream over C (train_kernels.hip: thin_dgrad_kernel)
+    const float* D;        // [M, ldd]: dL/d(head output), K leading columns
+    const float* W;        // [K, ldw]: the head's weights (row k = output k)
+    float* C;              // [M, ldc], N columns
+    int64_t M, ldd, ldw, ldc;
+    int K, N, accumulate;
+    float alpha;
+    // optional activation backward of the layer below (as the row GEMMs' epilogue): pre-activations, [a | b] table (N each), BatchNorm
+    // mean / istd (or NULL), the double column sums [2][N]
+    const float* ez;
+    int64_t eld;
+    const float *etab, *emu, *eistd;
+    double* stats;
+};
+bool thin_dgrad_ok(const ThinDgradArgs& a);
+hipError_t launch_thin_dgrad(const ThinDgradArgs& a, hipStream_t st);
 
 // BatchNorm finalize: mean = sum/M, var = m2/M, istd; EMA of running stats (momentum 0.01, unbiased var)
 hipError_t launch_bn_finalize(const float* colsum, const float* m2, int64_t M, int C, float* mean, float* istd,

@@ -226,6 +226,127 @@ static hipError_t launch_colpass_vec(const ColArgs& a, const float* sdy, const f
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Input gradient of a head with K <= 4 outputs (colour 3, density 1, solar visibility 1):
+//   C[m, n] = (accumulate ? C[m, n] : 0) + alpha * sum_k D[m, k] W[k, n],   then optionally the activation backward of the layer below
+//   (C *= cos(2 pi (a z + b)), column sums of C and C * xhat as the row GEMMs' epilogue leaves them).
+// A rank-K update is a stream over C, not a GEMM: exact fp32 FMAs, a thread owns four columns (its K x 4 weights in registers) and walks
+// down the rows; the row GEMM spent 230-260 us on each of these at 4096 x 96, the stream 90-135 us.  (With K = 12 - the class adjustments,
+// 256 columns - the same stream took 400 us against the GEMM's 186: 48 FMAs per 16 bytes; those stay on the GEMM.)
+template <bool ACT, int KMAX>      // KMAX: 4
+__global__ __launch_bounds__(256) void thin_dgrad_kernel(const ThinDgradArgs A, int C4, int cpt, int rows_per_block) {
+    __shared__ float red[2][256][4];
+    const int tc = threadIdx.x % cpt, tr = threadIdx.x / cpt, rows_pass = 256 / cpt;
+    const bool live = tc < C4;
+    float w[KMAX][4];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) w[k][q] = (live && k < A.K) ? A.W[(int64_t)k * A.ldw + tc * 4 + q] : 0.f;
+    float ea[4] = {0.f, 0.f, 0.f, 0.f}, eb[4] = {0.f, 0.f, 0.f, 0.f}, mu[4] = {0.f, 0.f, 0.f, 0.f}, is[4] = {0.f, 0.f, 0.f, 0.f};
+    if (ACT && live) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = tc * 4 + q;
+            ea[q] = A.etab[c]; eb[q] = A.etab[A.N + c];
+            if (A.emu) { mu[q] = A.emu[c]; is[q] = A.eistd[c]; }
+        }
+    }
+    float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
+    // persistent blocks over chunks of rows_per_block rows (the column sums leave each block once); U rows of a thread in flight at a time
+    constexpr int U = KMAX <= 4 ? 4 : 2;                    // (register budget: three waves per SIMD)
+    const bool vec_d = (A.ldd & 3) == 0 && ((uintptr_t)A.D & 15) == 0 && ((A.K + 3) & ~3) <= A.ldd;
+    const int64_t n_chunks = (A.M + rows_per_block - 1) / rows_per_block;
+    if (live) {
+        for (int64_t ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
+            const int64_t r0 = ch * rows_per_block;
+            const int64_t r1 = r0 + rows_per_block < A.M ? r0 + rows_per_block : A.M;
+            for (int64_t rb = r0 + tr; rb < r1; rb += (int64_t)U * rows_pass) {
+                float d[U][KMAX];
+                f32x4_t cold[U], z[U];
+                bool ok[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int64_t r = rb + (int64_t)u * rows_pass;
+                    ok[u] = r < r1;
+                    const int64_t rc = ok[u] ? r : r1 - 1;
+                    if (vec_d) {                                         // uniform: the K values of a row as 16-byte loads
+#pragma unroll
+                        for (int k4 = 0; k4 < KMAX / 4; ++k4) {
+                            f32x4_t t4 = {0.f, 0.f, 0.f, 0.f};
+                            if (4 * k4 < A.K) t4 = *(const f32x4_t*)(A.D + rc * A.ldd + 4 * k4);      // (columns past K: multiplied by zero weights)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) d[u][4 * k4 + q] = t4[q];
+                        }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < KMAX; ++k) d[u][k] = k < A.K ? A.D[rc * A.ldd + k] : 0.f;
+                    }
+                    if (A.accumulate) cold[u] = *(const f32x4_t*)(A.C + rc * A.ldc + tc * 4);
+                    if (ACT) z[u] = *(const f32x4_t*)(A.ez + rc * A.eld + tc * 4);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int k = 0; k < KMAX; ++k) {
+                        if (k < A.K) {                                  // uniform
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) acc[q] = __builtin_fmaf(d[u][k], w[k][q], acc[q]);
+                        }
+                    }
+                    f32x4_t v;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = A.alpha * acc[q];
+                    if (A.accumulate) v += cold[u];
+                    if (ACT) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            v[q] *= __builtin_amdgcn_cosf(__builtin_fmaf(ea[q], z[u][q], eb[q]));
+                            s0[q] += ok[u] ? v[q] : 0.f;
+                            s1[q] += ok[u] ? v[q] * ((z[u][q] - mu[q]) * is[q]) : 0.f;
+                        }
+                    }
+                    if (ok[u]) *(f32x4_t*)(A.C + (rb + (int64_t)u * rows_pass) * A.ldc + tc * 4) = v;
+                }
+            }
+        }
+    }
+    if (ACT) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { red[0][threadIdx.x][q] = s0[q]; red[1][threadIdx.x][q] = s1[q]; }
+        __syncthreads();
+        if (tr == 0 && live) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                double a = 0.0, b = 0.0;
+                for (int p = 0; p < rows_pass; ++p) { a += (double)red[0][p * cpt + tc][q]; b += (double)red[1][p * cpt + tc][q]; }
+                const int c = tc * 4 + q;
+                atomicAdd(A.stats + c, a);
+                atomicAdd(A.stats + A.N + c, b);
+            }
+        }
+    }
+}
+bool thin_dgrad_ok(const ThinDgradArgs& a) {
+    return a.K >= 1 && a.K <= 4 && a.N % 4 == 0 && a.N <= 1024 && a.ldc % 4 == 0 && (uintptr_t)a.C % 16 == 0 &&
+           (!a.ez || (a.eld % 4 == 0 && (uintptr_t)a.ez % 16 == 0 && a.etab && a.stats));
+}
+hipError_t launch_thin_dgrad(const ThinDgradArgs& a, hipStream_t st) {
+    if (a.M <= 0 || a.N <= 0) return hipSuccess;
+    if (!thin_dgrad_ok(a)) return hipErrorInvalidValue;
+    const int C4 = a.N / 4;
+    int cpt = 1;
+    while (cpt < C4) cpt <<= 1;
+    int rpb = 256;
+    while (rpb > 32 && rpb > 256 / cpt && (a.M + rpb - 1) / rpb < 1024) rpb >>= 1;
+    int64_t blocks = (a.M + rpb - 1) / rpb;
+    if (blocks > 1024) blocks = 1024;                       // four resident blocks per CU, each leaves its column sums once
+    if (a.ez) hipLaunchKernelGGL((thin_dgrad_kernel<true, 4>), dim3((unsigned)blocks), dim3(256), 0, st, a, C4, cpt, rpb);
+    else hipLaunchKernelGGL((thin_dgrad_kernel<false, 4>), dim3((unsigned)blocks), dim3(256), 0, st, a, C4, cpt, rpb);
+    return hipGetLastError();
+}
+
 hipError_t launch_colreduce(const ColArgs& a, hipStream_t st) {
     if (a.M <= 0) return hipSuccess;
     if (colpass_vec_ok(a) && a.mode == 1) return launch_colpass_vec<1>(a, nullptr, nullptr, st);
