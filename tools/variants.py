@@ -4,7 +4,9 @@
     python tools/variants.py run [--precision i8x3] [--width 256]        # on the GPU box: one process per library
 
 Each variant = build/variants/lib_<name>.so: the named source compiled with the extra flags, linked with the other objects of
-the regular build (build/obj, made by season_nerf_amd/build.py)."""
+the regular build (build/obj, made by season_nerf_amd/build.py).  A build in which a kernel with hand-issued loads spills is refused
+(see `one` below); VARIANTS_UNUSED=<substring of the mangled name>[,...] exempts kernels the timed script will not launch.  Only the
+ctypes path (`SNERF_LIB`) sees a variant: the torch op library links the in-tree build."""
 import glob
 import os
 import subprocess
