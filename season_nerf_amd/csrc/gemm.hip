@@ -671,11 +671,12 @@ __global__ __launch_bounds__(512) void gemm_rows_full_kernel(const GemmX g) {
 // Stage = 32 points; double-buffered LDS (2 x 64 KiB), one barrier per stage; the loads of stage s+1 fly during the MFMAs of s.
 // Direction of the next streaming kernel (row GEMMs on the 16x16x32 form, weight gradients): they alternate, so that a kernel starts with the
 // rows its producer touched last - some of which are still in the Infinity Cache (forward 256 -> 256: 182 -> 177 us; SNERF_SNAKE=0: always forwards)
-int stream_direction() {
+int stream_direction(int64_t rows) {
     static int snake = -1;
     static std::atomic<unsigned> launches{0};
     if (snake < 0) { const char* e = getenv("SNERF_SNAKE"); snake = (e && e[0] == '0') ? 0 : 1; }
-    return snake ? (int)(launches.fetch_add(1, std::memory_order_relaxed) & 1u) : 0;
+    if (!snake || rows < 32768) return 0;                  // (a small launch neither gains from a direction nor takes a turn)
+    return (int)(launches.fetch_add(1, std::memory_order_relaxed) & 1u);
 }
 
 static int ro_grid_blocks() {
@@ -978,7 +979,7 @@ hipError_t launch_wgrad_bf16x3(float* dZ, int64_t ldz, const float* In, int64_t 
     if (rows < 4 * WG_STAGE) rows = 4 * WG_STAGE;
     bx = (M + rows - 1) / rows;
     g.rows_per_block = rows;
-    g.reverse = stream_direction();
+    g.reverse = stream_direction(M);
     const bool full = n_out % 256 == 0 && n_in % 256 == 0;
     const dim3 grid((unsigned)bx, by, bz);
     static int two_stage = -1;

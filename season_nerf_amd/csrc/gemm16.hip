@@ -737,7 +737,7 @@ bool gemm_wreg_ok(const GemmX& gx) {
 // gx: as launch_gemm_bf16x3 prepared it for the full-tile path (raw weights in gx.W, K in whole 32-k steps, N = 32 n_tiles)
 hipError_t launch_gemm_rows16(const GemmX& gx_in, int aol_mode, int act_mode, dim3 grid, size_t lds, hipStream_t st) {
     GemmX gx = gx_in;
-    gx.reverse = stream_direction();      // every other streaming launch walks its row tiles backwards (gemm.hip)
+    gx.reverse = stream_direction(gx.M);      // every other streaming launch walks its row tiles backwards (gemm.hip)
     const int KS32 = gx.ksteps / 2;
     hipError_t e = launch_split_weights16(gx.W, gx.w_rows, gx.w_cols, gx.w_transpose != 0, const_cast<uint16_t*>(gx.frag), 2 * gx.n_tiles, KS32, st);
     if (e != hipSuccess) return e;

@@ -63,7 +63,7 @@ struct WgradBN {
     float bias_alpha;
     float* dbias;              // += bias_alpha * sum_m dZ
 };
-int stream_direction();      // 0 / 1, alternating per streaming launch (gemm.hip)
+int stream_direction(int64_t rows);      // 0 / 1, alternating per large streaming launch (gemm.hip)
 hipError_t launch_wgrad_bf16x3(float* dZ, int64_t ldz, const float* In, int64_t ldi, int64_t M, int n_out, int n_in, float alpha,
                                float* dW, int64_t ldw, hipStream_t st, const float* in_tab = nullptr, int in_cols = 0,
                                const WgradBN* bn = nullptr, int in_tab_stride = 0);      // in_tab_stride: see WgradX (0 = in_cols)
