@@ -131,14 +131,86 @@ def cpu_baseline():
 TRAIN_KERNEL = "snerf::gemm_rows16_kernel<8,4,1,0>"
 
 
-def train_dominant_kernel(dev, launches=20):
+def w512_kernel_roofline(dev, d, tv, launches=20):
+    """`snerf::mlp_i8_kernel<0,512,0>` on the benchmark's rays: T_NeRF(512, 4) (the reference's default width, main_lite.py:80), default precision.
+    Returns (summary, roofline object); HIP events on the stream the C ABI launches on (torch's current stream)."""
+    import season_nerf_amd as sn
+    L = sn._lib.lib()
+    n5 = sn.T_NeRF(512, NC)
+    n5.load_state_dict(sn.synthetic_state_dict(n5, 0))
+    n5 = n5.to(dev).eval()                          # default precision ("auto"): the fused int8-digit kernel for these weights
+    m5 = n5.device_model()
+    e = lambda *s_: torch.empty(*s_, device=dev)
+    cls, rho, sv, col = torch.softmax(torch.rand(R, NC, device=dev), 1), e(R * S), e(R * S), e(R * S, 3)
+    fo = sn._lib.FieldOut(d_rho=rho.data_ptr(), d_solar_vis=sv.data_ptr(), d_col=col.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    run5 = lambda: sn._lib.check(L.snerf_field_forward_rays(m5, 0, R, S, d["Top"].data_ptr(), d["Bot"].data_ptr(), tv.data_ptr(), 1, d["Sun_Angle"].data_ptr(),
+                                                           cls.data_ptr(), C.byref(fo), st), "field")
+    for _ in range(2):
+        run5()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(launches):
+        run5()
+    e1.record()
+    torch.cuda.synchronize()
+    ms5 = e0.elapsed_time(e1) / launches
+    flop5 = 2 * (2896896 + 273152 / 96.0) * R * S        # SURVEY 8d, W = 512
+    tr5 = None
+    try:
+        tr5 = json.load(open(_profile_file("w512_traffic.json")))["bytes_per_launch"]
+    except Exception:
+        pass
+    roof = {"bound": "mfma", "kernel": "snerf::mlp_i8_kernel<0,512,0> (fused field network at W = 512, int8 digits, one wave per SIMD, activations in AGPRs)",
+            "achieved": flop5 / (ms5 * 1e-3) / 1e12, "peak": PEAK_BF16_DENSE / 1e12, "unit": "TFLOP/s",
+            "frac": flop5 / (ms5 * 1e-3) / PEAK_BF16_DENSE, "frac_of_int8_peak": flop5 / (ms5 * 1e-3) / PEAK_INT8_DENSE,
+            "traffic": tr5, "kernel_ms": ms5, "algorithmic_flop": flop5}
+    summ = {"field_kernel_ms": ms5, "precision": f"auto -> {n5.resolved_precision}", "i8_rgb_pred": n5.i8_estimate()["rgb_pred"],
+            "ray_samples_per_s_kernel": R * S / (ms5 * 1e-3), "roofline_frac_algorithmic_of_bf16_peak": flop5 / (ms5 * 1e-3) / PEAK_BF16_DENSE,
+            "note": "T_NeRF(512,4), the reference's default width: fused int8-digit kernel (activations parked in AGPRs)"}
+    return summ, roof
+
+
+def sweep_kernel_roofline(dev, rays=512 * 512, T=12, launches=5):
+    """`snerf::sweep_kernel` (csrc/kernels.hip; mg_Img_Eval.get_imgs_from_Img_Dict_t_step, :192-228) alone at configs[4]'s size: 512 x 512 rays x 96
+    samples, 12 time steps per pass.  Algorithmic bytes: the 17 floats per sample it reads once for all T (rho, col_raw 3, adjust C x 3, solar_vis)
+    + the [T, R, 3] x 2 + [R, 7] it writes.  HIP events on torch's current stream = the stream the op launches on."""
+    import season_nerf_amd as sn
+    sn.ops.load()
+    g = torch.Generator(device=dev).manual_seed(1)
+    rn = lambda *sh: torch.rand(*sh, device=dev, generator=g)
+    top = torch.cat([rn(rays, 2) * 2 - 1, torch.ones(rays, 1, device=dev)], 1)
+    bot = torch.cat([rn(rays, 2) * 2 - 1, -torch.ones(rays, 1, device=dev)], 1)
+    tv = sn.sample_parameters(S, eval_mode=True).to(dev)
+    rho, colr, adj, sv = rn(rays, S, 1) * 3, rn(rays, S, 3) - 0.5, rn(rays, S, NC, 3) - 0.5, rn(rays, S, 1)
+    sky, cv = rn(3), torch.softmax(rn(T, NC), 1)
+    run = lambda: torch.ops.season_nerf.composite_sweep(top, bot, tv, rho, colr, adj, sv, sky, cv, 0, False)
+    run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(launches):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / launches
+    nbytes = 4.0 * (rays * S * (5 + 3 * NC) + 2 * T * rays * 3 + rays * 7)
+    traffic = None
+    try:
+        traffic = json.load(open(_profile_file("sweep_traffic.json")))["bytes_per_launch"]
+    except Exception:
+        pass
+    return {"bound": "hbm", "kernel": "snerf::sweep_kernel (512 x 512 rays x 96 samples, 12 time steps per pass)", "achieved": nbytes / (ms * 1e-3) / 1e9, "peak": 8000.0,
+            "unit": "GB/s", "frac": nbytes / (ms * 1e-3) / 8e12, "traffic": traffic, "kernel_ms": ms, "algorithmic_bytes": nbytes}
+
+
+def train_dominant_kernel(dev, launches=20, width=256):
     """The training step's dominant kernel on its own, live: the forward row GEMM of a 256 -> 256 SineLayer at M = 393 216 points
     (activation on load from the stored pre-activation of the layer below, BatchNorm column sums in the epilogue) - 21 of the
     step's launches, ~23 % of its time.  Algorithmic bytes: read Z_in, write Z_out = 4 M (K + N).  HIP events on the stream the
     C ABI launches on (torch's current stream)."""
     import season_nerf_amd as sn
     L = sn._lib.lib()
-    M, K, N = R * S, 256, 256
+    M, K, N = R * S, width, width
     A = torch.randn(M, K, device=dev) * 4
     Wt = torch.randn(N, K, device=dev) / 16
     b = torch.randn(N, device=dev)
@@ -164,7 +236,10 @@ def train_dominant_kernel(dev, launches=20):
         traffic = json.load(open(_profile_file("train_kernel_traffic.json")))["bytes_per_launch"]
     except Exception:
         pass
-    return {"bound": "hbm", "kernel": TRAIN_KERNEL + " (forward 256->256 SineLayer, activation on load + BatchNorm sums in the epilogue, M = 393216)",
+    if width != 256:
+        traffic = None                                        # the committed counter passes are of the 256-wide kernel
+    name = TRAIN_KERNEL if width == 256 else f"snerf::gemm_rows*_kernel (the row GEMM snerf_linear_forward selects for {width} -> {width})"
+    return {"bound": "hbm", "kernel": name + f" (forward {width}->{width} SineLayer, activation on load + BatchNorm sums in the epilogue, M = 393216)",
             "achieved": nbytes / (us * 1e-6) / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": nbytes / (us * 1e-6) / 8e12, "traffic": traffic,
             "kernel_us": us, "algorithmic_bytes": nbytes, "launches_per_step": 21}
 
@@ -225,7 +300,8 @@ def bench_train(a, standalone=True):
         marks[i].record()
         tot = step()
     marks[steps].record()
-    host_ms = (time.perf_counter() - t0) / steps * 1e3       # what the host needs to ENQUEUE a step (diagnostic: below ms_per_step = the GPU is never waiting for it)
+    host_loop_ms = (time.perf_counter() - t0) / steps * 1e3  # wall time of the enqueue loop per step: includes back-pressure (the pinned upload ring
+                                                             # lets the host run at most ~5 steps ahead, then it waits for the GPU) - NOT the host's own cost
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
@@ -235,6 +311,16 @@ def bench_train(a, standalone=True):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     dt /= steps
+    # what the HOST needs to enqueue one step (Python, dispatcher, C ABI, ~100 launches): every step issued onto an IDLE GPU
+    # (synchronize first), so nothing the host waits for is in it; outside the timed region
+    hq = []
+    for _ in range(6):
+        torch.cuda.synchronize()
+        th = time.perf_counter()
+        step()
+        hq.append((time.perf_counter() - th) * 1e3)
+    torch.cuda.synchronize()
+    host_ms = sorted(hq)[len(hq) // 2]
     per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))     # stream time of each step (diagnostic)
     gemm = os.environ.get("SNERF_TRAIN_GEMM", "bf16x3")
     # algorithmic FLOPs: image rays 3 x forward; sun rays: trunk+heads+solar forward + 3 x solar/sky heads
@@ -288,7 +374,9 @@ def bench_train(a, standalone=True):
                                       + ("" if Wt == 256 else " - at the reference's default width (main_lite.py:80), not the BASELINE config"),
                           "parallelism": f"rays sharded over {world} GPU(s), one all-reduce of the flat gradient arena, BatchNorm statistics "
                                          + ("over the global batch (all-reduced)" if a.bn_sync == "global" and use_dist else "per rank")},
-               "final_loss": float(tot.detach()), "step_ms_median": per_step[len(per_step) // 2], "step_ms_min": per_step[0], "host_enqueue_ms_per_step": host_ms,
+               "final_loss": float(tot.detach()), "step_ms_median": per_step[len(per_step) // 2], "step_ms_min": per_step[0], "host_enqueue_ms_per_step": host_ms, "host_loop_ms_per_step": host_loop_ms,
+               "host_note": "host_enqueue = wall time to enqueue one step onto an idle GPU (median of 6; the host's own cost); host_loop = the timed "
+                            "loop's enqueue time per step (contains waits for the GPU once the host is ~5 steps ahead)",
                "collectives": dict(sn.parallel.COLLECTIVES) if use_dist else None,
                "roofline": None,
                "step_roofline": {"bound": "hbm", "achieved": hbm_bytes / dt / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": hbm_bytes / dt / 8e12,
@@ -297,8 +385,8 @@ def bench_train(a, standalone=True):
                                          "a pass over [393216 x width] fp32 arrays; achieved = bytes that design moves per step (counted from "
                                          "the layer table, DESIGN 5.4) / step time, traffic = HBM bytes per step by the PMC counters, "
                                          "peak = HBM3E 8 TB/s (MI355X_MICROARCH.md); per-kernel times in profiles/*/train_kernel_stats.csv"}}
-        if Wt == 256 and world == 1:
-            out["roofline"] = train_dominant_kernel(dev)
+        if world == 1:
+            out["roofline"] = train_dominant_kernel(dev, width=Wt)
         if not a.no_cpu_baseline and world == 1:      # reported at N = 1 only (rank 0)
             from oracle import season_nerf_oracle as orc          # CPU-baseline leg only
             torch.set_num_threads(min(host_cpus(), 32))
@@ -365,6 +453,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--prewarm", type=int, default=200, help="untimed steps run before --warmup (reported as `prewarm_steps`): clock ramp of a cold chip")
     ap.add_argument("--precision", default="auto", choices=["auto", "i8x3", "bf16x3", "bf16"],
                     help="arithmetic of the fused field kernel in the headline timed region (include/season_nerf_hip.h SNERF_PREC_*): "
                          "auto = what season_nerf_amd.T_NeRF picks by default: i8x3 where the pack-time error bound of the int8-digit "
@@ -383,6 +472,8 @@ def main():
                     help="only the headline timed region (no per-mode table, seam, sweep, training step, CPU baseline): profiler passes")
     ap.add_argument("--no-train", action="store_true", help="render workload: skip the extra training-step measurement (train_* keys)")
     ap.add_argument("--train-kernel-only", action="store_true", help="--workload train: only the dominant training kernel (`--steps` launches), for profiler passes")
+    ap.add_argument("--aux-kernel", default=None, choices=["sweep", "w512"], help="only that auxiliary kernel, `--steps` launches (profiler passes): "
+                                                                              "the seasonal-sweep kernel at 512x512x96, or the W = 512 fused field kernel")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help=argparse.SUPPRESS)   # gloo: CPU test of the launcher only
     ap.add_argument("--bn_sync", default="local", choices=["local", "global"],
                     help="--workload train, N > 1: BatchNorm statistics per rank, or over the global batch (RCCL all-reduces of the "
@@ -399,6 +490,15 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but the launcher started {world} ranks")
     if a.backend == "gloo":
         return launcher_selftest(a, world, rank)
+    if a.aux_kernel:
+        torch.cuda.set_device(local)
+        dv = torch.device("cuda", local)
+        if a.aux_kernel == "sweep":
+            print(json.dumps(sweep_kernel_roofline(dv, launches=max(a.steps, 1))))
+        else:
+            import season_nerf_amd as sn
+            print(json.dumps(w512_kernel_roofline(dv, synth(0, dv), sn.sample_parameters(S, eval_mode=True).to(dv), launches=max(a.steps, 1))[1]))
+        return
     if a.workload == "train" and a.train_kernel_only:        # profiler passes over the dominant training kernel alone
         torch.cuda.set_device(local)
         print(json.dumps(train_dominant_kernel(torch.device("cuda", local), launches=max(a.steps, 1))))
@@ -455,6 +555,10 @@ def main():
         if use_dist:
             tg.commit()
 
+    # declared, untimed pre-warm BEFORE the driver's --warmup: the chip's clock depends on its load history, and a 20-step sample taken 5 steps
+    # after start-up read 8 % slower than the same block repeated right after (round 3: 0.818 against a median of 0.752 ms)
+    for _ in range(a.prewarm):
+        step()
     for _ in range(a.warmup):
         step()
     if use_dist:
@@ -527,27 +631,7 @@ def main():
             del netp
         # the reference's default width (main_lite.py:80), fused on the int8 pipe only: same rays, T_NeRF(512, 4)
         try:
-            n5 = sn.T_NeRF(512, NC)
-            n5.load_state_dict(sn.synthetic_state_dict(n5, 0))
-            n5 = n5.to(dev).eval()                          # default precision ("auto"): the fused int8-digit kernel for these weights
-            m5 = n5.device_model()
-            run5 = lambda: sn._lib.check(L.snerf_field_forward_rays(m5, 0, R, S, top.data_ptr(), bot.data_ptr(), tv.data_ptr(), 1, sun.data_ptr(),
-                                                                   cls.data_ptr(), C.byref(fo), st), "field")
-            for _ in range(2):
-                run5()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(20):
-                run5()
-            e1.record()
-            torch.cuda.synchronize()
-            ms5 = e0.elapsed_time(e1) / 20
-            flop5 = 2 * (2896896 + 273152 / 96.0) * R * S        # SURVEY 8d, W = 512
-            extra["w512"] = {"field_kernel_ms": ms5, "precision": f"auto -> {n5.resolved_precision}", "i8_rgb_pred": n5.i8_estimate()["rgb_pred"],
-                             "ray_samples_per_s_kernel": R * S / (ms5 * 1e-3),
-                             "roofline_frac_algorithmic_of_bf16_peak": flop5 / (ms5 * 1e-3) / PEAK_BF16_DENSE,
-                             "note": "T_NeRF(512,4), the reference's default width: fused int8-digit kernel (activations parked in AGPRs)"}
-            del n5
+            extra["w512"], extra["w512_roofline"] = w512_kernel_roofline(dev, d, tv)
         except Exception as ex:
             extra["w512_error"] = repr(ex)
         extra["modes"] = modes
@@ -568,6 +652,7 @@ def main():
                     t_sweep = min(t_sweep, time.perf_counter() - t1)
             extra.update({"image_512x512x96_12step_sweep_ms": t_sweep * 1e3, "sweep_output_shape": list(img.shape)})
             del img
+            extra["sweep_roofline"] = sweep_kernel_roofline(dev)
         except Exception as ex:      # never let the auxiliary measurement break the headline line
             extra["image_sweep_error"] = repr(ex)
 
@@ -611,10 +696,28 @@ def main():
                               "train_metric": tr["metric"], "train_steps": tr["steps"], "train_final_loss": tr["final_loss"],
                               "train_dtype": tr["dtype"], "train_roofline": tr["roofline"], "train_step_roofline": tr["step_roofline"],
                               "train_config": tr["config"]})
+                extra["train_host_enqueue_ms_per_step"] = tr["host_enqueue_ms_per_step"]
+                extra["train_host_note"] = tr["host_note"]
                 if "cpu_baseline" in tr:
                     extra["train_cpu_baseline"] = tr["cpu_baseline"]
             except Exception as ex:      # never let the auxiliary measurement break the headline line
                 extra["train_error"] = repr(ex)
+            try:      # configs[2] names the Barron loss: the same step with the adaptive loss object + its own Adam (PARITY UNPINNED)
+                torch.cuda.empty_cache()
+                tb = bench_train(argparse.Namespace(**{**vars(a), "loss": "barron", "no_cpu_baseline": True}), standalone=False)
+                extra.update({"train_barron_ms_per_step": tb["ms_per_step"], "train_barron_final_loss": tb["final_loss"],
+                              "train_barron_note": "same step with the Barron adaptive colour loss (configs[2] names it) and its second Adam; the loss "
+                                                   "object restates robust_loss_pytorch from its published definition: parity UNPINNED (no importable "
+                                                   "reference, no reference-held fixture) - a timing, not a reference-checked result"})
+            except Exception as ex:
+                extra["train_barron_error"] = repr(ex)
+            try:      # the reference's DEFAULT width (main_lite.py:80, fc_units = 512), MSE loss
+                torch.cuda.empty_cache()
+                t5 = bench_train(argparse.Namespace(**{**vars(a), "loss": "mse", "width": 512, "no_cpu_baseline": True}), standalone=False)
+                extra.update({"train_w512_ms_per_step": t5["ms_per_step"], "train_w512_value": t5["value"], "train_w512_roofline": t5["roofline"],
+                              "train_w512_config": t5["config"], "train_w512_host_enqueue_ms_per_step": t5["host_enqueue_ms_per_step"]})
+            except Exception as ex:
+                extra["train_w512_error"] = repr(ex)
 
     if rank == 0:
         value = world * R * S * a.steps / dt
@@ -628,7 +731,7 @@ def main():
             pass
         out = {
             "metric": "ray-samples/sec (4096 rays x 96 samples forward render, T_NeRF 8x256)",
-            "value": value, "unit": "ray-samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "value": value, "unit": "ray-samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "prewarm_steps": a.prewarm,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": DTYPES[prec], "precision": a.precision, "precision_resolved": prec, "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: forward render 4096 rays x 96 samples, T_NeRF(256,4) eval-mode, "

@@ -201,6 +201,10 @@ int snerf_composite_sweep(int64_t n_rays, int n_samples, int n_classes, int n_ti
 typedef struct snerf_trainer snerf_trainer;
 snerf_trainer* snerf_trainer_create(int layer_width, int n_classes);
 void snerf_trainer_destroy(snerf_trainer* t);
+/* class count of a live trainer; -1 if `t` is not one (never created by this library, or already destroyed): handle validation for
+ * callers that carry the pointer as an integer (torch.ops.season_nerf.train_*; no reference counterpart - the reference's trainer is
+ * a Python object, Net_Tool_2.py:11-61). */
+int snerf_trainer_classes(const snerf_trainer* t);
 int64_t snerf_trainer_param_floats(const snerf_trainer* t);
 int64_t snerf_trainer_buffer_floats(const snerf_trainer* t);
 int snerf_trainer_tensor_count(const snerf_trainer* t);
@@ -209,6 +213,8 @@ int snerf_trainer_tensor_info(const snerf_trainer* t, int index, char* key, int 
 size_t snerf_trainer_workspace_bytes(snerf_trainer* t, int64_t n_rays, int64_t n_solar_rays, int n_samples);
 int snerf_trainer_bind(snerf_trainer* t, float* d_params, float* d_grads, float* d_adam_m, float* d_adam_v, float* d_buffers,
                        void* d_workspace, size_t workspace_bytes, int64_t n_rays, int64_t n_solar_rays, int n_samples);
+/* the sizes the trainer is bound to (any pointer may be NULL); SNERF_E_STATE before snerf_trainer_bind */
+int snerf_trainer_bound_sizes(const snerf_trainer* t, int64_t* n_rays, int64_t* n_solar_rays, int* n_samples);
 /* image-ray pass: T_NeRF.forward + compositing.  train_bn: 1 = batch statistics + EMA update, 0 = running statistics. */
 int snerf_trainer_forward_image(snerf_trainer* t, int64_t n_rays, int n_samples, const float* d_top, const float* d_bot,
                                 const float* d_tvals, const float* d_sun, const float* d_time, int train_bn, int flags,

@@ -74,6 +74,10 @@ def lib():
     L.snerf_trainer_create.argtypes = [i32, i32]
     L.snerf_trainer_destroy.argtypes = [vp]
     L.snerf_trainer_destroy.restype = None
+    L.snerf_trainer_bound_sizes.restype = i32
+    L.snerf_trainer_bound_sizes.argtypes = [vp, vp, vp, vp]
+    L.snerf_trainer_classes.restype = i32
+    L.snerf_trainer_classes.argtypes = [vp]
     L.snerf_trainer_param_floats.restype = i64
     L.snerf_trainer_param_floats.argtypes = [vp]
     L.snerf_trainer_buffer_floats.restype = i64
@@ -126,7 +130,7 @@ EXPORTS = ["snerf_last_error", "snerf_abi_version", "snerf_model_create", "snerf
            "snerf_composite_rays", "snerf_composite_sweep", "snerf_render_workspace_bytes", "snerf_render_rays", "snerf_rays_from_camera", "snerf_field_kernel_info",
            "snerf_prior_density", "snerf_surface_distance", "snerf_image_error", "snerf_transmittance",
            "snerf_linear_scratch_bytes", "snerf_linear_forward", "snerf_linear_dgrad", "snerf_linear_wgrad",
-           "snerf_trainer_create", "snerf_trainer_destroy", "snerf_trainer_param_floats", "snerf_trainer_buffer_floats",
-           "snerf_trainer_tensor_count", "snerf_trainer_tensor_info", "snerf_trainer_workspace_bytes", "snerf_trainer_bind",
+           "snerf_trainer_create", "snerf_trainer_destroy", "snerf_trainer_classes", "snerf_trainer_param_floats", "snerf_trainer_buffer_floats",
+           "snerf_trainer_tensor_count", "snerf_trainer_tensor_info", "snerf_trainer_workspace_bytes", "snerf_trainer_bind", "snerf_trainer_bound_sizes",
            "snerf_trainer_forward_image", "snerf_trainer_backward_image", "snerf_trainer_backward_points", "snerf_trainer_forward_solar",
            "snerf_trainer_backward_solar", "snerf_trainer_zero_grad", "snerf_trainer_set_allreduce", "snerf_trainer_adam_step", "snerf_adam_step", "snerf_trainer_debug_read"]

@@ -671,14 +671,26 @@ __global__ __launch_bounds__(512) void gemm_rows_full_kernel(const GemmX g) {
 // Stage = 32 points; double-buffered LDS (2 x 64 KiB), one barrier per stage; the loads of stage s+1 fly during the MFMAs of s.
 // Direction of the next streaming kernel (row GEMMs on the 16x16x32 form, weight gradients): they alternate, so that a kernel starts with the
 // rows its producer touched last - some of which are still in the Infinity Cache (forward 256 -> 256: 182 -> 177 us; SNERF_SNAKE=0: always forwards)
+static int ro_grid_blocks_public();
+// Launch context of the calling thread (set by a training pass, train.cpp CtxGuard): the launch parity of ITS trainer - reset at the start of
+// every pass, so the direction of each launch (and with it the order in which wgrad_bf16x3_kernel accumulates its fp32 stages) is a function of the
+// launch's position in the pass, not of the process's launch history - and that trainer's pre-allocated partial-sum scratch.
+struct LaunchCtx { float* wgrad_partial = nullptr; size_t wgrad_floats = 0; unsigned* parity = nullptr; };
+static thread_local LaunchCtx tl_ctx;
+void gemm_launch_context(float* wgrad_partial, size_t wgrad_floats, unsigned* parity) { tl_ctx = LaunchCtx{wgrad_partial, wgrad_floats, parity}; }
+size_t gemm_wgrad_partial_floats() { return (size_t)(ro_grid_blocks_public() < 256 ? 256 : ro_grid_blocks_public()) * 8 * 2 * 4 * 1024; }
+
 int stream_direction(int64_t rows) {
     static int snake = -1;
-    static std::atomic<unsigned> launches{0};
+    static std::atomic<unsigned> launches{0};        // stand-alone launches (snerf_linear_*): one process-wide parity
     if (snake < 0) { const char* e = getenv("SNERF_SNAKE"); snake = (e && e[0] == '0') ? 0 : 1; }
     if (!snake || rows < 32768) return 0;                  // (a small launch neither gains from a direction nor takes a turn)
+    if (tl_ctx.parity) return (int)((*tl_ctx.parity)++ & 1u);
     return (int)(launches.fetch_add(1, std::memory_order_relaxed) & 1u);
 }
 
+static int ro_grid_blocks();
+static int ro_grid_blocks_public() { return ro_grid_blocks(); }
 static int ro_grid_blocks() {
     static int n = 0;
     if (!n) {
@@ -931,8 +943,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     if (o < n_out && i < n_in) dW[(int64_t)o * ldw + i] += alpha * s[0];
 }
 
-// partial-sum scratch of the two-stage reduction, one per stream (grown on demand, never freed: 64 MiB for a 256 x 256 layer on 256 CUs)
+// partial-sum scratch of the two-stage reduction: the calling trainer's (carved from its workspace at bind time, gemm_launch_context); for
+// the stand-alone entry point snerf_linear_wgrad one block per stream (grown on demand, never freed: 64 MiB for a 256 x 256 layer on 256 CUs)
 static float* wgrad_scratch(hipStream_t st, size_t floats) {
+    if (tl_ctx.wgrad_partial && floats <= tl_ctx.wgrad_floats) return tl_ctx.wgrad_partial;
     struct Buf { float* p; size_t cap; };
     static std::mutex mu;
     static std::map<hipStream_t, Buf> bufs;

@@ -244,8 +244,13 @@ void fused_adam_(Tensor param, const Tensor& grad, Tensor m, Tensor v, double lr
 }
 
 // ---- training engine ---------------------------------------------------------------------------------------------------
-snerf_trainer* trainer_of(int64_t h) {
+// The trainer travels through the op schemas as an integer: never dereference it before the library has confirmed it is a live trainer;
+// n_classes >= 0: must be the trainer's class count (the passes write [.., C] arrays sized by the caller).
+snerf_trainer* trainer_of(int64_t h, int64_t n_classes = -1) {
     TORCH_CHECK(h != 0, "season_nerf::train_*: NULL trainer handle");
+    const int c = snerf_trainer_classes((const snerf_trainer*)h);
+    TORCH_CHECK(c > 0, "season_nerf::train_*: ", h, " is not the handle of a live training engine (destroyed, or never created)");
+    TORCH_CHECK(n_classes < 0 || n_classes == c, "season_nerf::train_*: n_classes = ", n_classes, " but the engine was built for ", c, " classes");
     return (snerf_trainer*)h;
 }
 const float* optptr(const c10::optional<Tensor>& t, const char* name, int64_t numel) {
@@ -272,7 +277,7 @@ Tensor prior_density(const Tensor& pts, const Tensor& delta, const Tensor& heigh
 std::vector<Tensor> train_fwd_image(int64_t trainer, const Tensor& top, const Tensor& bot, const Tensor& tvals, const Tensor& sun, const Tensor& time,
                                     bool train_bn, bool classic, int64_t n_classes, const c10::optional<Tensor>& height_map, double trust,
                                     at::TensorList /*params*/) {
-    snerf_trainer* t = trainer_of(trainer);
+    snerf_trainer* t = trainer_of(trainer, n_classes);
     check_shape(top, "top", -1, 3);
     const int64_t R = top.size(0);
     check_shape(bot, "bot", R, 3); check_shape(sun, "sun", R, 3); check_shape(time, "time", R, 4);
@@ -334,7 +339,7 @@ void train_bwd_image(int64_t trainer, Tensor grads, const c10::optional<Tensor>&
 
 std::vector<Tensor> train_fwd_points(int64_t trainer, const Tensor& x, const Tensor& sun, const Tensor& time, bool train_bn, int64_t n_classes,
                                      at::TensorList /*params*/) {
-    snerf_trainer* t = trainer_of(trainer);
+    snerf_trainer* t = trainer_of(trainer, n_classes);
     check_shape(x, "x", -1, 3);
     const int64_t N = x.size(0), C = n_classes;
     check_shape(sun, "sun", N, 3); check_shape(time, "time", N, 4);
@@ -355,7 +360,7 @@ std::vector<Tensor> train_fwd_points(int64_t trainer, const Tensor& x, const Ten
 
 void train_bwd_points(int64_t trainer, Tensor grads, const c10::optional<Tensor>& g_rho, const c10::optional<Tensor>& g_col, const c10::optional<Tensor>& g_sv,
                       const c10::optional<Tensor>& g_sky, const c10::optional<Tensor>& g_cls, int64_t n_points, int64_t n_classes) {
-    snerf_trainer* t = trainer_of(trainer);
+    snerf_trainer* t = trainer_of(trainer, n_classes);
     check_dev_f32(grads, "grads");
     const int64_t N = n_points;
     c10::hip::HIPGuardMasqueradingAsCUDA g(grads.device());
@@ -385,6 +390,10 @@ void train_bwd_solar(int64_t trainer, Tensor grads, const Tensor& g_sv) {
     snerf_trainer* t = trainer_of(trainer);
     check_dev_f32(grads, "grads");
     check_dev_f32(g_sv, "g_solar_vis");
+    int64_t rs = 0;
+    int ns = 0;
+    ck(snerf_trainer_bound_sizes(t, nullptr, &rs, &ns), "train_bwd_solar");
+    TORCH_CHECK(g_sv.numel() == rs * ns, "g_solar_vis must hold ", rs * ns, " elements (the sun rays x samples of the forward), got ", g_sv.sizes());
     c10::hip::HIPGuardMasqueradingAsCUDA g(grads.device());
     ck(snerf_trainer_backward_solar(t, fptr(g_sv), cur_stream(grads)), "train_bwd_solar");
 }

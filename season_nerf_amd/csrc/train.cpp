@@ -9,6 +9,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <mutex>
+#include <set>
 #include <vector>
 
 #include "kernels.h"
@@ -79,6 +81,16 @@ struct snerf_trainer {
     snerf_allreduce_fn ar_fn = nullptr;
     void* ar_user = nullptr;
     int world = 1;
+    float* wgrad_partial = nullptr;                 // partial dW blocks of the two-stage weight-gradient reduction (carved: no hipMalloc in a step)
+    size_t wgrad_partial_floats = 0;
+    unsigned launch_parity = 0;                     // direction of the next streaming launch; reset at the start of every pass
+};
+
+// Every pass runs under its trainer's launch context (gemm.hip): the row direction of a streaming launch - and with it the summation order of the
+// weight gradients' fp32 stages - depends on the launch's position in the pass only, and the partial sums land in this trainer's workspace.
+struct CtxGuard {
+    explicit CtxGuard(snerf_trainer* t) { t->launch_parity = 0; gemm_launch_context(t->wgrad_partial, t->wgrad_partial_floats, &t->launch_parity); }
+    ~CtxGuard() { gemm_launch_context(nullptr, 0, nullptr); }
 };
 
 // sum the buffer over all ranks (no-op without a registered collective)
@@ -189,6 +201,8 @@ static size_t carve(snerf_trainer* t, char* base, int64_t R, int64_t Rs, int S) 
     const int64_t frag_bytes = (int64_t)((W + 64 + 31) / 32) * ((W + 64 + 15) / 16) * 2048;
     t->w_frag = (uint16_t*)c.take(frag_bytes / 4);
     t->bn_stats = (double*)c.take(4 * W + 2);
+    t->wgrad_partial_floats = gemm_wgrad_partial_floats();
+    t->wgrad_partial = c.take((int64_t)t->wgrad_partial_floats);
     return c.off;
 }
 
@@ -507,6 +521,9 @@ static int forward_pass(snerf_trainer* t, snerf_trainer::Pass& P, bool solar, in
 
 extern "C" {
 
+static std::mutex g_live_mu;
+static std::set<const snerf_trainer*> g_live;          // trainers created and not yet destroyed
+
 snerf_trainer* snerf_trainer_create(int layer_width, int n_classes) {
     if (layer_width < 16 || layer_width % 4 != 0 || n_classes < 1 || n_classes > 5) {
         snerf_set_error(SNERF_E_INVALID, "snerf_trainer_create: width must be a multiple of 4 (>=16), classes in [1,5]");
@@ -517,9 +534,32 @@ snerf_trainer* snerf_trainer_create(int layer_width, int n_classes) {
     if (const char* e = getenv("SNERF_TRAIN_GEMM")) t->gemm_mode = std::strcmp(e, "fp32") == 0 ? 0 : 1;
     if (const char* e = getenv("SNERF_TRAIN_AOL")) t->aol_mode = std::strcmp(e, "0") == 0 ? 0 : 1;
     build_layers(t);
+    {
+        std::lock_guard<std::mutex> lock(g_live_mu);
+        g_live.insert(t);
+    }
     return t;
 }
-void snerf_trainer_destroy(snerf_trainer* t) { delete t; }
+void snerf_trainer_destroy(snerf_trainer* t) {
+    {
+        std::lock_guard<std::mutex> lock(g_live_mu);
+        g_live.erase(t);
+    }
+    delete t;
+}
+// Class count of a LIVE trainer, -1 for a pointer that is not one (never created here, or destroyed): what a caller that holds the handle as
+// a plain integer (the PyTorch custom ops, csrc/ops.cpp) checks before it dereferences it or sizes an output by a class count.
+int snerf_trainer_classes(const snerf_trainer* t) {
+    std::lock_guard<std::mutex> lock(g_live_mu);
+    return g_live.count(t) ? t->C : -1;
+}
+int snerf_trainer_bound_sizes(const snerf_trainer* t, int64_t* n_rays, int64_t* n_solar_rays, int* n_samples) {
+    if (!t || !t->ws) return snerf_set_error(SNERF_E_STATE, "trainer not bound (call snerf_trainer_bind)");
+    if (n_rays) *n_rays = t->R;
+    if (n_solar_rays) *n_solar_rays = t->Rs;
+    if (n_samples) *n_samples = t->S;
+    return SNERF_OK;
+}
 int64_t snerf_trainer_param_floats(const snerf_trainer* t) { return t ? t->n_params : 0; }
 int64_t snerf_trainer_buffer_floats(const snerf_trainer* t) { return t ? t->n_buffers : 0; }
 int snerf_trainer_tensor_count(const snerf_trainer* t) {
@@ -599,6 +639,7 @@ int snerf_trainer_forward_image(snerf_trainer* t, int64_t n_rays, int n_samples,
                                 void* stream) {
     RC(check_bound(t, n_rays, n_samples, false));
     if (!d_top || !d_bot || !d_tvals || !d_sun || !d_time || !out) return snerf_set_error(SNERF_E_INVALID, "snerf_trainer_forward_image: bad argument");
+    CtxGuard ctx(t);
     t->img_flags = flags;
     hipStream_t st = (hipStream_t)stream;
     RC(forward_pass(t, t->img, false, n_rays, n_samples, d_top, d_bot, d_tvals, d_sun, d_time, train_bn != 0, st,
@@ -628,6 +669,7 @@ int snerf_trainer_backward_image(snerf_trainer* t, const float* d_g_rgb, const f
                                  const float* d_g_pe, const float* d_rho_prior, float trust, const float* d_g_rgb_merged,
                                  const float* d_g_albedo_merged, void* stream) {
     if (!t || !t->ws) return snerf_set_error(SNERF_E_STATE, "trainer not bound");
+    CtxGuard ctx(t);
     hipStream_t st = (hipStream_t)stream;
     snerf_trainer::Pass& P = t->img;
     const int S = t->S;
@@ -648,6 +690,7 @@ int snerf_trainer_backward_image(snerf_trainer* t, const float* d_g_rgb, const f
 int snerf_trainer_backward_points(snerf_trainer* t, const float* d_g_rho, const float* d_g_col, const float* d_g_solar_vis,
                                   const float* d_g_sky, const float* d_g_classes, void* stream) {
     if (!t || !t->ws) return snerf_set_error(SNERF_E_STATE, "trainer not bound");
+    CtxGuard ctx(t);
     hipStream_t st = (hipStream_t)stream;
     snerf_trainer::Pass& P = t->img;
     const int64_t R = P.R, N = P.N;
@@ -734,6 +777,7 @@ int snerf_trainer_forward_solar(snerf_trainer* t, int64_t n_rays, int n_samples,
                                 float* d_pe, float* d_sky_raw, float* d_rho, float* d_points, float* d_delta, void* stream) {
     RC(check_bound(t, n_rays, n_samples, true));
     if (!d_top || !d_bot || !d_tvals || !d_sun) return snerf_set_error(SNERF_E_INVALID, "snerf_trainer_forward_solar: bad argument");
+    CtxGuard ctx(t);
     hipStream_t st = (hipStream_t)stream;
     snerf_trainer::Pass& P = t->sol;
     RC(forward_pass(t, P, true, n_rays, n_samples, d_top, d_bot, d_tvals, d_sun, nullptr, train_bn != 0, st));
@@ -751,6 +795,7 @@ int snerf_trainer_forward_solar(snerf_trainer* t, int64_t n_rays, int n_samples,
 
 int snerf_trainer_backward_solar(snerf_trainer* t, const float* d_g_solar_vis, void* stream) {
     if (!t || !t->ws || !d_g_solar_vis) return snerf_set_error(SNERF_E_STATE, "trainer not bound / NULL gradient");
+    CtxGuard ctx(t);
     hipStream_t st = (hipStream_t)stream;
     snerf_trainer::Pass& P = t->sol;
     const int W2 = t->W2;

@@ -64,6 +64,9 @@ struct WgradBN {
     float* dbias;              // += bias_alpha * sum_m dZ
 };
 int stream_direction(int64_t rows);      // 0 / 1, alternating per large streaming launch (gemm.hip)
+// per-thread launch context of a training pass: the trainer's wgrad partial-sum scratch and its launch parity (nullptr / 0: none)
+void gemm_launch_context(float* wgrad_partial, size_t wgrad_floats, unsigned* parity);
+size_t gemm_wgrad_partial_floats();      // floats the two-stage weight-gradient reduction needs at most (grid blocks x 8 x 8 x 1024)
 hipError_t launch_wgrad_bf16x3(float* dZ, int64_t ldz, const float* In, int64_t ldi, int64_t M, int n_out, int n_in, float alpha,
                                float* dW, int64_t ldw, hipStream_t st, const float* in_tab = nullptr, int in_cols = 0,
                                const WgradBN* bn = nullptr, int in_tab_stride = 0);      // in_tab_stride: see WgradX (0 = in_cols)

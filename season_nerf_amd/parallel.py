@@ -16,9 +16,24 @@ COLLECTIVES = collections.Counter()
 
 
 def data_parallel(group=None):
-    """True where the data-parallel exchanges run: an initialised process group - a world of ONE rank included, so that the RCCL
-    code path can be exercised on a single GPU."""
-    return dist.is_available() and dist.is_initialized()
+    """True where the data-parallel exchanges run: an initialised process group THIS rank is a member of - a world of ONE rank
+    included, so that the RCCL code path can be exercised on a single GPU (tests/test_gpu_rccl_world1.py); a rank outside
+    `group` never enters its collectives."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return group is None or dist.get_rank(group) >= 0
+
+
+def global_min(local_min, group=None):
+    """(minimum over all ranks, world size) of a small detached tensor: ONE `ReduceOp.MIN` all-reduce (RCCL, stream-ordered).
+    Used by `training.get_loss` for the `SK_Albedo` term, whose minimum the reference takes over the WHOLE batch
+    (Eval_Tools_2.py:374).  Without a process group: (local_min, 1)."""
+    if not data_parallel(group):
+        return local_min, 1
+    g = local_min.detach().clone()
+    dist.all_reduce(g, op=dist.ReduceOp.MIN, group=group)
+    COLLECTIVES["albedo_min_all_reduce"] += 1
+    return g, dist.get_world_size(group)
 
 
 def shard_bounds(n, world):

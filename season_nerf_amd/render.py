@@ -363,6 +363,20 @@ def get_imgs_from_Img_Dict_t_step(Img_Dict, out_img_size: tuple, class_vecs_arra
     return np.array([_scatter(sh[t], ij, hw, 3) for t in range(sh.shape[0])])
 
 
+def season_sweep_tile(the_network, view_el_az, sun_el_az, time_fracs, out_img_size: tuple, W2C, W2L_H, device, ray_range=None,
+                      include_exact_solar=False, render_time_frac=None):
+    """One rank's share of `render_season_sweep`: rays ray_range = (lo, hi) of the row-major H x W grid (None: all of them) through the
+    component render, the class vectors of all `time_fracs` and the sweep kernel -> [T, hi - lo, 3] on the GPU.  The tiles of
+    `parallel.shard_bounds(H * W, world)` concatenated along the ray axis ARE the whole image (tests/test_gpu_fullsize.py)."""
+    with torch.no_grad():
+        tf0 = time_fracs[0] if render_time_frac is None else render_time_frac
+        d = _render_by_dir_device(the_network, view_el_az, sun_el_az, tf0, out_img_size, W2C, W2L_H, device, include_exact_solar,
+                                  ray_range=ray_range)
+        times = _f32(np.stack([encode_time(t) for t in time_fracs]), d["Rho"].device)
+        cls = the_network.get_class_only(times)
+        return _sweep(d, cls.cpu().numpy(), "Exact_Solar" if include_exact_solar else "Est_Solar_Vis")["shaded"]
+
+
 def render_season_sweep(the_network, view_el_az, sun_el_az, time_fracs, out_img_size: tuple, W2C, W2L_H, device,
                         include_exact_solar=False, render_time_frac=None, group=None, sharded=False):
     """BASELINE config 5 in one GPU pipeline: one component render + class vectors of all `time_fracs` + sweep kernel
@@ -371,19 +385,14 @@ def render_season_sweep(the_network, view_el_az, sun_el_az, time_fracs, out_img_
     sharded=True (one process per GPU, torch.distributed initialised): every rank renders a contiguous block of the
     H*W rays and the [rays, T, 3] tiles are all-gathered over RCCL (BASELINE configs[4]); every rank gets the full sweep."""
     with torch.no_grad():
-        tf0 = time_fracs[0] if render_time_frac is None else render_time_frac
         n_total = out_img_size[0] * out_img_size[1]
         rr = None
         if sharded:
             import torch.distributed as dist
             from .parallel import shard_bounds
             rr = shard_bounds(n_total, dist.get_world_size(group))[dist.get_rank(group)]
-        d = _render_by_dir_device(the_network, view_el_az, sun_el_az, tf0, out_img_size, W2C, W2L_H, device, include_exact_solar,
-                                  ray_range=rr)
-        times = _f32(np.stack([encode_time(t) for t in time_fracs]), d["Rho"].device)
-        cls = the_network.get_class_only(times)
-        o = _sweep(d, cls.cpu().numpy(), "Exact_Solar" if include_exact_solar else "Est_Solar_Vis")
-        shaded = o["shaded"]                                                  # [T, rays(local), 3]
+        shaded = season_sweep_tile(the_network, view_el_az, sun_el_az, time_fracs, out_img_size, W2C, W2L_H, device, rr,
+                                   include_exact_solar, render_time_frac)             # [T, rays(local), 3]
         if sharded:
             from .parallel import gather_rows
             shaded = gather_rows(shaded.permute(1, 0, 2).contiguous(), n_total, group).permute(1, 0, 2).contiguous()

@@ -259,7 +259,7 @@ def _engine_of(handle):
 
 
 def _check_serial(ctx, what):
-    eng = _engine_of(ctx.trainer)
+    eng = ctx.eng
     if eng.serial[ctx.kind] != ctx.serial:
         raise RuntimeError(f"season_nerf_amd: backward of {what} pass whose engine has run another such forward since (serial {ctx.serial} -> "
                            f"{eng.serial[ctx.kind]}): the engine keeps the activations of its last forward of each kind only - one forward per "
@@ -282,7 +282,8 @@ def _register_autograd():
     def setup(ctx, inputs, output, kind="solar"):
         # the engine holds two stashes: the image-ray (or per-point) pass and the sun-ray pass - a training step runs one of each
         ctx.trainer, ctx.kind = int(inputs[0]), kind
-        ctx.serial = _engine_of(ctx.trainer).serial[kind]
+        ctx.eng = _engine_of(ctx.trainer)          # a STRONG reference: the graph keeps its engine (and the activations it holds) alive even
+        ctx.serial = ctx.eng.serial[kind]          # when other batch sizes evict it from the network's engine cache before backward()
         # no gradient travels through autograd: one None per input, a list of Nones for the parameter list (the last input)
         ctx.no_grads = (None,) * (len(inputs) - 1) + ([None] * len(inputs[-1]),)
 
@@ -428,7 +429,7 @@ def _after_train_forward(net):
         net.invalidate_packed()
 
 
-_ENGINE_CACHE = 2          # engines (workspaces) kept per network: e.g. the training batch and a validation batch
+_ENGINE_CACHE = 4          # engines (workspaces) kept per network: the training batch, a validation batch, the sibling forwards' sizes
 
 
 def _engine_for(net, R, Rs, S):
@@ -506,6 +507,25 @@ def eval_rho_only_train(ev, data_dict, net, train_mode, current_step=0):
     return {"PE": pe, "PV_Exact": pv, "Solar_Vis": sv, "Sky_Col": sky_raw.unsqueeze(1).expand(R, S, 3)}
 
 
+def albedo_min_loss(albedo, group=None):
+    """`Albedo_Color` of Eval_Tools_2.py:374-379: sum over the three channels of (1 - a / 0.2)^2 where a = min over the batch's rays of
+    the albedo < 0.2, divided by the number of rays.  The reference selects with boolean indexing (a device->host sync per step);
+    the masked sum gives the same value without leaving the stream.
+    Data parallel (an initialised process group): the reference's minimum runs over the WHOLE batch - one MIN all-reduce of 3 floats
+    (parallel.global_min).  The VALUE is the global-batch term (global minimum, global ray count); the GRADIENT travels through the
+    local minimum on the rank that owns the global one, divided by the local ray count, so that the rank average of the gradients
+    (FusedAdam / allreduce_gradients) is the global-batch gradient f'(a) / R_global."""
+    from . import parallel
+    alb_min, _ = torch.min(albedo, 0)
+    hinge = lambda a: torch.sum(torch.where(a < .2, (1. - a / .2) ** 2, torch.zeros_like(a)))
+    n_local = albedo.shape[0]
+    if not parallel.data_parallel(group):
+        return hinge(alb_min) / n_local
+    g_min, world = parallel.global_min(alb_min, group)
+    own = hinge(torch.where(alb_min.detach() == g_min, alb_min, g_min)) / n_local
+    return hinge(g_min) / (n_local * world) + (own - own.detach())
+
+
 def get_loss(ev, data_dict, net, current_step, train_mode):
     """Eval_Tools_2.py:340-459: {name: [value, weight]}; total = sum value*weight (mg_run_NeRF.py:305)."""
     args, dev = ev.args, ev.device
@@ -523,8 +543,8 @@ def get_loss(ev, data_dict, net, current_step, train_mode):
         if not args.Solar_Type_2:
             # the reference selects with boolean indexing (`SK_Albedo[SK_Albedo < .2]`, `SK_Sky[SK_Sky > 0]`, :374-388), a
             # device->host sync per step; masked sums give the same values without leaving the stream
-            alb_min, _ = torch.min(out["Albedo_Color"], 0)
-            alb_loss = torch.sum(torch.where(alb_min < .2, (1. - alb_min / .2) ** 2, torch.zeros_like(alb_min))) / out["Albedo_Color"].shape[0]
+            store = getattr(net, "_param_store", None)
+            alb_loss = albedo_min_loss(out["Albedo_Color"], store.bn_sync[0] if (store is not None and store.bn_sync is not None) else None)
             x = (out["Sky_Col"] - .5) / .5
             sk = torch.sum(torch.where(x > 0, x ** 2, torch.zeros_like(x))) / x.numel()
             if ev.use_prior:

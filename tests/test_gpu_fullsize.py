@@ -213,3 +213,45 @@ def test_training_trajectory_fused_vs_fp32(monkeypatch):
     fused, exact = run("bf16x3"), run("fp32")
     np.testing.assert_allclose(fused, exact, rtol=2e-3)
     assert fused[-1] < 0.9 * fused[0]
+
+
+def test_config4_full_size_sweep_properties():
+    """BASELINE configs[4] at its real size on one GPU: a 512 x 512 x 96 novel view + the 12-step seasonal sweep
+    (mg_Img_Eval.py:96-115 component render, :192-228 t-step sweep; `render_season_sweep`), T_NeRF(256, 4), default precision.
+    Size-independent properties: finite and inside [0, 1]; bit-reproducible run to run; the 8 ray tiles of
+    `render_season_sweep(..., sharded=True)` (parallel.shard_bounds - the blocks the ranks all-gather) concatenated ARE the whole
+    image, bit for bit; 64 rays scattered over the image against the CPU oracle's float64 restatement (1e-4 relative on the colour)."""
+    import season_nerf_amd as sn
+    sd = orc.init_weights(W, C, 0)
+    net = sn.T_NeRF(W, C)
+    net.load_state_dict(sd)
+    net = net.to("cuda").eval()
+    WC, H4 = np.array([41.29, -95.9, 300.0]), np.array([[310.0, 12.0, 0.0, -11650.0], [-9.0, 240.0, 0.0, 23390.0], [0.0, 0.0, 0.01, -3.0], [0, 0, 0, 1.0]])
+    size, view, sun = (512, 512, S), (80, 0), (30, 90)
+    taus = [k / 12.0 for k in range(12)]
+    dev = torch.device("cuda")
+    img = sn.render_season_sweep(net, view, sun, taus, size, WC, H4, dev)
+    assert tuple(img.shape) == (12, 512, 512, 3) and bool(torch.isfinite(img).all())
+    assert float(img.min()) >= 0.0 and float(img.max()) <= 1.0
+    assert float(img.std()) > 1e-3                                           # a picture, not a constant
+    again = sn.render_season_sweep(net, view, sun, taus, size, WC, H4, dev)
+    assert torch.equal(img, again)                                           # deterministic
+    n = size[0] * size[1]
+    tiles = [sn.render.season_sweep_tile(net, view, sun, taus, size, WC, H4, dev, ray_range=rr) for rr in sn.parallel.shard_bounds(n, 8)]
+    assert [t.shape[1] for t in tiles] == [n // 8] * 8
+    assert torch.equal(torch.cat(tiles, 1).reshape(12, 512, 512, 3), img)    # the all-gather layout of the sharded render
+    # scattered rays against the oracle (the grid and the ray construction restated in float64 there)
+    idx = np.arange(64) * 4099 + 17
+    g = np.stack(np.meshgrid(np.linspace(1, -1, 512), np.linspace(-1, 1, 512), indexing="ij"), -1).reshape(-1, 2)[idx]
+    g = np.concatenate([g, np.zeros((64, 1))], 1)
+    v = orc.world_angle_2_local_vec(view[0], view[1], WC, H4)
+    sunv = orc.world_angle_2_local_vec(sun[0], sun[1], WC, H4)
+    d = orc.internal_render(sd, torch.tensor(g + (v / v[2])[None]).float(), torch.tensor(g - (v / v[2])[None]).float(), sunv, taus[0], S)
+    d["Image_Points"] = np.stack([np.arange(64), np.zeros(64, dtype=int)], 1)
+    with torch.no_grad():
+        cls = orc.class_probs(sd, torch.tensor(np.stack([orc.encode_time(t) for t in taus])).float()).numpy().astype(np.float64)
+    ref = orc.images_t_step(d, (64, 1), cls)[:, :, 0]                         # [12, 64, 3]
+    got = img.reshape(12, n, 3)[:, idx].cpu().double().numpy()
+    rel = np.abs(got - ref) / np.maximum(np.abs(ref), 1e-3)
+    print(f"  512x512x96 sweep: 64 scattered rays vs oracle, max rel {rel.max():.2e}")
+    assert rel.max() < 1e-4

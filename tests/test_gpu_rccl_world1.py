@@ -32,7 +32,7 @@ def _run(extra, timeout=900):
 
 
 def test_render_tile_gather_over_rccl_world1():
-    d = _run(["--steps", "16", "--warmup", "8", "--no-cpu-baseline", "--no-sweep", "--no-train"])
+    d = _run(["--steps", "16", "--warmup", "8", "--prewarm", "0", "--no-cpu-baseline", "--no-sweep", "--no-train"])
     assert d["n_gpus"] == 1 and d["value"] > 1e7
     c = d["collectives"]
     # 8 warm-up steps = one full tile group, 16 timed steps = two: three asynchronous all-gathers
@@ -47,6 +47,7 @@ def test_training_collectives_over_rccl_world1():
     steps = 4 + 2
     for c in (cl, cg):
         assert c["grad_arena_all_reduce"] == steps and c["ada_loss_all_reduce"] == steps, c
+        assert c["albedo_min_all_reduce"] == steps, c          # the batch-wide minimum of get_loss's Albedo_Color term (Eval_Tools_2.py:374)
     assert "bn_stats_all_reduce" not in cl
     # global-batch BatchNorm: 8 BatchNorm layers x (2 passes forward + backward sums) - enabled after the engine's first step
     per_step = cg["bn_stats_all_reduce"] / (steps - 1)

@@ -477,3 +477,36 @@ def test_sibling_forwards_train_mode_gradients_vs_oracle():
             worst = max(worst, float((got - gr).abs().max()) / max(float(gr.abs().max()), 1e-3 * gmax))
         print(f"  {case}: loss {float(loss):.6f} (oracle {ref_loss:.6f}), worst relative gradient error {worst:.2e}")
         assert worst < 5e-4, (case, worst)
+
+
+def test_backward_survives_engine_eviction():
+    """a training forward, then forwards of several OTHER sizes (each makes its own engine; the network keeps a few),
+    then backward(): the autograd graph holds its engine - and the activations of its forward - alive, so the gradients are those of
+    an undisturbed forward/backward."""
+    import season_nerf_amd as sn
+    from season_nerf_amd import training
+    W, C, N = 64, 4, 1100
+    sd = orc.init_weights(W, C, 5, bn_stats="identity")
+    rng = np.random.Generator(np.random.PCG64(3))
+    X, wr = T(rng.uniform(-1, 1, (N, 3))).cuda(), T(rng.normal(size=(N, 1))).cuda()
+
+    def grads(disturb):
+        net = sn.T_NeRF(W, C)
+        net.load_state_dict(sd)
+        net = net.cuda().train()
+        loss = (net.forward_Classic_Sigma_Only(X) * wr).sum()
+        if disturb:
+            eng = net._train_engine
+            with torch.no_grad():
+                for n in range(training._ENGINE_CACHE + 1):                # more sizes than the cache holds: the first engine is evicted
+                    net.forward_Classic_Sigma_Only(X[: 300 + 64 * n])
+            assert eng not in net._train_engines.values()
+        loss.backward()
+        return float(loss), {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
+
+    l0, g0 = grads(False)
+    l1, g1 = grads(True)
+    assert l0 == l1
+    gmax = max(float(v.abs().max()) for v in g0.values())
+    for k, v in g0.items():
+        assert float((v - g1[k]).abs().max()) <= 1e-5 * max(float(v.abs().max()), 1e-3 * gmax), k

@@ -249,6 +249,36 @@ def test_eval_on_trained_like_weights(golden_dir, tag):
     close(loc, g["eval_surf_loc"], **loose); close(dist, g["eval_surf_dist"], **loose)
 
 
+def trained_state_dict(g):
+    """The state_dict a `trained_W*.npz` fixture carries (the reference's own arrays after its own training loop)."""
+    return {k[3:]: torch.tensor(v) for k, v in g.items() if k.startswith("sd_")}
+
+
+@pytest.mark.parametrize("W", [64, 256])
+def test_eval_on_really_trained_weights(golden_dir, W):
+    """Weights nobody designed: the reference's own loop (get_loss -> backward -> Adam -> OneCycleLR, mg_run_NeRF.py:288-326, Net_Tool_2.py:111-130)
+    ran for hundreds of steps on a synthetic scene (tools/make_trained_golden.py); the fixture holds the resulting state_dict and the
+    reference's eval of held-out rays (Eval_Tools_2.py:165-252).  The oracle follows it as on the init law."""
+    g = load(golden_dir, f"trained_W{W}.npz")
+    assert int(g["n_steps"]) >= 300
+    traj = g["loss_trajectory"]
+    assert traj[-20:, 1].mean() < 0.5 * traj[:20, 1].mean()              # it did train: the colour loss fell by more than half
+    sd = trained_state_dict(g)
+    init = orc.init_weights(W, int(g["C"]), 40)
+    moved = max(float((sd[k] - init[k]).abs().max() / init[k].abs().max()) for k in sd if k.endswith("linear.weight"))
+    assert moved > 0.3                                                     # and the weights left the init law
+    with torch.no_grad():
+        r = orc.eval_rays(sd, rays_of(g), int(g["S"]), train_mode=False)
+    loose = dict(rtol=1e-4, atol=5e-5)
+    close(r["Rendered_Col"], g["eval_Rendered_Col"], **loose)
+    close(r["Albedo_Color"], g["eval_Albedo_Color"], **loose)
+    close(r["Rho"], g["eval_Rho"], rtol=3e-4, atol=1e-4)
+    close(r["Solar_Vis"], g["eval_Solar_Vis"], **loose)
+    close(r["Col"], g["eval_Col"], **loose)
+    loc, dist = orc.surface_depth(r["PS"], r["sample_pts"], r["deltas"])
+    close(loc, g["eval_surf_loc"], **loose); close(dist, g["eval_surf_dist"], **loose)
+
+
 def test_eval_at_the_benchmark_size(golden_dir):
     """BASELINE configs[1] through the reference at full size (4096 rays x 96 samples, W = 256): per-ray results of all rays, the
     per-sample fields of every 64th."""

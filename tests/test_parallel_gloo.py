@@ -162,3 +162,45 @@ def test_adaptive_loss_parameters_stay_identical_across_ranks():
     optimise different objectives.  Net_tool.train_step calls `_allreduce_mean_grads` before `optim2.step()`."""
     port = 29500 + (os.getpid() + 77) % 2000
     mp.spawn(_ada_worker, args=(2, port), nprocs=2, join=True)
+
+
+def _albedo_worker(rank, world, port):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    spec = importlib.util.spec_from_file_location("season_nerf_amd", os.path.join(REPO, "season_nerf_amd", "__init__.py"),
+                                                  submodule_search_locations=[os.path.join(REPO, "season_nerf_amd")])
+    import sys
+    pkg = importlib.util.module_from_spec(spec)
+    sys.modules["season_nerf_amd"] = pkg
+    spec.loader.exec_module(pkg)
+    from season_nerf_amd.training import albedo_min_loss
+    from season_nerf_amd import parallel
+    g = torch.Generator().manual_seed(5)
+    full = 0.25 + torch.rand(16, 3, generator=g) * 0.5
+    full[3, 0], full[12, 1] = 0.05, 0.02                              # minima on rank 0 and on rank 1; the third channel stays above the hinge
+    n = full.shape[0] // world
+    before = parallel.COLLECTIVES["albedo_min_all_reduce"]
+    # the single-process reference: minimum over the whole batch, divided by the whole batch's ray count (Eval_Tools_2.py:374-379)
+    ref_in = full.clone().requires_grad_(True)
+    a = ref_in.min(0)[0]
+    ref = torch.sum(torch.where(a < .2, (1 - a / .2) ** 2, torch.zeros_like(a))) / full.shape[0]
+    ref.backward()
+    mine = full[rank * n:(rank + 1) * n].clone().requires_grad_(True)
+    loss = albedo_min_loss(mine)
+    loss.backward()
+    assert parallel.COLLECTIVES["albedo_min_all_reduce"] == before + 1
+    assert torch.allclose(loss.detach(), ref.detach(), rtol=1e-6), (loss, ref)          # every rank reports the global-batch value
+    grads = [torch.zeros_like(mine.grad) for _ in range(world)]
+    dist.all_gather(grads, mine.grad)
+    avg = torch.cat(grads) / world                                                       # what the gradient all-reduce (mean) leaves
+    assert torch.allclose(avg, ref_in.grad, rtol=1e-6, atol=1e-9), (avg, ref_in.grad)
+    assert float(ref_in.grad.abs().sum()) > 0
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_albedo_minimum_is_taken_over_the_global_batch():
+    """`Albedo_Color` (Eval_Tools_2.py:374-379) takes its minimum over the whole batch; under data parallelism that is
+    one MIN all-reduce of 3 floats, the global ray count in the denominator, and the gradient on the rank that owns the minimum."""
+    port = 29500 + (os.getpid() + 1277) % 2000
+    mp.spawn(_albedo_worker, args=(2, port), nprocs=2, join=True)
