@@ -278,12 +278,14 @@ def bench_train(a, standalone=True):
     # the reference's optimisation step as the training seam runs it (trainer.Net_tool.train_step = mg_run_NeRF.py:288-326):
     # FusedAdam (all-reduces the flat gradient arena under data parallelism) + a second Adam on the loss object's parameters
     # (their gradients travel as one small all-reduce) + OneCycleLR on both
-    tool = sn.Net_tool(net, ev, 10 ** -4.86, total_steps=steps + warm + 1, lr_alpha_scale=1000.0, writer=None)
+    tool = sn.Net_tool(net, ev, 10 ** -4.86, total_steps=steps + warm + 8, lr_alpha_scale=1000.0, writer=None)
     np.random.seed(rank)
     torch.manual_seed(rank)
 
     def step():
-        loss = tool.train_step(d, 0)
+        return tool.train_step(d, 0)           # the loss dict; its total is formed once, after the timed region
+
+    def total_of(loss):
         return sum(v.detach() * w for v, w in loss.values())
 
     step()                                   # builds the engine
@@ -374,7 +376,7 @@ def bench_train(a, standalone=True):
                                       + ("" if Wt == 256 else " - at the reference's default width (main_lite.py:80), not the BASELINE config"),
                           "parallelism": f"rays sharded over {world} GPU(s), one all-reduce of the flat gradient arena, BatchNorm statistics "
                                          + ("over the global batch (all-reduced)" if a.bn_sync == "global" and use_dist else "per rank")},
-               "final_loss": float(tot.detach()), "step_ms_median": per_step[len(per_step) // 2], "step_ms_min": per_step[0], "host_enqueue_ms_per_step": host_ms, "host_loop_ms_per_step": host_loop_ms,
+               "final_loss": float(total_of(tot)), "step_ms_median": per_step[len(per_step) // 2], "step_ms_min": per_step[0], "host_enqueue_ms_per_step": host_ms, "host_loop_ms_per_step": host_loop_ms,
                "host_note": "host_enqueue = wall time to enqueue one step onto an idle GPU (median of 6; the host's own cost); host_loop = the timed "
                             "loop's enqueue time per step (contains waits for the GPU once the host is ~5 steps ahead)",
                "collectives": dict(sn.parallel.COLLECTIVES) if use_dist else None,

@@ -280,6 +280,22 @@ int snerf_linear_wgrad(int64_t n_points, int n_in, int n_out, const float* d_gra
 int snerf_trainer_debug_read(snerf_trainer* t, const char* name, float* host_out, int64_t n_floats);
 /* torch.optim.Adam semantics (no weight decay) over the whole parameter arena in one launch; step counts from 1. */
 int snerf_trainer_adam_step(snerf_trainer* t, float lr, float beta1, float beta2, float eps, int step, void* stream);
+/* ---- the scalar loss terms of a training step: All_in_One_Eval.get_loss, Eval_Tools_2.py:340-420, in the default training configuration (MSE colour
+ * loss :413, solar rays on :350-372, default solar model, no DSM prior).  forward: d_vals5 = [Solar_Correction (:361), Solar_Correction_2 (:366,
+ * a value only: detached in this configuration), Sky_Color_Var (:381-388), Albedo_Color (:374-379), Color (:413)], d_min3 = the per-channel albedo
+ * minimum the Albedo_Color term used.  d_sky is the per-ray sky colour [R,3] (the reference's [R,S,3] tensor holds S copies of it).
+ * d_albedo_min_global (optional, [3]) + world: data-parallel training - the minimum over the global batch (one MIN all-reduce by the caller), the
+ * value divided by n_rays * world.  backward: from dL/d(vals5) to dL/dRendered_Col, dL/dAlbedo_Color, dL/dSky_Col [R,3] and dL/dSolar_Vis [Rs,S]
+ * (what snerf_trainer_backward_image / _solar take).  d_scratch: snerf_loss_scratch_bytes() bytes, initialised ONCE by snerf_loss_scratch_init (the
+ * forward leaves it initialised). */
+size_t snerf_loss_scratch_bytes(void);
+int snerf_loss_scratch_init(void* d_scratch, void* stream);
+int snerf_loss_terms_forward(int64_t n_rays, int64_t n_solar_rays, int n_samples, const float* d_rgb, const float* d_gt, const float* d_albedo,
+                             const float* d_sky, const float* d_solar_vis, const float* d_pv_exact, const float* d_pe, const float* d_albedo_min_global,
+                             int world, void* d_scratch, float* d_vals5, float* d_min3, void* stream);
+int snerf_loss_terms_backward(int64_t n_rays, int64_t n_solar_rays, int n_samples, const float* d_rgb, const float* d_gt, const float* d_albedo,
+                              const float* d_sky, const float* d_solar_vis, const float* d_pv_exact, const float* d_min3, int world, const float* d_g_vals5,
+                              float* d_g_rgb, float* d_g_albedo, float* d_g_sky, float* d_g_solar_vis, void* stream);
 /* the same update (torch.optim.Adam, mg_run_NeRF.py:312-320) on caller-owned flat arenas of n floats */
 int snerf_adam_step(float* d_params, const float* d_grads, float* d_m, float* d_v, int64_t n, float lr, float beta1, float beta2,
                     float eps, int step, void* stream);
@@ -291,6 +307,18 @@ int snerf_adam_step(float* d_params, const float* d_grads, float* d_m, float* d_
  * columns (mg_run_NeRF.py:122-133; sun, time, weight, colour are per-image constants / image data) - and
  * d_valid [rows*cols] = 1 where Top and Bot lie inside [-1,1]^2 (the reference drops the others). */
 int snerf_rays_from_camera(const double* P_3x4, int rows, int cols, int downscale, float* d_rows, uint8_t* d_valid, void* stream);
+
+/* ---- novel-view ray grids on the GPU (the float64 numpy arithmetic of the reference, rounded to fp32 at its casts: bit-identical rays).
+ * mode 0: component_render_by_dir (T_NeRF_Eval_Utils/mg_Img_Eval.py:96-115): grid rows linspace(1,-1,rows) (cube x), columns linspace(-1,1,cols)
+ *         (cube y), z = 0; Top = grid + q, Bot = grid - q with params = q = v / v_z (3 doubles); no culling (d_valid: all 1).
+ * mode 1: Quick_Run_Net._get_input_dict (T_NeRF_Full_2/Quick_Run.py:77-109): mids = XY * 2 / (size - 1) - 1 [remapped onto params[3..6] = region
+ *         (x0, x1, y0, y1) when n_params == 7], Top / Bot = mids +- q; d_valid = 1 where Top and Bot lie in [-1,1]^3 (:95).
+ * mode 2: component_render_by_P (mg_Img_Eval.py:74-94): params = 3x4 camera (12, row-major) + source image rows, cols; output pixel (r, c) looks at
+ *         source pixel round(linspace(0, img - 1, out)) (d_pixels [n, 2], optional), rays by invert_P (pre_NeRF/P_Img.py:133-147) at h = +1 / -1,
+ *         d_valid = 1 where both ends lie in [-1,1]^2 (:84-85).
+ * Rays lo .. hi-1 of the row-major rows x cols grid (a rank's tile of a sharded render); params: HOST pointer; d_top / d_bot [hi - lo, 3]. */
+int snerf_ray_grid(int mode, int rows, int cols, int64_t lo, int64_t hi, const double* params, int n_params, float* d_top, float* d_bot, uint8_t* d_valid,
+                   int32_t* d_pixels, void* stream);
 
 /* ---- DSM prior and validation helpers: the gathers the reference runs on the CPU between passes.
  * snerf_prior_density = T_NeRF.Supervised_Sample (T_NeRF_net_v2.py:175-181): rho = -log(1 - min(HM[ix,iy] >= z, .99)) / delta

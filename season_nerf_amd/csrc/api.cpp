@@ -492,6 +492,26 @@ int snerf_rays_from_camera(const double* P_3x4, int rows, int cols, int downscal
     return e == hipSuccess ? SNERF_OK : fail_hip(e, "ray generation kernel launch");
 }
 
+int snerf_ray_grid(int mode, int rows, int cols, int64_t lo, int64_t hi, const double* params, int n_params, float* d_top, float* d_bot, uint8_t* d_valid,
+                   int32_t* d_pixels, void* stream) {
+    if (mode < 0 || mode > 2 || rows < 1 || cols < 1 || lo < 0 || hi < lo || hi > (int64_t)rows * cols || !params || (hi > lo && (!d_top || !d_bot)))
+        return fail(SNERF_E_INVALID, "snerf_ray_grid: bad argument");
+    RayGridArgs a{};
+    a.mode = mode; a.rows = rows; a.cols = cols; a.lo = lo; a.hi = hi; a.top = d_top; a.bot = d_bot; a.valid = d_valid; a.pix = d_pixels;
+    if (mode == 2) {
+        if (n_params != 14 || params[12] < 1 || params[13] < 1) return fail(SNERF_E_INVALID, "snerf_ray_grid: mode 2 takes the 12 camera entries + image rows, cols");
+        for (int i = 0; i < 12; ++i) a.P[i] = params[i];
+        a.img_rows = (int)params[12]; a.img_cols = (int)params[13];
+    } else {
+        if (n_params != 3 && !(mode == 1 && n_params == 7)) return fail(SNERF_E_INVALID, "snerf_ray_grid: modes 0 / 1 take the view vector / v_z (3 doubles) [+ region (4)]");
+        for (int i = 0; i < 3; ++i) a.q[i] = params[i];
+        a.has_region = n_params == 7;
+        for (int i = 0; i < 4 && a.has_region; ++i) a.region[i] = params[3 + i];
+    }
+    hipError_t e = launch_ray_grid(a, (hipStream_t)stream);
+    return e == hipSuccess ? SNERF_OK : fail_hip(e, "ray grid kernel launch");
+}
+
 int snerf_prior_density(int64_t n_points, const float* d_points, const float* d_delta, const double* d_height_map, int hm_rows, int hm_cols,
                         const float* d_outside, float* d_rho_prior, void* stream) {
     if (n_points < 0) return fail(SNERF_E_INVALID, "snerf_prior_density: negative point count");

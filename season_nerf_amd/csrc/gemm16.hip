@@ -443,6 +443,13 @@ hipError_t launch_split_weights16(const float* W, int rows, int cols, bool trans
 }
 
 
+// The register-resident-weight row GEMM of round 3 (measured: no gain over gemm_rows16_kernel) is an EXPERIMENT, not product code:
+// it is compiled only with -DSNERF_WITH_WREG=1 (tools/variants.py builds such a library; SNERF_GEMM_WREG=1 then routes the eligible shapes to it,
+// tools/compare_gemm_paths.py with SNERF_CMP_WREG=1 compares it bit for bit).  The shipped library does not contain it.
+#ifndef SNERF_WITH_WREG
+#define SNERF_WITH_WREG 0
+#endif
+#if SNERF_WITH_WREG
 // ---------------------------------------------------------------------------------------------------------------------
 // Row GEMM with the WEIGHTS IN REGISTERS and the activations shared through LDS.
 // What bounds gemm_rows16_kernel (and its 32x32x16 predecessor) is the vector-memory path of the CU, ~16 B per clock
@@ -734,6 +741,8 @@ bool gemm_wreg_ok(const GemmX& gx) {
     return mode && gx.W && KS32 == 8 && gx.ksteps == 16 && (gx.N == 256 || gx.N == 128) && gx.N == (int64_t)gx.n_tiles * 32;
 }
 
+#endif      // SNERF_WITH_WREG
+
 // gx: as launch_gemm_bf16x3 prepared it for the full-tile path (raw weights in gx.W, K in whole 32-k steps, N = 32 n_tiles)
 hipError_t launch_gemm_rows16(const GemmX& gx_in, int aol_mode, int act_mode, dim3 grid, size_t lds, hipStream_t st) {
     GemmX gx = gx_in;
@@ -741,9 +750,11 @@ hipError_t launch_gemm_rows16(const GemmX& gx_in, int aol_mode, int act_mode, di
     const int KS32 = gx.ksteps / 2;
     hipError_t e = launch_split_weights16(gx.W, gx.w_rows, gx.w_cols, gx.w_transpose != 0, const_cast<uint16_t*>(gx.frag), 2 * gx.n_tiles, KS32, st);
     if (e != hipSuccess) return e;
+#if SNERF_WITH_WREG
     if (gemm_wreg_ok(gx)) {      // weights in registers, activations through LDS: each A byte crosses the memory path once
         return gx.N == 256 ? launch_wreg<2, 8>(gx, aol_mode, act_mode, st) : launch_wreg<1, 8>(gx, aol_mode, act_mode, st);
     }
+#endif
     // 32-k steps of A in flight: 4 with activation on load (244 registers, no scratch), 2 otherwise (the plain form spills at 4,
     // the activation-backward epilogue needs the registers); must divide the k-step count
     int pf16 = (aol_mode && !act_mode && KS32 % 4 == 0) ? 4 : (KS32 % 2 == 0 ? 2 : 1);

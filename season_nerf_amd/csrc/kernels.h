@@ -63,6 +63,22 @@ struct RayGenArgs {
 };
 hipError_t launch_rays_from_camera(const RayGenArgs& a, hipStream_t st);
 
+// novel-view ray grids (float64 arithmetic as the reference's numpy, rounded to fp32 at the end)
+struct RayGridArgs {
+    int mode;              // 0: by direction (mg_Img_Eval.py:96-115), 1: Quick_Run (Quick_Run.py:77-109), 2: through a 3x4 camera (mg_Img_Eval.py:74-94)
+    int rows, cols;        // the output grid H x W
+    int64_t lo, hi;        // rays lo .. hi-1 of the row-major grid
+    double q[3];           // modes 0, 1: view vector / its z component
+    int has_region;        // mode 1
+    double region[4];
+    double P[12];          // mode 2
+    int img_rows, img_cols;
+    float *top, *bot;      // [hi - lo, 3]
+    uint8_t* valid;        // [hi - lo] or NULL
+    int32_t* pix;          // mode 2, optional: [hi - lo, 2] source pixel (row, col)
+};
+hipError_t launch_ray_grid(const RayGridArgs& a, hipStream_t st);
+
 struct SweepArgs {
     int64_t n_rays;
     int n_samples, n_classes, n_times, flags;

@@ -691,6 +691,76 @@ hipError_t launch_rays_from_camera(const RayGenArgs& a, hipStream_t st) {
 }
 
 // =====================================================================================================
+// Novel-view ray grids on the device, in the float64 arithmetic of the reference's numpy (one rounding per operation, no contraction: the
+// library is built with -ffp-contract=off), rounded to fp32 where the reference casts: bit-identical rays.
+// numpy.linspace(start, stop, num)[i] = i * ((stop - start) / (num - 1)) + start, last element = stop exactly, num == 1 -> start.
+__device__ inline double linspace_at(double start, double stop, int num, int i) {
+    if (num <= 1) return start;
+    if (i == num - 1) return stop;
+    const double step = (stop - start) / (double)(num - 1);
+    return (double)i * step + start;
+}
+__global__ void ray_grid_kernel(const RayGridArgs A) {
+    const int64_t n = A.hi - A.lo;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = A.lo + t;
+        const int r = (int)(i / A.cols), c = (int)(i - (int64_t)r * A.cols);
+        double tx, ty, tz, bx, by, bz;
+        bool good = true;
+        if (A.mode == 2) {
+            // mg_Img_Eval.py:77-84: source pixel = round(linspace(0, img - 1, out)) (half to even, as numpy.round), rays by invert_P at h = +1 / -1
+            const double row = rint(linspace_at(0.0, (double)(A.img_rows - 1), A.rows, r)), col = rint(linspace_at(0.0, (double)(A.img_cols - 1), A.cols, c));
+            const double* P = A.P;
+            const double a11 = P[0] - P[8] * row, a12 = P[1] - P[9] * row, a21 = P[4] - P[8] * col, a22 = P[5] - P[9] * col;
+            const double den = a11 * a22 - a12 * a21;
+            double xy[2][2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const double hgt = k == 0 ? 1.0 : -1.0;
+                const double c2 = P[6] * hgt + P[7] - P[10] * hgt * col - P[11] * col;
+                const double c1 = P[2] * hgt + P[3] - P[10] * hgt * row - P[11] * row;
+                xy[k][0] = (a12 * c2 - a22 * c1) / den;
+                xy[k][1] = (-a11 * c2 + a21 * c1) / den;
+            }
+            tx = xy[0][0]; ty = xy[0][1]; tz = 1.0; bx = xy[1][0]; by = xy[1][1]; bz = -1.0;
+            good = tx >= -1.0 && ty <= 1.0 && bx >= -1.0 && by <= 1.0 && ty >= -1.0 && tx <= 1.0 && by >= -1.0 && bx <= 1.0;
+            if (A.pix) { A.pix[t * 2] = (int32_t)row; A.pix[t * 2 + 1] = (int32_t)col; }
+        } else {
+            double gx, gy;
+            if (A.mode == 0) {               // mg_Img_Eval.py:99-101: rows linspace(1, -1, H) (cube x), columns linspace(-1, 1, W) (cube y), z = 0
+                gx = linspace_at(1.0, -1.0, A.rows, r);
+                gy = linspace_at(-1.0, 1.0, A.cols, c);
+            } else {                         // Quick_Run.py:82-90: XY * 2. / (size - 1) - 1, optional affine remap onto a region
+                gx = ((double)r * 2.0) / (double)(A.rows - 1) - 1.0;
+                gy = ((double)c * 2.0) / (double)(A.cols - 1) - 1.0;
+                if (A.has_region) {
+                    gx = (gx + 1.0) / 2.0 * (A.region[1] - A.region[0]) + A.region[0];
+                    gy = (gy + 1.0) / 2.0 * (A.region[3] - A.region[2]) + A.region[2];
+                }
+            }
+            tx = gx + A.q[0]; ty = gy + A.q[1]; tz = 0.0 + A.q[2];
+            bx = gx - A.q[0]; by = gy - A.q[1]; bz = 0.0 - A.q[2];
+            if (A.mode == 1)                 // Quick_Run.py:95: keep rays whose tops AND bots lie in [-1, 1]^3
+                good = bx <= 1.0 && bx >= -1.0 && by <= 1.0 && by >= -1.0 && bz <= 1.0 && bz >= -1.0 &&
+                       tx <= 1.0 && tx >= -1.0 && ty <= 1.0 && ty >= -1.0 && tz <= 1.0 && tz >= -1.0;
+        }
+        float* o = A.top + t * 3;
+        o[0] = (float)tx; o[1] = (float)ty; o[2] = (float)tz;
+        o = A.bot + t * 3;
+        o[0] = (float)bx; o[1] = (float)by; o[2] = (float)bz;
+        if (A.valid) A.valid[t] = good ? 1 : 0;
+    }
+}
+hipError_t launch_ray_grid(const RayGridArgs& a, hipStream_t st) {
+    const int64_t n = a.hi - a.lo;
+    if (n <= 0) return hipSuccess;
+    int64_t b = (n + 255) / 256;
+    if (b > 65536) b = 65536;
+    hipLaunchKernelGGL(ray_grid_kernel, dim3((unsigned)b), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+// =====================================================================================================
 // launchers
 template <int PROG, int W, int VARIANT, bool FAST = false>
 static hipError_t launch_mlp_t(const MlpArgs& a, int n_cu, hipStream_t st) {

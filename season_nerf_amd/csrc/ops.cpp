@@ -36,6 +36,8 @@
 
 #include <string>
 #include <tuple>
+#include <map>
+#include <mutex>
 #include <vector>
 
 #include "../../include/season_nerf_hip.h"
@@ -398,6 +400,53 @@ void train_bwd_solar(int64_t trainer, Tensor grads, const Tensor& g_sv) {
     ck(snerf_trainer_backward_solar(t, fptr(g_sv), cur_stream(grads)), "train_bwd_solar");
 }
 
+// the self-cleaning reduction scratch of loss_terms: one per device, created (and initialised, in stream order) at first use; launches of one
+// device are serialised by their stream, and the forward leaves the scratch in its initial state
+static Tensor loss_scratch(const Tensor& like) {
+    static std::mutex mu;
+    static auto* per_device = new std::map<int, Tensor>();      // leaked on purpose: no tensor destructor after the HIP runtime has shut down
+    std::lock_guard<std::mutex> lock(mu);
+    Tensor& s = (*per_device)[like.get_device()];
+    if (!s.defined()) {
+        s = at::empty({(int64_t)snerf_loss_scratch_bytes()}, like.options().dtype(at::kByte));
+        ck(snerf_loss_scratch_init(s.data_ptr(), cur_stream(like)), "loss_scratch");
+    }
+    return s;
+}
+
+// ---- scalar loss terms of a training step (get_loss, Eval_Tools_2.py:340-420, default configuration) ---------------------------------
+// loss_terms(rgb, gt, albedo, sky, solar_vis, pv_exact, pe, albedo_min_global?, world) -> (vals[5], min[3]);  loss_terms_bwd: the gradients
+std::tuple<Tensor, Tensor> loss_terms(const Tensor& rgb, const Tensor& gt, const Tensor& albedo, const Tensor& sky, const Tensor& sv, const Tensor& pv,
+                                      const Tensor& pe, const c10::optional<Tensor>& alb_min_global, int64_t world) {
+    check_shape(rgb, "rgb", -1, 3);
+    const int64_t R = rgb.size(0);
+    check_shape(gt, "gt", R, 3); check_shape(albedo, "albedo", R, 3); check_shape(sky, "sky", R, 3);
+    check_dev_f32(sv, "solar_vis"); check_dev_f32(pv, "pv_exact"); check_dev_f32(pe, "pe");
+    TORCH_CHECK(sv.dim() >= 2 && pv.numel() == sv.numel() && pe.numel() == sv.numel(), "solar_vis, pv_exact and pe must be [Rs, S(, 1)] tensors of one size");
+    const int64_t Rs = sv.size(0), S = sv.numel() / Rs;
+    TORCH_CHECK(world >= 1, "world must be >= 1");
+    c10::hip::HIPGuardMasqueradingAsCUDA g(rgb.device());
+    Tensor scratch = loss_scratch(rgb);
+    Tensor vals = at::empty({5}, rgb.options()), minv = at::empty({3}, rgb.options());
+    ck(snerf_loss_terms_forward(R, Rs, (int)S, fptr(rgb), fptr(gt), fptr(albedo), fptr(sky), fptr(sv), fptr(pv), fptr(pe), optptr(alb_min_global, "albedo_min_global", 3),
+                                (int)world, scratch.data_ptr(), mptr(vals), mptr(minv), cur_stream(rgb)), "loss_terms");
+    return {vals, minv};
+}
+std::tuple<Tensor, Tensor, Tensor, Tensor> loss_terms_bwd(const Tensor& g_vals, const Tensor& rgb, const Tensor& gt, const Tensor& albedo, const Tensor& sky,
+                                                          const Tensor& sv, const Tensor& pv, const Tensor& minv, int64_t world) {
+    check_shape(rgb, "rgb", -1, 3);
+    const int64_t R = rgb.size(0);
+    check_shape(gt, "gt", R, 3); check_shape(albedo, "albedo", R, 3); check_shape(sky, "sky", R, 3);
+    check_dev_f32(sv, "solar_vis"); check_dev_f32(pv, "pv_exact"); check_dev_f32(g_vals, "g_vals"); check_dev_f32(minv, "min");
+    TORCH_CHECK(g_vals.numel() == 5 && minv.numel() == 3 && pv.numel() == sv.numel() && sv.dim() >= 2, "g_vals [5], min [3], pv_exact like solar_vis");
+    const int64_t Rs = sv.size(0), S = sv.numel() / Rs;
+    c10::hip::HIPGuardMasqueradingAsCUDA g(rgb.device());
+    Tensor d_rgb = at::empty_like(rgb), d_alb = at::empty_like(albedo), d_sky = at::empty_like(sky), d_sv = at::empty_like(sv);
+    ck(snerf_loss_terms_backward(R, Rs, (int)S, fptr(rgb), fptr(gt), fptr(albedo), fptr(sky), fptr(sv), fptr(pv), fptr(minv), (int)world, fptr(g_vals),
+                                 mptr(d_rgb), mptr(d_alb), mptr(d_sky), mptr(d_sv), cur_stream(rgb)), "loss_terms_bwd");
+    return {d_rgb, d_alb, d_sky, d_sv};
+}
+
 }  // namespace
 
 TORCH_LIBRARY(season_nerf, m) {
@@ -422,6 +471,10 @@ TORCH_LIBRARY(season_nerf, m) {
           "int flags, bool classic) -> Tensor[]");
     m.def("fused_adam_(Tensor(a!) param, Tensor grad, Tensor(b!) m, Tensor(c!) v, float lr, float beta1, float beta2, float eps, int step) -> ()");
     m.def("prior_density(Tensor pts, Tensor delta, Tensor height_map, Tensor? outside) -> Tensor");
+    m.def("loss_terms(Tensor rgb, Tensor gt, Tensor albedo, Tensor sky, Tensor solar_vis, Tensor pv_exact, Tensor pe, Tensor? albedo_min_global, int world) "
+          "-> (Tensor, Tensor)");
+    m.def("loss_terms_bwd(Tensor g_vals, Tensor rgb, Tensor gt, Tensor albedo, Tensor sky, Tensor solar_vis, Tensor pv_exact, Tensor min, int world) "
+          "-> (Tensor, Tensor, Tensor, Tensor)");
     m.def("train_fwd_image(int trainer, Tensor top, Tensor bot, Tensor tvals, Tensor sun, Tensor time, bool train_bn, bool classic, int n_classes, "
           "Tensor? height_map, float trust, Tensor[] params) -> Tensor[]");
     m.def("train_bwd_image(int trainer, Tensor(a!) grads, Tensor? g_rgb, Tensor? g_albedo, Tensor? g_sky, Tensor? g_pe, Tensor? rho_prior, float trust, "
@@ -439,6 +492,8 @@ TORCH_LIBRARY_IMPL(season_nerf, CUDA, m) {      // "CUDA" is the dispatch key of
     m.impl("render_fwd", render_fwd);
     m.impl("composite", composite);
     m.impl("composite_sweep", composite_sweep);
+    m.impl("loss_terms", loss_terms);
+    m.impl("loss_terms_bwd", loss_terms_bwd);
     m.impl("fused_adam_", fused_adam_);
     m.impl("prior_density", prior_density);
     m.impl("train_fwd_image", train_fwd_image);

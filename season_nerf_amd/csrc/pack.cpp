@@ -352,10 +352,14 @@ bool estimate_i8(const Weights& w, int W, int C, I8Estimate* out, std::string* e
     // What an error of a raw head output does to the rendered colour, relative (Eval_Tools_2.py:187-215): the density enters through
     // the transmittance weights PS (and alone sets the depth), colour and seasonal adjustment through a sigmoid (slope <= 1/4) averaged
     // over the samples of a ray, the solar visibility through the shading term.  (The per-ray networks - class softmax, sky colour -
-    // never run in int8 digits: their error would not average over a ray's samples.)  Weights fitted
-    // with tools/calibrate_i8_bound.py so that the sum is ~2x the worst relative colour error over a batch of rays (W = 64 ... 512,
-    // init-law, outlier, heavy-tailed and high-gain weight sets).
-    out->rgb_pred = 0.35 * out->head_rms[0] + 0.15 * out->head_rms[1] + 0.20 * out->head_rms[3] + 0.10 * out->head_rms[2];
+    // never run in int8 digits: their error would not average over a ray's samples.)  Weights: round 3 fitted 0.35 / 0.15 / 0.20 / 0.10 on
+    // synthetic weight families (tools/calibrate_i8_bound.py: init law, outliers, heavy tails, gains: prediction ~2x the worst observed error).
+    // Round 4 measured REALLY TRAINED weights - the reference's own loop, 400-600 steps (tests/golden/trained_W*.npz, tools/trained_modes.py on
+    // the GPU against the reference's eval): per unit of predicted head error they render 3-4x worse than the synthetic families (observed
+    // 3.5-3.7e-5 against a prediction of 1.8-2.4e-5), so the weights are scaled x2.3: the prediction now covers every measured set with >= 15 %
+    // to spare (trained W = 256: 4.0e-5 predicted / 3.5e-5 observed; init law 5.1e-5 / 1.4e-5; x4-outlier and Laplace families 1.7-1.9e-4 /
+    // 3.1-5.8e-5 - those now go to bf16x3: the guard errs on the safe side for weights unlike anything training produced here).
+    out->rgb_pred = 0.80 * out->head_rms[0] + 0.35 * out->head_rms[1] + 0.46 * out->head_rms[3] + 0.23 * out->head_rms[2];
     return true;
 }
 

@@ -943,6 +943,41 @@ int snerf_trainer_adam_step(snerf_trainer* t, float lr, float beta1, float beta2
     return SNERF_OK;
 }
 
+/* The scalar terms of All_in_One_Eval.get_loss (Eval_Tools_2.py:340-420) for the default training configuration - MSE colour loss, solar rays
+ * on, default solar model, no DSM prior - in two launches, and their gradients in one (see include/season_nerf_hip.h). */
+size_t snerf_loss_scratch_bytes(void) { return 4 * sizeof(double) + 4 * sizeof(unsigned); }
+int snerf_loss_scratch_init(void* d_scratch, void* stream) {
+    if (!d_scratch) return snerf_set_error(SNERF_E_INVALID, "snerf_loss_scratch_init: NULL scratch");
+    HIPCK(launch_loss_scratch_init(d_scratch, (hipStream_t)stream));
+    return SNERF_OK;
+}
+static int loss_args(LossArgs* a, int64_t n_rays, int64_t n_solar_rays, int n_samples, const float* d_rgb, const float* d_gt, const float* d_albedo,
+                     const float* d_sky, const float* d_solar_vis, const float* d_pv_exact, const float* d_pe, const float* d_albedo_min_global, int world) {
+    if (n_rays < 1 || n_solar_rays < 1 || n_samples < 1 || world < 1 || !d_rgb || !d_gt || !d_albedo || !d_sky || !d_solar_vis || !d_pv_exact)
+        return snerf_set_error(SNERF_E_INVALID, "snerf_loss_terms: bad argument");
+    *a = LossArgs{n_rays, n_solar_rays, n_samples, d_rgb, d_gt, d_albedo, d_sky, d_solar_vis, d_pv_exact, d_pe, d_albedo_min_global, d_albedo_min_global ? world : 1};
+    return SNERF_OK;
+}
+int snerf_loss_terms_forward(int64_t n_rays, int64_t n_solar_rays, int n_samples, const float* d_rgb, const float* d_gt, const float* d_albedo,
+                             const float* d_sky, const float* d_solar_vis, const float* d_pv_exact, const float* d_pe, const float* d_albedo_min_global,
+                             int world, void* d_scratch, float* d_vals5, float* d_min3, void* stream) {
+    LossArgs a;
+    RC(loss_args(&a, n_rays, n_solar_rays, n_samples, d_rgb, d_gt, d_albedo, d_sky, d_solar_vis, d_pv_exact, d_pe, d_albedo_min_global, world));
+    if (!d_pe || !d_scratch || !d_vals5 || !d_min3) return snerf_set_error(SNERF_E_INVALID, "snerf_loss_terms_forward: bad argument");
+    HIPCK(launch_loss_terms(a, d_scratch, d_vals5, d_min3, (hipStream_t)stream));
+    return SNERF_OK;
+}
+int snerf_loss_terms_backward(int64_t n_rays, int64_t n_solar_rays, int n_samples, const float* d_rgb, const float* d_gt, const float* d_albedo,
+                              const float* d_sky, const float* d_solar_vis, const float* d_pv_exact, const float* d_min3, int world, const float* d_g_vals5,
+                              float* d_g_rgb, float* d_g_albedo, float* d_g_sky, float* d_g_solar_vis, void* stream) {
+    LossArgs a;
+    RC(loss_args(&a, n_rays, n_solar_rays, n_samples, d_rgb, d_gt, d_albedo, d_sky, d_solar_vis, d_pv_exact, nullptr, nullptr, 1));
+    (void)world;      // the value's denominator only: the gradient is per local ray count (see loss_bwd_kernel)
+    if (!d_min3 || !d_g_vals5 || !d_g_rgb || !d_g_albedo || !d_g_sky || !d_g_solar_vis) return snerf_set_error(SNERF_E_INVALID, "snerf_loss_terms_backward: bad argument");
+    HIPCK(launch_loss_terms_bwd(a, d_g_vals5, d_min3, d_g_rgb, d_g_albedo, d_g_sky, d_g_solar_vis, (hipStream_t)stream));
+    return SNERF_OK;
+}
+
 /* the same update on caller-owned arenas (no trainer object): what season_nerf::fused_adam_ binds */
 int snerf_adam_step(float* d_params, const float* d_grads, float* d_m, float* d_v, int64_t n, float lr, float beta1, float beta2, float eps,
                     int step, void* stream) {

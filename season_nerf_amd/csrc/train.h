@@ -183,6 +183,18 @@ hipError_t launch_copy_cols(const float* src, int64_t ld_src, float* dst, int64_
 // broadcast per-group rows [G,C] to per-point rows [G*S, C] and the transposed reduction
 hipError_t launch_bcast_rows(const float* src, int C, float* dst, int64_t ld_dst, int col0, int64_t n, int n_samples, hipStream_t st);
 hipError_t launch_reduce_rows(const float* src, int64_t ld_src, int col0, int C, float* dst, int64_t n_groups, int n_samples, hipStream_t st);
+// the scalar loss terms of get_loss (MSE colour loss, solar rays, default solar model, no prior) and their gradients (train_kernels.hip)
+struct LossArgs {
+    int64_t R, Rs;                             // image rays, sun rays
+    int S;
+    const float *rgb, *gt, *albedo, *sky;      // [R,3] each (sky: per ray, after the sigmoid)
+    const float *sv, *pv, *pe;                 // sun-ray pass [Rs,S]: Solar_Vis, PV_Exact, PE
+    const float* alb_min_in;                   // optional [3]: the albedo minimum over the GLOBAL batch (data parallel); NULL: the local one
+    int world;                                 // ranks the global batch spans (1 without alb_min_in)
+};
+hipError_t launch_loss_scratch_init(void* scratch, hipStream_t st);
+hipError_t launch_loss_terms(const LossArgs& a, void* scratch, float* vals5, float* minv3, hipStream_t st);
+hipError_t launch_loss_terms_bwd(const LossArgs& a, const float* g5, const float* minv3, float* d_rgb, float* d_albedo, float* d_sky, float* d_sv, hipStream_t st);
 // Adam on a flat arena (torch.optim.Adam semantics, no weight decay)
 hipError_t launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps, int step, hipStream_t st);
 

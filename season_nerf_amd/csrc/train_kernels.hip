@@ -915,4 +915,93 @@ hipError_t launch_adam(float* p, const float* g, float* m, float* v, int64_t n, 
     return hipGetLastError();
 }
 
+// ---- the scalar loss terms of a training step in three launches (get_loss, Eval_Tools_2.py:340-420: MSE colour loss, solar rays on, default solar
+// model, no DSM prior).  The reference forms them with ~45 small tensor ops (and as many again in autograd's backward): ~110 launches of 3-5 us
+// each per step here, a tenth of a step in launch gaps alone.  scratch: 4 doubles (sums) + 4 uints (albedo minima as float bits; slot 3 unused);
+// self-cleaning - the finalize kernel leaves it in its initial state (sums 0, minima +inf), loss_scratch_init sets that state once.
+__global__ void loss_scratch_init_kernel(double* sums, unsigned* mins) {
+    if (threadIdx.x < 4) { sums[threadIdx.x] = 0.0; mins[threadIdx.x] = 0x7f800000u; }
+}
+__global__ __launch_bounds__(256) void loss_partial_kernel(const LossArgs A, double* sums, unsigned* mins) {
+    float color = 0.f, sk = 0.f, sc = 0.f, ab = 0.f;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x, t0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    for (int64_t i = t0; i < A.R * 3; i += stride) {
+        const float d = A.rgb[i] - A.gt[i];
+        color += d * d;
+        const float x = (A.sky[i] - .5f) / .5f;
+        if (x > 0.f) sk += x * x;
+        if (!A.alb_min_in) atomicMin(mins + (int)(i % 3), __float_as_uint(fmaxf(A.albedo[i], 0.f)));      // non-negative floats order as their bits
+    }
+    for (int64_t j = t0; j < A.Rs * A.S; j += stride) {
+        const float v = A.sv[j], p = A.pv[j], d = v - p;
+        sc += d * d;
+        ab += A.pe[j] * p * v;
+    }
+    __shared__ float red[4][4];
+    float vals[4] = {sc, ab, sk, color};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float v = vals[k];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+        if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) atomicAdd(sums + threadIdx.x, (double)red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
+}
+__global__ void loss_finalize_kernel(const LossArgs A, double* sums, unsigned* mins, float* vals, float* minv) {
+    if (threadIdx.x != 0) return;
+    const double Rs = (double)A.Rs, R = (double)A.R;
+    vals[0] = (float)(sums[0] / Rs);                          // Solar_Correction   = mean_r sum_s (Solar_Vis - PV_Exact)^2      (:361)
+    vals[1] = (float)(1.0 - sums[1] / Rs);                    // Solar_Correction_2 = mean_r (1 - sum_s PE PV_Exact Solar_Vis)  (:366, detached)
+    vals[2] = (float)(sums[2] / (3.0 * R));                   // Sky_Color_Var      = sum_{x > 0} x^2 / numel over [R, S, 3]: S copies of each ray's sky (:381-388)
+    float h = 0.f;
+    for (int c = 0; c < 3; ++c) {
+        const float a = A.alb_min_in ? A.alb_min_in[c] : __uint_as_float(mins[c]);
+        minv[c] = a;
+        if (a < .2f) { const float u = 1.f - a / .2f; h += u * u; }
+    }
+    vals[3] = h / (float)(R * A.world);                       // Albedo_Color       = sum_c [a_c < .2] (1 - a_c / .2)^2 / R, a = min over the batch (:374-379)
+    vals[4] = (float)(sums[3] / (3.0 * R));                   // Color              = MSE(Rendered_Col, GT_Color)                (:413)
+    for (int k = 0; k < 4; ++k) { sums[k] = 0.0; mins[k] = 0x7f800000u; }
+}
+__global__ __launch_bounds__(256) void loss_bwd_kernel(const LossArgs A, const float* g, const float* minv, float* d_rgb, float* d_albedo, float* d_sky,
+                                                       float* d_sv) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x, t0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const float g_sc = g[0], g_sk = g[2], g_al = g[3], g_col = g[4];
+    const float inv3r = 1.f / (3.f * (float)A.R), invr = 1.f / (float)A.R, invrs = 1.f / (float)A.Rs;
+    for (int64_t i = t0; i < A.R * 3; i += stride) {
+        d_rgb[i] = g_col * 2.f * (A.rgb[i] - A.gt[i]) * inv3r;
+        const float x = (A.sky[i] - .5f) / .5f;
+        d_sky[i] = x > 0.f ? g_sk * 4.f * x * inv3r : 0.f;                              // d x^2 / d sky = 2 x / .5
+        const float a = minv[i % 3], al = A.albedo[i];
+        // the minimum's gradient goes to the row that attains it (on the rank that owns the global minimum, divided by the LOCAL ray count:
+        // the rank average of the gradients is then the global-batch gradient, training.albedo_min_loss)
+        d_albedo[i] = (al == a && a < .2f) ? g_al * 2.f * (1.f - a / .2f) * (-1.f / .2f) * invr : 0.f;
+    }
+    for (int64_t j = t0; j < A.Rs * A.S; j += stride) d_sv[j] = g_sc * 2.f * (A.sv[j] - A.pv[j]) * invrs;
+}
+hipError_t launch_loss_scratch_init(void* scratch, hipStream_t st) {
+    hipLaunchKernelGGL(loss_scratch_init_kernel, dim3(1), dim3(64), 0, st, (double*)scratch, (unsigned*)((double*)scratch + 4));
+    return hipGetLastError();
+}
+hipError_t launch_loss_terms(const LossArgs& a, void* scratch, float* vals, float* minv, hipStream_t st) {
+    double* sums = (double*)scratch;
+    unsigned* mins = (unsigned*)(sums + 4);
+    int64_t n = a.Rs * a.S > a.R * 3 ? a.Rs * a.S : a.R * 3;
+    int64_t b = (n + 255) / 256;
+    if (b > 1024) b = 1024;
+    if (b < 1) b = 1;
+    hipLaunchKernelGGL(loss_partial_kernel, dim3((unsigned)b), dim3(256), 0, st, a, sums, mins);
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, st, a, sums, mins, vals, minv);
+    return hipGetLastError();
+}
+hipError_t launch_loss_terms_bwd(const LossArgs& a, const float* g, const float* minv, float* d_rgb, float* d_albedo, float* d_sky, float* d_sv, hipStream_t st) {
+    int64_t n = a.Rs * a.S > a.R * 3 ? a.Rs * a.S : a.R * 3;
+    int64_t b = (n + 255) / 256;
+    if (b > 2048) b = 2048;
+    if (b < 1) b = 1;
+    hipLaunchKernelGGL(loss_bwd_kernel, dim3((unsigned)b), dim3(256), 0, st, a, g, minv, d_rgb, d_albedo, d_sky, d_sv);
+    return hipGetLastError();
+}
+
 }  // namespace snerf

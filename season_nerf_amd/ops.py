@@ -51,6 +51,14 @@ def _register_fakes():
     def _(pts, delta, height_map, outside):
         return pts.new_empty(pts.shape[0], 1)
 
+    @reg("season_nerf::loss_terms")
+    def _(rgb, gt, albedo, sky, solar_vis, pv_exact, pe, albedo_min_global, world):
+        return rgb.new_empty(5), rgb.new_empty(3)
+
+    @reg("season_nerf::loss_terms_bwd")
+    def _(g_vals, rgb, gt, albedo, sky, solar_vis, pv_exact, min, world):
+        return torch.empty_like(rgb), torch.empty_like(albedo), torch.empty_like(sky), torch.empty_like(solar_vis)
+
     @reg("season_nerf::train_fwd_image")
     def _(trainer, top, bot, tvals, sun, time, train_bn, classic, n_classes, height_map, trust, params):
         R, S, C = top.shape[0], tvals.numel(), n_classes

@@ -85,6 +85,22 @@ def _exact_solar_visibility(net: T_NeRF, pts, sun_vec, S, zero_oob, chunk_rays=6
     return vis
 
 
+def _ray_grid(mode, rows, cols, params, device, lo=0, hi=None, want_pixels=False):
+    """snerf_ray_grid (csrc/kernels.hip ray_grid_kernel): the novel-view ray grids in the reference's float64 arithmetic, on the GPU ->
+    (top [n,3], bot [n,3], valid [n] bool[, source pixels [n,2] int32]) for rays lo .. hi-1 of the row-major rows x cols grid."""
+    dev = torch.device(device)
+    hi = rows * cols if hi is None else hi
+    n = hi - lo
+    top, bot = torch.empty(n, 3, device=dev), torch.empty(n, 3, device=dev)
+    valid = torch.empty(n, dtype=torch.uint8, device=dev)
+    pix = torch.empty(n, 2, dtype=torch.int32, device=dev) if want_pixels else None
+    pr = np.ascontiguousarray(np.asarray(params, dtype=np.float64).reshape(-1))
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().snerf_ray_grid(mode, rows, cols, lo, hi, pr.ctypes.data, pr.size, top.data_ptr(), bot.data_ptr(), valid.data_ptr(),
+                                             pix.data_ptr() if want_pixels else None, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "ray_grid")
+    return (top, bot, valid.bool()) + ((pix,) if want_pixels else ())
+
+
 # ------------------------------------------------------------------------------------------------ path A
 class Quick_Run_Net:
     def __init__(self, network, args, world_center_LLA, World_2_Local_H, device, max_input_size=50000, use_tqdm=False,
@@ -101,26 +117,23 @@ class Quick_Run_Net:
         self.max_input_size = max_input_size      # kept for API compatibility; one launch renders the whole image
 
     def _get_input_dict(self, camera_el_az, solar_el_az, time_frac, out_img_size, region):
-        """Quick_Run.py:77-109."""
+        """Quick_Run.py:77-109: the H x W ray grid of a view direction (optionally over a sub-region of the cube), rays leaving the cube
+        dropped; the grid, the cull and the compaction run on the GPU (snerf_ray_grid mode 1), only the kept pixel indices come back."""
         is_tuple = isinstance(out_img_size, tuple)
         hw = out_img_size if is_tuple else (out_img_size, out_img_size)
-        X, Y = np.meshgrid(np.arange(0, hw[0]), np.arange(0, hw[1]), indexing="ij")
-        XY = np.stack([X, Y], 2).reshape([-1, 2])
-        mids = np.concatenate([XY * 2. / (np.array([[hw[0], hw[1]]]) - 1) - 1, np.zeros([XY.shape[0], 1])], 1)
-        if region is not None:
-            mids[:, 0] = (mids[:, 0] + 1) / 2 * (region[1] - region[0]) + region[0]
-            mids[:, 1] = (mids[:, 1] + 1) / 2 * (region[3] - region[2]) + region[2]
         cam = world_angle_2_local_vec(camera_el_az[0], camera_el_az[1], self.world_center_LLA, self.W2L_H)
-        tops, bots = mids + cam / cam[2], mids - cam / cam[2]
-        good = np.all((bots <= 1) * (bots >= -1) * (tops <= 1) * (tops >= -1), 1)
-        XY = XY[good]
+        params = list(cam / cam[2]) + ([float(v) for v in region] if region is not None else [])
+        dev = self.device
+        top, bot, good = _ray_grid(1, hw[0], hw[1], params, dev)
+        keep = torch.nonzero(good).reshape(-1)
+        idx = keep.cpu().numpy()
+        XY = np.stack([idx // hw[1], idx % hw[1]], 1)
         if not is_tuple:
             XY[:, 0] = out_img_size - XY[:, 0] - 1
         n = XY.shape[0]
         sun = world_angle_2_local_vec(solar_el_az[0], solar_el_az[1], self.world_center_LLA, self.W2L_H)
-        dev = self.device
-        return {"Top": _f32(tops[good], dev), "Bot": _f32(bots[good], dev), "XY": XY,
-                "Sun_Angle": _f32(np.tile(sun, (n, 1)), dev), "Time_Encoded": _f32(np.tile(encode_time(time_frac), (n, 1)), dev)}
+        return {"Top": top.index_select(0, keep), "Bot": bot.index_select(0, keep), "XY": XY,
+                "Sun_Angle": _f32(sun.reshape(1, 3), dev).expand(n, 3).contiguous(), "Time_Encoded": _f32(encode_time(time_frac).reshape(1, 4), dev).expand(n, 4).contiguous()}
 
     def _eval(self, d, exact):
         if exact and d["Top"].shape[0] > 0:
@@ -206,14 +219,10 @@ def _render_by_dir_device(net, view_el_az, sun_el_az, time_frac, out_img_size, W
                           ray_range=None):
     """ray_range=(lo, hi): render only rays lo..hi-1 of the row-major H*W grid (a rank's tile in a sharded render)."""
     Hh, Ww, S = out_img_size
-    dev = torch.device(device)
-    g = np.stack(np.meshgrid(np.linspace(1, -1, Hh), np.linspace(-1, 1, Ww), indexing="ij"), -1).reshape([-1, 2])
-    g = np.concatenate([g, np.zeros([g.shape[0], 1])], 1)
-    if ray_range is not None:
-        g = g[ray_range[0]:ray_range[1]]
     v = world_angle_2_local_vec(view_el_az[0], view_el_az[1], W2C, W2L_H)
     sunv = world_angle_2_local_vec(sun_el_az[0], sun_el_az[1], W2C, W2L_H)
-    top, bot = _f32(g + np.expand_dims(v / v[2], 0), dev), _f32(g - np.expand_dims(v / v[2], 0), dev)
+    lo, hi = (0, Hh * Ww) if ray_range is None else ray_range
+    top, bot, _ = _ray_grid(0, Hh, Ww, v / v[2], device, lo, hi)          # mg_Img_Eval.py:99-104 on the GPU (no culling on this path)
     return _internal_render_device(net, top, bot, sunv, time_frac, S, device, include_exact_solar)
 
 
@@ -238,20 +247,32 @@ def component_render_by_P(the_network, a_P_img, out_img_size: tuple, device, max
     Adds `Image_Points_in_GT_Img` and `Image_Points` (rows of the kept rays)."""
     with torch.no_grad():
         Hh, Ww, S = out_img_size
-        XY = np.stack(np.meshgrid(np.linspace(0, a_P_img.img.shape[0] - 1, Hh), np.linspace(0, a_P_img.img.shape[1] - 1, Ww), indexing="ij"), -1)
-        XY = np.round(XY).astype(int).reshape([-1, 2])
-        x, y, _ = a_P_img.invert_P(XY[:, 0], XY[:, 1], 1.)
-        tops = np.stack([x, y, np.ones_like(x)], -1)
-        x, y, _ = a_P_img.invert_P(XY[:, 0], XY[:, 1], -1.)
-        bots = np.stack([x, y, -np.ones_like(x)], -1)
-        good = (tops[:, 0] >= -1) * (tops[:, 1] <= 1) * (bots[:, 0] >= -1) * (bots[:, 1] <= 1) * \
-               (tops[:, 1] >= -1) * (tops[:, 0] <= 1) * (bots[:, 1] >= -1) * (bots[:, 0] <= 1)
         dev = torch.device(device)
-        d = _internal_render_device(the_network, _f32(tops[good], dev), _f32(bots[good], dev), np.asarray(a_P_img.sun_el_and_az_vec, dtype=np.float64),
-                                    a_P_img.get_year_frac(), S, device, include_exact_solar)
+        P = getattr(a_P_img, "P", None)
+        if P is not None and np.asarray(P).shape == (3, 4):
+            # a projective camera (the reference's P_img_Pinhole holds its matrix as .P): pixel grid, invert_P, cube test and compaction on the GPU
+            params = list(np.asarray(P, dtype=np.float64).reshape(-1)) + [a_P_img.img.shape[0], a_P_img.img.shape[1]]
+            top, bot, good_d, pix = _ray_grid(2, Hh, Ww, params, dev, want_pixels=True)
+            keep = torch.nonzero(good_d).reshape(-1)
+            tops_d, bots_d = top.index_select(0, keep), bot.index_select(0, keep)
+            idx = keep.cpu().numpy()
+            src_pix = pix.index_select(0, keep).cpu().numpy().astype(int)
+        else:
+            # any other camera object: its own invert_P on the host (a Python method cannot run on the device)
+            rr, cc = np.round(np.linspace(0, a_P_img.img.shape[0] - 1, Hh)).astype(int), np.round(np.linspace(0, a_P_img.img.shape[1] - 1, Ww)).astype(int)
+            XY = np.stack([np.repeat(rr, Ww), np.tile(cc, Hh)], 1)
+            ends = []
+            for h in (1., -1.):
+                x, y, _ = a_P_img.invert_P(XY[:, 0], XY[:, 1], h)
+                ends.append(np.stack([x, y, np.full_like(x, h)], -1))
+            inside = np.all((np.abs(ends[0][:, :2]) <= 1) & (np.abs(ends[1][:, :2]) <= 1), 1)
+            idx = np.nonzero(inside)[0]
+            tops_d, bots_d, src_pix = _f32(ends[0][idx], dev), _f32(ends[1][idx], dev), XY[idx]
+        d = _internal_render_device(the_network, tops_d, bots_d, np.asarray(a_P_img.sun_el_and_az_vec, dtype=np.float64), a_P_img.get_year_frac(), S, device,
+                                    include_exact_solar)
         res = _to_img_dict(d, the_network, S, include_exact_solar)
-        res["Image_Points_in_GT_Img"] = XY[good]
-        res["Image_Points"] = np.stack(np.meshgrid(np.arange(Hh), np.arange(Ww), indexing="ij"), -1).reshape([-1, 2])[good]
+        res["Image_Points_in_GT_Img"] = src_pix
+        res["Image_Points"] = np.stack([idx // Ww, idx % Ww], 1)
     return res
 
 

@@ -102,9 +102,12 @@ class Net_tool:
         if self.optim2 is not None:
             self.optim2.zero_grad()
         loss = self.eval_tool.get_loss(data_dict, self.network, current_step, train_mode=True)
-        total_loss = 0
-        for k in loss:
-            total_loss = total_loss + loss[k][0] * loss[k][1]
+        if getattr(loss, "vec", None) is not None:      # the terms are elements of one vector (training.LossDict): one dot product
+            total_loss = loss.total()
+        else:
+            total_loss = 0
+            for k in loss:
+                total_loss = total_loss + loss[k][0] * loss[k][1]
         total_loss.backward()
         self.optim.step()                    # FusedAdam all-reduces the flat network-gradient arena under data parallelism
         if self.optim2 is not None:

@@ -164,6 +164,8 @@ class TrainEngine:
         into directly (no per-parameter copies through autograd).  A .grad that is None (optimizer.zero_grad(set_to_none=True))
         gets a zeroed view; a foreign .grad tensor is copied into its slice first."""
         views = self.store.grad_views
+        if all(p.grad is v for p, v in zip(self.param_list, views)):      # the steady state: every .grad still IS its view object
+            return
         state = [0 if p.grad is None else (1 if p.grad.data_ptr() == v.data_ptr() else 2) for p, v in zip(self.param_list, views)]
         if all(s_ == 1 for s_ in state):
             return
@@ -321,6 +323,17 @@ def _register_autograd():
             ops.train_bwd_solar(ctx.trainer, eng.grads, g[0])
         return ctx.no_grads
 
+    def setup_loss(ctx, inputs, output):
+        rgb, gt, albedo, sky, sv, pv, pe, alb_min_global, world = inputs
+        ctx.save_for_backward(rgb, gt, albedo, sky, sv, pv, output[1])
+        ctx.world = int(world)
+
+    def bwd_loss(ctx, g_vals, g_min):
+        rgb, gt, albedo, sky, sv, pv, minv = ctx.saved_tensors
+        d_rgb, d_alb, d_sky, d_sv = ops.loss_terms_bwd(g_vals.contiguous(), rgb, gt, albedo, sky, sv, pv, minv, ctx.world)
+        return d_rgb, None, d_alb, d_sky, d_sv, None, None, None, None
+
+    torch.library.register_autograd("season_nerf::loss_terms", bwd_loss, setup_context=setup_loss)
     torch.library.register_autograd("season_nerf::train_fwd_image", bwd_image, setup_context=setup_image)
     torch.library.register_autograd("season_nerf::train_fwd_points", bwd_points, setup_context=setup_points)
     torch.library.register_autograd("season_nerf::train_fwd_solar", bwd_solar, setup_context=setup)
@@ -423,9 +436,11 @@ def _after_train_forward(net):
     """Bookkeeping torch would do: BatchNorm1d.num_batches_tracked += 1 per train-mode forward; the running statistics
     were updated by the engine outside torch's version counters, so the packed inference weights are stale."""
     if net.training:
-        nbt = [m.num_batches_tracked for m in net.modules() if isinstance(m, torch.nn.BatchNorm1d)]
-        if nbt:
-            torch._foreach_add_(nbt, 1)
+        mods = net.__dict__.get("_bn_modules")
+        if mods is None:                                   # the module tree is fixed after construction: walk it once
+            mods = net.__dict__["_bn_modules"] = [m for m in net.modules() if isinstance(m, torch.nn.BatchNorm1d)]
+        if mods:
+            torch._foreach_add_([m.num_batches_tracked for m in mods], 1)
         net.invalidate_packed()
 
 
@@ -449,6 +464,65 @@ def _engine_for(net, R, Rs, S):
     return eng
 
 
+class _TrainOut(dict):
+    """The evaluator's result dict (the reference's keys) + `.sky_ray`, the per-ray tensor behind the expanded "Sky_Col"."""
+    sky_ray = None
+
+
+class LossDict(dict):
+    """`get_loss`'s {name: [value, weight]} (Eval_Tools_2.py:340-459) when the terms came out of the fused loss op: `vec` holds the values
+    in the order of `names` (each dict value is an element of it), so a caller that knows can form sum(value * weight) as ONE dot product
+    instead of one multiply and one add per term (trainer.Net_tool.train_step)."""
+    vec = None
+    names = ()
+
+    def total(self):
+        w = [self[k][1] for k in self.names]
+        key = tuple(float(x) for x in w)
+        cache = LossDict._wcache
+        dev = self.vec.device
+        wt = cache.get((key, dev))
+        if wt is None:
+            if len(cache) > 64:
+                cache.clear()
+            wt = cache[(key, dev)] = torch.tensor(key, dtype=torch.float32, device=dev)
+        return torch.dot(self.vec, wt)
+
+    _wcache = {}
+
+
+def _fused_loss_ok(ev, args, out, so):
+    import os
+    return (os.environ.get("SNERF_FUSED_LOSS", "1") != "0" and args.Use_Solar and not args.Solar_Type_2 and ev.use_MSE_loss and not ev.use_prior
+            and isinstance(out, _TrainOut) and out.sky_ray is not None and out["Rendered_Col"].is_cuda and so["Solar_Vis"].is_cuda)
+
+
+def _fused_loss(ev, net, out, so, gt, weight):
+    """The five terms of the default training configuration from ONE forward op (two launches) and one backward launch
+    (csrc/train_kernels.hip loss_*_kernel) instead of ~45 tensor ops and their autograd graph."""
+    from . import parallel
+    from .network import _ops
+    _register_autograd()
+    ops = _ops()
+    rgb = out["Rendered_Col"]
+    store = getattr(net, "_param_store", None)
+    group = store.bn_sync[0] if (store is not None and store.bn_sync is not None) else None
+    g_min, world = None, 1
+    if parallel.data_parallel(group):          # the reference's minimum runs over the WHOLE batch (:374): one MIN all-reduce of 3 floats
+        g_min, world = parallel.global_min(out["Albedo_Color"].detach().min(0).values, group)
+    vals, _ = ops.loss_terms(rgb, gt.contiguous(), out["Albedo_Color"], out.sky_ray, so["Solar_Vis"], so["PV_Exact"].detach(), so["PE"].detach(), g_min, world)
+    v = vals.unbind(0)
+    w_sc = weight["Solar_Correction"]
+    L = LossDict()
+    L["Solar_Correction"] = [v[0], w_sc]
+    L["Solar_Correction_2"] = [v[1].detach(), w_sc]
+    L["Sky_Color_Var"] = [v[2], w_sc]
+    L["Albedo_Color"] = [v[3], w_sc]
+    L["Color"] = [v[4], weight["Color"]]
+    L.vec, L.names = vals, ("Solar_Correction", "Solar_Correction_2", "Sky_Color_Var", "Albedo_Color", "Color")
+    return L
+
+
 def eval_train(ev, data_dict, net, train_mode, current_step=0):
     """`All_in_One_Eval.eval` on the layer-wise engine: a network in .train() mode (batch-statistics BatchNorm,
     differentiable) or a width without a fused kernel (eval mode)."""
@@ -466,9 +540,10 @@ def eval_train(ev, data_dict, net, train_mode, current_step=0):
     _after_train_forward(net)
     Cn = net.n_classes
     sky_e = sky.unsqueeze(1).expand(R, S, 3)
-    out = {"Rendered_Col": rgb, "PE": pe, "PV": pv, "PS": ps, "Solar_Vis": sv, "Sky_Col": sky_e,
+    out = _TrainOut({"Rendered_Col": rgb, "PE": pe, "PV": pv, "PS": ps, "Solar_Vis": sv, "Sky_Col": sky_e,
            "Classes": cls.unsqueeze(1).expand(R, S, Cn), "Adjust": adjc, "Rho": rho, "Col": col, "Col_Adj": -1, "deltas": dl,
-           "sample_pts": pts, "Albedo_Color": alb}
+           "sample_pts": pts, "Albedo_Color": alb})
+    out.sky_ray = sky                                             # [R, 3]: what "Sky_Col" holds S copies of (the fused loss terms read it)
     if ev.use_prior:
         keys = ["PV_Supervised", "PE_Supervised", "PS_Supervised", "PV_Merged", "PE_Merged", "PS_Merged", "Rho_Merged"]
         out.update(dict(zip(keys, res[16:])))                    # res[15] = the DSM-prior density itself
@@ -537,6 +612,8 @@ def get_loss(ev, data_dict, net, current_step, train_mode):
     if args.Use_Solar:
         starts, ends, vec, stime, _ = ev.solar_creation_tool(n_rays, include_times=True)
         so = ev.eval_Rho_Only({"Top": starts, "Bot": ends, "Sun_Angle": vec, "Time_Encoded": stime}, net, train_mode, current_step)
+        if _fused_loss_ok(ev, args, out, so):
+            return _fused_loss(ev, net, out, so, data_dict["GT_Color"].to(dev), weight)
         Loss["Solar_Correction"] = [torch.mean(torch.sum((so["Solar_Vis"] - so["PV_Exact"].detach()) ** 2, 1)), weight["Solar_Correction"]]
         absorb = torch.mean(1 - torch.sum(so["PE"].detach() * so["PV_Exact"].detach() * so["Solar_Vis"], 1))
         Loss["Solar_Correction_2"] = [absorb.detach() if not args.Solar_Type_2 else absorb, weight["Solar_Correction"]]

@@ -461,18 +461,19 @@ def _estimate(lib, m):
 
 @pytest.mark.parametrize("W", [64, 256, 512])
 def test_auto_precision_follows_the_error_bound(lib, W):
-    """Well-conditioned weights (init law, mild outliers, heavy tails) clear the bound and run in int8 digits; rows with a
-    dominant weight (x16) or a trained-like mix of gains and outliers do not and are routed to bf16x3 (512: no bf16 kernel ->
-    SNERF_E_INVALID, the host falls back to the layer-wise engine).  The thresholds are tools/calibrate_i8_bound.py's."""
+    """Weights of the init law clear the bound and run in int8 digits (so do the really-trained fixtures: test_trained_fixtures_clear_the_bound);
+    synthetic families with per-row outliers (x4, x16), heavy tails or a mix of gains and outliers do not - since round 4's refit on really
+    trained weights the guard is conservative for them - and are routed to bf16x3 (512: no bf16 kernel -> SNERF_E_INVALID, the host falls back
+    to the layer-wise engine)."""
     AUTO, I8, BF3 = 3, 2, 0
-    for kind, want in [("init", I8), ("outlier4", I8), ("laplace", I8), ("outlier16", BF3), ("trained", BF3)]:
+    for kind, want in [("init", I8), ("outlier4", BF3), ("laplace", BF3), ("outlier16", BF3), ("trained", BF3)]:
         sd = orc.init_weights(W, 4, 0) if kind == "init" else orc.stress_weights(W, 4, 0, kind)
         m = _host_model(lib, W, sd, AUTO)
         e = _estimate(lib, m)
         assert e.budget == pytest.approx(1e-4) and e.acc_bound < 2 ** 31
         assert bool(e.ok) == (want == I8), (kind, e.rgb_pred)
         if kind == "init":
-            assert 1e-5 < e.rgb_pred < 4e-5 and max(e.head_rms) == pytest.approx(e.worst)
+            assert 3e-5 < e.rgb_pred < 7e-5 and max(e.head_rms) == pytest.approx(e.worst)
         r = lib.snerf_model_resolve_precision(m)
         if want == BF3 and W == 512:
             assert r == -1 and b"512" in lib.snerf_last_error()
@@ -481,6 +482,20 @@ def test_auto_precision_follows_the_error_bound(lib, W):
             ns = C.c_size_t()
             assert lib.snerf_model_pack_host(m, 2, None, C.byref(ns), None, None) == (0 if want == I8 else -4)
         lib.snerf_model_destroy(m)
+
+
+@pytest.mark.parametrize("W", [64, 256])
+def test_trained_fixtures_clear_the_bound(lib, golden_dir, W):
+    """The reference's own training loop, 400-600 steps (tests/golden/trained_W*.npz): `auto` keeps these on the int8 pipe, and the prediction
+    is above what the GPU measures against the reference for them (3.5-3.7e-5, tests/test_gpu_stress.py)."""
+    import os
+    g = dict(np.load(os.path.join(golden_dir, f"trained_W{W}.npz"), allow_pickle=False))
+    sd = {k[3:]: torch.tensor(v) for k, v in g.items() if k.startswith("sd_")}
+    m = _host_model(lib, W, sd, 3)
+    e = _estimate(lib, m)
+    assert e.ok and 3.7e-5 < e.rgb_pred < 1e-4, e.rgb_pred
+    assert lib.snerf_model_resolve_precision(m) == 2
+    lib.snerf_model_destroy(m)
 
 
 def test_int8_accumulator_bound_is_enforced(lib):

@@ -231,3 +231,67 @@ def test_training_ops_validate_and_fake():
     hm = torch.rand(9, 7, dtype=torch.float64, device="cuda")
     pts, dl = torch.rand(50, 3, device="cuda") * 2 - 1, torch.rand(50, device="cuda") * 0.05
     torch.library.opcheck(o.prior_density.default, (pts, dl, hm, None), test_utils=("test_schema", "test_faketensor"))
+
+
+def _loss_inputs(R=1500, Rs=700, S=40, seed=0, dark=True):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    r = lambda *s: torch.rand(*s, device="cuda", generator=g)
+    rgb, gt, sky = r(R, 3), r(R, 3), r(R, 3)
+    albedo = r(R, 3) * 0.8 + (0.05 if dark else 0.3)             # dark: channel minima below the 0.2 hinge, the term is active
+    sv, pv, pe = r(Rs, S, 1), r(Rs, S, 1), r(Rs, S, 1) * 0.1
+    return rgb, gt, albedo, sky, sv, pv, pe
+
+
+def _loss_terms_torch(rgb, gt, albedo, sky, sv, pv, pe, S):
+    """The terms as season_nerf_amd.training.get_loss forms them with tensor ops (Eval_Tools_2.py:361-389, :413)."""
+    R = rgb.shape[0]
+    sc = torch.mean(torch.sum((sv - pv) ** 2, 1))
+    sc2 = torch.mean(1 - torch.sum(pe * pv * sv, 1)).detach()      # a value only in this configuration (Eval_Tools_2.py:367-368)
+    x = (sky.unsqueeze(1).expand(R, S, 3) - .5) / .5
+    sk = torch.sum(torch.where(x > 0, x ** 2, torch.zeros_like(x))) / x.numel()
+    a = albedo.min(0).values
+    al = torch.sum(torch.where(a < .2, (1 - a / .2) ** 2, torch.zeros_like(a))) / R
+    col = torch.mean((rgb - gt) ** 2)
+    return torch.stack([sc, sc2, sk, al, col])
+
+
+@pytest.mark.parametrize("dark", [True, False])
+def test_fused_loss_terms_vs_tensor_ops(dark):
+    """season_nerf::loss_terms (+ its registered backward) against the same five terms formed with tensor ops and differentiated by
+    autograd: values to fp32 rounding, gradients of a weighted total element by element."""
+    ops()
+    from season_nerf_amd import training
+    training._register_autograd()
+    S = 40
+    ins = _loss_inputs(S=S, dark=dark)
+    w = torch.tensor([0.03, 0.03, 0.03, 0.03, 1.0], device="cuda")
+    leaves_a = [t.clone().requires_grad_(True) for t in ins]
+    ref = _loss_terms_torch(*leaves_a, S)
+    (ref * w).sum().backward()
+    leaves_b = [t.clone().requires_grad_(True) for t in ins]
+    rgb, gt, albedo, sky, sv, pv, pe = leaves_b
+    for rep in range(2):                                                  # twice: the op's reduction scratch must come back clean
+        vals, minv = torch.ops.season_nerf.loss_terms(rgb, gt, albedo, sky, sv, pv.detach(), pe.detach(), None, 1)
+        np.testing.assert_allclose(vals.detach().cpu().numpy(), ref.detach().cpu().numpy(), rtol=2e-6, atol=1e-7)
+        np.testing.assert_array_equal(minv.detach().cpu().numpy(), albedo.detach().min(0).values.cpu().numpy())
+    torch.dot(vals, w).backward()
+    for name, a, b in zip(["rgb", "gt", "albedo", "sky", "sv"], leaves_a, leaves_b):
+        if name == "gt":
+            continue                                                      # the fused op treats the ground truth as a constant
+        ga, gb = a.grad, b.grad
+        assert gb is not None, name
+        np.testing.assert_allclose(gb.cpu().numpy(), ga.cpu().numpy(), rtol=1e-5, atol=1e-9, err_msg=name)
+    assert bool((leaves_b[2].grad != 0).any()) == dark
+    # data parallel: the global minimum and world size come in from outside (one MIN all-reduce by the caller)
+    g_min = albedo.detach().min(0).values * torch.tensor([1.0, 0.5, 1.0], device="cuda")        # another rank owns channel 1's minimum
+    vals2, minv2 = torch.ops.season_nerf.loss_terms(rgb, gt, albedo, sky, sv, pv.detach(), pe.detach(), g_min, 2)
+    h = torch.sum(torch.where(g_min < .2, (1 - g_min / .2) ** 2, torch.zeros_like(g_min))) / (2 * rgb.shape[0])
+    np.testing.assert_allclose(float(vals2[3]), float(h), rtol=2e-6)
+    albedo.grad = None
+    vals2[3].backward()
+    own = albedo.detach() == g_min
+    assert not bool(own[:, 1].any()) and bool((albedo.grad[:, 1] == 0).all())                 # no gradient for a minimum this rank does not own
+    if dark:
+        assert bool((albedo.grad[:, 0] != 0).sum() == 1)
+    torch.library.opcheck(torch.ops.season_nerf.loss_terms.default, (rgb.detach(), gt.detach(), albedo.detach(), sky.detach(), sv.detach(), pv.detach(), pe.detach(),
+                                                                     None, 1), test_utils=("test_schema", "test_faketensor"))

@@ -44,7 +44,7 @@ def test_training_collectives_over_rccl_world1():
     local = _run(["--workload", "train", "--steps", "4", "--warmup", "2", "--loss", "barron", "--no-cpu-baseline"])
     glob = _run(["--workload", "train", "--steps", "4", "--warmup", "2", "--loss", "barron", "--bn_sync", "global", "--no-cpu-baseline"])
     cl, cg = local["collectives"], glob["collectives"]
-    steps = 4 + 2
+    steps = 4 + 2 + 6          # timed + warm-up + the six steps bench.py enqueues onto an idle GPU afterwards (host_enqueue_ms_per_step)
     for c in (cl, cg):
         assert c["grad_arena_all_reduce"] == steps and c["ada_loss_all_reduce"] == steps, c
         assert c["albedo_min_all_reduce"] == steps, c          # the batch-wide minimum of get_loss's Albedo_Color term (Eval_Tools_2.py:374)

@@ -192,9 +192,12 @@ def test_evaluator_exact_solar_seam(setup):
     np.testing.assert_allclose(out["Rendered_Col"].cpu().numpy(), ((ps * col).sum(1) * (sv3 + (1 - sv3) * sky.mean(1))).cpu().numpy(), rtol=1e-6)
 
 
-def test_component_render_by_P(golden_dir):
+@pytest.mark.parametrize("device_grid", [True, False])
+def test_component_render_by_P(golden_dir, device_grid):
     """component_render_by_P (mg_Img_Eval.py:74-94) against the reference's own output through a hand-made camera
-    (tests/golden/renderP_W64_s2.npz); the camera object is duck-typed like the reference's P_img."""
+    (tests/golden/renderP_W64_s2.npz); the camera object is duck-typed like the reference's P_img.  device_grid: the camera exposes its
+    3x4 matrix as `.P` (as P_img_Pinhole does) and the pixel grid / invert_P / cube test run on the GPU (snerf_ray_grid mode 2); without it
+    the object's own invert_P runs on the host.  Both must reproduce the reference's rays bit for bit (World_Points: atol = rtol = 0)."""
     import season_nerf_amd as sn
     g = dict(np.load(os.path.join(golden_dir, "renderP_W64_s2.npz"), allow_pickle=False))
     net = sn.T_NeRF(int(g["W"]), int(g["C"]))
@@ -212,6 +215,8 @@ def test_component_render_by_P(golden_dir):
         def get_year_frac(self):
             return float(g["year_frac"])
 
+    if device_grid:
+        Cam.P = g["P"]
     size = tuple(int(v) for v in g["size"])
     d = sn.component_render_by_P(net, Cam(), size, "cuda", include_exact_solar=True)
     assert (d["Image_Points"] == g["P_Image_Points"]).all() and (d["Image_Points_in_GT_Img"] == g["P_Image_Points_in_GT_Img"]).all()

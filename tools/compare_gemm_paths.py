@@ -72,7 +72,8 @@ if len(sys.argv) > 1:
 os.makedirs("/tmp/cmp", exist_ok=True)
 # m0: general kernel; m1: full-tile 32x32x16 kernel (bit-identical to m0); m2: full-tile 16x16x32 kernel where the launcher picks it
 # (same products, the k terms of a 32-k step summed in another order: equal to fp32 summation rounding, never bitwise by design)
-# (SNERF_CMP_WREG=1: mode 2 additionally routes the eligible shapes to the opt-in gemm_wreg_kernel, weights in registers)
+# (SNERF_CMP_WREG=1 with SNERF_LIB pointing at a library built with -DSNERF_WITH_WREG=1 (python tools/variants.py build gemm16.hip wreg="-DSNERF_WITH_WREG=1"):
+#  mode 2 additionally routes the eligible shapes to the experimental gemm_wreg_kernel, weights in registers - not part of the shipped library)
 for mode, env_ in (("0", {"SNERF_GEMM_FULL": "0"}), ("1", {"SNERF_GEMM_FULL": "1", "SNERF_GEMM16": "0"}),
                    ("2", {"SNERF_GEMM_FULL": "1", "SNERF_GEMM16": "1", "SNERF_GEMM_WREG": os.environ.get("SNERF_CMP_WREG", "0")})):
     subprocess.check_call([sys.executable, __file__, f"/tmp/cmp/m{mode}.npz"], env=dict(os.environ, **env_))
