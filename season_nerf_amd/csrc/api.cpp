@@ -476,6 +476,7 @@ int snerf_composite_sweep(int64_t n_rays, int n_samples, int n_classes, int n_ti
     a.n_rays = n_rays; a.n_samples = n_samples; a.n_classes = n_classes; a.n_times = n_times; a.flags = flags;
     a.top = d_top; a.bot = d_bot; a.tvals = d_tvals; a.deltas = d_deltas; a.classic = out->d_classic;
     a.rho = d_rho; a.col_raw = d_col_raw; a.adjust = d_adjust;
+    a.adjust_vec4 = (n_classes == 4 && (reinterpret_cast<uintptr_t>(d_adjust) & 15) == 0) ? 1 : 0;
     a.solar_vis = d_solar_vis; a.sky = d_sky; a.class_vecs = d_class_vecs;
     a.season = out->d_season; a.shaded = out->d_shaded; a.base = out->d_base; a.shadow_adjust = out->d_shadow_adjust;
     a.raw_shadow = out->d_raw_shadow;

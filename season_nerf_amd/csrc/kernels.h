@@ -85,6 +85,7 @@ struct SweepArgs {
     const float *top, *bot, *tvals;
     const float* deltas;       // optional [R,S]: explicit segment lengths (then top / bot / tvals are not read)
     const float *rho, *col_raw, *adjust, *solar_vis;
+    int adjust_vec4;           // adjust is 16-byte aligned and n_classes == 4: a sample's 12 values are three 16-byte loads
     const float* sky;          // [3]
     const float* class_vecs;   // [T,C]
     float *season, *shaded;    // [T,R,3]

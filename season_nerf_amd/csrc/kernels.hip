@@ -546,9 +546,17 @@ __global__ __launch_bounds__(256) void composite_kernel(const CompArgs A) {
 // Reads 17 floats per sample once per T_CHUNK time-steps, but is bound by the 36 sigmoids per sample (v_exp + v_rcp),
 // not by HBM: 1.7 GB in 2.2 ms = 0.78 TB/s at 512 x 512 x 96.
 constexpr int T_CHUNK = 12;
+// sigmoid on the transcendental unit: v_exp_f32 (base 2) + v_rcp_f32, 4 instructions instead of the ~30 of expf + an IEEE division - the sweep
+// evaluates 3 + 3 T of them per sample.  Error ~2e-7 relative (1 ulp each + the rounding of x log2 e); the image tolerances are 1e-5.
+__device__ __forceinline__ float sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x * -1.44269504088896341f)); }
+// Lane map (round 4): the two halves of a wavefront work on the SAME 32 samples of the ray and split the T_CHUNK class vectors between them (6 each):
+// no idle lanes at S = 96 (three 32-sample steps; one 64-lane step + a half-empty one before), half the accumulator registers per lane, the loads
+// of both halves coalesce (same addresses); the transmittance scan runs over 32 lanes, redundantly in both halves.  The next step's 17 values per
+// sample are requested before the current step is evaluated.
 template <bool CLASSIC>
 __global__ __launch_bounds__(256) void sweep_kernel(const SweepArgs A) {
-    const int lane = threadIdx.x & 63;
+    constexpr int TH = T_CHUNK / 2;
+    const int lane = threadIdx.x & 63, sl = lane & 31, half = lane >> 5;
     const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= A.n_rays) return;
     const int S = A.n_samples, C = A.n_classes;
@@ -562,53 +570,87 @@ __global__ __launch_bounds__(256) void sweep_kernel(const SweepArgs A) {
     }
     const bool zero_oob = (A.flags & 2) && !explicit_delta;
     const float sky0 = A.sky[0], sky1 = A.sky[1], sky2 = A.sky[2];
+    struct In { float rho, sv, dl, k[3], ad[kMaxClasses][3]; };
+    auto fetch = [&](int base) {
+        In v;
+        const int s = base + sl;
+        const int64_t idx = r * S + (s < S ? s : S - 1);
+        v.rho = A.rho[idx];
+        v.sv = A.solar_vis[idx];
+        v.dl = explicit_delta ? A.deltas[idx] : (zero_oob ? A.tvals[s < S ? s : S - 1] : 0.f);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) v.k[k] = A.col_raw[idx * 3 + k];
+        if (A.adjust_vec4 && kMaxClasses >= 4) {            // the usual class count: a sample's 12 adjust values are three aligned 16-byte loads
+            const float4* p = reinterpret_cast<const float4*>(A.adjust + idx * 12);
+            const float4 q0 = p[0], q1 = p[1], q2 = p[2];
+            const float f[12] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
+#pragma unroll
+            for (int c = 0; c < kMaxClasses; ++c)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) v.ad[c][k] = c < 4 ? f[c * 3 + k] : 0.f;
+            return v;
+        }
+#pragma unroll
+        for (int c = 0; c < kMaxClasses; ++c)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) v.ad[c][k] = c < C ? A.adjust[(idx * C + c) * 3 + k] : 0.f;
+        return v;
+    };
+    auto half_sum = [](float v) {
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        return v;
+    };
     for (int t0 = 0; t0 < A.n_times; t0 += T_CHUNK) {
-        float cw[T_CHUNK][kMaxClasses];
+        const int tb = t0 + half * TH;                     // this half's class vectors: tb .. tb + TH - 1
+        float cw[TH][kMaxClasses];
 #pragma unroll
-        for (int t = 0; t < T_CHUNK; ++t)
+        for (int t = 0; t < TH; ++t)
 #pragma unroll
-            for (int c = 0; c < kMaxClasses; ++c) cw[t][c] = (t0 + t < A.n_times && c < C) ? A.class_vecs[(t0 + t) * C + c] : 0.f;
-        float acc[T_CHUNK][3];
-        float accc[CLASSIC ? T_CHUNK : 1][3];
+            for (int c = 0; c < kMaxClasses; ++c) cw[t][c] = (tb + t < A.n_times && c < C) ? A.class_vecs[(tb + t) * C + c] : 0.f;
+        float acc[TH][3];
+        float accc[CLASSIC ? TH : 1][3];
 #pragma unroll
-        for (int t = 0; t < T_CHUNK; ++t) acc[t][0] = acc[t][1] = acc[t][2] = 0.f;
+        for (int t = 0; t < TH; ++t) acc[t][0] = acc[t][1] = acc[t][2] = 0.f;
 #pragma unroll
-        for (int t = 0; t < (CLASSIC ? T_CHUNK : 1); ++t) accc[t][0] = accc[t][1] = accc[t][2] = 0.f;
+        for (int t = 0; t < (CLASSIC ? TH : 1); ++t) accc[t][0] = accc[t][1] = accc[t][2] = 0.f;
         float carry = 0.f, svsum = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f;
-        for (int base = 0; base < S; base += 64) {
-            const int s = base + lane;
+        In nxt = fetch(0);
+        for (int base = 0; base < S; base += 32) {
+            const In cur = nxt;
+            if (base + 32 < S) nxt = fetch(base + 32);
+            const int s = base + sl;
             const bool in = s < S;
-            const int64_t idx = r * S + (in ? s : S - 1);
             float delta = delta_ray;
             if (explicit_delta) {
-                delta = A.deltas[idx];
+                delta = cur.dl;
             } else if (zero_oob) {
-                const float tt = A.tvals[in ? s : S - 1], omt = __fsub_rn(1.f, tt);
+                const float tt = cur.dl, omt = __fsub_rn(1.f, tt);
                 const float px = __fadd_rn(__fmul_rn(tx, omt), __fmul_rn(bx, tt));
                 const float py = __fadd_rn(__fmul_rn(ty, omt), __fmul_rn(by, tt));
                 const float pz = __fadd_rn(__fmul_rn(tz, omt), __fmul_rn(bz, tt));
                 if (px > 1.f || px < -1.f || py > 1.f || py < -1.f || pz > 1.f || pz < -1.f) delta = 0.f;
             }
-            const float y = in ? A.rho[idx] * delta : 0.f;
-            const float incl = wave_incl_scan(y, lane);
+            const float y = in ? cur.rho * delta : 0.f;
+            float incl = y;                                // inclusive scan over the 32 lanes of the half (the same in both halves)
+#pragma unroll
+            for (int o = 1; o < 32; o <<= 1) {
+                const float t = __shfl_up(incl, o, 32);
+                if (sl >= o) incl += t;
+            }
             const float excl = carry + (incl - y);
-            carry += __shfl(incl, 63, 64);
+            carry += __shfl(incl, 31, 32);
             const float ps = in ? expf(-excl) * (1.f - expf(-y)) : 0.f;
-            const float sv = in ? A.solar_vis[idx] : 0.f;
+            const float sv = in ? cur.sv : 0.f;
             svsum += ps * sv;
-            const float k0 = A.col_raw[idx * 3], k1 = A.col_raw[idx * 3 + 1], k2 = A.col_raw[idx * 3 + 2];
-            b0 += ps * sigmoid_f(k0); b1 += ps * sigmoid_f(k1); b2 += ps * sigmoid_f(k2);
-            float ad[kMaxClasses][3];
+            const float k0 = cur.k[0], k1 = cur.k[1], k2 = cur.k[2];
+            b0 += ps * sigmoid_fast(k0); b1 += ps * sigmoid_fast(k1); b2 += ps * sigmoid_fast(k2);
 #pragma unroll
-            for (int c = 0; c < kMaxClasses; ++c)
-#pragma unroll
-                for (int k = 0; k < 3; ++k) ad[c][k] = c < C ? A.adjust[(idx * C + c) * 3 + k] : 0.f;
-#pragma unroll
-            for (int t = 0; t < T_CHUNK; ++t) {
+            for (int t = 0; t < TH; ++t) {
                 float m0 = 0.f, m1 = 0.f, m2 = 0.f;
 #pragma unroll
-                for (int c = 0; c < kMaxClasses; ++c) { m0 += cw[t][c] * ad[c][0]; m1 += cw[t][c] * ad[c][1]; m2 += cw[t][c] * ad[c][2]; }
-                const float q0 = ps * sigmoid_f(k0 + m0), q1 = ps * sigmoid_f(k1 + m1), q2 = ps * sigmoid_f(k2 + m2);
+                for (int c = 0; c < kMaxClasses; ++c) { m0 += cw[t][c] * cur.ad[c][0]; m1 += cw[t][c] * cur.ad[c][1]; m2 += cw[t][c] * cur.ad[c][2]; }
+                const float q0 = ps * sigmoid_fast(k0 + m0), q1 = ps * sigmoid_fast(k1 + m1), q2 = ps * sigmoid_fast(k2 + m2);
                 acc[t][0] += q0; acc[t][1] += q1; acc[t][2] += q2;
                 if constexpr (CLASSIC) {     // per-sample shading, the use_classic_shadows branch of mg_Img_Eval.py:165-170
                     accc[t][0] += q0 * (sv + (1.f - sv) * sky0);
@@ -617,17 +659,17 @@ __global__ __launch_bounds__(256) void sweep_kernel(const SweepArgs A) {
                 }
             }
         }
-        svsum = wave_sum(svsum);
-        b0 = wave_sum(b0); b1 = wave_sum(b1); b2 = wave_sum(b2);
+        svsum = half_sum(svsum);
+        b0 = half_sum(b0); b1 = half_sum(b1); b2 = half_sum(b2);
         const float mask = sigmoid_f((svsum - 0.2f) * 30.f);
         const float f0 = mask + (1.f - mask) * sky0, f1 = mask + (1.f - mask) * sky1, f2 = mask + (1.f - mask) * sky2;
 #pragma unroll
-        for (int t = 0; t < T_CHUNK; ++t) {
-            const float v0 = wave_sum(acc[t][0]), v1 = wave_sum(acc[t][1]), v2 = wave_sum(acc[t][2]);
+        for (int t = 0; t < TH; ++t) {
+            const float v0 = half_sum(acc[t][0]), v1 = half_sum(acc[t][1]), v2 = half_sum(acc[t][2]);
             float c0 = 0.f, c1 = 0.f, c2 = 0.f;
-            if constexpr (CLASSIC) { c0 = wave_sum(accc[t][0]); c1 = wave_sum(accc[t][1]); c2 = wave_sum(accc[t][2]); }
-            if (lane == 0 && t0 + t < A.n_times) {
-                const int64_t o = ((int64_t)(t0 + t) * A.n_rays + r) * 3;
+            if constexpr (CLASSIC) { c0 = half_sum(accc[t][0]); c1 = half_sum(accc[t][1]); c2 = half_sum(accc[t][2]); }
+            if (sl == 0 && tb + t < A.n_times) {
+                const int64_t o = ((int64_t)(tb + t) * A.n_rays + r) * 3;
                 if (A.season) { A.season[o] = v0; A.season[o + 1] = v1; A.season[o + 2] = v2; }
                 if (A.shaded) { A.shaded[o] = v0 * f0; A.shaded[o + 1] = v1 * f1; A.shaded[o + 2] = v2 * f2; }
                 if constexpr (CLASSIC) { A.classic[o] = c0; A.classic[o + 1] = c1; A.classic[o + 2] = c2; }
