@@ -356,9 +356,10 @@ bool estimate_i8(const Weights& w, int W, int C, I8Estimate* out, std::string* e
     // synthetic weight families (tools/calibrate_i8_bound.py: init law, outliers, heavy tails, gains: prediction ~2x the worst observed error).
     // Round 4 measured REALLY TRAINED weights - the reference's own loop, 400-600 steps (tests/golden/trained_W*.npz, tools/trained_modes.py on
     // the GPU against the reference's eval): per unit of predicted head error they render 3-4x worse than the synthetic families (observed
-    // 3.5-3.7e-5 against a prediction of 1.8-2.4e-5), so the weights are scaled x2.3: the prediction now covers every measured set with >= 15 %
-    // to spare (trained W = 256: 4.0e-5 predicted / 3.5e-5 observed; init law 5.1e-5 / 1.4e-5; x4-outlier and Laplace families 1.7-1.9e-4 /
-    // 3.1-5.8e-5 - those now go to bf16x3: the guard errs on the safe side for weights unlike anything training produced here).
+    // 3.5-3.7e-5 against a prediction of 1.8-2.4e-5), so the weights are scaled x2.3: the prediction now covers every measured set
+    // (trained W = 64 / 256 / 512: 5.5 / 4.0 / 3.6e-5 predicted against 3.7 / 3.5 / 3.2-3.4e-5 observed; init law 5.1e-5 / 1.4e-5; x4-outlier and
+    // Laplace families 1.7-1.9e-4 / 3.1-5.8e-5 - those now go to bf16x3: the guard errs on the safe side for weights unlike anything training
+    // produced here).
     out->rgb_pred = 0.80 * out->head_rms[0] + 0.35 * out->head_rms[1] + 0.46 * out->head_rms[3] + 0.23 * out->head_rms[2];
     return true;
 }

@@ -925,12 +925,27 @@ __global__ void loss_scratch_init_kernel(double* sums, unsigned* mins) {
 __global__ __launch_bounds__(256) void loss_partial_kernel(const LossArgs A, double* sums, unsigned* mins) {
     float color = 0.f, sk = 0.f, sc = 0.f, ab = 0.f;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x, t0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    for (int64_t i = t0; i < A.R * 3; i += stride) {
-        const float d = A.rgb[i] - A.gt[i];
-        color += d * d;
-        const float x = (A.sky[i] - .5f) / .5f;
-        if (x > 0.f) sk += x * x;
-        if (!A.alb_min_in) atomicMin(mins + (int)(i % 3), __float_as_uint(fmaxf(A.albedo[i], 0.f)));      // non-negative floats order as their bits
+    // rows, not elements: a thread sees all three channels of its rays, so the channel minima reduce in registers and the wave (one atomic per
+    // wave and channel: thousands of atomics on three addresses cost 85 us when every element issued its own)
+    float mn[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
+    for (int64_t rr = t0; rr < A.R; rr += stride) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int64_t i = rr * 3 + c;
+            const float d = A.rgb[i] - A.gt[i];
+            color += d * d;
+            const float x = (A.sky[i] - .5f) / .5f;
+            if (x > 0.f) sk += x * x;
+            mn[c] = fminf(mn[c], fmaxf(A.albedo[i], 0.f));
+        }
+    }
+    if (!A.alb_min_in) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float v = mn[c];
+            for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+            if ((threadIdx.x & 63) == 0 && v < __builtin_inff()) atomicMin(mins + c, __float_as_uint(v));      // non-negative floats order as their bits
+        }
     }
     for (int64_t j = t0; j < A.Rs * A.S; j += stride) {
         const float v = A.sv[j], p = A.pv[j], d = v - p;

@@ -287,6 +287,46 @@ def test_ragged_batch_vs_oracle():
     assert worst < 2e-3, worst
 
 
+def test_w512_step_with_streaming_directions_vs_oracle():
+    """the reference's default width (fc_units = 512, main_lite.py:80) at 342 rays x 96 samples = 32 832 points - above the 32 768 rows
+    from which streaming launches alternate their row direction (both directions of the row GEMMs and of the weight-gradient kernels run), the
+    two-stage weight-gradient reduction over a full grid, and the BatchNorm-fused weight gradient with its activation table in two column windows
+    (> 256 input columns) - against the oracle's autograd: loss terms and every parameter gradient."""
+    import season_nerf_amd as sn
+    W, C, R, S = 512, 4, 342, 96
+    sd = orc.init_weights(W, C, 4, bn_stats="identity")
+    net = sn.T_NeRF(W, C)
+    net.load_state_dict(sd)
+    net = net.to("cuda").train()
+    rng = np.random.Generator(np.random.PCG64(31))
+    sun = rng.uniform(0.1, 1, (R, 3)); sun /= np.linalg.norm(sun, axis=1, keepdims=True)
+    tau = rng.uniform(0, 1, (R, 2))
+    data = {"Top": T(np.concatenate([rng.uniform(-1, 1, (R, 2)), np.ones((R, 1))], 1)),
+            "Bot": T(np.concatenate([rng.uniform(-1, 1, (R, 2)), -np.ones((R, 1))], 1)), "Sun_Angle": T(sun),
+            "Time_Encoded": T(np.stack([np.cos(6.28 * tau[:, 0]), np.sin(6.28 * tau[:, 0]), np.cos(6.28 * tau[:, 1]), np.sin(6.28 * tau[:, 1])], 1)),
+            "GT_Color": T(rng.uniform(0, 1, (R, 3)))}
+    st = np.concatenate([rng.uniform(-1, 1, (R, 2)), np.ones((R, 1))], 1)
+    solar = {"Top": T(st), "Bot": T(st - 2 * sun / sun[:, 2:]), "Sun_Angle": T(sun)}
+    args = SimpleNamespace(n_samples=S, Use_Reg=True, Solar_Type_2=False, Use_MSE_loss=True, Use_Solar=True, sc_lambda=0.03, number_low_frequency_cases=C)
+    ev = sn.All_in_One_Eval(args, torch.device("cuda"), 10, False, None, np.eye(4), np.zeros(3))
+    ev.solar_creation_tool = lambda n, include_times=True: (solar["Top"], solar["Bot"], solar["Sun_Angle"], torch.zeros(R, 4), None)
+    loss = ev.get_loss(data, net, 0, False)
+    total = sum(v * w for v, w in loss.values())
+    total.backward()
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+    sd_g = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
+    ref_loss, _ = orc.get_loss_mse(sd_g, data, solar, S, 0.03, train_mode=False, train_bn=True)
+    orc.total_loss(ref_loss).backward()
+    for k, (v, w) in ref_loss.items():
+        assert abs(float(loss[k][0].detach()) - float(v)) <= 2e-5 * max(1.0, abs(float(v))) + 1e-6, k
+    params = dict(net.named_parameters())
+    live = [n for n, v in sd_g.items() if v.is_floating_point() and v.grad is not None and float(v.grad.abs().max()) > 0]
+    gmax = max(float(sd_g[n].grad.abs().max()) for n in live)
+    worst = max(float((params[n].grad.cpu() - sd_g[n].grad).abs().max()) / max(float(sd_g[n].grad.abs().max()), 1e-3 * gmax) for n in live)
+    print(f"  W=512, 32 832 points: worst relative gradient error {worst:.2e}")
+    assert worst < 2e-3, worst
+
+
 def _reference_style_loss(net, g, data, solar, dev):
     """The reference's evaluator flow written with plain torch ops around `Network(X, Sun, Time)` / `Network.forward_Solar`
     calls (Eval_Tools_2.py:165-215, 297-337, 340-420; MSE loss, Use_Solar, no prior): only seam B1 is ours here - the

@@ -254,7 +254,7 @@ def trained_state_dict(g):
     return {k[3:]: torch.tensor(v) for k, v in g.items() if k.startswith("sd_")}
 
 
-@pytest.mark.parametrize("W", [64, 256])
+@pytest.mark.parametrize("W", [64, 256, 512])
 def test_eval_on_really_trained_weights(golden_dir, W):
     """Weights nobody designed: the reference's own loop (get_loss -> backward -> Adam -> OneCycleLR, mg_run_NeRF.py:288-326, Net_Tool_2.py:111-130)
     ran for hundreds of steps on a synthetic scene (tools/make_trained_golden.py); the fixture holds the resulting state_dict and the

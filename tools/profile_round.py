@@ -9,6 +9,8 @@ Collects under gpurun_out/round_TAG/ what profiles/ needs for one build:
   traffic.json          HBM bytes per launch of the dominant kernel (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)
   recompute.txt         frac = algorithmic FLOP / AverageNs / peak, from the stats file alone
   train_*               the same for `bench.py --workload train` (kernel stats; traffic of the whole step)
+  sweep_* / w512_*      kernel stats, PMC passes and HBM traffic of `bench.py --aux-kernel sweep | w512` (the seasonal-sweep kernel at 512 x 512 x 96 x 12, the
+                        fused field kernel at W = 512): what `sweep_roofline` / `w512_roofline` of the bench line are measured on
 rocprofv3 runs `python3 bench.py ...` directly (no shell / env hop after the `--`)."""
 import collections
 import csv
@@ -143,6 +145,31 @@ def main():
             json.dump({"kernel": "snerf::gemm_rows16_kernel<8,4,1,0>, forward 256->256, M = 393216", "command": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE -- python3 bench.py " + " ".join(kargs),
                        "FETCH_SIZE_KB": tk["FETCH_SIZE"], "WRITE_SIZE_KB": tk["WRITE_SIZE"], "correction": "gfx950: FETCH_SIZE x2 (16 B/lane streaming reads)",
                        "bytes_per_launch": (2 * tk["FETCH_SIZE"] + tk["WRITE_SIZE"]) * 1024.0}, open(os.path.join(out, "train_kernel_traffic.json"), "w"), indent=1)
+    # the two auxiliary kernels the bench line carries a roofline for: the seasonal-sweep kernel at configs[4]'s size and the fused field kernel at W = 512
+    for aux, match, counters in (("sweep", "sweep_kernel", ["SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_INSTS_VALU", "GRBM_GUI_ACTIVE"]),
+                                 ("w512", "mlp_i8_kernel", ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_INSTS_MFMA", "SQ_LDS_BANK_CONFLICT", "GRBM_GUI_ACTIVE"])):
+        kargs = ["--aux-kernel", aux, "--steps", "6"]
+        with open(os.path.join(out, aux + "_bench.json"), "w") as f:
+            subprocess.call(["python3", "bench.py"] + kargs, stdout=f, stderr=subprocess.DEVNULL, cwd=REPO)
+        d = os.path.join(out, "prof_" + aux)
+        sh(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "--", "python3", "bench.py"] + kargs, os.path.join(out, f"prof_{aux}.log"))
+        st = find(d, "*kernel_stats.csv")
+        if st:
+            shutil.copy(st, os.path.join(out, aux + "_kernel_stats.csv"))
+        shutil.rmtree(d, ignore_errors=True)
+        ak, lines = {}, []
+        for name, ctrs in (("FETCH_SIZE", ["FETCH_SIZE"]), ("WRITE_SIZE", ["WRITE_SIZE"]), ("SQ", counters)):
+            acc = pmc(out, aux + "_" + name, ctrs, kargs)
+            for k, v in acc.items():
+                if match in k:
+                    for c, vals in v.items():
+                        ak[c] = sum(vals) / len(vals)
+                        lines.append(f"{k[:60]:62s} {c:28s} n={len(vals):3d} mean={sum(vals) / len(vals):.6g}")
+        open(os.path.join(out, aux + "_pmc.txt"), "w").write("\n".join(lines) + "\n")
+        if "FETCH_SIZE" in ak and "WRITE_SIZE" in ak:
+            json.dump({"kernel": match, "command": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE -- python3 bench.py " + " ".join(kargs) + " (separate passes)",
+                       "FETCH_SIZE_KB": ak["FETCH_SIZE"], "WRITE_SIZE_KB": ak["WRITE_SIZE"], "correction": "gfx950: FETCH_SIZE x2 (MI355X_MICROARCH.md, HBM)",
+                       "bytes_per_launch": (2 * ak["FETCH_SIZE"] + ak["WRITE_SIZE"]) * 1024.0}, open(os.path.join(out, aux + "_traffic.json"), "w"), indent=1)
     print(open(os.path.join(out, "recompute.txt")).read())
     print({k: v for k, v in tot.items()})
 
