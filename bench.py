@@ -282,8 +282,11 @@ def bench_train(a, standalone=True):
     np.random.seed(rank)
     torch.manual_seed(rank)
 
+    # --train-graph: one hipGraph launch per step; its first two calls are eager (they build the engine), the third captures - all before the timed region
+    graphed = sn.GraphedTrainStep(tool, d, warmup=2) if getattr(a, "train_graph", False) else None
+
     def step():
-        return tool.train_step(d, 0)           # the loss dict; its total is formed once, after the timed region
+        return graphed(d, 0) if graphed is not None else tool.train_step(d, 0)      # the loss dict; its total is formed once, after the timed region
 
     def total_of(loss):
         return sum(v.detach() * w for v, w in loss.values())
@@ -372,6 +375,7 @@ def bench_train(a, standalone=True):
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "f32 storage; " + ("bf16x3 split MFMA GEMMs (forward with activation on load, dgrad, wgrad)" if gemm != "fp32" else "fp32 MFMA GEMMs"),
                "data": "synthetic",
+               "train_graph": graphed is not None,
                "config": {"workload": f"BASELINE configs[2]: training step 4096x96, T_NeRF({Wt},4) train-mode BatchNorm, solar branch on, {lname}"
                                       + ("" if Wt == 256 else " - at the reference's default width (main_lite.py:80), not the BASELINE config"),
                           "parallelism": f"rays sharded over {world} GPU(s), one all-reduce of the flat gradient arena, BatchNorm statistics "
@@ -472,6 +476,7 @@ def main():
     ap.add_argument("--width", type=int, default=256, choices=[256, 512], help="--workload train: fc_units (256 = BASELINE configs[2]; 512 = the reference's default)")
     ap.add_argument("--headline-only", action="store_true",
                     help="only the headline timed region (no per-mode table, seam, sweep, training step, CPU baseline): profiler passes")
+    ap.add_argument("--train-graph", action="store_true", help="--workload train: the step as one hipGraph launch (season_nerf_amd.GraphedTrainStep; MSE loss, one GPU)")
     ap.add_argument("--no-train", action="store_true", help="render workload: skip the extra training-step measurement (train_* keys)")
     ap.add_argument("--train-kernel-only", action="store_true", help="--workload train: only the dominant training kernel (`--steps` launches), for profiler passes")
     ap.add_argument("--aux-kernel", default=None, choices=["sweep", "w512"], help="only that auxiliary kernel, `--steps` launches (profiler passes): "
@@ -704,6 +709,15 @@ def main():
                     extra["train_cpu_baseline"] = tr["cpu_baseline"]
             except Exception as ex:      # never let the auxiliary measurement break the headline line
                 extra["train_error"] = repr(ex)
+            try:      # the same MSE step replayed as ONE hipGraph launch per step (season_nerf_amd.GraphedTrainStep): what the host costs then
+                torch.cuda.empty_cache()
+                tg_ = bench_train(argparse.Namespace(**{**vars(a), "loss": "mse", "train_graph": True, "no_cpu_baseline": True}), standalone=False)
+                extra.update({"train_graph_ms_per_step": tg_["ms_per_step"], "train_graph_host_enqueue_ms_per_step": tg_["host_enqueue_ms_per_step"],
+                              "train_graph_final_loss": tg_["final_loss"],
+                              "train_graph_note": "the eager step above captured once and replayed as one hipGraph per step; per step the host draws the jitter "
+                                                  "vectors and the random sun rays (host RNG, the reference's order), uploads them and Adam's scalars, launches the graph"})
+            except Exception as ex:
+                extra["train_graph_error"] = repr(ex)
             try:      # configs[2] names the Barron loss: the same step with the adaptive loss object + its own Adam (PARITY UNPINNED)
                 torch.cuda.empty_cache()
                 tb = bench_train(argparse.Namespace(**{**vars(a), "loss": "barron", "no_cpu_baseline": True}), standalone=False)

@@ -280,6 +280,10 @@ int snerf_linear_wgrad(int64_t n_points, int n_in, int n_out, const float* d_gra
 int snerf_trainer_debug_read(snerf_trainer* t, const char* name, float* host_out, int64_t n_floats);
 /* torch.optim.Adam semantics (no weight decay) over the whole parameter arena in one launch; step counts from 1. */
 int snerf_trainer_adam_step(snerf_trainer* t, float lr, float beta1, float beta2, float eps, int step, void* stream);
+/* the same update with its per-step scalars in DEVICE memory: d_hyper6 = [lr, beta1, beta2, eps, 1 - beta1^step, 1 - beta2^step].  For a training
+ * step captured in a hipGraph (kernel arguments are frozen at capture): the host rewrites the six floats before every replay (OneCycleLR,
+ * Net_Tool_2.py:123-130; Adam's bias corrections). */
+int snerf_trainer_adam_step_dev(snerf_trainer* t, const float* d_hyper6, void* stream);
 /* ---- the scalar loss terms of a training step: All_in_One_Eval.get_loss, Eval_Tools_2.py:340-420, in the default training configuration (MSE colour
  * loss :413, solar rays on :350-372, default solar model, no DSM prior).  forward: d_vals5 = [Solar_Correction (:361), Solar_Correction_2 (:366,
  * a value only: detached in this configuration), Sky_Color_Var (:381-388), Albedo_Color (:374-379), Color (:413)], d_min3 = the per-channel albedo

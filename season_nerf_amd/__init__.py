@@ -17,6 +17,6 @@ __all__ = ["T_NeRF", "SineLayer", "All_in_One_Eval", "sample_parameters", "get_P
 from .adaptive_loss import AdaptiveLossFunction  # noqa: E402,F401
 from . import validation  # noqa: E402,F401
 from .validation import DSM_Distance, eval_img, image_error  # noqa: E402,F401
-from .trainer import Net_tool, T_NeRF_Net_Tool  # noqa: E402,F401
+from .trainer import GraphedTrainStep, Net_tool, T_NeRF_Net_Tool  # noqa: E402,F401
 from .model_io import load_model, load_t_nerf, load_args_from_json, parse_time, render_novel_view  # noqa: E402,F401
 from .synthetic import synthetic_state_dict, per_point_layer_shapes  # noqa: E402,F401

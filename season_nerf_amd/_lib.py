@@ -98,6 +98,7 @@ def lib():
     L.snerf_trainer_set_allreduce.argtypes = [vp, vp, vp, i32]
     L.snerf_trainer_debug_read.argtypes = [vp, C.c_char_p, vp, i64]
     L.snerf_trainer_adam_step.argtypes = [vp, C.c_float, C.c_float, C.c_float, C.c_float, i32, vp]
+    L.snerf_trainer_adam_step_dev.argtypes = [vp, vp, vp]
     L.snerf_adam_step.argtypes = [vp, vp, vp, vp, i64, C.c_float, C.c_float, C.c_float, C.c_float, i32, vp]
     L.snerf_rays_from_camera.argtypes = [vp, i32, i32, i32, vp, vp, vp]
     L.snerf_ray_grid.argtypes = [i32, i32, i32, i64, i64, vp, i32, vp, vp, vp, vp, vp]
@@ -134,5 +135,5 @@ EXPORTS = ["snerf_last_error", "snerf_abi_version", "snerf_model_create", "snerf
            "snerf_trainer_create", "snerf_trainer_destroy", "snerf_trainer_classes", "snerf_trainer_param_floats", "snerf_trainer_buffer_floats",
            "snerf_trainer_tensor_count", "snerf_trainer_tensor_info", "snerf_trainer_workspace_bytes", "snerf_trainer_bind", "snerf_trainer_bound_sizes",
            "snerf_trainer_forward_image", "snerf_trainer_backward_image", "snerf_trainer_backward_points", "snerf_trainer_forward_solar",
-           "snerf_trainer_backward_solar", "snerf_trainer_zero_grad", "snerf_trainer_set_allreduce", "snerf_trainer_adam_step", "snerf_adam_step", "snerf_trainer_debug_read",
+           "snerf_trainer_backward_solar", "snerf_trainer_zero_grad", "snerf_trainer_set_allreduce", "snerf_trainer_adam_step", "snerf_trainer_adam_step_dev", "snerf_adam_step", "snerf_trainer_debug_read",
            "snerf_loss_scratch_bytes", "snerf_loss_scratch_init", "snerf_loss_terms_forward", "snerf_loss_terms_backward"]

@@ -943,6 +943,14 @@ int snerf_trainer_adam_step(snerf_trainer* t, float lr, float beta1, float beta2
     return SNERF_OK;
 }
 
+/* the same update with lr / betas / eps / bias corrections read from device memory: what a captured (hipGraph) training step launches */
+int snerf_trainer_adam_step_dev(snerf_trainer* t, const float* d_hyper6, void* stream) {
+    if (!t || !t->params || !t->adam_m || !t->adam_v) return snerf_set_error(SNERF_E_STATE, "trainer not bound (Adam state)");
+    if (!d_hyper6) return snerf_set_error(SNERF_E_INVALID, "snerf_trainer_adam_step_dev: NULL hyper-parameter vector");
+    HIPCK(launch_adam_dev(t->params, t->grads, t->adam_m, t->adam_v, t->n_params, d_hyper6, (hipStream_t)stream));
+    return SNERF_OK;
+}
+
 /* The scalar terms of All_in_One_Eval.get_loss (Eval_Tools_2.py:340-420) for the default training configuration - MSE colour loss, solar rays
  * on, default solar model, no DSM prior - in two launches, and their gradients in one (see include/season_nerf_hip.h). */
 size_t snerf_loss_scratch_bytes(void) { return 4 * sizeof(double) + 4 * sizeof(unsigned); }

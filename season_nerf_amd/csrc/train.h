@@ -195,6 +195,7 @@ struct LossArgs {
 hipError_t launch_loss_scratch_init(void* scratch, hipStream_t st);
 hipError_t launch_loss_terms(const LossArgs& a, void* scratch, float* vals5, float* minv3, hipStream_t st);
 hipError_t launch_loss_terms_bwd(const LossArgs& a, const float* g5, const float* minv3, float* d_rgb, float* d_albedo, float* d_sky, float* d_sv, hipStream_t st);
+hipError_t launch_adam_dev(float* params, const float* grads, float* m, float* v, int64_t n, const float* d_hyper6, hipStream_t st);
 // Adam on a flat arena (torch.optim.Adam semantics, no weight decay)
 hipError_t launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps, int step, hipStream_t st);
 

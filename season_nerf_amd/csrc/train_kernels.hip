@@ -909,6 +909,23 @@ __global__ void adam_kernel(float* p, const float* g, float* m, float* v, int64_
         p[i] = p[i] - (lr / bc1) * (mi / (sqrtf(vi) / sqrtf(bc2) + eps));
     }
 }
+// the same update with its per-step scalars read from DEVICE memory - hyper = [lr, beta1, beta2, eps, 1 - beta1^step, 1 - beta2^step] - so that a
+// captured launch (hipGraph: kernel arguments are frozen at capture time) follows the learning-rate schedule and the bias corrections
+__global__ void adam_dev_kernel(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper) {
+    const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], bc1 = hyper[4], bc2 = hyper[5];
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float gi = g[i];
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] = p[i] - (lr / bc1) * (mi / (sqrtf(vi) / sqrtf(bc2) + eps));
+    }
+}
+hipError_t launch_adam_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, hipStream_t st) {
+    LAUNCH_1D(adam_dev_kernel, n, st, p, g, m, v, n, hyper);
+    return hipGetLastError();
+}
 hipError_t launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps, int step, hipStream_t st) {
     const float bc1 = 1.f - powf(b1, (float)step), bc2 = 1.f - powf(b2, (float)step);
     LAUNCH_1D(adam_kernel, n, st, p, g, m, v, n, lr, b1, b2, eps, bc1, bc2);

@@ -140,6 +140,105 @@ class Net_tool:
         return loss
 
 
+class GraphedTrainStep:
+    """`Net_tool.train_step` (mg_run_NeRF.py:288-326) as ONE hipGraph launch per step.
+
+    The eager step costs the host ~3 ms (Python, dispatcher, autograd, ~220 kernel launches); the GPU needs ~14 ms for it at 4096 x 96, so the
+    host is not on the critical path today - it would be for a faster step, or on a busier host.  Captured once (after `warmup` eager steps have
+    built the engine and every lazily created buffer), the whole sequence - zero_grad, both forward passes, the loss terms, backward, fused Adam -
+    replays from fixed device buffers; per step the host only draws what the reference draws on the host (the two jitter vectors and the random
+    sun rays, in the reference's order: seeded runs reproduce the eager step's draws), uploads them, refreshes Adam's scalars (learning rate of
+    the schedule, bias corrections: device-resident, `FusedAdam.make_capturable`) and launches the graph.
+
+    Limits (checked): the default training configuration only - MSE colour loss, solar rays on, default solar model, no DSM prior (its trust
+    factor is a per-step kernel argument), fused Adam, no process group (the collectives are issued from Python).  Fixed ray count.
+
+        step = GraphedTrainStep(tool, example_batch)
+        for k in range(n): loss = step(batch_k, k)          # loss: the step's LossDict (device tensors, not read back)
+    """
+
+    @staticmethod
+    def eligible(tool):
+        """None if `tool`'s current phase can run captured, else the reason it cannot."""
+        from . import parallel
+        ev = tool.eval_tool
+        a = ev.args
+        if not (tool.fused_adam and ev.use_MSE_loss and a.Use_Solar and not a.Solar_Type_2 and not ev.use_prior):
+            return "only the default training configuration (fused Adam, MSE loss, solar rays, default solar model, no prior)"
+        if parallel.data_parallel():
+            return "not under torch.distributed (the data-parallel exchanges are issued from Python)"
+        return None
+
+    def __init__(self, tool, data_dict, warmup=3):
+        from . import training
+        ev, net = tool.eval_tool, tool.network
+        a = ev.args
+        why = self.eligible(tool)
+        if why:
+            raise ValueError("GraphedTrainStep: " + why)
+        self.tool, self.ev, self.net, self._training = tool, ev, net, training
+        self.dev = dev = ev.device
+        self.R, self.S = data_dict["Top"].shape[0], a.n_samples
+        e = lambda *sh: torch.empty(*sh, device=dev)
+        self.data = {k: e(*data_dict[k].shape) for k in ("Top", "Bot", "Sun_Angle", "Time_Encoded", "GT_Color")}
+        self.tv = {"tv_image": e(self.S), "tv_solar": e(self.S)}
+        self.sol = (e(self.R, 3), e(self.R, 3), e(self.R, 3), e(self.R, 4))
+        self._gen = ev.solar_creation_tool
+        self.warmup, self.calls, self.graph, self.loss = int(warmup), 0, None, None
+
+    def _load(self, data_dict):
+        """Host draws in the reference's order (image jitter, sun rays, sun-ray jitter: Eval_Tools_2.py:169,349,301) + uploads into the fixed buffers."""
+        tr = self._training
+        for k, dst in self.data.items():
+            dst.copy_(tr._to_dev(data_dict[k], self.dev))
+        self.tv["tv_image"].copy_(tr._to_dev(tr.sample_parameters(self.S, eval_mode=False), self.dev))
+        st, en, vec, stime, _ = self._gen(self.R, include_times=True)
+        for dst, src in zip(self.sol, (st, en, vec, stime)):
+            dst.copy_(tr._to_dev(src, self.dev))
+        self.tv["tv_solar"].copy_(tr._to_dev(tr.sample_parameters(self.S, eval_mode=False, include_end_pt=True), self.dev))
+
+    def _body(self):
+        tool, ev = self.tool, self.ev
+        tool.optim.zero_grad()
+        loss = ev.get_loss(self.data, self.net, 0, train_mode=True)
+        loss.total().backward()
+        tool.optim.step()
+        return loss
+
+    def _capture(self):
+        tool, ev = self.tool, self.ev
+        tool.optim.make_capturable()
+        ev.static_inputs = self.tv
+        ev.solar_creation_tool = lambda n, include_times=True: self.sol + (None,)
+        try:
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.loss = self._body()
+        finally:
+            ev.static_inputs = None
+            ev.solar_creation_tool = self._gen
+
+    def __call__(self, data_dict, current_step=0):
+        tool = self.tool
+        if self.calls < self.warmup:                   # eager steps first: the engine, its scratch and every cached constant exist before the capture
+            self.calls += 1
+            return tool.train_step(data_dict, current_step)
+        if data_dict["Top"].shape[0] != self.R:
+            raise ValueError(f"GraphedTrainStep: captured for {self.R} rays, got {data_dict['Top'].shape[0]}")
+        self._load(data_dict)
+        if self.graph is None:
+            self._capture()
+        tool.optim.set_hyper()
+        self.graph.replay()
+        self.net.invalidate_packed()
+        tool.sched.step()
+        tool._log("Training/", self.loss, current_step)
+        tool.last_loss = self.loss
+        self.calls += 1
+        return self.loss
+
+
 class T_NeRF_Net_Tool(Net_tool):
     """`T_NeRF_Net_Tool(args, training_DSM, GT_DSM, device, H, WC)` of Net_Tool_2.py:11-61, `reset_eval` (:63-130) and `step`
     (:134-145).
@@ -151,7 +250,7 @@ class T_NeRF_Net_Tool(Net_tool):
     """
 
     def __init__(self, args, training_DSM, GT_DSM, device, H, WC, *, get_data=None, solar_vecs=None, writer=None, eval_img=None,
-                 fused_adam=True, log_every=1, ada_factory=None):
+                 fused_adam=True, log_every=1, ada_factory=None, use_graph=False):
         from .network import T_NeRF
         self.args, self.device = args, torch.device(device)
         self.writer, self.log_every, self.fused_adam = writer, max(int(log_every), 1), fused_adam
@@ -159,6 +258,7 @@ class T_NeRF_Net_Tool(Net_tool):
         self.batch_size = getattr(args, "batch_size", None)
         self.training_DSM, self.GT_DSM = training_DSM, GT_DSM
         self._step_count = 0
+        self.use_graph, self._graphed = bool(use_graph), None      # use_graph: phases that allow it run as one hipGraph launch per step (GraphedTrainStep)
         self._get_data, self._eval_img, self.solar_vecs = get_data, eval_img, solar_vecs
         # Learning phases (Net_Tool_2.py:23-54): fractions of the run spent in phase 1 (DSM-prior "jump start"), 2, 3 and - the
         # remainder - 4 (free learning); phases 2 and 3 are empty in the reference's schedule.  Attribute names are the reference's
@@ -216,6 +316,7 @@ class T_NeRF_Net_Tool(Net_tool):
         else:
             raise ValueError(f"T_NeRF_Net_Tool: invalid learning mode {mode}")
         self._build_optimisers(args.lr, self.Section_Steps[mode - 1], args.lr_alpha_scale)
+        self._graphed = None                   # a new evaluator and new optimisers: a captured step of the previous phase is stale
 
     def get_data(self, eval_mode=False):
         if self._get_data is None:
@@ -230,7 +331,13 @@ class T_NeRF_Net_Tool(Net_tool):
             self.learning_mode = mode
             self.reset_eval()
         self.network.train()
-        self.train_step(self.get_data(eval_mode=False), self._step_count)
+        data = self.get_data(eval_mode=False)
+        if self.use_graph and GraphedTrainStep.eligible(self) is None:
+            if self._graphed is None or self._graphed.R != data["Top"].shape[0]:
+                self._graphed = GraphedTrainStep(self, data, warmup=2)
+            self._graphed(data, self._step_count)
+        else:
+            self.train_step(data, self._step_count)
         self._step_count += 1
         if self._step_count in self.sub_section_outputs[mode - 1]:
             self.eval_step(self.get_data(eval_mode=True), self._step_count - 1)

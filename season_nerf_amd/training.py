@@ -232,6 +232,10 @@ class TrainEngine:
         _lib.check(self.L.snerf_trainer_adam_step(self.h, float(lr), betas[0], betas[1], eps, self.store.adam_steps, self.stream()),
                    "trainer_adam_step")
 
+    def adam_step_dev(self, hyper):
+        """The Adam launch with lr / betas / eps / bias corrections read from the device vector `hyper` (6 floats): capturable in a hipGraph."""
+        _lib.check(self.L.snerf_trainer_adam_step_dev(self.h, hyper.data_ptr(), self.stream()), "trainer_adam_step_dev")
+
     def __del__(self):
         try:
             _ENGINES.pop(self.handle, None)
@@ -486,7 +490,7 @@ class LossDict(dict):
             if len(cache) > 64:
                 cache.clear()
             wt = cache[(key, dev)] = torch.tensor(key, dtype=torch.float32, device=dev)
-        return torch.dot(self.vec, wt)
+        return (self.vec * wt).sum()
 
     _wcache = {}
 
@@ -532,7 +536,8 @@ def eval_train(ev, data_dict, net, train_mode, current_step=0):
     R, S = top.shape[0], ev.args.n_samples
     n_solar = R if ev.args.Use_Solar else 0
     eng = _engine_for(net, R, n_solar, S)
-    tv = _to_dev(sample_parameters(S, eval_mode=not train_mode), dev)
+    static = getattr(ev, "static_inputs", None)                # a captured step (trainer.GraphedTrainStep): the sample parameters sit in fixed device tensors
+    tv = static["tv_image"] if static is not None else _to_dev(sample_parameters(S, eval_mode=not train_mode), dev)
     eng.classic_solar = bool(ev.use_classic_solar)            # Solar_Type_2: per-sample shading, Solar_Vis carries gradient
     res = _image_pass(eng, top, bot, tv, sun, tim, net.training, net.height_map_on(dev) if ev.use_prior else None,
                       current_step / ev.n_steps if ev.use_prior else 1.0)
@@ -567,7 +572,8 @@ def eval_rho_only_train(ev, data_dict, net, train_mode, current_step=0):
         if torch.is_grad_enabled() and net.training:
             raise RuntimeError("season_nerf_amd: the sun-ray pass must follow an image pass of the same step with as many rays")
         eng = _engine_for(net, R, R, S)
-    tv = _to_dev(sample_parameters(S, eval_mode=not train_mode, include_end_pt=True), dev)
+    static = getattr(ev, "static_inputs", None)
+    tv = static["tv_solar"] if static is not None else _to_dev(sample_parameters(S, eval_mode=not train_mode, include_end_pt=True), dev)
     sv, pv, pe, sky_raw, rho, pts, dl = _solar_pass(eng, top, bot, tv, sun, net.training)
     _after_train_forward(net)
     if ev.use_prior:                                              # Eval_Tools_2.py:319-334
@@ -670,6 +676,27 @@ class FusedAdam(torch.optim.Optimizer):
             store.adam_m.zero_()
             store.adam_v.zero_()
             store.adam_steps = 0
+        self.hyper = None              # device vector [lr, beta1, beta2, eps, 1 - beta1^t, 1 - beta2^t] of the capturable form
+        self._hyper_host = None
+
+    def make_capturable(self):
+        """Switch to the form a hipGraph can hold: `step()` launches the Adam kernel that reads its scalars from `self.hyper`; the host
+        refreshes them with `set_hyper()` before every replay (the learning-rate schedule and the step count live on the host)."""
+        store = self.net._param_store
+        self.hyper = torch.zeros(6, device=store.dev)
+        self._hyper_host = torch.zeros(6).pin_memory()
+        return self
+
+    def set_hyper(self):
+        """Upload the scalars of the NEXT Adam step (param_groups' lr / betas / eps, step count + 1) - stream-ordered, no sync."""
+        g = self.param_groups[0]
+        store = self.net._param_store
+        store.adam_steps += 1
+        t = store.adam_steps
+        b1, b2 = g["betas"]
+        h = self._hyper_host
+        h[0], h[1], h[2], h[3], h[4], h[5] = float(g["lr"]), b1, b2, g["eps"], 1.0 - b1 ** t, 1.0 - b2 ** t
+        self.hyper.copy_(h, non_blocking=True)
 
     def state_dict(self):
         """Checkpointable state: torch's param_groups plus the flat Adam moments and the step count of the network's store."""
@@ -717,5 +744,10 @@ class FusedAdam(torch.optim.Optimizer):
             parallel.COLLECTIVES["grad_arena_all_reduce"] += 1
             if torch.distributed.get_world_size() > 1:
                 eng.grads /= torch.distributed.get_world_size()
-        eng.adam_step(g["lr"], g["betas"], g["eps"])
+        if self.hyper is not None:     # capturable form: the step's scalars come from device memory (a replayed graph: set_hyper before every replay)
+            if not torch.cuda.is_current_stream_capturing():
+                self.set_hyper()       # an eager step after make_capturable(): refresh them here
+            eng.adam_step_dev(self.hyper)
+        else:
+            eng.adam_step(g["lr"], g["betas"], g["eps"])
         self.net.invalidate_packed()  # parameters changed outside torch's version counters: re-pack before inference

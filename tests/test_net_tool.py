@@ -116,3 +116,99 @@ def test_phase_switch_and_lr_trajectory(golden_dir):
         tool.sched.step()                                # the LR law only: no gradient step needed (torch warns about the order)
         got.append(tool.sched.get_last_lr()[0])
     np.testing.assert_allclose(got, g["onecycle_lr"], rtol=1e-12)
+
+
+@pytest.mark.gpu
+def test_graphed_train_step_follows_the_eager_step():
+    """trainer.GraphedTrainStep: the training step (mg_run_NeRF.py:288-326) captured once and replayed as one hipGraph launch per step must BE the
+    eager step: same host draws (jitter, random sun rays: seeded alike), same loss values, same parameters after eight steps under the OneCycleLR
+    schedule (the learning rate and Adam's bias corrections reach the captured Adam kernel through device memory) - to the noise of atomically
+    reduced gradients."""
+    import season_nerf_amd as sn
+    from oracle import season_nerf_oracle as orc
+    W, R, S, n_steps = 64, 96, 32, 8
+    WC, H4 = np.array([41.29, -95.9, 300.0]), np.array([[310.0, 12.0, 0.0, -11650.0], [-9.0, 240.0, 0.0, 23390.0], [0.0, 0.0, 0.01, -3.0], [0, 0, 0, 1.0]])
+    rng = np.random.Generator(np.random.PCG64(5))
+    t = lambda a: torch.tensor(a, dtype=torch.float32, device="cuda")
+    sun = rng.uniform(0.1, 1, (R, 3)); sun /= np.linalg.norm(sun, axis=1, keepdims=True)
+    tau = rng.uniform(0, 1, (R, 2))
+    batches = []
+    for k in range(n_steps):
+        batches.append({"Top": t(np.concatenate([rng.uniform(-1, 1, (R, 2)), np.ones((R, 1))], 1)), "Bot": t(np.concatenate([rng.uniform(-1, 1, (R, 2)), -np.ones((R, 1))], 1)),
+                        "Sun_Angle": t(sun), "Time_Encoded": t(np.stack([np.cos(6.28 * tau[:, 0]), np.sin(6.28 * tau[:, 0]), np.cos(6.28 * tau[:, 1]), np.sin(6.28 * tau[:, 1])], 1)),
+                        "GT_Color": t(rng.uniform(0, 1, (R, 3)))})
+
+    def run(graphed):
+        net = sn.T_NeRF(W, 4)
+        net.load_state_dict(orc.init_weights(W, 4, 7, bn_stats="identity"))
+        net = net.cuda().train()
+        args = SimpleNamespace(n_samples=S, Use_Reg=True, Solar_Type_2=False, Use_MSE_loss=True, Use_Solar=True, sc_lambda=0.03, number_low_frequency_cases=4)
+        ev = sn.All_in_One_Eval(args, torch.device("cuda"), 10, False, None, H4, WC)
+        tool = sn.Net_tool(net, ev, 3e-4, total_steps=n_steps + 1, writer=None)   # (a large rate lets Adam amplify the rounding noise of the atomics into the losses)
+        step = sn.GraphedTrainStep(tool, batches[0], warmup=2) if graphed else None
+        np.random.seed(11); torch.manual_seed(11)
+        losses = []
+        for k in range(n_steps):
+            loss = step(batches[k], k) if graphed else tool.train_step(batches[k], k)
+            losses.append({n: float(v[0]) for n, v in loss.items()})
+        if graphed:
+            assert step.graph is not None and step.calls == n_steps
+        return losses, {k: v.detach().clone() for k, v in net.state_dict().items()}, tool.sched.get_last_lr()[0]
+
+    le, pe, lre = run(False)
+    lg, pg, lrg = run(True)
+    assert lre == lrg
+    for k in range(n_steps):
+        for n, v in le[k].items():
+            assert abs(lg[k][n] - v) <= 2e-4 * max(abs(v), 1e-3), (k, n, lg[k][n], v)
+    # Parameters: Adam divides by sqrt(v), so the rounding noise of atomically reduced gradients moves weights whose gradient is ~0 by up to lr per
+    # step in either run - element-wise equality is not a property of the eager step either.  What must hold: the two runs made the SAME update
+    # (schedule, bias corrections, moments), i.e. their difference is small against the distance travelled from the initial weights.
+    p0 = orc.init_weights(W, 4, 7, bn_stats="identity")
+    moved = diff = 0.0
+    for k, v in pe.items():
+        if v.is_floating_point() and "running" not in k:
+            moved += float((v.cpu() - p0[k]).abs().sum())
+            diff += float((pg[k] - v).abs().sum())
+        elif not v.is_floating_point():
+            assert torch.equal(pg[k], v), k                      # num_batches_tracked: the captured step counts its forwards too
+    print(f"  graphed vs eager after {n_steps} steps: sum |difference| / sum |update| = {diff / moved:.2e}")
+    assert moved > 0 and diff < 0.02 * moved, (diff, moved)
+    for k, v in pe.items():
+        if "running" in k:
+            assert float((pg[k] - v).abs().max()) <= 5e-3 * max(float(v.abs().max()), 1e-2), k
+
+
+@pytest.mark.gpu
+def test_driver_with_use_graph_switches_to_the_captured_step():
+    """T_NeRF_Net_Tool(..., use_graph=True): 12 steps - phase 1 (DSM prior: not capturable, eager) then phase 4, whose first two steps run eagerly and
+    the rest as one hipGraph launch each; a new phase (new evaluator / optimisers) drops the captured step.  The learning rate follows the same
+    OneCycleLR trajectory as the eager driver, Adam's step count too, and the loss keeps falling through the switch."""
+    import season_nerf_amd as sn
+    from oracle import season_nerf_oracle as orc
+    rng = np.random.Generator(np.random.PCG64(3))
+    hm = rng.uniform(-0.8, 0.6, (24, 24))
+    R = 48
+    t = lambda a: torch.tensor(a, dtype=torch.float32)
+    data = {"Top": t(np.concatenate([rng.uniform(-1, 1, (R, 2)), np.ones((R, 1))], 1)), "Bot": t(np.concatenate([rng.uniform(-1, 1, (R, 2)), -np.ones((R, 1))], 1)),
+            "Sun_Angle": torch.nn.functional.normalize(t(rng.uniform(0.1, 1, (R, 3))), dim=1), "Time_Encoded": t(rng.uniform(-1, 1, (R, 4))),
+            "GT_Color": t(rng.uniform(0, 1, (R, 3)))}
+    WC, H4 = np.array([41.29, -95.9, 300.0]), np.array([[310.0, 12.0, 0.0, -11650.0], [-9.0, 240.0, 0.0, 23390.0], [0.0, 0.0, 0.01, -3.0], [0, 0, 0, 1.0]])
+    out = {}
+    for use_graph in (False, True):
+        args = _args(12, n_saves=5, use_mse=True)
+        tool = sn.T_NeRF_Net_Tool(args, hm, hm, "cuda", H4, WC, get_data=lambda eval_mode: data, use_graph=use_graph)
+        tool.network.load_state_dict(orc.init_weights(64, 4, 1))
+        np.random.seed(3); torch.manual_seed(3)
+        lrs, steps, colour, graphed = [], [], [], []
+        for s_ in range(12):
+            tool.step()
+            lrs.append(tool.sched.get_last_lr()[0])
+            steps.append(tool.network._param_store.adam_steps)
+            colour.append(float(tool.last_loss["Color"][0]))
+            graphed.append(tool._graphed is not None and tool._graphed.graph is not None)
+        out[use_graph] = (lrs, steps, colour, graphed)
+    assert out[False][3] == [False] * 12
+    assert out[True][3] == [False] * 4 + [True] * 8          # steps 0-1: prior phase; 2-3: eager warm-up of the new phase; from step 4 on: replays
+    assert out[True][0] == out[False][0] and out[True][1] == out[False][1]
+    np.testing.assert_allclose(out[True][2], out[False][2], rtol=2e-3)
