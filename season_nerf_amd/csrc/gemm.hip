@@ -1142,6 +1142,13 @@ hipError_t launch_gemm_bf16x3(const GemmX& g, hipStream_t st) {
             if (mode16 && g.W && k32 && ntf == 4 && (!aol || g.act_cols % 32 == 0) && lds_f + 128 * 4 * 5 <= 160 * 1024) {
                 return launch_gemm_rows16(gx, aol_mode, act_mode, grid_f, lds_f + 128 * 4 * (act_mode ? 5 : 1), st);      // + per-column constants
             }
+            // the K = 320 layer ([fc4 | PE]: 64-column groups, four of them read every A row): its forward on the same kernel, whose quad-coalesced
+            // A loads cost the vector-memory path half of what the lane-per-row operand layout of the 32x32x16 form does
+            static int mode16_k320 = -1;
+            if (mode16_k320 < 0) { const char* e = getenv("SNERF_GEMM16_K320"); mode16_k320 = (e && e[0] == '0') ? 0 : 1; }
+            if (mode16 && mode16_k320 && g.W && k32 && ntf == 2 && !act && g.n_tiles % 2 == 0 && (!aol || g.act_cols % 32 == 0) && lds_f + 128 * 4 <= 160 * 1024) {
+                return launch_gemm_rows16(gx, aol_mode, 0, grid_f, lds_f + 128 * 4, st, 4);
+            }
             {
                 hipError_t e = split32();
                 if (e != hipSuccess) return e;

@@ -744,7 +744,9 @@ bool gemm_wreg_ok(const GemmX& gx) {
 #endif      // SNERF_WITH_WREG
 
 // gx: as launch_gemm_bf16x3 prepared it for the full-tile path (raw weights in gx.W, K in whole 32-k steps, N = 32 n_tiles)
-hipError_t launch_gemm_rows16(const GemmX& gx_in, int aol_mode, int act_mode, dim3 grid, size_t lds, hipStream_t st) {
+// nt16: 16-column n-tiles per column group - 8 (128 columns; K <= 256) or 4 (64 columns: the K = 320 layer, whose 128-column slice of hi / lo weights
+// does not fit the LDS beside its table)
+hipError_t launch_gemm_rows16(const GemmX& gx_in, int aol_mode, int act_mode, dim3 grid, size_t lds, hipStream_t st, int nt16) {
     GemmX gx = gx_in;
     gx.reverse = stream_direction(gx.M);      // every other streaming launch walks its row tiles backwards (gemm.hip)
     const int KS32 = gx.ksteps / 2;
@@ -761,6 +763,11 @@ hipError_t launch_gemm_rows16(const GemmX& gx_in, int aol_mode, int act_mode, di
     if (R16_RT == 1) {                      // experimental geometry (16 waves x 16 rows, 128 registers): only the scratch-free forms
         if (act_mode) return hipErrorInvalidValue;
         pf16 = 1;
+    }
+    if (nt16 == 4) {
+        if (act_mode) return hipErrorInvalidValue;               // (the 64-column form exists for forwards only)
+        if (pf16 == 4) return launch_rows16<4, 4>(gx, 1, 0, grid, lds, st);
+        return pf16 == 2 ? launch_rows16<4, 2>(gx, aol_mode, 0, grid, lds, st) : launch_rows16<4, 1>(gx, aol_mode, 0, grid, lds, st);
     }
     if (pf16 == 4) return launch_rows16<8, 4>(gx, 1, 0, grid, lds, st);
     return pf16 == 2 ? launch_rows16<8, 2>(gx, aol_mode, act_mode, grid, lds, st) : launch_rows16<8, 1>(gx, aol_mode, act_mode, grid, lds, st);
