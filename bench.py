@@ -459,7 +459,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--prewarm", type=int, default=200, help="untimed steps run before --warmup (reported as `prewarm_steps`): clock ramp of a cold chip")
+    ap.add_argument("--prewarm", type=int, default=200, help="untimed steps run before --warmup (reported as `prewarm_steps`): clock ramp of a cold chip; 0 = none")
+    ap.add_argument("--prewarm-seconds", type=float, default=2.0, help="the pre-warm lasts at least this long (the part's clock settles over seconds, not over 200 steps)")
     ap.add_argument("--precision", default="auto", choices=["auto", "i8x3", "bf16x3", "bf16"],
                     help="arithmetic of the fused field kernel in the headline timed region (include/season_nerf_hip.h SNERF_PREC_*): "
                          "auto = what season_nerf_amd.T_NeRF picks by default: i8x3 where the pack-time error bound of the int8-digit "
@@ -564,8 +565,12 @@ def main():
 
     # declared, untimed pre-warm BEFORE the driver's --warmup: the chip's clock depends on its load history, and a 20-step sample taken 5 steps
     # after start-up read 8 % slower than the same block repeated right after (round 3: 0.818 against a median of 0.752 ms)
-    for _ in range(a.prewarm):
-        step()
+    n_pre, t_pre = 0, time.perf_counter()
+    while n_pre < a.prewarm or (a.prewarm > 0 and time.perf_counter() - t_pre < a.prewarm_seconds):      # at least --prewarm steps AND --prewarm-seconds of load
+        for _ in range(50):
+            step()
+        torch.cuda.synchronize()
+        n_pre += 50
     for _ in range(a.warmup):
         step()
     if use_dist:
@@ -599,8 +604,9 @@ def main():
                 step()
             torch.cuda.synchronize()
             bl.append((time.perf_counter() - tb) / a.steps * 1e3)
+        seq = list(bl)
         bl.sort()
-        blocks = {"blocks": len(bl), "steps_per_block": a.steps, "ms_per_step_median": bl[len(bl) // 2], "ms_per_step_min": bl[0],
+        blocks = {"ms_per_step_in_order": seq, "blocks": len(bl), "steps_per_block": a.steps, "ms_per_step_median": bl[len(bl) // 2], "ms_per_step_min": bl[0],
                   "ms_per_step_max": bl[-1], "value_at_median": R * S / (bl[len(bl) // 2] * 1e-3)}
 
     extra = {}
@@ -747,7 +753,7 @@ def main():
             pass
         out = {
             "metric": "ray-samples/sec (4096 rays x 96 samples forward render, T_NeRF 8x256)",
-            "value": value, "unit": "ray-samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "prewarm_steps": a.prewarm,
+            "value": value, "unit": "ray-samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "prewarm_steps": n_pre,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": DTYPES[prec], "precision": a.precision, "precision_resolved": prec, "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: forward render 4096 rays x 96 samples, T_NeRF(256,4) eval-mode, "
