@@ -400,6 +400,31 @@ void train_bwd_solar(int64_t trainer, Tensor grads, const Tensor& g_sv) {
     ck(snerf_trainer_backward_solar(t, fptr(g_sv), cur_stream(grads)), "train_bwd_solar");
 }
 
+// ---- the engine's optimiser step and gradient reset as ops (dispatcher- and profiler-visible; `params` / `grads` are the flat arenas the trainer is bound to)
+void trainer_adam_step_(int64_t trainer, Tensor params, const Tensor& grads, double lr, double beta1, double beta2, double eps, int64_t step) {
+    snerf_trainer* t = trainer_of(trainer);
+    check_dev_f32(params, "params"); check_dev_f32(grads, "grads");
+    TORCH_CHECK(grads.numel() == params.numel() && params.numel() == snerf_trainer_param_floats(t), "params / grads must be the trainer's flat arenas (",
+                snerf_trainer_param_floats(t), " floats)");
+    c10::hip::HIPGuardMasqueradingAsCUDA g(params.device());
+    ck(snerf_trainer_adam_step(t, (float)lr, (float)beta1, (float)beta2, (float)eps, (int)step, cur_stream(params)), "trainer_adam_step_");
+}
+void trainer_adam_step_dev_(int64_t trainer, Tensor params, const Tensor& grads, const Tensor& hyper) {
+    snerf_trainer* t = trainer_of(trainer);
+    check_dev_f32(params, "params"); check_dev_f32(grads, "grads"); check_dev_f32(hyper, "hyper");
+    TORCH_CHECK(hyper.numel() == 6, "hyper must hold [lr, beta1, beta2, eps, 1 - beta1^t, 1 - beta2^t]");
+    TORCH_CHECK(grads.numel() == params.numel() && params.numel() == snerf_trainer_param_floats(t), "params / grads must be the trainer's flat arenas");
+    c10::hip::HIPGuardMasqueradingAsCUDA g(params.device());
+    ck(snerf_trainer_adam_step_dev(t, fptr(hyper), cur_stream(params)), "trainer_adam_step_dev_");
+}
+void trainer_zero_grad_(int64_t trainer, Tensor grads) {
+    snerf_trainer* t = trainer_of(trainer);
+    check_dev_f32(grads, "grads");
+    TORCH_CHECK(grads.numel() == snerf_trainer_param_floats(t), "grads must be the trainer's flat gradient arena");
+    c10::hip::HIPGuardMasqueradingAsCUDA g(grads.device());
+    ck(snerf_trainer_zero_grad(t, cur_stream(grads)), "trainer_zero_grad_");
+}
+
 // the self-cleaning reduction scratch of loss_terms: one per device, created (and initialised, in stream order) at first use; launches of one
 // device are serialised by their stream, and the forward leaves the scratch in its initial state
 static Tensor loss_scratch(const Tensor& like) {
@@ -471,6 +496,9 @@ TORCH_LIBRARY(season_nerf, m) {
           "int flags, bool classic) -> Tensor[]");
     m.def("fused_adam_(Tensor(a!) param, Tensor grad, Tensor(b!) m, Tensor(c!) v, float lr, float beta1, float beta2, float eps, int step) -> ()");
     m.def("prior_density(Tensor pts, Tensor delta, Tensor height_map, Tensor? outside) -> Tensor");
+    m.def("trainer_adam_step_(int trainer, Tensor(a!) params, Tensor grads, float lr, float beta1, float beta2, float eps, int step) -> ()");
+    m.def("trainer_adam_step_dev_(int trainer, Tensor(a!) params, Tensor grads, Tensor hyper) -> ()");
+    m.def("trainer_zero_grad_(int trainer, Tensor(a!) grads) -> ()");
     m.def("loss_terms(Tensor rgb, Tensor gt, Tensor albedo, Tensor sky, Tensor solar_vis, Tensor pv_exact, Tensor pe, Tensor? albedo_min_global, int world) "
           "-> (Tensor, Tensor)");
     m.def("loss_terms_bwd(Tensor g_vals, Tensor rgb, Tensor gt, Tensor albedo, Tensor sky, Tensor solar_vis, Tensor pv_exact, Tensor min, int world) "
@@ -492,6 +520,9 @@ TORCH_LIBRARY_IMPL(season_nerf, CUDA, m) {      // "CUDA" is the dispatch key of
     m.impl("render_fwd", render_fwd);
     m.impl("composite", composite);
     m.impl("composite_sweep", composite_sweep);
+    m.impl("trainer_adam_step_", trainer_adam_step_);
+    m.impl("trainer_adam_step_dev_", trainer_adam_step_dev_);
+    m.impl("trainer_zero_grad_", trainer_zero_grad_);
     m.impl("loss_terms", loss_terms);
     m.impl("loss_terms_bwd", loss_terms_bwd);
     m.impl("fused_adam_", fused_adam_);

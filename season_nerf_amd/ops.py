@@ -47,6 +47,18 @@ def _register_fakes():
     def _(param, grad, m, v, lr, beta1, beta2, eps, step):
         return None
 
+    @reg("season_nerf::trainer_adam_step_")
+    def _(trainer, params, grads, lr, beta1, beta2, eps, step):
+        return None
+
+    @reg("season_nerf::trainer_adam_step_dev_")
+    def _(trainer, params, grads, hyper):
+        return None
+
+    @reg("season_nerf::trainer_zero_grad_")
+    def _(trainer, grads):
+        return None
+
     @reg("season_nerf::prior_density")
     def _(pts, delta, height_map, outside):
         return pts.new_empty(pts.shape[0], 1)

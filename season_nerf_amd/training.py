@@ -224,17 +224,20 @@ class TrainEngine:
     def stream(self):
         return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
+    # the optimiser step and the gradient reset go through torch.ops.season_nerf.trainer_* (csrc/ops.cpp): dispatcher- and profiler-visible like the passes
     def zero_grad(self):
-        _lib.check(self.L.snerf_trainer_zero_grad(self.h, self.stream()), "trainer_zero_grad")
+        from .network import _ops
+        _ops().trainer_zero_grad_(self.handle, self.grads)
 
     def adam_step(self, lr, betas=(0.9, 0.999), eps=1e-8):
+        from .network import _ops
         self.store.adam_steps += 1
-        _lib.check(self.L.snerf_trainer_adam_step(self.h, float(lr), betas[0], betas[1], eps, self.store.adam_steps, self.stream()),
-                   "trainer_adam_step")
+        _ops().trainer_adam_step_(self.handle, self.params, self.grads, float(lr), betas[0], betas[1], eps, self.store.adam_steps)
 
     def adam_step_dev(self, hyper):
         """The Adam launch with lr / betas / eps / bias corrections read from the device vector `hyper` (6 floats): capturable in a hipGraph."""
-        _lib.check(self.L.snerf_trainer_adam_step_dev(self.h, hyper.data_ptr(), self.stream()), "trainer_adam_step_dev")
+        from .network import _ops
+        _ops().trainer_adam_step_dev_(self.handle, self.params, self.grads, hyper)
 
     def __del__(self):
         try:
