@@ -746,7 +746,8 @@ class FusedAdam(torch.optim.Optimizer):
             torch.distributed.all_reduce(eng.grads)
             parallel.COLLECTIVES["grad_arena_all_reduce"] += 1
             if torch.distributed.get_world_size() > 1:
-                eng.grads /= torch.distributed.get_world_size()
+                eng.grads.div_(torch.distributed.get_world_size())      # (`eng.grads /= n` would try to rebind the read-only property: found by the
+                                                                        # first run with two real ranks, tests/test_gpu_two_ranks.py)
         if self.hyper is not None:     # capturable form: the step's scalars come from device memory (a replayed graph: set_hyper before every replay)
             if not torch.cuda.is_current_stream_capturing():
                 self.set_hyper()       # an eager step after make_capturable(): refresh them here
