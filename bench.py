@@ -71,6 +71,20 @@ def host_cpus():
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
+
+def _local_device():
+    """The GPU of this rank: LOCAL_RANK.  SNERF_BENCH_DEVICE overrides it - the two-rank rehearsal on a ONE-GPU box puts every rank on device 0
+    (tests/test_gpu_two_ranks.py), together with SNERF_BENCH_BACKEND=gloo (RCCL refuses two ranks on one device; gloo reduces device tensors)."""
+    return int(os.environ.get("SNERF_BENCH_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+
+
+def _init_group(dist, dev):
+    backend = os.environ.get("SNERF_BENCH_BACKEND", "nccl")          # "nccl" IS RCCL on ROCm
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=dev)
+    else:
+        dist.init_process_group(backend)
+
 R, S, W, NC = 4096, 96, 256, 4
 # SURVEY 8(d): algorithmic forward cost per ray-sample at W=256, C=4, S=96 (2 FLOP per MAC, per-ray branches amortised)
 FLOP_PER_SAMPLE = 2 * (743936 + 71040 / 96.0)
@@ -254,13 +268,13 @@ def bench_train(a, standalone=True):
     import season_nerf_amd as sn
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    dev = torch.device("cuda", _local_device())
     torch.cuda.set_device(dev)
     dist = None
     use_dist = standalone and (world > 1 or "RANK" in os.environ)      # under torch.distributed.run the RCCL path runs even with one rank
     if use_dist:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        _init_group(dist, dev)
     steps, warm = (min(a.steps, 20), min(a.warmup, 3)) if standalone else (12, 3)
     Wt = getattr(a, "width", W)
     net = sn.T_NeRF(Wt, NC)
@@ -493,7 +507,7 @@ def main():
         sys.exit(self_launch(a, sys.argv[1:]))          # child ranks; nothing here has touched the GPU
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = _local_device()
     if a.gpus != world and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but the launcher started {world} ranks")
     if a.backend == "gloo":
@@ -522,7 +536,7 @@ def main():
     use_dist = world > 1 or "RANK" in os.environ          # under torch.distributed.run the RCCL path runs even with one rank
     if use_dist:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        _init_group(dist, dev)
 
     import season_nerf_amd as sn
     L = sn._lib.lib()

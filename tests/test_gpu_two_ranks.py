@@ -161,3 +161,37 @@ def test_two_real_ranks_render_tiles_and_gather():
         for i, step in enumerate((3, 4)):
             for src in range(2):
                 assert bool((r["tiles"][i, src] == float(10 * src + step)).all()), (step, src)
+
+
+def _bench_two_ranks(extra):
+    """`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 ...` - the command the driver runs for its scaling curve - with both ranks on
+    device 0 and gloo instead of RCCL (SNERF_BENCH_DEVICE / SNERF_BENCH_BACKEND): the N > 1 code of bench.py itself, executed with two real processes."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SNERF_BENCH_DEVICE="0", SNERF_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+           str(29500 + (os.getpid() + 6543) % 2000), os.path.join(repo, "bench.py"), "--gpus", "2"] + extra
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_render_with_two_real_ranks():
+    d = _bench_two_ranks(["--steps", "16", "--warmup", "8", "--prewarm", "0", "--no-cpu-baseline", "--no-sweep", "--no-train"])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 1e7
+    assert d["collectives"]["tile_group_all_gather"] == 3                       # 8 warm-up steps = one tile group, 16 timed = two
+    print(f"  bench.py --gpus 2, both ranks on one GPU over gloo: {d['value']:.3e} ray-samples/s (two ranks SHARE the GPU: not a scaling number)")
+
+
+def test_bench_training_with_two_real_ranks():
+    d = _bench_two_ranks(["--workload", "train", "--steps", "3", "--warmup", "2", "--bn_sync", "global", "--no-cpu-baseline"])
+    steps = 3 + 2 + 6
+    c = d["collectives"]
+    assert d["n_gpus"] == 2 and c["grad_arena_all_reduce"] == steps and c["albedo_min_all_reduce"] == steps and c["bn_stats_all_reduce"] == 24 * (steps - 1), c
+    assert np.isfinite(d["final_loss"]) and 0 < d["final_loss"] < 10
