@@ -136,6 +136,24 @@ __global__ __launch_bounds__(512) void probe(float* out, uint64_t* cyc, int iter
             t1 = __builtin_amdgcn_s_memtime();
             for (int t = 0; t < 4; ++t) sink ^= (uint32_t)A4[t][t];
         }
+    } else if (MODE == 5) {
+        // ---- the yardstick with LIVE data: the same 48 register-fed MFMAs per iteration, but every MFMA gets another pair of random operands (eight sets in
+        // rotation, taken from the hashed LDS image): operand toggling as in the real kernel - what clock does the chip hold for THAT?
+        if (wave < 4) {
+            i32x16 A4[4];
+            for (int t = 0; t < 4; ++t) for (int e = 0; e < 16; ++e) A4[t][e] = 0;
+            i32x4 ra[8], rb[8];
+            for (int q = 0; q < 8; ++q) { ra[q] = *(const i32x4*)(lds + W_OFF + q * 1024 + lane * 16); rb[q] = *(const i32x4*)(lds + W_OFF + (8 + q) * 1024 + lane * 16); }
+            t0 = __builtin_amdgcn_s_memtime();
+            for (int it = 0; it < iters; ++it) {
+#pragma unroll
+                for (int k = 0; k < 12; ++k)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) A4[t] = MFMA(ra[(4 * k + t) & 7], rb[(4 * k + t + 3) & 7], A4[t]);
+            }
+            t1 = __builtin_amdgcn_s_memtime();
+            for (int t = 0; t < 4; ++t) sink ^= (uint32_t)A4[t][t];
+        }
     } else if (MODE == 2) {
         // ---- MFMA only, waves 0-3 two tiles each (48 per iteration), waves 4-7 idle
         if (wave < 4) {
@@ -263,6 +281,7 @@ int main() {
     float* out; uint64_t* cyc;
     hipMalloc(&out, 256 * 512 * 4); hipMalloc(&cyc, 256);
     const double base = run<4>("MFMA-regs", out, cyc, 0);      // 32 cycles each by construction: the tick -> cycle yardstick
+    run<5>("MFMA-live", out, cyc, base);     // the same with random operands that change every MFMA
     run<2>("MFMA+LDS", out, cyc, base);
     for (int rep = 0; rep < 2; ++rep) {
         run<0>("SYM", out, cyc, base);
