@@ -781,6 +781,9 @@ def main():
                          "kernel": KERNELS[prec], "kernel_ms": field_ms,
                          "executed_tops": MFMAS_PER_WAVE_TILE[prec] * 65536 * (R * S / 32) / (field_ms * 1e-3) / 1e12,
                          "frac_of_int8_peak": (achieved / PEAK_INT8_DENSE) if prec == "i8x3" else None,
+                         # measured, not nominal: back-to-back int8 MFMAs whose operands change every instruction hold 1.60 GHz on this part = 3.35 POP/s
+                         # (tools/probes/wave_spec_i8.hip "MFMA-live", profiles/r4/wave_spec_i8_probe.txt; constant operands: 2.10 GHz); an extra, `frac` is unchanged
+                         "executed_frac_of_sustained_int8_rate": (MFMAS_PER_WAVE_TILE[prec] * 65536 * (R * S / 32) / (field_ms * 1e-3) / 3.35e15) if prec == "i8x3" else None,
                          "note": "achieved = algorithmic 1.489 MFLOP/ray-sample x 393216 / kernel time, peak = dense bf16 MFMA (the north "
                                  "star's dtype; MI355X_MICROARCH.md); frac_of_int8_peak = the same against the 5 Pop/s of the kernel's own "
                                  "dtype (int8 MFMA: 2x bf16 per clock). " + EXEC_NOTE[prec]},
