@@ -553,12 +553,15 @@ def test_backward_survives_engine_eviction():
         assert float((v - g1[k]).abs().max()) <= 1e-5 * float(v.abs().max()) + 2e-7 * gmax, k
 
 
-def test_training_follows_the_reference_trajectory(golden_dir):
+@pytest.mark.parametrize("graphed", [False, True])
+def test_training_follows_the_reference_trajectory(golden_dir, graphed):
     """40 CONSECUTIVE steps of the reference's own training loop (tools/make_trajectory_golden.py: mg_run_NeRF.py:288-326 with the optimiser / OneCycleLR of
     Net_Tool_2.py:111-130 on fixed batches of a synthetic scene, host RNGs seeded once) replayed through season_nerf_amd.Net_tool with the same seeds: the RNG
     draw order (image jitter, sun-ray angles / positions / times, sun-ray jitter - Eval_Tools_2.py:169,349,301), the sun-ray generator, both passes, the loss terms,
     backward, fused Adam, the schedule and the BatchNorm running statistics - every step against the reference's loss dict.  Rounding differences compound through
-    Adam, so the band widens with the step count; a wrong schedule, moment, draw order or statistic leaves it within a few steps."""
+    Adam, so the band widens with the step count; a wrong schedule, moment, draw order or statistic leaves it within a few steps.
+    graphed: the same 40 steps with the step captured once and replayed as one hipGraph launch (trainer.GraphedTrainStep) from step 2 on - the captured step against
+    the REFERENCE, learning-rate schedule and bias corrections through device memory included."""
     import season_nerf_amd as sn
     g = dict(np.load(os.path.join(golden_dir, "trajectory_W64.npz"), allow_pickle=False))
     Wd, S, n_steps, lr = int(g["W"]), int(g["S"]), int(g["n_steps"]), float(g["lr"])
@@ -574,9 +577,12 @@ def test_training_follows_the_reference_trajectory(golden_dir):
     np.random.seed(int(g["seed"]))
     torch.manual_seed(int(g["seed"]))
     worst = []
+    stepper = None
     for step in range(n_steps):
         data = {k: T(g[f"step{step}_{k}"]) for k in ("Top", "Bot", "Sun_Angle", "Time_Encoded", "GT_Color")}
-        loss = tool.train_step(data, step)
+        if graphed and stepper is None:
+            stepper = sn.GraphedTrainStep(tool, data, warmup=2)
+        loss = stepper(data, step) if graphed else tool.train_step(data, step)
         assert tool.sched.get_last_lr()[0] == pytest.approx(float(g["lrs"][step]), rel=1e-12)
         band = 3e-5 + 1.5e-4 * step / n_steps                      # relative; observed 3e-7 at step 0, 2e-5 after 40 steps of Adam
         rel = 0.0
@@ -585,7 +591,8 @@ def test_training_follows_the_reference_trajectory(golden_dir):
             rel = max(rel, abs(float(loss[k][0]) - ref) / max(abs(ref), 1e-2))
         worst.append(rel)
         assert rel < band, (step, rel, band, {k: (float(loss[k][0]), float(g["loss_values"][step, j])) for j, k in enumerate(names[:-1])})
-    print(f"  reference trajectory, {n_steps} steps: worst relative loss-term deviation per step: first {worst[0]:.1e}, middle {worst[n_steps // 2]:.1e}, last {worst[-1]:.1e}")
+    assert not graphed or (stepper.graph is not None and stepper.calls == n_steps)
+    print(f"  reference trajectory{' (hipGraph replay)' if graphed else ''}, {n_steps} steps: worst relative loss-term deviation per step: first {worst[0]:.1e}, middle {worst[n_steps // 2]:.1e}, last {worst[-1]:.1e}")
     # Final state.  Parameters with a real gradient follow the reference to ~1e-6.  The linear biases IN FRONT OF a train-mode BatchNorm have no gradient
     # (BatchNorm removes them); what Adam sees is the rounding noise of a sum that should be zero, which it normalises into steps of up to lr - in the
     # reference too (its biases drift MORE than ours over these 40 steps).  They do not enter the network function in train mode; the running mean tracks
