@@ -553,25 +553,29 @@ def test_backward_survives_engine_eviction():
         assert float((v - g1[k]).abs().max()) <= 1e-5 * float(v.abs().max()) + 2e-7 * gmax, k
 
 
-@pytest.mark.parametrize("graphed", [False, True])
-def test_training_follows_the_reference_trajectory(golden_dir, graphed):
+@pytest.mark.parametrize("fixture,graphed", [("trajectory_W64.npz", False), ("trajectory_W64.npz", True), ("trajectory_W256.npz", False), ("trajectory_W256.npz", True),
+                                             ("trajectory_prior_W64.npz", False)])
+def test_training_follows_the_reference_trajectory(golden_dir, fixture, graphed):
     """40 CONSECUTIVE steps of the reference's own training loop (tools/make_trajectory_golden.py: mg_run_NeRF.py:288-326 with the optimiser / OneCycleLR of
     Net_Tool_2.py:111-130 on fixed batches of a synthetic scene, host RNGs seeded once) replayed through season_nerf_amd.Net_tool with the same seeds: the RNG
     draw order (image jitter, sun-ray angles / positions / times, sun-ray jitter - Eval_Tools_2.py:169,349,301), the sun-ray generator, both passes, the loss terms,
     backward, fused Adam, the schedule and the BatchNorm running statistics - every step against the reference's loss dict.  Rounding differences compound through
     Adam, so the band widens with the step count; a wrong schedule, moment, draw order or statistic leaves it within a few steps.
     graphed: the same 40 steps with the step captured once and replayed as one hipGraph launch (trainer.GraphedTrainStep) from step 2 on - the captured step against
-    the REFERENCE, learning-rate schedule and bias corrections through device memory included."""
+    the REFERENCE, learning-rate schedule and bias corrections through device memory included.
+    Fixtures: W = 64 (40 steps), W = 256 (24 steps: the benchmark's width; of the large tensors only the norms are stored), and 16 steps of the DSM-prior phase
+    (use_prior: supervised density, merged renderings, Alpha_Adjust, trust = step / n_steps, Eval_Tools_2.py:218-248,413-420)."""
     import season_nerf_amd as sn
-    g = dict(np.load(os.path.join(golden_dir, "trajectory_W64.npz"), allow_pickle=False))
+    g = dict(np.load(os.path.join(golden_dir, fixture), allow_pickle=False))
+    prior = bool(int(g["prior"]))
     Wd, S, n_steps, lr = int(g["W"]), int(g["S"]), int(g["n_steps"]), float(g["lr"])
     WC, H4 = np.array([41.29, -95.9, 300.0]), np.array([[310.0, 12.0, 0.0, -11650.0], [-9.0, 240.0, 0.0, 23390.0], [0.0, 0.0, 0.01, -3.0], [0, 0, 0, 1.0]])
     sd0 = orc.init_weights(Wd, int(g["C"]), int(g["init_seed"]))
-    net = sn.T_NeRF(Wd, int(g["C"]))
+    net = sn.T_NeRF(Wd, int(g["C"]), HM=g["hm"]) if prior else sn.T_NeRF(Wd, int(g["C"]))
     net.load_state_dict(sd0)
     net = net.to("cuda").train()
     args = SimpleNamespace(n_samples=S, Use_Reg=True, Solar_Type_2=False, Use_MSE_loss=True, Use_Solar=True, sc_lambda=0.03, number_low_frequency_cases=4)
-    ev = sn.All_in_One_Eval(args, torch.device("cuda"), n_steps, False, None, H4, WC)
+    ev = sn.All_in_One_Eval(args, torch.device("cuda"), n_steps, prior, None, H4, WC)
     tool = sn.Net_tool(net, ev, lr, total_steps=n_steps, writer=None)
     names = [str(n) for n in g["loss_names"]]
     np.random.seed(int(g["seed"]))
@@ -584,7 +588,7 @@ def test_training_follows_the_reference_trajectory(golden_dir, graphed):
             stepper = sn.GraphedTrainStep(tool, data, warmup=2)
         loss = stepper(data, step) if graphed else tool.train_step(data, step)
         assert tool.sched.get_last_lr()[0] == pytest.approx(float(g["lrs"][step]), rel=1e-12)
-        band = 3e-5 + 1.5e-4 * step / n_steps                      # relative; observed 3e-7 at step 0, 2e-5 after 40 steps of Adam
+        band = 5e-5 + 3e-4 * step / n_steps                        # relative; observed: 3e-7 at step 0; W = 64: 2e-5 after 40 steps, W = 256: 7e-5 after 5, prior: 5e-5
         rel = 0.0
         for j, k in enumerate(names[:-1]):
             ref = float(g["loss_values"][step, j])
@@ -601,6 +605,10 @@ def test_training_follows_the_reference_trajectory(golden_dir, graphed):
     bn_layers = sorted({k.rsplit(".norm.", 1)[0] for k in sd if ".norm.running_mean" in k})
     worst_real = 0.0
     for k, v in sd.items():
+        if "sd_" + k not in g:                                            # a large tensor of a wide network: its norm only
+            if "sdnorm_" + k in g:
+                assert float(v.double().norm()) == pytest.approx(float(g["sdnorm_" + k]), rel=2e-5), k
+            continue
         ref = torch.tensor(g["sd_" + k])
         layer = k.rsplit(".", 2)[0]
         if not v.is_floating_point():
@@ -608,7 +616,7 @@ def test_training_follows_the_reference_trajectory(golden_dir, graphed):
         elif k.endswith("running_var"):
             np.testing.assert_allclose(v.cpu().numpy(), ref.numpy(), rtol=1e-3, atol=1e-5, err_msg=k)
         elif k.endswith("running_mean"):
-            drift = float((sd[layer + ".linear.bias"].cpu() - torch.tensor(g["sd_" + layer + ".linear.bias"])).abs().max())
+            drift = float((sd[layer + ".linear.bias"].cpu() - torch.tensor(g["sd_" + layer + ".linear.bias"])).abs().max())      # (biases are small tensors: always stored)
             assert float((v.cpu() - ref).abs().max()) <= 30.0 * drift + 1e-3, (k, drift)
         elif k.endswith("linear.bias") and layer in bn_layers:
             assert float((v.cpu() - sd0[k]).abs().max()) <= 2 * float((ref - sd0[k]).abs().max()) + 1e-4, k      # noise-driven: bounded by the reference's own drift
