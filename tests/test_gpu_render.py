@@ -267,3 +267,34 @@ def test_sweep_many_time_steps_vs_oracle(setup):
     close("sweep29", got, ref, rtol=1e-5, atol=1e-6)
     one = sn.get_imgs_from_Img_Dict_t_step(d, size, cv[17:18])
     close("sweep_single", one[0], ref[17], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("precision", ["auto", "bf16x3"])
+def test_renderers_on_really_trained_weights(golden_dir, precision):
+    """The renderer seams - component_render_by_dir + get_imgs_from_Img_Dict + the 12-step seasonal sweep (mg_Img_Eval.py:96-228), Quick_Run_Net.render_img / get_DSM
+    (Quick_Run.py:173-226) - on weights the reference's own training loop produced (tests/golden/trained_W256.npz), against the reference's renderings of the same
+    weights (tools/make_trained_render_golden.py).  Default precision ("auto" -> int8 digits for these weights) and bf16x3: images within the north star's 1e-4."""
+    import season_nerf_amd as sn
+    g = dict(np.load(os.path.join(golden_dir, "trained_render_W256.npz"), allow_pickle=False))
+    t = dict(np.load(os.path.join(golden_dir, "trained_W256.npz"), allow_pickle=False))
+    net = sn.T_NeRF(int(g["W"]), int(g["C"]))
+    net.load_state_dict({k[3:]: torch.tensor(v) for k, v in t.items() if k.startswith("sd_")})
+    net.precision = precision
+    net = net.to("cuda").eval()
+    assert net.resolved_precision == ("i8x3" if precision == "auto" else precision)
+    size = tuple(int(v) for v in g["size"])
+    view, sun, tf = tuple(g["view"]), tuple(g["sun"]), float(g["time_frac"])
+    d = sn.component_render_by_dir(net, view, sun, tf, size, g["WC"], g["H"], torch.device("cuda"), include_exact_solar=False)
+    im = sn.get_imgs_from_Img_Dict(d, size, False)
+    tol = dict(rtol=1e-4, atol=2e-5)
+    for k in ["Base_Img", "Season_Adj_Img", "Shadow_Adjust", "Shadow_Mask", "Raw_Shadow_Mask"]:
+        close(f"{precision} {k}", im[k], g["img_" + k], **tol)
+    sweep = sn.get_imgs_from_Img_Dict_t_step(d, size, g["sweep_classes"].astype(np.float64))
+    close(f"{precision} sweep", sweep, g["sweep_imgs"], **tol)
+    args = SimpleNamespace(n_samples=96, Use_Reg=True, Solar_Type_2=False, Use_MSE_loss=True, Use_Solar=True, sc_lambda=0.03, number_low_frequency_cases=4)
+    qr = sn.Quick_Run_Net(net, args, g["WC"], g["H"], torch.device("cuda"), use_full_solar=False)
+    imgs, mask = qr.render_img((65, 20), (50, 100), 0.3, 22)
+    assert (mask == g["qr_mask"]).all()
+    close(f"{precision} Col_Img", imgs["Col_Img"], g["qr_Col_Img"], **tol)
+    close(f"{precision} Shadow_Mask", imgs["Shadow_Mask"], g["qr_Shadow_Mask"], **tol)
+    close(f"{precision} DSM", qr.get_DSM((14, 14)), g["qr_DSM"], rtol=1e-4, atol=3e-5)
