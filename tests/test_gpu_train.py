@@ -554,7 +554,7 @@ def test_backward_survives_engine_eviction():
 
 
 @pytest.mark.parametrize("fixture,graphed", [("trajectory_W64.npz", False), ("trajectory_W64.npz", True), ("trajectory_W256.npz", False), ("trajectory_W256.npz", True),
-                                             ("trajectory_prior_W64.npz", False)])
+                                             ("trajectory_prior_W64.npz", False), ("trajectory_classic_W64.npz", False)])
 def test_training_follows_the_reference_trajectory(golden_dir, fixture, graphed):
     """40 CONSECUTIVE steps of the reference's own training loop (tools/make_trajectory_golden.py: mg_run_NeRF.py:288-326 with the optimiser / OneCycleLR of
     Net_Tool_2.py:111-130 on fixed batches of a synthetic scene, host RNGs seeded once) replayed through season_nerf_amd.Net_tool with the same seeds: the RNG
@@ -564,17 +564,18 @@ def test_training_follows_the_reference_trajectory(golden_dir, fixture, graphed)
     graphed: the same 40 steps with the step captured once and replayed as one hipGraph launch (trainer.GraphedTrainStep) from step 2 on - the captured step against
     the REFERENCE, learning-rate schedule and bias corrections through device memory included.
     Fixtures: W = 64 (40 steps), W = 256 (24 steps: the benchmark's width; of the large tensors only the norms are stored), and 16 steps of the DSM-prior phase
-    (use_prior: supervised density, merged renderings, Alpha_Adjust, trust = step / n_steps, Eval_Tools_2.py:218-248,413-420)."""
+    (use_prior: supervised density, merged renderings, Alpha_Adjust, trust = step / n_steps, Eval_Tools_2.py:218-248,413-420), and 16 steps with the classic solar
+    model (Solar_Type_2: per-sample shading, Solar_Correction_2 with gradient, :211-212,366-370)."""
     import season_nerf_amd as sn
     g = dict(np.load(os.path.join(golden_dir, fixture), allow_pickle=False))
-    prior = bool(int(g["prior"]))
+    prior, classic = bool(int(g["prior"])), bool(int(g["classic"])) if "classic" in g else False
     Wd, S, n_steps, lr = int(g["W"]), int(g["S"]), int(g["n_steps"]), float(g["lr"])
     WC, H4 = np.array([41.29, -95.9, 300.0]), np.array([[310.0, 12.0, 0.0, -11650.0], [-9.0, 240.0, 0.0, 23390.0], [0.0, 0.0, 0.01, -3.0], [0, 0, 0, 1.0]])
     sd0 = orc.init_weights(Wd, int(g["C"]), int(g["init_seed"]))
     net = sn.T_NeRF(Wd, int(g["C"]), HM=g["hm"]) if prior else sn.T_NeRF(Wd, int(g["C"]))
     net.load_state_dict(sd0)
     net = net.to("cuda").train()
-    args = SimpleNamespace(n_samples=S, Use_Reg=True, Solar_Type_2=False, Use_MSE_loss=True, Use_Solar=True, sc_lambda=0.03, number_low_frequency_cases=4)
+    args = SimpleNamespace(n_samples=S, Use_Reg=True, Solar_Type_2=classic, Use_MSE_loss=True, Use_Solar=True, sc_lambda=0.03, number_low_frequency_cases=4)
     ev = sn.All_in_One_Eval(args, torch.device("cuda"), n_steps, prior, None, H4, WC)
     tool = sn.Net_tool(net, ev, lr, total_steps=n_steps, writer=None)
     names = [str(n) for n in g["loss_names"]]

@@ -25,12 +25,13 @@ mg = mt.mg
 def main():
     W = int(ARGV[0]) if ARGV else 64
     n_steps = int(ARGV[1]) if len(ARGV) > 1 else 40
+    classic = "--classic" in ARGV                                 # Solar_Type_2: per-sample shading, the solar branch trained from the image pass (Eval_Tools_2.py:211-212,366-370)
     prior = "--prior" in ARGV                                     # the DSM-prior ("jump start") phase: use_prior, trust = step / n_steps (Eval_Tools_2.py:218-248)
     batch, S, lr = 192, 48, (5e-4 if W <= 64 else 1e-4)         # (a wide network's hidden weights span +-0.005: 5e-4 per Adam step would move them by 10 % a step)
     torch.set_num_threads(4)
     hm = np.random.Generator(np.random.PCG64(9)).uniform(-0.8, 0.6, (48, 48)) if prior else None
     net, _ = mg.make_net(W, 4, 41, hm=hm, train=True)
-    ev = mg.All_in_One_Eval(mg.args_ns(S), torch.device("cpu"), n_steps, prior, None, mg.H4, mg.WC)
+    ev = mg.All_in_One_Eval(mg.args_ns(S, classic), torch.device("cpu"), n_steps, prior, None, mg.H4, mg.WC)
     opt = torch.optim.Adam(net.parameters(), lr=lr)
     sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=lr, total_steps=n_steps, base_momentum=0.85, max_momentum=0.95, cycle_momentum=False)
     pool = mt.make_scene(6, 1024, 21)
@@ -40,7 +41,7 @@ def main():
     rng = np.random.Generator(np.random.PCG64(5))
     np.random.seed(2024)
     torch.manual_seed(2024)
-    out = {"W": W, "C": 4, "S": S, "n_steps": n_steps, "batch": batch, "lr": lr, "seed": 2024, "init_seed": 41, "prior": int(prior)}
+    out = {"W": W, "C": 4, "S": S, "n_steps": n_steps, "batch": batch, "lr": lr, "seed": 2024, "init_seed": 41, "prior": int(prior), "classic": int(classic)}
     if prior:
         out["hm"] = hm
     names, vals, lrs, snaps = None, [], [], []
@@ -73,7 +74,7 @@ def main():
             out["sd_" + k] = v.detach().cpu().numpy()
         else:
             out["sdnorm_" + k] = np.float64(v.double().norm())
-    path = os.path.join(mg.OUT, f"trajectory{'_prior' if prior else ''}_W{W}.npz")
+    path = os.path.join(mg.OUT, f"trajectory{'_prior' if prior else ''}{'_classic' if classic else ''}_W{W}.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")
 
