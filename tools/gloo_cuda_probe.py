@@ -1,3 +1,5 @@
+"""Can gloo reduce DEVICE tensors between two processes that share one GPU?  (It can: sum, min, float64 - what tests/test_gpu_two_ranks.py builds on.)
+    python tools/gloo_cuda_probe.py        # on an MI355X box"""
 import os, sys, torch, torch.distributed as dist, torch.multiprocessing as mp
 def w(rank, world, port):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
