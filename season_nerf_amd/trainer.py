@@ -155,6 +155,10 @@ class GraphedTrainStep:
 
         step = GraphedTrainStep(tool, example_batch)
         for k in range(n): loss = step(batch_k, k)          # loss: the step's LossDict (device tensors, not read back)
+
+    The LossDict a replayed step returns (and `tool.last_loss`) ALIASES the graph's static output: its tensors live in the graph's private
+    pool and are overwritten by the next replay.  A caller that keeps losses across steps passes `keep=True` (one 5-float device copy per
+    step, stream-ordered, no sync) or reads the value before the next call.
     """
 
     @staticmethod
@@ -169,8 +173,11 @@ class GraphedTrainStep:
             return "not under torch.distributed (the data-parallel exchanges are issued from Python)"
         return None
 
-    def __init__(self, tool, data_dict, warmup=3):
+    def __init__(self, tool, data_dict, warmup=3, keep=False):
         from . import training
+        if int(warmup) < 1:      # the capture may not allocate or upload: the engine, its scratch and LossDict's weight vector must exist already
+            raise ValueError("GraphedTrainStep: warmup must be >= 1 (the eager steps create every buffer the captured step uses)")
+        self.keep = bool(keep)
         ev, net = tool.eval_tool, tool.network
         a = ev.args
         why = self.eligible(tool)
@@ -233,10 +240,23 @@ class GraphedTrainStep:
         self.graph.replay()
         self.net.invalidate_packed()
         tool.sched.step()
-        tool._log("Training/", self.loss, current_step)
-        tool.last_loss = self.loss
+        loss = self._snapshot() if self.keep else self.loss
+        tool._log("Training/", loss, current_step)
+        if tool.writer is not None and current_step % tool.log_every == 0:       # as train_step logs it
+            tool.writer.add_scalar("LR/Learning_Rate", tool.sched.get_last_lr()[0], current_step)
+        tool.last_loss = loss
         self.calls += 1
-        return self.loss
+        return loss
+
+    def _snapshot(self):
+        """A LossDict of this step's values that the next replay does not overwrite (clone of the 5-float vector)."""
+        src = self.loss
+        vec = src.vec.detach().clone()
+        out = type(src)()
+        for i, k in enumerate(src.names):
+            out[k] = [vec[i], src[k][1]]
+        out.vec, out.names = vec, src.names
+        return out
 
 
 class T_NeRF_Net_Tool(Net_tool):

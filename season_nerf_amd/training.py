@@ -680,14 +680,12 @@ class FusedAdam(torch.optim.Optimizer):
             store.adam_v.zero_()
             store.adam_steps = 0
         self.hyper = None              # device vector [lr, beta1, beta2, eps, 1 - beta1^t, 1 - beta2^t] of the capturable form
-        self._hyper_host = None
 
     def make_capturable(self):
         """Switch to the form a hipGraph can hold: `step()` launches the Adam kernel that reads its scalars from `self.hyper`; the host
         refreshes them with `set_hyper()` before every replay (the learning-rate schedule and the step count live on the host)."""
         store = self.net._param_store
         self.hyper = torch.zeros(6, device=store.dev)
-        self._hyper_host = torch.zeros(6).pin_memory()
         return self
 
     def set_hyper(self):
@@ -697,9 +695,12 @@ class FusedAdam(torch.optim.Optimizer):
         store.adam_steps += 1
         t = store.adam_steps
         b1, b2 = g["betas"]
-        h = self._hyper_host
-        h[0], h[1], h[2], h[3], h[4], h[5] = float(g["lr"]), b1, b2, g["eps"], 1.0 - b1 ** t, 1.0 - b2 ** t
-        self.hyper.copy_(h, non_blocking=True)
+        # a single pinned buffer rewritten every step races with its own asynchronous DMA - the copy reads the
+        # pinned memory when it EXECUTES, and the host runs several steps ahead of the GPU, so step k's Adam kernel could see the
+        # scalars of step k+1..k+5.  The six floats go through the event-guarded ring of pinned slots instead (a slot is rewritten
+        # only after the copy that read it has executed), then device -> device into the fixed vector the captured kernel reads.
+        h = torch.tensor([float(g["lr"]), b1, b2, g["eps"], 1.0 - b1 ** t, 1.0 - b2 ** t], dtype=torch.float32)
+        self.hyper.copy_(_RING.upload(h, store.dev), non_blocking=True)
 
     def state_dict(self):
         """Checkpointable state: torch's param_groups plus the flat Adam moments and the step count of the network's store."""

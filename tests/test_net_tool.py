@@ -180,6 +180,53 @@ def test_graphed_train_step_follows_the_eager_step():
 
 
 @pytest.mark.gpu
+def test_graphed_steps_without_readback_keep_their_own_adam_scalars():
+    """`FusedAdam.set_hyper` used to rewrite ONE pinned buffer per step and copy it asynchronously - with no per-step sync the
+    host runs several steps ahead and the Adam kernel of step k could read the learning rate / bias corrections of step k+1..k+5 (just after the
+    capture 1 - beta1^t goes 0.1 -> 0.47: early step sizes change by large factors).  24 captured steps with NO host readback between them (the
+    host queues all of them before the GPU has finished the first few) must land on the eager run's parameters; `keep=True` losses, read only at
+    the end, must be the per-step values (not 24 copies of the last one)."""
+    import season_nerf_amd as sn
+    from oracle import season_nerf_oracle as orc
+    W, R, S, n_steps = 64, 512, 64, 24          # ~a millisecond of GPU work per step: the host queues far ahead
+    WC, H4 = np.array([41.29, -95.9, 300.0]), np.array([[310.0, 12.0, 0.0, -11650.0], [-9.0, 240.0, 0.0, 23390.0], [0.0, 0.0, 0.01, -3.0], [0, 0, 0, 1.0]])
+    rng = np.random.Generator(np.random.PCG64(9))
+    t = lambda a: torch.tensor(a, dtype=torch.float32, device="cuda")
+    sun = rng.uniform(0.1, 1, (R, 3)); sun /= np.linalg.norm(sun, axis=1, keepdims=True)
+    batch = {"Top": t(np.concatenate([rng.uniform(-1, 1, (R, 2)), np.ones((R, 1))], 1)), "Bot": t(np.concatenate([rng.uniform(-1, 1, (R, 2)), -np.ones((R, 1))], 1)),
+             "Sun_Angle": t(sun), "Time_Encoded": t(rng.uniform(-1, 1, (R, 4))), "GT_Color": t(rng.uniform(0, 1, (R, 3)))}
+
+    def run(graphed):
+        net = sn.T_NeRF(W, 4)
+        net.load_state_dict(orc.init_weights(W, 4, 7, bn_stats="identity"))
+        net = net.cuda().train()
+        args = SimpleNamespace(n_samples=S, Use_Reg=True, Solar_Type_2=False, Use_MSE_loss=True, Use_Solar=True, sc_lambda=0.03, number_low_frequency_cases=4)
+        ev = sn.All_in_One_Eval(args, torch.device("cuda"), 10, False, None, H4, WC)
+        tool = sn.Net_tool(net, ev, 3e-4, total_steps=n_steps + 1, writer=None)
+        step = sn.GraphedTrainStep(tool, batch, warmup=2, keep=True) if graphed else None
+        np.random.seed(5); torch.manual_seed(5)
+        kept = []
+        for k in range(n_steps):                      # no float(), no .cpu(), no synchronize inside the loop
+            kept.append((step(batch, k) if graphed else tool.train_step(batch, k))["Color"][0])
+        torch.cuda.synchronize()
+        return [float(v) for v in kept], {k: v.detach().clone() for k, v in net.state_dict().items()}
+
+    le, pe = run(False)
+    lg, pg = run(True)
+    assert len(set(lg[2:])) > n_steps // 2, lg        # per-step values survived the later replays
+    for k in range(n_steps):
+        assert abs(lg[k] - le[k]) <= 5e-4 * max(abs(le[k]), 1e-3), (k, lg[k], le[k])
+    p0 = orc.init_weights(W, 4, 7, bn_stats="identity")
+    moved = diff = 0.0
+    for k, v in pe.items():
+        if v.is_floating_point() and "running" not in k:
+            moved += float((v.cpu() - p0[k]).abs().sum())
+            diff += float((pg[k] - v).abs().sum())
+    print(f"  24 captured steps without readback vs eager: sum |difference| / sum |update| = {diff / moved:.2e}")
+    assert moved > 0 and diff < 0.03 * moved, (diff, moved)
+
+
+@pytest.mark.gpu
 def test_driver_with_use_graph_switches_to_the_captured_step():
     """T_NeRF_Net_Tool(..., use_graph=True): 12 steps - phase 1 (DSM prior: not capturable, eager) then phase 4, whose first two steps run eagerly and
     the rest as one hipGraph launch each; a new phase (new evaluator / optimisers) drops the captured step.  The learning rate follows the same
