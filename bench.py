@@ -185,6 +185,88 @@ def w512_kernel_roofline(dev, d, tv, launches=20):
     return summ, roof
 
 
+def sharp_state_dict(width):
+    """Weights WITH SURFACES: tests/golden/trained_W{width}.npz (the reference's own training loop) with the density head scaled by the g of
+    tests/golden/sharp_W{width}.npz (mean max-PS per ray >= 0.5 by the reference's eval; tools/make_sharp_golden.py).  Arrays only."""
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden")
+    g = np.load(os.path.join(here, f"sharp_W{width}.npz"), allow_pickle=False)
+    t = np.load(os.path.join(here, f"trained_W{width}.npz"), allow_pickle=False)
+    head = ("G_NeRF_net.fc10Sigma.weight", "G_NeRF_net.fc10Sigma.bias")
+    sd = {k[3:]: torch.tensor(t[k]) * (float(g["g"]) if k[3:] in head else 1.0) for k in t.files if k.startswith("sd_")}
+    return sd, float(g["g"]), float(g["max_ps"].mean())
+
+
+def converged_row(dev, d, tv, width, launches=20):
+    """The benchmark's batch (4096 rays x 96 samples) rendered with weights that have SURFACES in them, class default precision: what `auto`
+    resolves to for a converged checkpoint, and what a step (per-ray networks + field network + compositing) costs then."""
+    import season_nerf_amd as sn
+    sd, gain, mps = sharp_state_dict(width)
+    net = sn.T_NeRF(width, NC)
+    net.load_state_dict(sd)
+    net = net.to(dev).eval()
+    prec = net.resolved_precision
+    from types import SimpleNamespace
+    eargs = SimpleNamespace(n_samples=S, Use_Reg=True, Solar_Type_2=False, Use_MSE_loss=True, Use_Solar=True, sc_lambda=0.03, number_low_frequency_cases=NC)
+    ev = sn.All_in_One_Eval(eargs, dev, 10, False, None, np.eye(4), np.zeros(3))
+    with torch.no_grad():
+        for _ in range(2):
+            r = ev.render_summary(d, net) if hasattr(ev, "render_summary") and prec is not None else ev.eval(d, net, 0, False)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(launches):
+            r = ev.render_summary(d, net) if hasattr(ev, "render_summary") and prec is not None else ev.eval(d, net, 0, False)
+        e1.record()
+        torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / launches
+    flop = (FLOP_PER_SAMPLE if width == 256 else 2 * (2896896 + 273152 / 96.0)) * R * S
+    est = net.i8_estimate()
+    return {"weights": f"sharp_W{width}: tests/golden/trained_W{width}.npz (the reference's own training loop) with the density head x{gain:g}; mean max-PS per ray "
+                       f"{mps:.2f} by the reference's eval", "precision_resolved": prec if prec is not None else "layer-wise engine (no fused kernel passes the int8 bound at this width)",
+            "i8_rgb_pred": est["rgb_pred"], "ms_per_step": ms, "value": R * S / (ms * 1e-3), "unit": "ray-samples/s",
+            "roofline": {"bound": "mfma", "achieved": flop / (ms * 1e-3) / 1e12, "peak": PEAK_BF16_DENSE / 1e12, "unit": "TFLOP/s", "frac": flop / (ms * 1e-3) / PEAK_BF16_DENSE,
+                         "note": "whole step by HIP events (per-ray networks + field network + compositing), algorithmic FLOPs of SURVEY 8d"}}
+
+
+SIGMA_FLOP_PER_SAMPLE = 2 * 524800.0          # trunk fc1..fc9 + density head, W = 256 (SURVEY 8d: 16 128 + 6 x 65 536 + 81 664 + 32 768 + 128 ... = 524 800 MACs)
+
+
+def exact_solar_bench(dev, net, sizes=((256, 256, 96), (512, 512, 96))):
+    """The exact-solar pass (Eval_Tools_2.py:255-295 / mg_Img_Eval.py:57-70; the DEFAULT of both reference renderers): for every sample of every
+    primary ray a secondary ray towards the sun, S density-only evaluations each - R S^2 in all - as `season_nerf::ray_visibility` launches
+    (one float out per secondary ray).  Timed by HIP events on the launch stream, primary render excluded."""
+    import season_nerf_amd as sn
+    from season_nerf_amd import render as R_
+    WC, H4 = np.array([41.29, -95.9, 300.0]), np.array([[310.0, 12.0, 0.0, -11650.0], [-9.0, 240.0, 0.0, 23390.0], [0.0, 0.0, 0.01, -3.0], [0, 0, 0, 1.0]])
+    out = {}
+    for size in sizes:
+        Hh, Ww, Ss = size
+        with torch.no_grad():
+            dd = R_._render_by_dir_device(net, (80, 0), (30, 90), 0.25, size, WC, H4, dev, False)
+            pts = dd["World_Points"].reshape(-1, 3)
+            sunv = R_.world_angle_2_local_vec(30, 90, WC, H4)
+            sun_d = torch.tensor(sunv, dtype=torch.float32, device=dev)
+            vis = R_._exact_solar_visibility(net, pts[: 1 << 16], sun_d, Ss, zero_oob=True, sun64=sunv)          # warm-up
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            vis = R_._exact_solar_visibility(net, pts, sun_d, Ss, zero_oob=True, sun64=sunv)
+            e1.record()
+            torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1)
+        n = pts.shape[0] * Ss
+        out[f"{Hh}x{Ww}x{Ss}"] = {"ms": ms, "secondary_rays": int(pts.shape[0]), "sigma_samples": int(n), "sigma_samples_per_s": n / (ms * 1e-3),
+                                  "mean_visibility": float(vis.mean()),
+                                  "roofline": {"bound": "mfma", "achieved": SIGMA_FLOP_PER_SAMPLE * n / (ms * 1e-3) / 1e12, "peak": PEAK_BF16_DENSE / 1e12, "unit": "TFLOP/s",
+                                               "frac": SIGMA_FLOP_PER_SAMPLE * n / (ms * 1e-3) / PEAK_BF16_DENSE,
+                                               "frac_of_int8_peak": SIGMA_FLOP_PER_SAMPLE * n / (ms * 1e-3) / PEAK_INT8_DENSE if net.resolved_precision == "i8x3" else None}}
+        del dd, pts, vis
+        torch.cuda.empty_cache()
+    out["precision_resolved"] = net.resolved_precision
+    out["note"] = ("include_exact_solar=True of component_render_by_dir: the secondary-ray pass only (ray_visibility kernel = the density-only program, optical depth in registers, "
+                   "one float per secondary ray); algorithmic 524 800 MACs per secondary sample (trunk + density head, W = 256)")
+    return out
+
+
 def sweep_kernel_roofline(dev, rays=512 * 512, T=12, launches=5):
     """`snerf::sweep_kernel` (csrc/kernels.hip; mg_Img_Eval.get_imgs_from_Img_Dict_t_step, :192-228) alone at configs[4]'s size: 512 x 512 rays x 96
     samples, 12 time steps per pass.  Algorithmic bytes: the 17 floats per sample it reads once for all T (rho, col_raw 3, adjust C x 3, solar_vis)
@@ -494,7 +576,7 @@ def main():
     ap.add_argument("--train-graph", action="store_true", help="--workload train: the step as one hipGraph launch (season_nerf_amd.GraphedTrainStep; MSE loss, one GPU)")
     ap.add_argument("--no-train", action="store_true", help="render workload: skip the extra training-step measurement (train_* keys)")
     ap.add_argument("--train-kernel-only", action="store_true", help="--workload train: only the dominant training kernel (`--steps` launches), for profiler passes")
-    ap.add_argument("--aux-kernel", default=None, choices=["sweep", "w512"], help="only that auxiliary kernel, `--steps` launches (profiler passes): "
+    ap.add_argument("--aux-kernel", default=None, choices=["sweep", "w512", "exact_solar"], help="only that auxiliary kernel, `--steps` launches (profiler passes): "
                                                                               "the seasonal-sweep kernel at 512x512x96, or the W = 512 fused field kernel")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help=argparse.SUPPRESS)   # gloo: CPU test of the launcher only
     ap.add_argument("--bn_sync", default="local", choices=["local", "global"],
@@ -517,6 +599,12 @@ def main():
         dv = torch.device("cuda", local)
         if a.aux_kernel == "sweep":
             print(json.dumps(sweep_kernel_roofline(dv, launches=max(a.steps, 1))))
+        elif a.aux_kernel == "exact_solar":
+            import season_nerf_amd as sn
+            nx = sn.T_NeRF(W, NC)
+            nx.load_state_dict(sn.synthetic_state_dict(nx, 0))
+            nx.precision = a.precision
+            print(json.dumps(exact_solar_bench(dv, nx.to(dv).eval(), sizes=((256, 256, 96),))))
         else:
             import season_nerf_amd as sn
             print(json.dumps(w512_kernel_roofline(dv, synth(0, dv), sn.sample_parameters(S, eval_mode=True).to(dv), launches=max(a.steps, 1))[1]))
@@ -664,6 +752,23 @@ def main():
         extra["modes"] = modes
         extra["modes_note"] = ("parity bar (north star): RGB / depth within 1e-4 relative of the reference; measured against the reference's "
                                "goldens in tests/: bf16x3 ~3e-6, i8x3 ~1.5e-5 (W=512: 2.5e-5), bf16 1-2e-3 (outside the bar: fast mode only)")
+    if rank == 0 and world == 1 and not a.headline_only:
+        # converged-weights rows beside the random-weights headline (VERDICT r4 #1c): the same batch with weights that have SURFACES in them
+        for wv in (256, 512):
+            try:
+                extra["converged" if wv == 256 else "converged_w512"] = converged_row(dev, d, tv, wv)
+            except Exception as ex:
+                extra[f"converged_w{wv}_error"] = repr(ex)
+        try:      # the exact-solar pass (the default of both reference renderers), on the headline network and on the sharp one
+            extra["exact_solar"] = exact_solar_bench(dev, net)
+            sd_s, _, _ = sharp_state_dict(256)
+            ns = sn.T_NeRF(W, NC)
+            ns.load_state_dict(sd_s)
+            ns = ns.to(dev).eval()
+            extra["exact_solar_converged"] = exact_solar_bench(dev, ns, sizes=((256, 256, 96),))
+            del ns
+        except Exception as ex:
+            extra["exact_solar_error"] = repr(ex)
     if rank == 0 and world == 1 and not a.no_sweep:
         # outside the timed region: a whole 512x512x96 novel-view image and the 12-step seasonal sweep (BASELINE configs[4],
         # single GPU), through the renderer seam (component render + sweep kernel); wall clock incl. host-side ray grid

@@ -133,6 +133,19 @@ int snerf_field_forward_rays(const snerf_model* m, int variant, int64_t n_rays, 
                              int64_t rays_per_group, const float* d_sun, const float* d_classes,
                              const snerf_field_out* out, void* stream);
 
+/* ---- exact solar visibility of secondary rays: All_in_One_Eval._get_exact_solar (Eval_Tools_2.py:255-271) and the
+ * `include_exact_solar` block of _internal_render (T_NeRF_Eval_Utils/mg_Img_Eval.py:57-70) as ONE kernel: the density-only
+ * network (forward_Classic_Sigma_Only, G_NeRF.py:74-77) over the S samples of every ray with the optical depth kept in
+ * registers - no rho [R,S] round trip, no compositing launch:
+ *     vis[r] = exp(-sum_{j < S-1} rho(top[r] (1 - t_j) + bot[r] t_j) * ||top[r] - bot[r]|| / S)
+ * = PV_Exact[:, -1] of eval_Rho_Only / PV_solar_exact of _internal_render.  d_tvals [S] as for snerf_field_forward_rays
+ * (the callers use the end-point-inclusive vector, misc.py:236-239).  flags bit1: a sample outside [-1,1]^3 contributes
+ * nothing (mg_Img_Eval.py:65-66; path A leaves it unset).  The model's resolved precision applies (bf16x3 / int8 digits);
+ * SNERF_E_INVALID for the bf16 fast mode.  R * S^2 evaluations of the primary image: the default of both renderers
+ * (Quick_Run.py:62 use_full_solar=True, mg_Img_Eval.py:96 include_exact_solar=True). */
+int snerf_field_ray_visibility(const snerf_model* m, int64_t n_rays, int n_samples, const float* d_top, const float* d_bot,
+                               const float* d_tvals, int flags, float* d_vis, void* stream);
+
 /* ---- compositing: Eval_Tools_2.get_PV (:13-16) + PE/PS + albedo / solar shading (:187-215) + depth
  * (mg_run_NeRF.py:188-189).  One wavefront per ray, exclusive prefix by wave shuffles.
  * flags: bit0 = classic solar (Solar_Type_2), bit1 = zero delta for samples outside [-1,1]^3 (mg_Img_Eval.py:42).
@@ -286,8 +299,9 @@ int snerf_trainer_adam_step(snerf_trainer* t, float lr, float beta1, float beta2
 int snerf_trainer_adam_step_dev(snerf_trainer* t, const float* d_hyper6, void* stream);
 /* ---- the scalar loss terms of a training step: All_in_One_Eval.get_loss, Eval_Tools_2.py:340-420, in the default training configuration (MSE colour
  * loss :413, solar rays on :350-372, default solar model, no DSM prior).  forward: d_vals5 = [Solar_Correction (:361), Solar_Correction_2 (:366,
- * a value only: detached in this configuration), Sky_Color_Var (:381-388), Albedo_Color (:374-379), Color (:413)], d_min3 = the per-channel albedo
- * minimum the Albedo_Color term used.  d_sky is the per-ray sky colour [R,3] (the reference's [R,S,3] tensor holds S copies of it).
+ * a value only: detached in this configuration), Sky_Color_Var (:381-388), Albedo_Color (:374-379), Color (:413)], d_min3 (SIX floats) = the per-channel
+ * albedo minimum the Albedo_Color term used, then - as int32 bits - the ONE row that owns each minimum on this rank (the lowest tied row, as
+ * torch.min; -1 where the global minimum lives on another rank): the backward hands the minimum's gradient to that row only.  d_sky is the per-ray sky colour [R,3] (the reference's [R,S,3] tensor holds S copies of it).
  * d_albedo_min_global (optional, [3]) + world: data-parallel training - the minimum over the global batch (one MIN all-reduce by the caller), the
  * value divided by n_rays * world.  backward: from dL/d(vals5) to dL/dRendered_Col, dL/dAlbedo_Color, dL/dSky_Col [R,3] and dL/dSolar_Vis [Rs,S]
  * (what snerf_trainer_backward_image / _solar take).  d_scratch: snerf_loss_scratch_bytes() bytes, initialised ONCE by snerf_loss_scratch_init (the

@@ -640,6 +640,30 @@ def internal_render(sd, tops, bots, sunv, time_frac, S, mm=None):
             "Output_class": f(cls, C), "Adjust_col": adj.reshape(R, S, C, 3).numpy().astype(np.float64)}
 
 
+def exact_solar_visibility(sd, pts, sunv, S, path_b=True, mm=None):
+    """Transmittance from every point of `pts` [M,3] (fp32) towards the sun along S end-point-inclusive samples of the density-only network.
+    path_b=True:  the `include_exact_solar` block of _internal_render, mg_Img_Eval.py:57-70 - tops formed in float64 from the float64 numpy sun
+                  vector then rounded (`(new_bots + S * a_sun).float()`), samples outside the cube contribute nothing (:65-66);
+    path_b=False: All_in_One_Eval._get_exact_solar, Eval_Tools_2.py:255-271 - all fp32, no cube test; PV_Exact[:, -1] of eval_Rho_Only.
+    Either way exp(-sum_{j<S-1} rho_j delta_j): PV at the last sample is the exclusive prefix (Eval_Tools_2.py:13-16)."""
+    bots = pts.reshape(-1, 3).float()
+    sun = np.asarray(sunv, dtype=np.float64)
+    if path_b:
+        K = (1.0 - bots[:, 2]) / float(sun[2])
+        tops = (bots.double() + K.double().reshape(-1, 1) * torch.tensor(sun).reshape(1, 3)).float()
+    else:
+        s32 = torch.tensor(sun).float()
+        K = (1 - bots[:, 2]) / s32[2]
+        tops = bots + K.unsqueeze(1) * s32.reshape(1, 3)
+    p2, d2 = sample_pt_coarse(tops, bots, S, True, include_end_pt=True)
+    d2 = d2.clone()
+    if path_b:
+        d2[outside_cube(p2)] = 0.0
+    with torch.no_grad():
+        rho = forward_sigma_only(sd, p2.reshape(-1, 3), mm=mm).reshape(bots.shape[0], S, 1)
+    return torch.exp(-torch.sum((rho * d2)[:, 0:-1, :], 1)).reshape(-1)
+
+
 def render_by_dir(sd, view_el_az, sun_el_az, time_frac, out_size, W2C, W2L_H, mm=None):
     """component_render_by_dir + _internal_render without exact solar, mg_Img_Eval.py:17-72,96-115.
     Returns the float64 per-sample dict."""

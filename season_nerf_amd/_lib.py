@@ -62,6 +62,7 @@ def lib():
     L.snerf_group_forward.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp]
     L.snerf_field_forward_points.argtypes = [vp, i32, i64, vp, i64, vp, vp, C.POINTER(FieldOut), vp]
     L.snerf_field_forward_rays.argtypes = [vp, i32, i64, i32, vp, vp, vp, i64, vp, vp, C.POINTER(FieldOut), vp]
+    L.snerf_field_ray_visibility.argtypes = [vp, i64, i32, vp, vp, vp, i32, vp, vp]
     L.snerf_composite_rays.argtypes = [i64, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, C.c_float,
                                        C.POINTER(CompositeOut), vp]
     L.snerf_render_workspace_bytes.restype = C.c_size_t
@@ -128,7 +129,7 @@ def check(rc, what):
 EXPORTS = ["snerf_last_error", "snerf_abi_version", "snerf_model_create", "snerf_model_set_tensor",
            "snerf_model_finalize", "snerf_model_destroy", "snerf_model_width", "snerf_model_classes",
            "snerf_model_set_precision", "snerf_model_precision", "snerf_model_i8_estimate", "snerf_model_resolve_precision",
-           "snerf_model_pack_host", "snerf_group_forward", "snerf_field_forward_points", "snerf_field_forward_rays",
+           "snerf_model_pack_host", "snerf_group_forward", "snerf_field_forward_points", "snerf_field_forward_rays", "snerf_field_ray_visibility",
            "snerf_composite_rays", "snerf_composite_sweep", "snerf_render_workspace_bytes", "snerf_render_rays", "snerf_rays_from_camera", "snerf_ray_grid", "snerf_field_kernel_info",
            "snerf_prior_density", "snerf_surface_distance", "snerf_image_error", "snerf_transmittance",
            "snerf_linear_scratch_bytes", "snerf_linear_forward", "snerf_linear_dgrad", "snerf_linear_wgrad",

@@ -55,7 +55,7 @@ struct snerf_model {
 extern "C" {
 
 const char* snerf_last_error(void) { return g_err.c_str(); }
-int snerf_abi_version(void) { return 6; }
+int snerf_abi_version(void) { return 7; }
 
 snerf_model* snerf_model_create(int layer_width, int n_classes) {
     if (layer_width != 64 && layer_width != 256 && layer_width != 512) {
@@ -335,7 +335,8 @@ int snerf_group_forward(const snerf_model* m, int64_t n_groups, const float* d_t
 }
 
 static int field_launch(const snerf_model* m, int variant, MlpArgs& a, const snerf_field_out* out, void* stream) {
-    if (variant < 0 || variant > 2) return fail(SNERF_E_INVALID, "variant must be 0, 1 or 2");
+    if (variant < 0 || variant > 3) return fail(SNERF_E_INVALID, "variant must be 0, 1 or 2");
+    if (variant == 3 && m->precision == SNERF_PREC_BF16) return fail(SNERF_E_INVALID, "ray visibility: not available in the bf16 fast mode");
     a.stream = m->d_stream[PROG_FIELD];
     a.stream_bytes = (uint32_t)field_variant_chunks(m->W, m->C, variant) * kChunkBytes;
     a.bias = m->d_bias[PROG_FIELD];
@@ -401,6 +402,24 @@ int snerf_field_forward_rays(const snerf_model* m, int variant, int64_t n_rays, 
     a.sun = d_sun;
     a.classes = d_classes;
     return field_launch(m, variant, a, out, stream);
+}
+
+int snerf_field_ray_visibility(const snerf_model* m, int64_t n_rays, int n_samples, const float* d_top, const float* d_bot,
+                               const float* d_tvals, int flags, float* d_vis, void* stream) {
+    int rc = check_ready(m);
+    if (rc) return rc;
+    if (n_rays == 0) return SNERF_OK;
+    if (n_rays < 0 || n_samples < 1 || !d_top || !d_bot || !d_tvals || !d_vis) return fail(SNERF_E_INVALID, "snerf_field_ray_visibility: bad argument");
+    MlpArgs a{};
+    a.n = n_rays;                  // variant 3: one ray per wave, ceil(S / 32) passes of 32 samples (kernels.h)
+    a.top = d_top;
+    a.bot = d_bot;
+    a.tvals = d_tvals;
+    a.n_samples = n_samples;
+    a.group_size = 1;
+    a.ray_flags = flags & 2;
+    a.out.vis = d_vis;
+    return field_launch(m, 3, a, nullptr, stream);
 }
 
 int snerf_composite_rays(int64_t n_rays, int n_samples, const float* d_top, const float* d_bot, const float* d_tvals,

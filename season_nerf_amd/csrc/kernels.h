@@ -13,6 +13,7 @@ struct snerf_field_out_dev {
     float* col;
     float* adjust_col;
     float* points;
+    float* vis;               // VARIANT 3 only: [n_rays] exp(-sum_{j < S-1} rho_j delta_j), one value per ray
 };
 
 struct MlpArgs {
@@ -38,6 +39,9 @@ struct MlpArgs {
     float* g_sky_raw;          // [G,3]
     float* g_sky;              // [G,3]
     uint32_t debug;            // only read by -DSNERF_ABLATE builds
+    // VARIANT 3 (ray visibility: the density-only program with the sum over a ray's samples kept in registers): n = rays, every wave
+    // owns one ray of a group of `waves per workgroup` rays and walks its samples 32 at a time
+    int ray_flags;             // bit 1: a sample outside [-1,1]^3 contributes nothing (mg_Img_Eval.py:42,65-66)
 };
 
 struct CompOutDev {

@@ -300,17 +300,23 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpArgs A) {
     }
     __syncthreads();   // bias table visible (drains the prologue DMAs once; harmless)
 
-    const int64_t n_tiles = (A.n + TILE_PTS - 1) / TILE_PTS;
-    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    // VARIANT 3 (ray visibility, mlp_device.h RaySum): a "tile" is a group of 4 rays (one per wave), walked in `passes` steps of 32 samples
+    const int64_t n_tiles = VARIANT == 3 ? (A.n + 3) / 4 : (A.n + TILE_PTS - 1) / TILE_PTS;
+    const int passes = VARIANT == 3 ? (A.n_samples + 31) / 32 : 1;
+    int pass = 0;
+    RaySum rs;
+    for (int64_t tile = blockIdx.x; tile < n_tiles;) {
         const int64_t n = tile * TILE_PTS + wave * 32 + (lane & 31);
         const bool valid = n < A.n;
         const int64_t nc = valid ? n : A.n - 1;
-        const int64_t g = nc / A.group_size;
+        const int64_t g = VARIANT == 3 ? 0 : nc / A.group_size;
 
         if constexpr (PROG == PROG_FIELD) {
             // ---- sample position (misc.py:234-247 fused): top*(1-t) + bot*t, two roundings + one add, no fma
             float x0, x1, x2;
-            if (A.points) {
+            if constexpr (VARIANT == 3) {
+                raysum_point(rs, A, tile, 4, wave, pass, lane, x0, x1, x2);
+            } else if (A.points) {
                 x0 = A.points[nc * 3]; x1 = A.points[nc * 3 + 1]; x2 = A.points[nc * 3 + 2];
             } else {
                 const int64_t r = nc / A.n_samples;
@@ -382,7 +388,17 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpArgs A) {
             }
 #undef LAYER
             // ---- output non-linearities (T_NeRF_net_v2.py:91-98), lane-half 0 holds the head rows
-            if (h == 0 && valid) store_field_outputs<VARIANT>(A.out, n, C, x0, x1, x2, col_r, col_g, col_b, rho_raw, sv_raw, adj, pcls);
+            if constexpr (VARIANT == 3) {
+                raysum_add(rs, A, tile, 4, wave, pass, lane, rho_raw, x0, x1, x2);
+                if (++pass == passes) {
+                    raysum_end(rs, A, tile, 4, wave, lane);
+                    pass = 0;
+                    tile += gridDim.x;
+                }
+            } else {
+                if (h == 0 && valid) store_field_outputs<VARIANT>(A.out, n, C, x0, x1, x2, col_r, col_g, col_b, rho_raw, sv_raw, adj, pcls);
+                tile += gridDim.x;
+            }
         } else {
             // ---- group program: class softmax (T_NeRF_net_v2.py:77-78) and sky colour (G_NeRF.py:110-111)
             constexpr int KW = W / 16, W4P = pad32(W / 4), KW4 = W4P / 16;
@@ -422,6 +438,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpArgs A) {
                     if (A.g_sky) A.g_sky[n * 3 + k] = sigmoid_f(raw[k]);
                 }
             }
+            tile += gridDim.x;
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup
@@ -807,7 +824,7 @@ hipError_t launch_ray_grid(const RayGridArgs& a, hipStream_t st) {
 template <int PROG, int W, int VARIANT, bool FAST = false>
 static hipError_t launch_mlp_t(const MlpArgs& a, int n_cu, hipStream_t st) {
     const int lds_bytes = RING_BYTES + a.bias_floats * 4;
-    const int64_t n_tiles = (a.n + TILE_PTS - 1) / TILE_PTS;
+    const int64_t n_tiles = VARIANT == 3 ? (a.n + 3) / 4 : (a.n + TILE_PTS - 1) / TILE_PTS;
     int grid = (int)(n_tiles < n_cu ? n_tiles : n_cu);
     if (grid < 1) grid = 1;
     auto k = mlp_kernel<PROG, W, VARIANT, FAST>;
@@ -823,7 +840,9 @@ hipError_t launch_mlp(int prog, int W, int variant, bool fast, const MlpArgs& a,
         if (prog == PROG_GROUP) return launch_mlp_t<PROG_GROUP, Wv, 0>(a, n_cu, st);              \
         if (fast && variant == 0) return launch_mlp_t<PROG_FIELD, Wv, 0, true>(a, n_cu, st);      \
         if (fast && variant == 1) return launch_mlp_t<PROG_FIELD, Wv, 1, true>(a, n_cu, st);     \
+        if (fast && variant == 3) return hipErrorInvalidValue;      /* ray visibility: bf16x3 / int8 digits only */ \
         if (fast) return launch_mlp_t<PROG_FIELD, Wv, 2, true>(a, n_cu, st);                      \
+        if (variant == 3) return launch_mlp_t<PROG_FIELD, Wv, 3>(a, n_cu, st);                    \
         if (variant == 0) return launch_mlp_t<PROG_FIELD, Wv, 0>(a, n_cu, st);                    \
         if (variant == 1) return launch_mlp_t<PROG_FIELD, Wv, 1>(a, n_cu, st);                    \
         return launch_mlp_t<PROG_FIELD, Wv, 2>(a, n_cu, st);                                      \
@@ -840,7 +859,7 @@ const char* mlp_kernel_name() { return "mlp_kernel"; }
 
 // chunks consumed per tile by a variant of the field program (the DMA stream is cyclic over exactly these)
 int field_variant_chunks(int W, int C, int variant) {
-    const int last = variant == 0 ? (int)F_NUM : variant == 1 ? (int)F_A1 : (int)F_S1;
+    const int last = variant == 0 ? (int)F_NUM : variant == 1 ? (int)F_A1 : (int)F_S1;      // variant 3 = the layers of variant 2
     return prog_chunk_start(PROG_FIELD, W, C, last);
 }
 

@@ -84,11 +84,14 @@ constexpr int PF8 = SNERF_PF8;
 //   AG_IN0 / AG_OUT >= 0: the first input block / the output live in AGPRs from that register number on (W = 512; the
 //   pointer is then unused); the second input block, where there is one, is always an encoding in VGPRs.
 //   RAWL: the layer reads an encoding; rawx = its three raw coordinates, added in fp32 (mlp_i8_device.h add_raw).
-template <int NB, int KS0, int KS1, bool SIN, int D, int AG_IN0 = -1, int AG_OUT = -1, bool AG = false, bool RAWL = false>
+template <int NB, int KS0, int KS1, bool SIN, int D, int AG_IN0 = -1, int AG_OUT = -1, bool AG = false, bool RAWL = false, bool OPQ = false>
 __device__ __forceinline__ void run_layer8(Ring& rg, const uint8_t* stream, uint32_t stream_bytes, lds_char* lds, lds_cfloat* tab_l,
                                            const Frag8* in0, const Frag8* in1, Frag8* out, f32x16* raw, int wave, int lane,
                                            const float* rawx = nullptr) {
     static_assert(!RAWL || SIN, "raw coordinates only enter sine layers");
+    // OPQ (ray-visibility variant): the table base is made opaque per layer so that hipcc does not hoist one address register per table row out of
+    // the persistent tile loop (kernels_i8x2.hip run_layer8x2: the same measure; without it the W = 512 instance of the variant needs 32 bytes of scratch)
+    if constexpr (OPQ) asm volatile("" : "+v"(tab_l));
     lds_cfloat* raw_l = tab_l + 2 * 32 * NB;         // the layer's raw-weight table follows its scale / bias table
     Raw8 rw;
     constexpr int KS = KS0 + KS1, NP = NB * KS;
@@ -231,12 +234,16 @@ __global__ __launch_bounds__(256, 1) void mlp_i8_kernel(const MlpArgs A) {
     }
     __syncthreads();
 
-    const int64_t n_tiles = (A.n + TILE_PTS - 1) / TILE_PTS;
-    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    // VARIANT 3 (ray visibility, mlp_device.h RaySum): a "tile" is a group of 4 rays (one per wave), walked in `passes` steps of 32 samples
+    const int64_t n_tiles = VARIANT == 3 ? (A.n + 3) / 4 : (A.n + TILE_PTS - 1) / TILE_PTS;
+    const int passes = VARIANT == 3 ? (A.n_samples + 31) / 32 : 1;
+    int pass = 0;
+    RaySum rs;
+    for (int64_t tile = blockIdx.x; tile < n_tiles;) {
         const int64_t n = tile * TILE_PTS + wave * 32 + (lane & 31);
         const bool valid = n < A.n;
         const int64_t nc = valid ? n : A.n - 1;
-        const int64_t g = nc / A.group_size;
+        const int64_t g = VARIANT == 3 ? 0 : nc / A.group_size;
 
         if constexpr (PROG == PROG_GROUP) {
             // ---- group program: class softmax (T_NeRF_net_v2.py:77-78) and sky colour (G_NeRF.py:110-111); used where the
@@ -283,11 +290,14 @@ __global__ __launch_bounds__(256, 1) void mlp_i8_kernel(const MlpArgs A) {
                     if (A.g_sky) A.g_sky[n * 3 + k] = sigmoid_f(raw[k]);
                 }
             }
+            tile += gridDim.x;
             continue;
         }
         // ---- sample position (misc.py:234-247 fused): top*(1-t) + bot*t, two roundings + one add, no fma
         float x0, x1, x2;
-        if (A.points) {
+        if constexpr (VARIANT == 3) {
+            raysum_point(rs, A, tile, 4, wave, pass, lane, x0, x1, x2);
+        } else if (A.points) {
             x0 = A.points[nc * 3]; x1 = A.points[nc * 3 + 1]; x2 = A.points[nc * 3 + 2];
         } else {
             const int64_t r = nc / A.n_samples;
@@ -310,7 +320,7 @@ __global__ __launch_bounds__(256, 1) void mlp_i8_kernel(const MlpArgs A) {
             }
         }
         Frag8 pe[PEPOS_KS8];
-        make_pe_pos8(x0, x1, x2, h, pe);
+        make_pe_pos8<VARIANT == 3>(x0, x1, x2, h, pe);
 
         constexpr int KW = W / 32, KW2 = W2 / 32;
         Frag8 hA[KW], hB[KW];
@@ -323,10 +333,10 @@ __global__ __launch_bounds__(256, 1) void mlp_i8_kernel(const MlpArgs A) {
         constexpr int xA = AG_R0, xB = AG_R1, xX1 = AG_R0, xSA = AG_R1, xSB = AG_R1 + 64, NOAG = -1;
         if constexpr (AG) reserve_agprs();
 #define LAYER(L, NBv, K0, K1, SINv, IN0, IN0AG, IN1, OUT, OUTAG, RAW)                                                      \
-    run_layer8<NBv, K0, K1, SINv, D, AG ? IN0AG : -1, AG ? OUTAG : -1, AG>(rg, A.stream, A.stream_bytes, lds,                \
+    run_layer8<NBv, K0, K1, SINv, D, AG ? IN0AG : -1, AG ? OUTAG : -1, AG, false, VARIANT == 3>(rg, A.stream, A.stream_bytes, lds, \
         tab_lds + prog_table_start(PROG_FIELD, W, C_MAX, L), IN0, IN1, OUT, RAW, wave, lane)
 #define LAYER_RAW(L, NBv, K0, K1, IN0, IN0AG, IN1, OUT, OUTAG, RX)                                                         \
-    run_layer8<NBv, K0, K1, true, D, AG ? IN0AG : -1, AG ? OUTAG : -1, AG, true>(rg, A.stream, A.stream_bytes, lds,          \
+    run_layer8<NBv, K0, K1, true, D, AG ? IN0AG : -1, AG ? OUTAG : -1, AG, true, VARIANT == 3>(rg, A.stream, A.stream_bytes, lds, \
         tab_lds + prog_table_start(PROG_FIELD, W, C_MAX, L), IN0, IN1, OUT, nullptr, wave, lane, RX)
         const float rx_p[3] = {x0, x1, x2}, rx_s[3] = {s0, s1, s2};      // raw coordinates: fp32, no digit range
         // trunk (G_NeRF.py:80-91)
@@ -369,7 +379,17 @@ __global__ __launch_bounds__(256, 1) void mlp_i8_kernel(const MlpArgs A) {
         }
 #undef LAYER
 #undef LAYER_RAW
-        if (h == 0 && valid) store_field_outputs<VARIANT>(A.out, n, C, x0, x1, x2, col_r, col_g, col_b, rho_raw, sv_raw, adj, pcls);
+        if constexpr (VARIANT == 3) {
+            raysum_add(rs, A, tile, 4, wave, pass, lane, rho_raw, x0, x1, x2);
+            if (++pass == passes) {
+                raysum_end(rs, A, tile, 4, wave, lane);
+                pass = 0;
+                tile += gridDim.x;
+            }
+        } else {
+            if (h == 0 && valid) store_field_outputs<VARIANT>(A.out, n, C, x0, x1, x2, col_r, col_g, col_b, rho_raw, sv_raw, adj, pcls);
+            tile += gridDim.x;
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup
 }
@@ -377,7 +397,7 @@ __global__ __launch_bounds__(256, 1) void mlp_i8_kernel(const MlpArgs A) {
 template <int PROG, int W, int VARIANT>
 static hipError_t launch_mlp_i8_t(const MlpArgs& a, int n_cu, hipStream_t st) {
     const int lds_bytes = ring_depth8(W) * kChunkBytes + a.bias_floats * 4;
-    const int64_t n_tiles = (a.n + TILE_PTS - 1) / TILE_PTS;
+    const int64_t n_tiles = VARIANT == 3 ? (a.n + 3) / 4 : (a.n + TILE_PTS - 1) / TILE_PTS;
     int grid = (int)(n_tiles < n_cu ? n_tiles : n_cu);
     if (grid < 1) grid = 1;
     auto k = mlp_i8_kernel<PROG, W, VARIANT>;
@@ -395,6 +415,7 @@ hipError_t launch_mlp_i8_w512(int variant, const MlpArgs& a, int n_cu, hipStream
 hipError_t launch_mlp_i8_w512(int variant, const MlpArgs& a, int n_cu, hipStream_t st) {
     if (variant == 0) return launch_mlp_i8_t<PROG_FIELD, 512, 0>(a, n_cu, st);
     if (variant == 1) return launch_mlp_i8_t<PROG_FIELD, 512, 1>(a, n_cu, st);
+    if (variant == 3) return launch_mlp_i8_t<PROG_FIELD, 512, 3>(a, n_cu, st);
     return launch_mlp_i8_t<PROG_FIELD, 512, 2>(a, n_cu, st);
 }
 #else
@@ -404,6 +425,7 @@ hipError_t launch_mlp_i8(int prog, int W, int variant, const MlpArgs& a, int n_c
         if (prog != PROG_FIELD) return hipErrorInvalidValue;                              \
         if (variant == 0) return launch_mlp_i8_t<PROG_FIELD, Wv, 0>(a, n_cu, st);         \
         if (variant == 1) return launch_mlp_i8_t<PROG_FIELD, Wv, 1>(a, n_cu, st);         \
+        if (variant == 3) return launch_mlp_i8_t<PROG_FIELD, Wv, 3>(a, n_cu, st);         \
         return launch_mlp_i8_t<PROG_FIELD, Wv, 2>(a, n_cu, st);                           \
     }
     CASE(64)
@@ -420,7 +442,7 @@ hipError_t launch_mlp_i8(int prog, int W, int variant, const MlpArgs& a, int n_c
 
 // chunks consumed per tile by a variant of the int8 field program (the DMA stream is cyclic over exactly these)
 int field_variant_chunks_i8(int W, int C, int variant) {
-    const int last = variant == 0 ? (int)F_NUM : variant == 1 ? (int)F_A1 : (int)F_S1;
+    const int last = variant == 0 ? (int)F_NUM : variant == 1 ? (int)F_A1 : (int)F_S1;      // variant 3 = the layers of variant 2
     return prog_chunk_start(PROG_FIELD, W, C, last, FMT_I8);
 }
 #endif

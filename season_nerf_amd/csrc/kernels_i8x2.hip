@@ -142,11 +142,21 @@ __device__ __forceinline__ void dma_chunk4(const uint8_t* stream, uint32_t goff,
 struct TabQ {
     f32x4 sc, bi;
 };
+// per-row scale and bias from the layer's table start (block b, lane-half h, quad g)
 __device__ __forceinline__ TabQ load_tab_quad(lds_cfloat* tab_l, int b, int h, int g) {
+    typedef volatile const __attribute__((address_space(3))) f32x4 lds_vf32x4;      // volatile: see load_tab_quad_h
+    lds_vf32x4* tp = (lds_vf32x4*)(tab_l + (b * 2 + h) * 32);
+    TabQ t;
+    t.sc = tp[g];
+    t.bi = tp[4 + g];
+    return t;
+}
+// tab_h: a per-lane base that already points at this lane-half's rows of block 0 (tab_l + 32 h): block b, quad g are then IMMEDIATE offsets
+__device__ __forceinline__ TabQ load_tab_quad_h(lds_cfloat* tab_h, int b, int g) {
     // volatile: the table is loop-invariant data, and the optimiser otherwise gathers the loads of whole layers ahead of
     // the chain and parks them in scratch (1.7 KB per lane measured) - they must stay where the epilogue needs them
     typedef volatile const __attribute__((address_space(3))) f32x4 lds_vf32x4;
-    lds_vf32x4* tp = (lds_vf32x4*)(tab_l + (b * 2 + h) * 32);
+    lds_vf32x4* tp = (lds_vf32x4*)(tab_h + b * 64);
     TabQ t;
     t.sc = tp[g];
     t.bi = tp[4 + g];
@@ -163,15 +173,24 @@ __device__ __forceinline__ TabQ load_tab_quad(lds_cfloat* tab_l, int b, int h, i
 //   drops to 13 %, the kernel gains 2.5 %.  Tried on top without gain: the epilogue slices in the k-steps where a wave yields,
 //   biased levels ({0,2} against {1,3}: the younger wave then takes the older one's place), alternating the tie-break per
 //   k-step pair / per block (the two waves' barrier times even out, their sum and the kernel time do not change).
-template <int NB, int KS0, int KS1, bool SIN, bool RAWL = false, int PHASE = 0>
+template <int NB, int KS0, int KS1, bool SIN, bool RAWL = false, int PHASE = 0, bool OPQ = false>
 __device__ __forceinline__ void run_layer8x2(Ring2& rg, const uint8_t* stream, uint32_t stream_bytes, lds_char* lds, lds_cfloat* tab_l,
                                              const Frag8* in0, const Frag8* in1, Frag8* out, f32x16* raw, int wave, int lane,
                                              const float* rawx = nullptr) {
     constexpr int KS = KS0 + KS1, NP = NB * KS;
-    lds_cfloat* raw_l = tab_l + 2 * 32 * NB;
     typedef volatile const __attribute__((address_space(3))) f32x4 lds_vf32x4;
     f32x4 rq[4][3];        // raw-coordinate weights of the previous block's quads (RAWL), requested with the table entries
     const int h = lane >> 5;
+    // OPQ (the ray-visibility variant): table addresses from ONE opaque per-lane base per layer (this lane-half's rows of block 0), every block / quad an
+    // immediate offset from it.  Written as absolute addresses (LDS base + layer start + block + h-term: constants above the 64 KiB reach of a ds_read
+    // offset) hipcc gave every table row of THAT variant its own address register and hoisted all of them out of the persistent tile loop - ~25 registers
+    // alive across the whole chain, 72-104 bytes of scratch (tests/test_isa_guards.py); the asm makes the base un-hoistable, so it lives for one layer.
+    // The other variants compile without scratch as they are and keep their addressing (with the opaque bases the full program spills 116 bytes).
+    lds_cfloat* raw_l = tab_l + 2 * 32 * NB;
+    lds_cfloat* tab_h = tab_l + 32 * h;
+    lds_cfloat* raw_h = raw_l + 48 * h;
+    if constexpr (OPQ) asm volatile("" : "+v"(tab_h), "+v"(raw_h));
+    auto tabq = [&](int b_, int g_) { return OPQ ? load_tab_quad_h(tab_h, b_, g_) : load_tab_quad(tab_l, b_, h, g_); };
     i32x4 fT[PFX], fL[PFX];
 #if defined(SNERF_ABLATE) && (ABL & 2)     // timing-only: weight fragments stay in registers, no LDS reads
     constexpr bool ABL2_ = true;
@@ -208,7 +227,7 @@ __device__ __forceinline__ void run_layer8x2(Ring2& rg, const uint8_t* stream, u
     TabQ tq[4];        // table entries of the previous block's quads: requested one k-step before their slice runs
     auto load_rq = [&](int g, int b_of) {
         if constexpr (RAWL) {
-            lds_vf32x4* tp = (lds_vf32x4*)(raw_l + ((b_of * 2 + h) * 4 + g) * 12);
+            lds_vf32x4* tp = OPQ ? (lds_vf32x4*)(raw_h + (b_of * 8 + g) * 12) : (lds_vf32x4*)(raw_l + ((b_of * 2 + h) * 4 + g) * 12);
             rq[g][0] = tp[0]; rq[g][1] = tp[1]; rq[g][2] = tp[2];
         }
     };
@@ -235,7 +254,7 @@ __device__ __forceinline__ void run_layer8x2(Ring2& rg, const uint8_t* stream, u
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         if (b > 0) {
-            tq[0] = load_tab_quad(tab_l, b - 1, h, 0);
+            tq[0] = tabq(b - 1, 0);
             load_rq(0, b - 1);
 #pragma unroll
             for (int i = 0; i < 16; ++i) m[i] = (int)(((uint32_t)acc.M[i] << 8) + (uint32_t)acc.X[i]);
@@ -257,7 +276,7 @@ __device__ __forceinline__ void run_layer8x2(Ring2& rg, const uint8_t* stream, u
 #pragma unroll
                 for (int g = 1; g < 4; ++g) {
                     const int sg = (g * KS) / 4, lg = sg > 0 ? sg - 1 : 0;
-                    if (lg == s) { tq[g] = load_tab_quad(tab_l, b - 1, h, g); load_rq(g, b - 1); }
+                    if (lg == s) { tq[g] = tabq(b - 1, g); load_rq(g, b - 1); }
                 }
             }
             mfma_i8x3(aT, aL, s < KS0 ? in0[s] : in1[s - KS0], acc);
@@ -287,7 +306,7 @@ __device__ __forceinline__ void run_layer8x2(Ring2& rg, const uint8_t* stream, u
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         asm volatile("" ::: "memory");
-        const TabQ t = load_tab_quad(tab_l, NB - 1, h, g);
+        const TabQ t = tabq(NB - 1, g);
         load_rq(g, NB - 1);
         quad(g, NB - 1, t);
         asm volatile("" ::: "memory");
@@ -349,16 +368,22 @@ __device__ __forceinline__ void field_tiles2(const MlpArgs& A, Ring2& rg, lds_ch
     constexpr int W2 = W / 2;
     const int h = lane >> 5;
     const int C = A.n_classes;
-    const int64_t n_tiles = (A.n + TILE2 - 1) / TILE2;
-    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    // VARIANT 3 (ray visibility, mlp_device.h RaySum): a "tile" is a group of NW2 rays, walked in `passes` steps of 32 samples
+    const int64_t n_tiles = VARIANT == 3 ? (A.n + NW2 - 1) / NW2 : (A.n + TILE2 - 1) / TILE2;
+    const int passes = VARIANT == 3 ? (A.n_samples + 31) / 32 : 1;
+    int pass = 0;
+    RaySum rs;
+    for (int64_t tile = blockIdx.x; tile < n_tiles;) {
         const int64_t n = tile * TILE2 + wave * 32 + (lane & 31);
         const bool valid = n < A.n;
         const int64_t nc = valid ? n : A.n - 1;
-        const int64_t g = nc / A.group_size;
+        const int64_t g = VARIANT == 3 ? 0 : nc / A.group_size;
 
         // ---- sample position (misc.py:234-247 fused): top*(1-t) + bot*t, two roundings + one add, no fma
         float x0, x1, x2;
-        if (A.points) {
+        if constexpr (VARIANT == 3) {
+            raysum_point(rs, A, tile, NW2, wave, pass, lane, x0, x1, x2);
+        } else if (A.points) {
             x0 = A.points[nc * 3]; x1 = A.points[nc * 3 + 1]; x2 = A.points[nc * 3 + 2];
         } else {
             const int64_t r = nc / A.n_samples;
@@ -385,17 +410,17 @@ __device__ __forceinline__ void field_tiles2(const MlpArgs& A, Ring2& rg, lds_ch
 #endif
         STAMP(0);
         Frag8 pe[PEPOS_KS8];
-        make_pe_pos8(x0, x1, x2, h, pe);
+        make_pe_pos8<VARIANT == 3>(x0, x1, x2, h, pe);
         STAMP(1);
 
         constexpr int KW = W / 32, KW2 = W2 / 32;
         Frag8 hA[KW], hB[KW];
         f32x16 raw;
 #define LAYER(L, NBv, K0, K1, SINv, IN0, IN1, OUT, RAW)                                                                       \
-    run_layer8x2<NBv, K0, K1, SINv, false, PHASE>(rg, A.stream, A.stream_bytes, lds, tab_lds + prog_table_start(PROG_FIELD, W, C_MAX, L), \
+    run_layer8x2<NBv, K0, K1, SINv, false, PHASE, VARIANT == 3>(rg, A.stream, A.stream_bytes, lds, tab_lds + prog_table_start(PROG_FIELD, W, C_MAX, L), \
                                                   IN0, IN1, OUT, RAW, wave, lane)
 #define LAYER_RAW(L, NBv, K0, K1, IN0, IN1, OUT, RX)                                                                          \
-    run_layer8x2<NBv, K0, K1, true, true, PHASE>(rg, A.stream, A.stream_bytes, lds, tab_lds + prog_table_start(PROG_FIELD, W, C_MAX, L), \
+    run_layer8x2<NBv, K0, K1, true, true, PHASE, VARIANT == 3>(rg, A.stream, A.stream_bytes, lds, tab_lds + prog_table_start(PROG_FIELD, W, C_MAX, L), \
                                                  IN0, IN1, OUT, nullptr, wave, lane, RX)
         const float rx_p[3] = {x0, x1, x2}, rx_s[3] = {s0, s1, s2};      // raw coordinates: fp32, no digit range
         // trunk (G_NeRF.py:80-91)
@@ -438,7 +463,17 @@ __device__ __forceinline__ void field_tiles2(const MlpArgs& A, Ring2& rg, lds_ch
         }
 #undef LAYER
 #undef LAYER_RAW
-        if (h == 0 && valid) store_field_outputs<VARIANT>(A.out, n, C, x0, x1, x2, col_r, col_g, col_b, rho_raw, sv_raw, adj, pcls);
+        if constexpr (VARIANT == 3) {
+            raysum_add(rs, A, tile, NW2, wave, pass, lane, rho_raw, x0, x1, x2);
+            if (++pass == passes) {
+                raysum_end(rs, A, tile, NW2, wave, lane);
+                pass = 0;
+                tile += gridDim.x;
+            }
+        } else {
+            if (h == 0 && valid) store_field_outputs<VARIANT>(A.out, n, C, x0, x1, x2, col_r, col_g, col_b, rho_raw, sv_raw, adj, pcls);
+            tile += gridDim.x;
+        }
         STAMP(20);
     }
     __builtin_amdgcn_s_setprio(0);
@@ -447,7 +482,7 @@ __device__ __forceinline__ void field_tiles2(const MlpArgs& A, Ring2& rg, lds_ch
 template <int W, int VARIANT>
 static hipError_t launch_mlp_i8x2_t(const MlpArgs& a, int n_cu, hipStream_t st) {
     const int lds_bytes = RING2_D * kChunkBytes + a.bias_floats * 4;
-    const int64_t n_tiles = (a.n + TILE2 - 1) / TILE2;
+    const int64_t n_tiles = VARIANT == 3 ? (a.n + NW2 - 1) / NW2 : (a.n + TILE2 - 1) / TILE2;
     int grid = (int)(n_tiles < n_cu ? n_tiles : n_cu);
     if (grid < 1) grid = 1;
     auto k = mlp_i8x2_kernel<W, VARIANT>;
@@ -462,6 +497,7 @@ hipError_t launch_mlp_i8x2(int W, int variant, const MlpArgs& a, int n_cu, hipSt
     if (W == Wv) {                                                            \
         if (variant == 0) return launch_mlp_i8x2_t<Wv, 0>(a, n_cu, st);       \
         if (variant == 1) return launch_mlp_i8x2_t<Wv, 1>(a, n_cu, st);       \
+        if (variant == 3) return launch_mlp_i8x2_t<Wv, 3>(a, n_cu, st);       \
         return launch_mlp_i8x2_t<Wv, 2>(a, n_cu, st);                         \
     }
     CASE(64)

@@ -135,6 +135,53 @@ __device__ __forceinline__ void pe_sincos(const PeArg& a, double scale, float& c
 __device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }   // torch Softplus(beta 1, thr 20)
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
 
+// VARIANT 3 ("ray visibility", Eval_Tools_2.py:255-271 / mg_Img_Eval.py:57-70): the density-only program over the samples of a ray, the
+// optical depth sum_{j < S-1} rho_j delta_j kept in a register across the ray's ceil(S / 32) passes, one float out per ray:
+// vis = exp(-sum).  A wave owns ray `group * waves + wave`; lane l & 31 of pass p evaluates sample 32 p + (l & 31).
+struct RaySum {
+    float sum;                      // running optical depth of this lane's samples (lives across the ray's passes)
+};
+// sample position of this lane in pass p (misc.py:234-247: top (1 - t) + bot t, two roundings + one add).  The ray's end points are re-read
+// every pass (cached loads before the MFMA chain) and once more after it for the segment length: nothing but `sum` lives across the chain.
+__device__ __forceinline__ void raysum_point(RaySum& q, const MlpArgs& A, int64_t group, int waves, int wave, int p, int lane, float& x0, float& x1, float& x2) {
+    const int64_t ray = group * waves + wave;
+    const int64_t r = ray < A.n ? ray : A.n - 1;
+    if (p == 0) q.sum = 0.f;
+    const int s = p * 32 + (lane & 31);
+    const float t = A.tvals[s < A.n_samples ? s : A.n_samples - 1], omt = __fsub_rn(1.f, t);
+    x0 = __fadd_rn(__fmul_rn(A.top[r * 3], omt), __fmul_rn(A.bot[r * 3], t));
+    x1 = __fadd_rn(__fmul_rn(A.top[r * 3 + 1], omt), __fmul_rn(A.bot[r * 3 + 1], t));
+    x2 = __fadd_rn(__fmul_rn(A.top[r * 3 + 2], omt), __fmul_rn(A.bot[r * 3 + 2], t));
+}
+// lane-half 0 holds the density row; the last sample never counts (PV at the last sample is the EXCLUSIVE prefix, Eval_Tools_2.py:13-16);
+// delta = ||top - bot|| / S (misc.py:243) with the composite kernel's operations
+__device__ __forceinline__ void raysum_add(RaySum& q, const MlpArgs& A, int64_t group, int waves, int wave, int p, int lane, float rho_raw, float x0, float x1, float x2) {
+    // its own basic block (as the `if (h == 0 && valid)` around the other variants' stores): straight-line code here is scheduled up into the last
+    // layer's epilogue, where the softplus / division expansions cost 26 registers of scratch (measured)
+    if (lane >= 32) return;
+    const int64_t ray = group * waves + wave;
+    const int64_t r = ray < A.n ? ray : A.n - 1;
+    const float dx = A.top[r * 3] - A.bot[r * 3], dy = A.top[r * 3 + 1] - A.bot[r * 3 + 1], dz = A.top[r * 3 + 2] - A.bot[r * 3 + 2];
+    const float delta = __fdiv_rn(__fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz))), (float)A.n_samples);
+    const int s = p * 32 + (lane & 31);
+    {   // the sample position again (the registers that held it during the chain are long gone: fewer values live across it)
+        const float t = A.tvals[s < A.n_samples ? s : A.n_samples - 1], omt = __fsub_rn(1.f, t);
+        x0 = __fadd_rn(__fmul_rn(A.top[r * 3], omt), __fmul_rn(A.bot[r * 3], t));
+        x1 = __fadd_rn(__fmul_rn(A.top[r * 3 + 1], omt), __fmul_rn(A.bot[r * 3 + 1], t));
+        x2 = __fadd_rn(__fmul_rn(A.top[r * 3 + 2], omt), __fmul_rn(A.bot[r * 3 + 2], t));
+    }
+    const bool oob = x0 > 1.f || x0 < -1.f || x1 > 1.f || x1 < -1.f || x2 > 1.f || x2 < -1.f;
+    const bool on = s < A.n_samples - 1 && !((A.ray_flags & 2) && oob);
+    q.sum += on ? __fmul_rn(softplus_f(rho_raw), delta) : 0.f;
+}
+__device__ __forceinline__ void raysum_end(RaySum& q, const MlpArgs& A, int64_t group, int waves, int wave, int lane) {
+    float v = q.sum;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    const int64_t ray = group * waves + wave;
+    if (lane == 0 && ray < A.n) A.out.vis[ray] = expf(-v);
+}
+
 // output non-linearities of the field program (T_NeRF_net_v2.py:91-98) for one point; called by the lanes that hold the head rows
 template <int VARIANT>
 __device__ __forceinline__ void store_field_outputs(const snerf_field_out_dev& O, int64_t n, int C, float x0, float x1, float x2,

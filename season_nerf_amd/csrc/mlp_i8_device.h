@@ -102,10 +102,16 @@ __device__ __forceinline__ void epi_A(const Acc8& acc, const Tab8& t, int e, flo
 }
 
 // PE(pos): 32 values per lane-half (program.h pepos_feature), two k-steps
+template <bool OPQ = false>
 __device__ __forceinline__ void make_pe_pos8(float x0, float x1, float x2, int h, Frag8* pe) {
     float v[32];
     const float xs[3] = {x0, x1, x2};
-    const int e0 = 5 * h;                         // lane-half h evaluates frequencies 2^(5h) .. 2^(5h+4)
+    // lane-half h evaluates frequencies 2^(5h) .. 2^(5h+4).  The five exponents are loop-invariant per lane: left alone, hipcc hoists them out of the
+    // persistent tile loop and keeps five registers alive across the whole MFMA chain (the ray-visibility variant of the two-wave kernel spilled them);
+    // OPQ makes them opaque: recomputed per tile (five v_add per 32 points).  Off for the other variants (their allocation is at its edge as it is).
+    int hv = h;
+    if constexpr (OPQ) asm volatile("" : "+v"(hv));
+    const int e0 = 5 * hv;
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
         const PeArg a = pe_arg(xs[d]);

@@ -10,6 +10,7 @@
 //     .set_tensor(key, cpu_f32)  .resolve()  .i8_estimate()  .finalize()  .width()  .classes()  .precision()  .handle()
 //   season_nerf::group_fwd(Model, time[G,4], sun[G,3]) -> (classes[G,C], sky_raw[G,3], sky[G,3])        get_class_only + sky head
 //   season_nerf::points_fwd(Model, x[N,3], sun[G,3]?, classes[G,C]?, group_size, variant)               T_NeRF.forward* on points
+//   season_nerf::ray_visibility(Model, top[R,3], bot[R,3], tvals[S], flags) -> vis[R]                     exact solar visibility of secondary rays
 //        -> (rho[N,1], solar_vis[N,1], col_raw[N,3], adjust[N,C,3], col[N,3], adjust_col[N,3])
 //   season_nerf::render_fwd(Model, top[R,3], bot[R,3], sun[R,3], time[R,4], tvals[S], flags, want_per_sample, want_unmixed=False)
 //        -> (rgb[R,3], depth[R,2] = (surface distance, accumulated weight), albedo[R,3], per_sample[])  All_in_One_Eval.eval
@@ -141,6 +142,19 @@ std::vector<Tensor> points_fwd(const ModelPtr& M, const Tensor& x, const c10::op
     ck(snerf_field_forward_points(M->m, (int)variant, N, fptr(x), group_size, sun.has_value() ? fptr(*sun) : nullptr,
                                   classes.has_value() ? fptr(*classes) : nullptr, &fo, cur_stream(x)), "points_fwd");
     return {rho, sv, col_raw, adjust, col, adjc};
+}
+
+// exact solar visibility of secondary rays (Eval_Tools_2.py:255-271, mg_Img_Eval.py:57-70): one launch, one float per ray
+Tensor ray_visibility(const ModelPtr& M, const Tensor& top, const Tensor& bot, const Tensor& tvals, int64_t flags) {
+    check_shape(top, "top", -1, 3);
+    const int64_t R = top.size(0);
+    check_shape(bot, "bot", R, 3);
+    TORCH_CHECK(tvals.dim() == 1 && tvals.numel() >= 1, "tvals must be [S]");
+    TORCH_CHECK(tvals.is_cuda() && tvals.scalar_type() == at::kFloat && tvals.is_contiguous(), "tvals must be a contiguous float32 device tensor");
+    c10::hip::HIPGuardMasqueradingAsCUDA g(top.device());
+    Tensor vis = at::empty({R}, top.options());
+    ck(snerf_field_ray_visibility(M->m, R, (int)tvals.numel(), fptr(top), fptr(bot), fptr(tvals), (int)flags, mptr(vis), cur_stream(top)), "ray_visibility");
+    return vis;
 }
 
 std::tuple<Tensor, Tensor, Tensor, std::vector<Tensor>> render_fwd(const ModelPtr& M, const Tensor& top, const Tensor& bot, const Tensor& sun,
@@ -425,13 +439,14 @@ void trainer_zero_grad_(int64_t trainer, Tensor grads) {
     ck(snerf_trainer_zero_grad(t, cur_stream(grads)), "trainer_zero_grad_");
 }
 
-// the self-cleaning reduction scratch of loss_terms: one per device, created (and initialised, in stream order) at first use; launches of one
-// device are serialised by their stream, and the forward leaves the scratch in its initial state
+// the self-cleaning reduction scratch of loss_terms: one per (device, stream), created (and initialised, in stream order) at first use; launches of one
+// stream are serialised, and the forward leaves the scratch in its initial state.  (one scratch per DEVICE let two streams of a device - a
+// captured step on its side stream next to an eager validation step, two networks trained side by side - mix their sums.)
 static Tensor loss_scratch(const Tensor& like) {
     static std::mutex mu;
-    static auto* per_device = new std::map<int, Tensor>();      // leaked on purpose: no tensor destructor after the HIP runtime has shut down
+    static auto* per_stream = new std::map<std::pair<int, void*>, Tensor>();      // leaked on purpose: no tensor destructor after the HIP runtime has shut down
     std::lock_guard<std::mutex> lock(mu);
-    Tensor& s = (*per_device)[like.get_device()];
+    Tensor& s = (*per_stream)[{like.get_device(), cur_stream(like)}];
     if (!s.defined()) {
         s = at::empty({(int64_t)snerf_loss_scratch_bytes()}, like.options().dtype(at::kByte));
         ck(snerf_loss_scratch_init(s.data_ptr(), cur_stream(like)), "loss_scratch");
@@ -440,7 +455,7 @@ static Tensor loss_scratch(const Tensor& like) {
 }
 
 // ---- scalar loss terms of a training step (get_loss, Eval_Tools_2.py:340-420, default configuration) ---------------------------------
-// loss_terms(rgb, gt, albedo, sky, solar_vis, pv_exact, pe, albedo_min_global?, world) -> (vals[5], min[3]);  loss_terms_bwd: the gradients
+// loss_terms(rgb, gt, albedo, sky, solar_vis, pv_exact, pe, albedo_min_global?, world) -> (vals[5], min[6]: the minima + the rows that own them);  loss_terms_bwd: the gradients
 std::tuple<Tensor, Tensor> loss_terms(const Tensor& rgb, const Tensor& gt, const Tensor& albedo, const Tensor& sky, const Tensor& sv, const Tensor& pv,
                                       const Tensor& pe, const c10::optional<Tensor>& alb_min_global, int64_t world) {
     check_shape(rgb, "rgb", -1, 3);
@@ -452,7 +467,7 @@ std::tuple<Tensor, Tensor> loss_terms(const Tensor& rgb, const Tensor& gt, const
     TORCH_CHECK(world >= 1, "world must be >= 1");
     c10::hip::HIPGuardMasqueradingAsCUDA g(rgb.device());
     Tensor scratch = loss_scratch(rgb);
-    Tensor vals = at::empty({5}, rgb.options()), minv = at::empty({3}, rgb.options());
+    Tensor vals = at::empty({5}, rgb.options()), minv = at::empty({6}, rgb.options());
     ck(snerf_loss_terms_forward(R, Rs, (int)S, fptr(rgb), fptr(gt), fptr(albedo), fptr(sky), fptr(sv), fptr(pv), fptr(pe), optptr(alb_min_global, "albedo_min_global", 3),
                                 (int)world, scratch.data_ptr(), mptr(vals), mptr(minv), cur_stream(rgb)), "loss_terms");
     return {vals, minv};
@@ -463,7 +478,7 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> loss_terms_bwd(const Tensor& g_vals, 
     const int64_t R = rgb.size(0);
     check_shape(gt, "gt", R, 3); check_shape(albedo, "albedo", R, 3); check_shape(sky, "sky", R, 3);
     check_dev_f32(sv, "solar_vis"); check_dev_f32(pv, "pv_exact"); check_dev_f32(g_vals, "g_vals"); check_dev_f32(minv, "min");
-    TORCH_CHECK(g_vals.numel() == 5 && minv.numel() == 3 && pv.numel() == sv.numel() && sv.dim() >= 2, "g_vals [5], min [3], pv_exact like solar_vis");
+    TORCH_CHECK(g_vals.numel() == 5 && minv.numel() == 6 && pv.numel() == sv.numel() && sv.dim() >= 2, "g_vals [5], min [6], pv_exact like solar_vis");
     const int64_t Rs = sv.size(0), S = sv.numel() / Rs;
     c10::hip::HIPGuardMasqueradingAsCUDA g(rgb.device());
     Tensor d_rgb = at::empty_like(rgb), d_alb = at::empty_like(albedo), d_sky = at::empty_like(sky), d_sv = at::empty_like(sv);
@@ -488,6 +503,7 @@ TORCH_LIBRARY(season_nerf, m) {
     m.def("model_from_handle(int handle) -> __torch__.torch.classes.season_nerf.Model", model_from_handle);
     m.def("group_fwd(__torch__.torch.classes.season_nerf.Model model, Tensor time, Tensor sun) -> (Tensor, Tensor, Tensor)");
     m.def("points_fwd(__torch__.torch.classes.season_nerf.Model model, Tensor x, Tensor? sun, Tensor? classes, int group_size, int variant) -> Tensor[]");
+    m.def("ray_visibility(__torch__.torch.classes.season_nerf.Model model, Tensor top, Tensor bot, Tensor tvals, int flags) -> Tensor");
     m.def("render_fwd(__torch__.torch.classes.season_nerf.Model model, Tensor top, Tensor bot, Tensor sun, Tensor time, Tensor tvals, int flags, "
           "bool want_per_sample, bool want_unmixed=False) -> (Tensor, Tensor, Tensor, Tensor[])");
     m.def("composite(Tensor top, Tensor bot, Tensor tvals, Tensor rho, Tensor col, Tensor solar_vis, Tensor sky, int flags, Tensor? rho_prior, float trust) "
@@ -518,6 +534,7 @@ TORCH_LIBRARY_IMPL(season_nerf, CUDA, m) {      // "CUDA" is the dispatch key of
     m.impl("group_fwd", group_fwd);
     m.impl("points_fwd", points_fwd);
     m.impl("render_fwd", render_fwd);
+    m.impl("ray_visibility", ray_visibility);
     m.impl("composite", composite);
     m.impl("composite_sweep", composite_sweep);
     m.impl("trainer_adam_step_", trainer_adam_step_);

@@ -360,7 +360,15 @@ bool estimate_i8(const Weights& w, int W, int C, I8Estimate* out, std::string* e
     // (trained W = 64 / 256 / 512: 5.5 / 4.0 / 3.6e-5 predicted against 3.7 / 3.5 / 3.2-3.4e-5 observed; init law 5.1e-5 / 1.4e-5; x4-outlier and
     // Laplace families 1.7-1.9e-4 / 3.1-5.8e-5 - those now go to bf16x3: the guard errs on the safe side for weights unlike anything training
     // produced here).
-    out->rgb_pred = 0.80 * out->head_rms[0] + 0.35 * out->head_rms[1] + 0.46 * out->head_rms[3] + 0.23 * out->head_rms[2];
+    // Round 5 put SURFACES into the weights - the trained fixtures with the density head scaled by g = 1 ... 256 (mean max-PS per ray 0.03 ... 0.87), rendered
+    // by the reference for every g (tests/golden/sharp_sweep_W*.npz) - and measured forced int8 digits against them on 128 rays per set (tools/sharp_modes.py,
+    // profiles/r5/sharp_modes_before_refit.txt): the round-4 weights UNDER-predicted the near-fog end, where the decision falls (observed / predicted 1.14 at
+    // W = 64 g = 1, 1.24 at W = 256 g = 4 - observed 1.06e-4, outside the bar, predicted 8.6e-5 -> int8 digits -, 1.39 at W = 512 g = 2), and over-predict
+    // hard surfaces 4-6x (the prediction is linear in g, the rendering saturates; those sets leave the bar in int8 digits anyway: observed 2-11e-4).  Scaled
+    // x1.5 so that the prediction covers every set of the ladder with a margin (1.20 / 0.525 / 0.69 / 0.345; x1.4 would cover W = 64 / 256, on which it was
+    // chosen, by >= 1.13x but the held-out W = 512 g = 2 rung by 1.00x): what stays on the int8 pipe is the init law and near-fog (max-PS below ~0.1);
+    // tests/test_cabi_host.py::test_error_model_covers_the_gain_ladder holds every rung of all three widths.
+    out->rgb_pred = 1.20 * out->head_rms[0] + 0.525 * out->head_rms[1] + 0.69 * out->head_rms[3] + 0.345 * out->head_rms[2];
     return true;
 }
 

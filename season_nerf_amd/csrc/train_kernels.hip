@@ -934,17 +934,20 @@ hipError_t launch_adam(float* p, const float* g, float* m, float* v, int64_t n, 
 
 // ---- the scalar loss terms of a training step in three launches (get_loss, Eval_Tools_2.py:340-420: MSE colour loss, solar rays on, default solar
 // model, no DSM prior).  The reference forms them with ~45 small tensor ops (and as many again in autograd's backward): ~110 launches of 3-5 us
-// each per step here, a tenth of a step in launch gaps alone.  scratch: 4 doubles (sums) + 4 uints (albedo minima as float bits; slot 3 unused);
+// each per step here, a tenth of a step in launch gaps alone.  scratch: 4 doubles (sums) + 4 64-bit keys (albedo minima: float bits << 32 | row; slot 3 unused);
 // self-cleaning - the finalize kernel leaves it in its initial state (sums 0, minima +inf), loss_scratch_init sets that state once.
-__global__ void loss_scratch_init_kernel(double* sums, unsigned* mins) {
-    if (threadIdx.x < 4) { sums[threadIdx.x] = 0.0; mins[threadIdx.x] = 0x7f800000u; }
+// mins: three 64-bit keys (albedo as float bits << 32 | row): the minimum AND the lowest row that attains it in one atomicMin - torch.min(albedo, 0)
+// hands its gradient to ONE row (with ties - a saturated albedo - every tied row used to receive it)
+constexpr unsigned long long kMinInit = 0x7f800000ffffffffull;
+__global__ void loss_scratch_init_kernel(double* sums, unsigned long long* mins) {
+    if (threadIdx.x < 4) { sums[threadIdx.x] = 0.0; mins[threadIdx.x] = kMinInit; }
 }
-__global__ __launch_bounds__(256) void loss_partial_kernel(const LossArgs A, double* sums, unsigned* mins) {
+__global__ __launch_bounds__(256) void loss_partial_kernel(const LossArgs A, double* sums, unsigned long long* mins) {
     float color = 0.f, sk = 0.f, sc = 0.f, ab = 0.f;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x, t0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     // rows, not elements: a thread sees all three channels of its rays, so the channel minima reduce in registers and the wave (one atomic per
     // wave and channel: thousands of atomics on three addresses cost 85 us when every element issued its own)
-    float mn[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
+    unsigned long long mn[3] = {kMinInit, kMinInit, kMinInit};
     for (int64_t rr = t0; rr < A.R; rr += stride) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -953,16 +956,19 @@ __global__ __launch_bounds__(256) void loss_partial_kernel(const LossArgs A, dou
             color += d * d;
             const float x = (A.sky[i] - .5f) / .5f;
             if (x > 0.f) sk += x * x;
-            mn[c] = fminf(mn[c], fmaxf(A.albedo[i], 0.f));
+            // non-negative floats order as their bits; the row in the low half breaks ties towards the lowest row
+            const unsigned long long key = ((unsigned long long)__float_as_uint(fmaxf(A.albedo[i], 0.f)) << 32) | (unsigned long long)(unsigned)rr;
+            mn[c] = key < mn[c] ? key : mn[c];
         }
     }
-    if (!A.alb_min_in) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            float v = mn[c];
-            for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
-            if ((threadIdx.x & 63) == 0 && v < __builtin_inff()) atomicMin(mins + c, __float_as_uint(v));      // non-negative floats order as their bits
+    for (int c = 0; c < 3; ++c) {
+        unsigned long long v = mn[c];
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long w = __shfl_xor(v, o);
+            v = w < v ? w : v;
         }
+        if ((threadIdx.x & 63) == 0 && v != kMinInit) atomicMin(mins + c, v);
     }
     for (int64_t j = t0; j < A.Rs * A.S; j += stride) {
         const float v = A.sv[j], p = A.pv[j], d = v - p;
@@ -980,7 +986,8 @@ __global__ __launch_bounds__(256) void loss_partial_kernel(const LossArgs A, dou
     __syncthreads();
     if (threadIdx.x < 4) atomicAdd(sums + threadIdx.x, (double)red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
 }
-__global__ void loss_finalize_kernel(const LossArgs A, double* sums, unsigned* mins, float* vals, float* minv) {
+// minv [6]: the three minima the Albedo_Color term used, then (as int bits) the row that owns each one on THIS rank (-1: the global minimum lives elsewhere)
+__global__ void loss_finalize_kernel(const LossArgs A, double* sums, unsigned long long* mins, float* vals, float* minv) {
     if (threadIdx.x != 0) return;
     const double Rs = (double)A.Rs, R = (double)A.R;
     vals[0] = (float)(sums[0] / Rs);                          // Solar_Correction   = mean_r sum_s (Solar_Vis - PV_Exact)^2      (:361)
@@ -988,13 +995,15 @@ __global__ void loss_finalize_kernel(const LossArgs A, double* sums, unsigned* m
     vals[2] = (float)(sums[2] / (3.0 * R));                   // Sky_Color_Var      = sum_{x > 0} x^2 / numel over [R, S, 3]: S copies of each ray's sky (:381-388)
     float h = 0.f;
     for (int c = 0; c < 3; ++c) {
-        const float a = A.alb_min_in ? A.alb_min_in[c] : __uint_as_float(mins[c]);
+        const float local = __uint_as_float((unsigned)(mins[c] >> 32));
+        const float a = A.alb_min_in ? A.alb_min_in[c] : local;
         minv[c] = a;
+        minv[3 + c] = __int_as_float(local == a ? (int)(unsigned)(mins[c] & 0xffffffffull) : -1);
         if (a < .2f) { const float u = 1.f - a / .2f; h += u * u; }
     }
     vals[3] = h / (float)(R * A.world);                       // Albedo_Color       = sum_c [a_c < .2] (1 - a_c / .2)^2 / R, a = min over the batch (:374-379)
     vals[4] = (float)(sums[3] / (3.0 * R));                   // Color              = MSE(Rendered_Col, GT_Color)                (:413)
-    for (int k = 0; k < 4; ++k) { sums[k] = 0.0; mins[k] = 0x7f800000u; }
+    for (int k = 0; k < 4; ++k) { sums[k] = 0.0; mins[k] = kMinInit; }
 }
 __global__ __launch_bounds__(256) void loss_bwd_kernel(const LossArgs A, const float* g, const float* minv, float* d_rgb, float* d_albedo, float* d_sky,
                                                        float* d_sv) {
@@ -1005,20 +1014,21 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(const LossArgs A, const f
         d_rgb[i] = g_col * 2.f * (A.rgb[i] - A.gt[i]) * inv3r;
         const float x = (A.sky[i] - .5f) / .5f;
         d_sky[i] = x > 0.f ? g_sk * 4.f * x * inv3r : 0.f;                              // d x^2 / d sky = 2 x / .5
-        const float a = minv[i % 3], al = A.albedo[i];
-        // the minimum's gradient goes to the row that attains it (on the rank that owns the global minimum, divided by the LOCAL ray count:
-        // the rank average of the gradients is then the global-batch gradient, training.albedo_min_loss)
-        d_albedo[i] = (al == a && a < .2f) ? g_al * 2.f * (1.f - a / .2f) * (-1.f / .2f) * invr : 0.f;
+        const float a = minv[i % 3];
+        const int own = __float_as_int(minv[3 + i % 3]);
+        // the minimum's gradient goes to the ONE row that attains it - the lowest such row, as torch.min(albedo, 0) (on the rank that owns the global
+        // minimum, divided by the LOCAL ray count: the rank average of the gradients is then the global-batch gradient, training.albedo_min_loss)
+        d_albedo[i] = ((int)(i / 3) == own && a < .2f) ? g_al * 2.f * (1.f - a / .2f) * (-1.f / .2f) * invr : 0.f;
     }
     for (int64_t j = t0; j < A.Rs * A.S; j += stride) d_sv[j] = g_sc * 2.f * (A.sv[j] - A.pv[j]) * invrs;
 }
 hipError_t launch_loss_scratch_init(void* scratch, hipStream_t st) {
-    hipLaunchKernelGGL(loss_scratch_init_kernel, dim3(1), dim3(64), 0, st, (double*)scratch, (unsigned*)((double*)scratch + 4));
+    hipLaunchKernelGGL(loss_scratch_init_kernel, dim3(1), dim3(64), 0, st, (double*)scratch, (unsigned long long*)((double*)scratch + 4));
     return hipGetLastError();
 }
 hipError_t launch_loss_terms(const LossArgs& a, void* scratch, float* vals, float* minv, hipStream_t st) {
     double* sums = (double*)scratch;
-    unsigned* mins = (unsigned*)(sums + 4);
+    unsigned long long* mins = (unsigned long long*)(sums + 4);
     int64_t n = a.Rs * a.S > a.R * 3 ? a.Rs * a.S : a.R * 3;
     int64_t b = (n + 255) / 256;
     if (b > 1024) b = 1024;

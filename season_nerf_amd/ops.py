@@ -65,7 +65,7 @@ def _register_fakes():
 
     @reg("season_nerf::loss_terms")
     def _(rgb, gt, albedo, sky, solar_vis, pv_exact, pe, albedo_min_global, world):
-        return rgb.new_empty(5), rgb.new_empty(3)
+        return rgb.new_empty(5), rgb.new_empty(6)
 
     @reg("season_nerf::loss_terms_bwd")
     def _(g_vals, rgb, gt, albedo, sky, solar_vis, pv_exact, min, world):

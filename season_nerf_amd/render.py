@@ -46,43 +46,55 @@ def _f32(a, dev):
     return torch.tensor(np.asarray(a), dtype=torch.float32, device=dev).contiguous()
 
 
-def _exact_solar_visibility(net: T_NeRF, pts, sun_vec, S, zero_oob, chunk_rays=65536, sun64=None):
+def _exact_solar_visibility(net: T_NeRF, pts, sun_vec, S, zero_oob, chunk_rays=1 << 20, sun64=None):
     """Transmittance from every sample point towards the sun: secondary rays Top = p + (1-p_z)/sun_z * sun, Bot = p,
     S end-point-inclusive samples, density only; visibility = exp(-sum_{j<S-1} rho_j delta_j), i.e. PV at the last
     sample (Eval_Tools_2.py:255-271 / mg_Img_Eval.py:57-70).  pts [M,3] (device), sun_vec [3] or [M,3] (device).
     sun64 (float64 numpy [3]): path B forms the tops in float64 (fp32 tensor * float64 numpy vector, then .float(),
-    mg_Img_Eval.py:58-60) - mirrored exactly because the out-of-cube test of the first sample depends on the last bit."""
+    mg_Img_Eval.py:58-60) - mirrored exactly because the out-of-cube test of the first sample depends on the last bit.
+
+    One launch per chunk of secondary rays (`season_nerf::ray_visibility`, csrc/mlp_device.h RaySum): the density-only network
+    over the S samples of each ray with the optical depth kept in registers - one float out per ray, no rho [M,S] round trip, no
+    compositing launch, no scratch tensors.  The tops of a chunk are formed chunk by chunk (M = R*S can be 2.5e7 for a 512 x 512 x 96
+    image: 300 MB of tops at once would cost more memory than the whole render).  A network without a fused kernel (a width outside
+    64 / 256 / 512, or 512 when the int8 bound fails) composes the same quantity from the layer-wise density and a transmittance scan."""
     dev = pts.device
-    L = _lib.lib()
-    st = net._stream()
     M = pts.shape[0]
     tv = sample_parameters_on(dev, S, eval_mode=True, include_end_pt=True)
-    sun = sun_vec if sun_vec.dim() == 2 else sun_vec.unsqueeze(0).expand(M, 3)
-    K = (1.0 - pts[:, 2]) / sun[:, 2]
-    if sun64 is None:
-        tops = (pts + K.unsqueeze(1) * sun).contiguous()
-    else:
-        s64 = torch.tensor(np.asarray(sun64, dtype=np.float64), device=dev).reshape(1, 3)
-        tops = (pts.double() + K.double().unsqueeze(1) * s64).float().contiguous()
+    per_ray_sun = sun_vec.dim() == 2
+    s64 = None if sun64 is None else torch.tensor(np.asarray(sun64, dtype=np.float64), device=dev).reshape(1, 3)
     vis = torch.empty(M, device=dev)
-    model = net.device_model()
+    fused = net.fused and net.resolved_precision != "bf16"
+    if not fused:
+        chunk_rays = min(chunk_rays, 1 << 16)
+    flags = 2 if zero_oob else 0
     for i in range(0, M, chunk_rays):
         j = min(M, i + chunk_rays)
-        n = j - i
-        t_, b_ = tops[i:j].contiguous(), pts[i:j].contiguous()
-        rho = torch.empty(n, S, device=dev)
-        fo = _lib.FieldOut(d_rho=rho.data_ptr())
-        _lib.check(L.snerf_field_forward_rays(model, 2, n, S, t_.data_ptr(), b_.data_ptr(), tv.data_ptr(), 1, None, None,
-                                              C.byref(fo), st), "field_forward_rays(sigma)")
-        pv = torch.empty(n, S, device=dev)
-        z1, z3 = torch.zeros(n, S, device=dev), torch.zeros(n, S, 3, device=dev)
-        sky0 = torch.zeros(n, 3, device=dev)
-        co = _lib.CompositeOut(d_pv=pv.data_ptr())
-        _lib.check(L.snerf_composite_rays(n, S, t_.data_ptr(), b_.data_ptr(), tv.data_ptr(), rho.data_ptr(), z3.data_ptr(),
-                                          z1.data_ptr(), sky0.data_ptr(), 2 if zero_oob else 0, None, 1.0, C.byref(co), st),
-                   "composite_rays")
-        vis[i:j] = pv[:, -1]
+        b_ = pts[i:j].contiguous()
+        sun = sun_vec[i:j] if per_ray_sun else sun_vec.unsqueeze(0)
+        K = (1.0 - b_[:, 2]) / sun[:, 2]
+        if s64 is None:
+            t_ = (b_ + K.unsqueeze(1) * sun).contiguous()
+        else:
+            t_ = (b_.double() + K.double().unsqueeze(1) * s64).float().contiguous()
+        if fused:
+            from .network import _ops
+            vis[i:j] = _ops().ray_visibility(net.op_model(), t_, b_, tv, flags)
+        else:
+            vis[i:j] = _visibility_layerwise(net, t_, b_, tv, S, zero_oob)
     return vis
+
+
+def _visibility_layerwise(net, tops, bots, tv, S, zero_oob):
+    """exp(-sum_{j<S-1} rho_j delta_j) of a chunk of rays from the layer-wise density (networks without a fused kernel)."""
+    n = tops.shape[0]
+    t = tv.reshape(1, S, 1)
+    p = tops.unsqueeze(1) * (1.0 - t) + bots.unsqueeze(1) * t            # misc.py:240-241 (two products and a sum, fp32)
+    delta = (torch.sqrt(torch.sum((tops - bots) ** 2, 1)) / S).reshape(n, 1).expand(n, S)
+    if zero_oob:
+        delta = torch.where((p.abs() > 1).any(2), torch.zeros_like(delta), delta)
+    rho = net.forward_Classic_Sigma_Only(p.reshape(-1, 3)).reshape(n, S)
+    return torch.exp(-torch.sum((rho * delta)[:, :-1], 1))
 
 
 def _ray_grid(mode, rows, cols, params, device, lo=0, hi=None, want_pixels=False):
@@ -253,6 +265,18 @@ def component_render_by_P(the_network, a_P_img, out_img_size: tuple, device, max
             # a projective camera (the reference's P_img_Pinhole holds its matrix as .P): pixel grid, invert_P, cube test and compaction on the GPU
             params = list(np.asarray(P, dtype=np.float64).reshape(-1)) + [a_P_img.img.shape[0], a_P_img.img.shape[1]]
             top, bot, good_d, pix = _ray_grid(2, Hh, Ww, params, dev, want_pixels=True)
+            # a camera class with a 3x4 `.P` but its OWN `invert_P` (scaling, normalisation) must not be rendered with the pinhole inversion:
+            # three probe pixels through the object's method decide (a handful of host solves); a mismatch takes the host path below
+            probe = torch.tensor(sorted({0, (Hh * Ww) // 2, Hh * Ww - 1}), device=dev)
+            pp = pix.index_select(0, probe).cpu().numpy().astype(int)
+            for h_, ends_ in ((1., top), (-1., bot)):
+                x, y, _ = a_P_img.invert_P(pp[:, 0], pp[:, 1], h_)
+                got = ends_.index_select(0, probe)[:, :2].double().cpu().numpy()
+                want = np.stack([np.asarray(x, dtype=np.float64).reshape(-1), np.asarray(y, dtype=np.float64).reshape(-1)], 1)
+                if not np.allclose(got, want, rtol=1e-5, atol=1e-5):
+                    P = None
+                    break
+        if P is not None and np.asarray(P).shape == (3, 4):
             keep = torch.nonzero(good_d).reshape(-1)
             tops_d, bots_d = top.index_select(0, keep), bot.index_select(0, keep)
             idx = keep.cpu().numpy()

@@ -34,7 +34,7 @@ def test_exports_match_header(lib):
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
     import season_nerf_amd as sn
     assert sorted(sn._lib.EXPORTS) == declared
-    assert lib.snerf_abi_version() == 6
+    assert lib.snerf_abi_version() == 7
 
 
 def test_custom_op_library_registers_without_a_gpu():
@@ -473,7 +473,7 @@ def test_auto_precision_follows_the_error_bound(lib, W):
         assert e.budget == pytest.approx(1e-4) and e.acc_bound < 2 ** 31
         assert bool(e.ok) == (want == I8), (kind, e.rgb_pred)
         if kind == "init":
-            assert 3e-5 < e.rgb_pred < 7e-5 and max(e.head_rms) == pytest.approx(e.worst)
+            assert 5e-5 < e.rgb_pred < 9.5e-5 and max(e.head_rms) == pytest.approx(e.worst)
         r = lib.snerf_model_resolve_precision(m)
         if want == BF3 and W == 512:
             assert r == -1 and b"512" in lib.snerf_last_error()
@@ -496,6 +496,35 @@ def test_trained_fixtures_clear_the_bound(lib, golden_dir, W):
     assert e.ok and 3.5e-5 < e.rgb_pred < 1e-4, e.rgb_pred
     assert lib.snerf_model_resolve_precision(m) == 2
     lib.snerf_model_destroy(m)
+
+
+# forced int8 digits against the REFERENCE on the density-gain ladder (trained fixture, density head x g), measured on the GPU: tools/sharp_modes.py ->
+# profiles/r5/sharp_modes_before_refit.txt, column "i8x3 vs ref" (worst of RGB / albedo / depth over 128 rays)
+LADDER_OBSERVED = {64: {1: 6.25e-5, 2: 8.15e-5, 4: 9.66e-5, 8: 9.97e-5, 16: 1.58e-4, 32: 1.87e-4, 64: 3.02e-4, 128: 5.55e-4, 256: 1.10e-3},
+                   256: {1: 3.83e-5, 2: 5.69e-5, 4: 1.06e-4, 8: 1.04e-4, 16: 1.21e-4, 32: 1.54e-4, 64: 2.01e-4, 128: 3.24e-4, 256: 6.25e-4},
+                   512: {1: 3.17e-5, 2: 6.95e-5, 4: 8.91e-5, 8: 1.07e-4, 16: 1.21e-4, 32: 1.61e-4, 64: 2.14e-4, 128: 4.52e-4, 256: 7.15e-4}}
+
+
+@pytest.mark.parametrize("W", [64, 256, 512])
+def test_error_model_covers_the_gain_ladder(lib, golden_dir, W):
+    """the pack-time error model against weights WITH SURFACES - the trained fixtures with the density head scaled by g = 1 ... 256 (mean
+    max-PS per ray 0.03 ... 0.87).  The scale of round 5 (x1.5 over round 4's weights) was chosen on W = 64 / 256; W = 512 is the held-out check.  Asserted for every rung: the
+    prediction is not below what the GPU measured in forced int8 digits, and `auto` never sends a set to int8 digits that was measured outside the bar."""
+    import os
+    g = dict(np.load(os.path.join(golden_dir, f"trained_W{W}.npz"), allow_pickle=False))
+    head = ("G_NeRF_net.fc10Sigma.weight", "G_NeRF_net.fc10Sigma.bias")
+    on_i8 = []
+    for gain, seen in LADDER_OBSERVED[W].items():
+        sd = {k[3:]: torch.tensor(v) * (float(gain) if k[3:] in head else 1.0) for k, v in g.items() if k.startswith("sd_")}
+        m = _host_model(lib, W, sd, 3)
+        e = _estimate(lib, m)
+        lib.snerf_model_destroy(m)
+        print(f"  W={W} g={gain:3d}: predicted {e.rgb_pred:.2e}, observed {seen:.2e} ({e.rgb_pred / seen:.2f}x) -> {'int8 digits' if e.ok else 'rejected'}")
+        assert e.rgb_pred >= 1.05 * seen, (W, gain, e.rgb_pred, seen)
+        assert not (e.ok and seen > 1e-4), (W, gain)
+        if e.ok:
+            on_i8.append(gain)
+    assert on_i8 and max(on_i8) <= 2               # what stays on the int8 pipe: fog and near-fog only
 
 
 def test_int8_accumulator_bound_is_enforced(lib):

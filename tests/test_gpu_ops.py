@@ -273,7 +273,8 @@ def test_fused_loss_terms_vs_tensor_ops(dark):
     for rep in range(2):                                                  # twice: the op's reduction scratch must come back clean
         vals, minv = torch.ops.season_nerf.loss_terms(rgb, gt, albedo, sky, sv, pv.detach(), pe.detach(), None, 1)
         np.testing.assert_allclose(vals.detach().cpu().numpy(), ref.detach().cpu().numpy(), rtol=2e-6, atol=1e-7)
-        np.testing.assert_array_equal(minv.detach().cpu().numpy(), albedo.detach().min(0).values.cpu().numpy())
+        np.testing.assert_array_equal(minv[:3].detach().cpu().numpy(), albedo.detach().min(0).values.cpu().numpy())
+        np.testing.assert_array_equal(minv[3:].detach().view(torch.int32).cpu().numpy(), albedo.detach().min(0).indices.cpu().numpy())      # the row that owns each minimum
     torch.dot(vals, w).backward()
     for name, a, b in zip(["rgb", "gt", "albedo", "sky", "sv"], leaves_a, leaves_b):
         if name == "gt":
@@ -295,6 +296,18 @@ def test_fused_loss_terms_vs_tensor_ops(dark):
         assert bool((albedo.grad[:, 0] != 0).sum() == 1)
     torch.library.opcheck(torch.ops.season_nerf.loss_terms.default, (rgb.detach(), gt.detach(), albedo.detach(), sky.detach(), sv.detach(), pv.detach(), pe.detach(),
                                                                      None, 1), test_utils=("test_schema", "test_faketensor"))
+    # ties: a saturated albedo shared by several rows - torch.min hands the gradient to ONE row (the first), and so must the fused backward
+    tied = albedo.detach().clone()
+    tied[[5, 17, 40], 0] = 0.01
+    tied[[8, 9], 2] = 0.0
+    ta = tied.clone().requires_grad_(True)
+    tb = tied.clone().requires_grad_(True)
+    _loss_terms_torch(rgb.detach(), gt, ta, sky.detach(), sv.detach(), pv, pe, S)[3].backward()
+    v3, m3 = torch.ops.season_nerf.loss_terms(rgb.detach(), gt, tb, sky.detach(), sv.detach(), pv.detach(), pe.detach(), None, 1)
+    v3[3].backward()
+    assert m3[3:].view(torch.int32).tolist()[0] == 5 and m3[3:].view(torch.int32).tolist()[2] == 8
+    np.testing.assert_allclose(tb.grad.cpu().numpy(), ta.grad.cpu().numpy(), rtol=1e-5, atol=1e-9)
+    assert int((tb.grad[:, 0] != 0).sum()) == 1 and int((tb.grad[:, 2] != 0).sum()) == 1
 
 
 def test_optimiser_step_runs_on_the_ops():

@@ -229,6 +229,13 @@ def test_component_render_by_P(golden_dir, device_grid):
     close("P_class", d["Output_class"][0, 0], g["P_Output_class0"]); close("P_sky", d["Sky_Col"][0, 0], g["P_Sky_Col0"])
     im = sn.get_imgs_from_Img_Dict(d, size)                          # the image assembly accepts the by-P dict as well
     assert im["Base_Img"].shape == (size[0], size[1], 3) and np.isnan(im["Base_Img"]).any() and np.isfinite(im["Base_Img"]).any()
+    if device_grid:
+        # a camera class that HAS a 3x4 `.P` but inverts differently (here: a matrix that is not the one its invert_P uses) must be rendered
+        # with ITS rays - the probe pixels send it down the host path, and the result is the reference's again
+        class Odd(Cam):
+            P = g["P"] * np.array([[1.0, 1.0, 1.0, 1.3]])
+        d2 = sn.component_render_by_P(net, Odd(), size, "cuda", include_exact_solar=False)
+        close("P_World_Points (own invert_P)", d2["World_Points"], g["P_World_Points"], rtol=0, atol=0)
 
 
 
@@ -298,3 +305,127 @@ def test_renderers_on_really_trained_weights(golden_dir, precision):
     close(f"{precision} Col_Img", imgs["Col_Img"], g["qr_Col_Img"], **tol)
     close(f"{precision} Shadow_Mask", imgs["Shadow_Mask"], g["qr_Shadow_Mask"], **tol)
     close(f"{precision} DSM", qr.get_DSM((14, 14)), g["qr_DSM"], rtol=1e-4, atol=3e-5)
+
+
+# ---------------------------------------------------------------------------------------------------------------- weights with surfaces; exact solar as a kernel
+def sharp_net(golden_dir, precision="auto"):
+    import season_nerf_amd as sn
+    g = dict(np.load(os.path.join(golden_dir, "sharp_W256.npz"), allow_pickle=False))
+    t = dict(np.load(os.path.join(golden_dir, str(g["source"])), allow_pickle=False))
+    head = ("G_NeRF_net.fc10Sigma.weight", "G_NeRF_net.fc10Sigma.bias")
+    sd = {k[3:]: torch.tensor(v) * (float(g["g"]) if k[3:] in head else 1.0) for k, v in t.items() if k.startswith("sd_")}
+    net = sn.T_NeRF(int(g["W"]), int(g["C"]))
+    net.load_state_dict(sd)
+    net.precision = precision
+    return sn, g, sd, net.to("cuda").eval()
+
+
+def test_renderers_on_weights_with_surfaces(golden_dir):
+    """both renderer seams on the sharp W = 256 weights (trained fixture, density head x64: mean max-PS per ray 0.59) against the reference's
+    renderings (tools/make_sharp_golden.py), INCLUDING the exact-solar pass that is the default of both (mg_Img_Eval.py:96, Quick_Run.py:62) at 24 x 20 x 96 -
+    46 080 secondary rays through `season_nerf::ray_visibility`.  Class default precision; `auto` must not pick int8 digits for these weights."""
+    sn, g, sd, net = sharp_net(golden_dir)
+    assert net.resolved_precision == "bf16x3", (net.resolved_precision, net.i8_estimate())
+    size = tuple(int(v) for v in g["size"])
+    view, sun, tf = tuple(g["view"]), tuple(g["sun"]), float(g["time_frac"])
+    dev = torch.device("cuda")
+    d = sn.component_render_by_dir(net, view, sun, tf, size, g["WC"], g["H"], dev, include_exact_solar=False)
+    im = sn.get_imgs_from_Img_Dict(d, size, False)
+    tol = dict(rtol=1e-4, atol=3e-5)
+    for k in ["Base_Img", "Season_Adj_Img", "Shadow_Adjust", "Shadow_Mask", "Raw_Shadow_Mask"]:
+        close(f"sharp {k}", im[k], g["img_" + k], **tol)
+    sweep = sn.get_imgs_from_Img_Dict_t_step(d, size, g["sweep_classes"].astype(np.float64))
+    close("sharp sweep", sweep, g["sweep_imgs"], **tol)
+    xs = tuple(int(v) for v in g["xs_size"])
+    dx = sn.component_render_by_dir(net, view, sun, tf, xs, g["WC"], g["H"], dev, include_exact_solar=True)
+    close("sharp Exact_Solar", dx["Exact_Solar"], g["xs_Exact_Solar"], rtol=1e-4, atol=3e-5)
+    imx = sn.get_imgs_from_Img_Dict(dx, xs, True)
+    # the masks are sigmoid(30 (raw - 0.2)) (mg_Img_Eval.py:150-155): an error e of the raw mask becomes up to 7.5 e
+    for k, t_ in [("Raw_Shadow_Mask_Exact", tol), ("Season_Adj_Img", tol), ("Shadow_Mask_Exact", dict(rtol=1e-4, atol=4e-4)), ("Shadow_Adjust_Exact", dict(rtol=1e-4, atol=4e-4))]:
+        close(f"sharp xs {k}", imx[k], g["xs_img_" + k], **t_)
+    args = SimpleNamespace(n_samples=96, Use_Reg=True, Solar_Type_2=False, Use_MSE_loss=True, Use_Solar=True, sc_lambda=0.03, number_low_frequency_cases=4)
+    qr = sn.Quick_Run_Net(net, args, g["WC"], g["H"], dev, use_full_solar=False)
+    imgs, mask = qr.render_img((65, 20), (50, 100), 0.3, 22)
+    assert (mask == g["qr_mask"]).all()
+    close("sharp Col_Img", imgs["Col_Img"], g["qr_Col_Img"], **tol)
+    close("sharp Shadow_Mask", imgs["Shadow_Mask"], g["qr_Shadow_Mask"], rtol=1e-4, atol=4e-4)
+    close("sharp DSM", qr.get_DSM((14, 14)), g["qr_DSM"], rtol=1e-4, atol=3e-5)
+    qx = sn.Quick_Run_Net(net, args, g["WC"], g["H"], dev, use_full_solar=True)
+    imgs, mask = qx.render_img((70, 200), (50, 100), 0.6, 9)
+    assert (mask == g["qrx_mask"]).all()
+    close("sharp x Col_Img", imgs["Col_Img"], g["qrx_Col_Img"], **tol)
+    close("sharp x Shadow_Mask", imgs["Shadow_Mask"], g["qrx_Shadow_Mask"], rtol=1e-4, atol=4e-4)
+    close("sharp x Est_Shadow_Mask", imgs["Estimated_Shadow_Mask"], g["qrx_Est_Shadow_Mask"], rtol=1e-4, atol=4e-4)
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "i8x3"])
+@pytest.mark.parametrize("S", [96, 33, 24, 100])
+def test_ray_visibility_kernel_vs_composition(setup, precision, S):
+    """`season_nerf::ray_visibility` (csrc/mlp_device.h RaySum: one wave per ray, ceil(S/32) passes, the optical depth in a register) against the SAME
+    quantity composed from the density-only op on explicit points + a torch sum: S a multiple of 32, not one, below 32, above 96; rays that leave the
+    cube with and without the out-of-cube rule of path B; a ray count that is not a multiple of the 8 (4) rays of a workgroup."""
+    sn, g, _, args = setup
+    import season_nerf_amd as sn_
+    net = sn_.T_NeRF(int(g["W"]), int(g["C"]))
+    net.load_state_dict(orc.init_weights(int(g["W"]), int(g["C"]), int(g["seed"])))
+    net.precision = precision
+    net = net.to("cuda").eval()
+    from season_nerf_amd.network import _ops
+    from season_nerf_amd.evaluator import sample_parameters_on
+    rng = np.random.Generator(np.random.PCG64(S))
+    M = 1003
+    bot = torch.tensor(rng.uniform(-1, 1, (M, 3)), dtype=torch.float32, device="cuda")
+    sun = torch.tensor([0.35, -0.4, 0.85], dtype=torch.float32, device="cuda")
+    top = (bot + ((1 - bot[:, 2]) / sun[2]).unsqueeze(1) * sun).contiguous()
+    tv = sample_parameters_on(torch.device("cuda"), S, eval_mode=True, include_end_pt=True)
+    t = tv.reshape(1, S, 1)
+    pts = top.unsqueeze(1) * (1 - t) + bot.unsqueeze(1) * t
+    rho = _ops().points_fwd(net.op_model(), pts.reshape(-1, 3).contiguous(), None, None, 1, 2)[0].reshape(M, S)
+    delta = (torch.sqrt(((top - bot) ** 2).sum(1)) / S).reshape(M, 1).expand(M, S)
+    for flags in (0, 2):
+        dl = torch.where((pts.abs() > 1).any(2), torch.zeros_like(delta), delta) if flags else delta
+        want = torch.exp(-(rho * dl)[:, :-1].sum(1))
+        got = _ops().ray_visibility(net.op_model(), top, bot, tv, flags)
+        assert got.shape == (M,)
+        err = float((got - want).abs().max())
+        print(f"  ray_visibility {precision} S={S} flags={flags}: max abs {err:.2e}; mean visibility {float(want.mean()):.3f}")
+        assert err < 2e-6, (precision, S, flags, err)
+    assert bool((pts.abs() > 1).any())                    # the out-of-cube rule was exercised
+
+
+def test_exact_solar_across_chunk_boundaries(golden_dir):
+    """render._exact_solar_visibility splits the secondary rays into chunks: a chunk boundary inside the image (chunks of 1000 rays against one chunk)
+    changes nothing, bit for bit - and a ragged last chunk neither."""
+    sn, g, sd, net = sharp_net(golden_dir, "bf16x3")
+    from season_nerf_amd import render as R_
+    rng = np.random.Generator(np.random.PCG64(4))
+    pts = torch.tensor(rng.uniform(-0.95, 0.95, (3333, 3)), dtype=torch.float32, device="cuda")
+    sunv = orc.world_angle_2_local_vec(40, 120, g["WC"], g["H"])
+    sun_d = torch.tensor(sunv, dtype=torch.float32, device="cuda")
+    one = R_._exact_solar_visibility(net, pts, sun_d, 96, zero_oob=True, sun64=sunv)
+    many = R_._exact_solar_visibility(net, pts, sun_d, 96, zero_oob=True, sun64=sunv, chunk_rays=1000)
+    assert torch.equal(one, many)
+    want = orc.exact_solar_visibility(sd, pts[::61].cpu(), sunv, 96, path_b=True)
+    close("chunked exact solar vs oracle", one[::61].cpu().numpy(), want.numpy(), rtol=1e-4, atol=3e-5)
+
+
+def test_exact_solar_image_64x64x96_vs_oracle(golden_dir):
+    """a 64 x 64 x 96 render with `include_exact_solar=True` (393 216 secondary rays, 3.8e7 density evaluations) against the oracle's
+    restatement of mg_Img_Eval.py:57-70 on scattered pixels, on the weights with surfaces; and the two arithmetic modes against each other."""
+    sn, g, sd, net = sharp_net(golden_dir, "bf16x3")
+    size = (64, 64, 96)
+    view, sun, tf = (80, 0), (30, 90), 0.25
+    d = sn.component_render_by_dir(net, view, sun, tf, size, g["WC"], g["H"], torch.device("cuda"), include_exact_solar=True)
+    ex = np.asarray(d["Exact_Solar"])[:, :, 0]
+    assert ex.shape == (4096, 96) and 0.05 < float((ex < 0.5).mean()) < 0.95
+    sunv = orc.world_angle_2_local_vec(sun[0], sun[1], g["WC"], g["H"])
+    rays = np.arange(17, 4096, 401)
+    want = orc.exact_solar_visibility(sd, torch.tensor(np.asarray(d["World_Points"])[rays]).float(), sunv, 96, path_b=True).reshape(len(rays), 96).numpy()
+    close("Exact_Solar 64x64x96 (scattered rays)", ex[rays], want, rtol=1e-4, atol=3e-5)
+    im = sn.get_imgs_from_Img_Dict(d, size, False)
+    assert np.isfinite(im["Shadow_Mask_Exact"]).all()
+    sn2, _, _, net8 = sharp_net(golden_dir, "i8x3")
+    d8 = sn.component_render_by_dir(net8, view, sun, tf, size, g["WC"], g["H"], torch.device("cuda"), include_exact_solar=True)
+    dev8 = np.abs(np.asarray(d8["Exact_Solar"])[:, :, 0] - ex)
+    print(f"  exact solar 64x64x96: int8 digits vs bf16x3 max abs {dev8.max():.2e}, mean {dev8.mean():.2e}")
+    assert dev8.max() < 5e-3

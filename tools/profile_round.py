@@ -9,8 +9,9 @@ Collects under gpurun_out/round_TAG/ what profiles/ needs for one build:
   traffic.json          HBM bytes per launch of the dominant kernel (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)
   recompute.txt         frac = algorithmic FLOP / AverageNs / peak, from the stats file alone
   train_*               the same for `bench.py --workload train` (kernel stats; traffic of the whole step)
-  sweep_* / w512_*      kernel stats, PMC passes and HBM traffic of `bench.py --aux-kernel sweep | w512` (the seasonal-sweep kernel at 512 x 512 x 96 x 12, the
-                        fused field kernel at W = 512): what `sweep_roofline` / `w512_roofline` of the bench line are measured on
+  sweep_* / w512_* / exact_solar_*   kernel stats, PMC passes and HBM traffic of `bench.py --aux-kernel sweep | w512 | exact_solar` (the seasonal-sweep kernel at
+                        512 x 512 x 96 x 12, the fused field kernel at W = 512, the ray-visibility kernel over the 6.3e6 secondary rays of a 256 x 256 x 96 image):
+                        what `sweep_roofline` / `w512_roofline` / `exact_solar` of the bench line are measured on
 rocprofv3 runs `python3 bench.py ...` directly (no shell / env hop after the `--`)."""
 import collections
 import csv
@@ -147,7 +148,9 @@ def main():
                        "bytes_per_launch": (2 * tk["FETCH_SIZE"] + tk["WRITE_SIZE"]) * 1024.0}, open(os.path.join(out, "train_kernel_traffic.json"), "w"), indent=1)
     # the two auxiliary kernels the bench line carries a roofline for: the seasonal-sweep kernel at configs[4]'s size and the fused field kernel at W = 512
     for aux, match, counters in (("sweep", "sweep_kernel", ["SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_INSTS_VALU", "GRBM_GUI_ACTIVE"]),
-                                 ("w512", "mlp_i8_kernel", ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_INSTS_MFMA", "SQ_LDS_BANK_CONFLICT", "GRBM_GUI_ACTIVE"])):
+                                 ("w512", "mlp_i8_kernel", ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_INSTS_MFMA", "SQ_LDS_BANK_CONFLICT", "GRBM_GUI_ACTIVE"]),
+                                 # the exact-solar pass at 256 x 256 x 96 (6.3e6 secondary rays through the ray-visibility variant of the field kernel)
+                                 ("exact_solar", "mlp_i8x2_kernel<256, 3>", ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_INSTS_MFMA", "SQ_LDS_BANK_CONFLICT", "GRBM_GUI_ACTIVE"])):
         kargs = ["--aux-kernel", aux, "--steps", "6"]
         with open(os.path.join(out, aux + "_bench.json"), "w") as f:
             subprocess.call(["python3", "bench.py"] + kargs, stdout=f, stderr=subprocess.DEVNULL, cwd=REPO)
