@@ -446,7 +446,8 @@ static Tensor loss_scratch(const Tensor& like) {
     static std::mutex mu;
     static auto* per_stream = new std::map<std::pair<int, void*>, Tensor>();      // leaked on purpose: no tensor destructor after the HIP runtime has shut down
     std::lock_guard<std::mutex> lock(mu);
-    Tensor& s = (*per_stream)[{like.get_device(), cur_stream(like)}];
+    static const bool per_dev = getenv("SNERF_LOSS_SCRATCH_PER_DEVICE") != nullptr;      // A/B switch (debug)
+    Tensor& s = (*per_stream)[{like.get_device(), per_dev ? nullptr : cur_stream(like)}];
     if (!s.defined()) {
         s = at::empty({(int64_t)snerf_loss_scratch_bytes()}, like.options().dtype(at::kByte));
         ck(snerf_loss_scratch_init(s.data_ptr(), cur_stream(like)), "loss_scratch");

@@ -217,12 +217,21 @@ class GraphedTrainStep:
         tool.optim.make_capturable()
         ev.static_inputs = self.tv
         ev.solar_creation_tool = lambda n, include_times=True: self.sol + (None,)
+        import gc
+        gc_was_on = gc.isenabled()
         try:
             torch.cuda.synchronize()
+            # Nothing may free device memory while the stream captures (capture mode "global": a hipFree from ANY thread invalidates the capture), and the
+            # cyclic collector can run at any allocation: an unreachable network of an earlier phase or test still owns a packed device model whose
+            # destructor calls hipFree.  Collect now, keep the collector off until the capture has ended.
+            gc.collect()
+            gc.disable()
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
                 self.loss = self._body()
         finally:
+            if gc_was_on:
+                gc.enable()
             ev.static_inputs = None
             ev.solar_creation_tool = self._gen
 

@@ -288,7 +288,12 @@ def test_renderers_on_really_trained_weights(golden_dir, precision):
     net.load_state_dict({k[3:]: torch.tensor(v) for k, v in t.items() if k.startswith("sd_")})
     net.precision = precision
     net = net.to("cuda").eval()
-    assert net.resolved_precision == ("i8x3" if precision == "auto" else precision)
+    if precision == "auto":       # the analytic model accepts these weights (rgb_pred 6e-5); the measured second stage decides (network.PROBE_*: int8 digits
+        probe = net.i8_probe()    # against bf16x3 on 1024 probe rays, kept below 5e-5) - whichever it picks, the images below are held to the same bar
+        print(f"  trained W=256 under auto: {net.resolved_precision}, probe {probe}")
+        assert net.i8_estimate()["ok"] and probe["ran"] and net.resolved_precision == ("i8x3" if probe["kept_int8"] else "bf16x3")
+    else:
+        assert net.resolved_precision == precision
     size = tuple(int(v) for v in g["size"])
     view, sun, tf = tuple(g["view"]), tuple(g["sun"]), float(g["time_frac"])
     d = sn.component_render_by_dir(net, view, sun, tf, size, g["WC"], g["H"], torch.device("cuda"), include_exact_solar=False)

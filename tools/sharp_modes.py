@@ -66,7 +66,7 @@ def main():
             neta, _ = render(sd, W, S, data, "auto")
             fl = float((np.abs(g[f"g{gain}_Rendered_Col"].astype(np.float64) - g[f"g{gain}_Rendered_Col64"]) / np.maximum(np.abs(g[f"g{gain}_Rendered_Col64"]), 1e-3)).max())
             print(f"{W:4d} {gain:4d} {float(g[f'g{gain}_max_ps'].mean()):7.3f} | {r8:11.2e} {x8:9.2e} {est['rgb_pred']:9.2e} {est['rgb_pred'] / r8:8.2f} | {b3} | {fl:10.2e} | "
-                  f"{neta.resolved_precision}", flush=True)
+                  f"{neta.resolved_precision}" + (f" (probe: rgb {pr['rgb_dev']:.1e} depth {pr['depth_dev']:.1e})" if (pr := neta.i8_probe()) and pr.get("ran") else ""), flush=True)
 
 
 if __name__ == "__main__":
