@@ -574,6 +574,8 @@ def main():
     ap.add_argument("--headline-only", action="store_true",
                     help="only the headline timed region (no per-mode table, seam, sweep, training step, CPU baseline): profiler passes")
     ap.add_argument("--train-graph", action="store_true", help="--workload train: the step as one hipGraph launch (season_nerf_amd.GraphedTrainStep; MSE loss, one GPU)")
+    ap.add_argument("--no-aux", action="store_true", help="render workload: skip the converged-weights rows and the exact-solar pass (kernel-stats passes: they launch the "
+                                                        "dominant kernel at other sizes)")
     ap.add_argument("--no-train", action="store_true", help="render workload: skip the extra training-step measurement (train_* keys)")
     ap.add_argument("--train-kernel-only", action="store_true", help="--workload train: only the dominant training kernel (`--steps` launches), for profiler passes")
     ap.add_argument("--aux-kernel", default=None, choices=["sweep", "w512", "exact_solar"], help="only that auxiliary kernel, `--steps` launches (profiler passes): "
@@ -752,7 +754,7 @@ def main():
         extra["modes"] = modes
         extra["modes_note"] = ("parity bar (north star): RGB / depth within 1e-4 relative of the reference; measured against the reference's "
                                "goldens in tests/: bf16x3 ~3e-6, i8x3 ~1.5e-5 (W=512: 2.5e-5), bf16 1-2e-3 (outside the bar: fast mode only)")
-    if rank == 0 and world == 1 and not a.headline_only:
+    if rank == 0 and world == 1 and not a.headline_only and not a.no_aux:
         # converged-weights rows beside the random-weights headline (VERDICT r4 #1c): the same batch with weights that have SURFACES in them
         for wv in (256, 512):
             try:

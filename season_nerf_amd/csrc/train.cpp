@@ -953,7 +953,7 @@ int snerf_trainer_adam_step_dev(snerf_trainer* t, const float* d_hyper6, void* s
 
 /* The scalar terms of All_in_One_Eval.get_loss (Eval_Tools_2.py:340-420) for the default training configuration - MSE colour loss, solar rays
  * on, default solar model, no DSM prior - in two launches, and their gradients in one (see include/season_nerf_hip.h). */
-size_t snerf_loss_scratch_bytes(void) { return 4 * sizeof(double) + 4 * sizeof(unsigned long long); }
+size_t snerf_loss_scratch_bytes(void) { return 4 * sizeof(double) + 3 * 1024 * sizeof(unsigned long long); }      // sums + per-block minima (<= 1024 blocks)
 int snerf_loss_scratch_init(void* d_scratch, void* stream) {
     if (!d_scratch) return snerf_set_error(SNERF_E_INVALID, "snerf_loss_scratch_init: NULL scratch");
     HIPCK(launch_loss_scratch_init(d_scratch, (hipStream_t)stream));

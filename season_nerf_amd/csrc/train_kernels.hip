@@ -934,13 +934,14 @@ hipError_t launch_adam(float* p, const float* g, float* m, float* v, int64_t n, 
 
 // ---- the scalar loss terms of a training step in three launches (get_loss, Eval_Tools_2.py:340-420: MSE colour loss, solar rays on, default solar
 // model, no DSM prior).  The reference forms them with ~45 small tensor ops (and as many again in autograd's backward): ~110 launches of 3-5 us
-// each per step here, a tenth of a step in launch gaps alone.  scratch: 4 doubles (sums) + 4 64-bit keys (albedo minima: float bits << 32 | row; slot 3 unused);
+// each per step here, a tenth of a step in launch gaps alone.  scratch: 4 doubles (sums) + 3 64-bit keys per block of the partial kernel (albedo minima: float bits << 32 | row; at most 1024 blocks);
 // self-cleaning - the finalize kernel leaves it in its initial state (sums 0, minima +inf), loss_scratch_init sets that state once.
-// mins: three 64-bit keys (albedo as float bits << 32 | row): the minimum AND the lowest row that attains it in one atomicMin - torch.min(albedo, 0)
+// mins: 64-bit keys (albedo as float bits << 32 | row): the minimum AND the lowest row that attains it in one comparison - torch.min(albedo, 0)
 // hands its gradient to ONE row (with ties - a saturated albedo - every tied row used to receive it)
 constexpr unsigned long long kMinInit = 0x7f800000ffffffffull;
 __global__ void loss_scratch_init_kernel(double* sums, unsigned long long* mins) {
-    if (threadIdx.x < 4) { sums[threadIdx.x] = 0.0; mins[threadIdx.x] = kMinInit; }
+    if (threadIdx.x < 4) sums[threadIdx.x] = 0.0;
+    (void)mins;
 }
 __global__ __launch_bounds__(256) void loss_partial_kernel(const LossArgs A, double* sums, unsigned long long* mins) {
     float color = 0.f, sk = 0.f, sc = 0.f, ab = 0.f;
@@ -961,6 +962,9 @@ __global__ __launch_bounds__(256) void loss_partial_kernel(const LossArgs A, dou
             mn[c] = key < mn[c] ? key : mn[c];
         }
     }
+    // per-block minima, no atomics (a 64-bit atomicMin under contention - 12 288 of them on three addresses - cost the step 6 ms: measured 20.2 against
+    // 13.8 ms): wave reduction, the four waves through LDS, one plain store per block and channel; loss_finalize_kernel reduces the blocks
+    __shared__ unsigned long long bmin[3][4];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         unsigned long long v = mn[c];
@@ -968,7 +972,13 @@ __global__ __launch_bounds__(256) void loss_partial_kernel(const LossArgs A, dou
             const unsigned long long w = __shfl_xor(v, o);
             v = w < v ? w : v;
         }
-        if ((threadIdx.x & 63) == 0 && v != kMinInit) atomicMin(mins + c, v);
+        if ((threadIdx.x & 63) == 0) bmin[c][threadIdx.x >> 6] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        unsigned long long v = bmin[threadIdx.x][0];
+        for (int k = 1; k < 4; ++k) v = bmin[threadIdx.x][k] < v ? bmin[threadIdx.x][k] : v;
+        mins[(size_t)blockIdx.x * 3 + threadIdx.x] = v;
     }
     for (int64_t j = t0; j < A.Rs * A.S; j += stride) {
         const float v = A.sv[j], p = A.pv[j], d = v - p;
@@ -987,7 +997,18 @@ __global__ __launch_bounds__(256) void loss_partial_kernel(const LossArgs A, dou
     if (threadIdx.x < 4) atomicAdd(sums + threadIdx.x, (double)red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
 }
 // minv [6]: the three minima the Albedo_Color term used, then (as int bits) the row that owns each one on THIS rank (-1: the global minimum lives elsewhere)
-__global__ void loss_finalize_kernel(const LossArgs A, double* sums, unsigned long long* mins, float* vals, float* minv) {
+__global__ void loss_finalize_kernel(const LossArgs A, double* sums, unsigned long long* mins, int nblocks, float* vals, float* minv) {
+    // one wave: the per-block minima of the partial kernel (3 keys per block) reduced by 64 lanes, then lane 0 writes the terms
+    unsigned long long key[3] = {kMinInit, kMinInit, kMinInit};
+    for (int b = threadIdx.x; b < nblocks; b += 64)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) key[c] = mins[(size_t)b * 3 + c] < key[c] ? mins[(size_t)b * 3 + c] : key[c];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long w = __shfl_xor(key[c], o);
+            key[c] = w < key[c] ? w : key[c];
+        }
     if (threadIdx.x != 0) return;
     const double Rs = (double)A.Rs, R = (double)A.R;
     vals[0] = (float)(sums[0] / Rs);                          // Solar_Correction   = mean_r sum_s (Solar_Vis - PV_Exact)^2      (:361)
@@ -995,15 +1016,15 @@ __global__ void loss_finalize_kernel(const LossArgs A, double* sums, unsigned lo
     vals[2] = (float)(sums[2] / (3.0 * R));                   // Sky_Color_Var      = sum_{x > 0} x^2 / numel over [R, S, 3]: S copies of each ray's sky (:381-388)
     float h = 0.f;
     for (int c = 0; c < 3; ++c) {
-        const float local = __uint_as_float((unsigned)(mins[c] >> 32));
+        const float local = __uint_as_float((unsigned)(key[c] >> 32));
         const float a = A.alb_min_in ? A.alb_min_in[c] : local;
         minv[c] = a;
-        minv[3 + c] = __int_as_float(local == a ? (int)(unsigned)(mins[c] & 0xffffffffull) : -1);
+        minv[3 + c] = __int_as_float(local == a ? (int)(unsigned)(key[c] & 0xffffffffull) : -1);
         if (a < .2f) { const float u = 1.f - a / .2f; h += u * u; }
     }
     vals[3] = h / (float)(R * A.world);                       // Albedo_Color       = sum_c [a_c < .2] (1 - a_c / .2)^2 / R, a = min over the batch (:374-379)
     vals[4] = (float)(sums[3] / (3.0 * R));                   // Color              = MSE(Rendered_Col, GT_Color)                (:413)
-    for (int k = 0; k < 4; ++k) { sums[k] = 0.0; mins[k] = kMinInit; }
+    for (int k = 0; k < 4; ++k) sums[k] = 0.0;      // (the per-block minima are rewritten by every launch)
 }
 __global__ __launch_bounds__(256) void loss_bwd_kernel(const LossArgs A, const float* g, const float* minv, float* d_rgb, float* d_albedo, float* d_sky,
                                                        float* d_sv) {
@@ -1034,7 +1055,7 @@ hipError_t launch_loss_terms(const LossArgs& a, void* scratch, float* vals, floa
     if (b > 1024) b = 1024;
     if (b < 1) b = 1;
     hipLaunchKernelGGL(loss_partial_kernel, dim3((unsigned)b), dim3(256), 0, st, a, sums, mins);
-    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, st, a, sums, mins, vals, minv);
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, st, a, sums, mins, (int)b, vals, minv);
     return hipGetLastError();
 }
 hipError_t launch_loss_terms_bwd(const LossArgs& a, const float* g, const float* minv, float* d_rgb, float* d_albedo, float* d_sky, float* d_sv, hipStream_t st) {

@@ -3,7 +3,7 @@
 
 Collects under gpurun_out/round_TAG/ what profiles/ needs for one build:
   bench.json            the default `python3 bench.py` line
-  kernel_stats.csv      rocprofv3 --kernel-trace --stats of `bench.py --no-cpu-baseline --no-sweep` (only 4096-ray launches of
+  kernel_stats.csv      rocprofv3 --kernel-trace --stats of `bench.py --no-cpu-baseline --no-sweep --no-train --no-aux` (only 4096-ray launches of
                         the dominant kernel, so its AverageNs IS roofline.kernel_ms)
   pmc.txt               PMC passes, one counter set per run (--pmc only, no tracing flags): FETCH_SIZE, WRITE_SIZE, the MFMA set
   traffic.json          HBM bytes per launch of the dominant kernel (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)
@@ -66,7 +66,7 @@ def main():
     # kernel stats of the same command (only the 4096-ray launches)
     d = os.path.join(out, "prof")
     sh(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "--", "python3", "bench.py", "--precision", prec,
-        "--no-cpu-baseline", "--no-sweep", "--no-train"], os.path.join(out, "prof.log"))
+        "--no-cpu-baseline", "--no-sweep", "--no-train", "--no-aux"], os.path.join(out, "prof.log"))
     st = find(d, "*kernel_stats.csv")
     rec = []
     if st:
