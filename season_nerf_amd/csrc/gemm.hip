@@ -1102,6 +1102,15 @@ hipError_t launch_gemm_bf16x3(const GemmX& g, hipStream_t st) {
     auto split32 = [&]() -> hipError_t {
         return g.W ? launch_split_weights(g.W, g.w_rows, g.w_cols, g.w_transpose != 0, const_cast<uint16_t*>(g.frag), g.n_tiles, g.ksteps, st) : hipSuccess;
     };
+    {   // K = 512 (the reference's default width): activations resident in AGPRs, weights streamed (gemm_areg.hip).  SNERF_GEMM_AREG=0 off, =2 also K = 256
+        static int areg_mode = -1;
+        if (areg_mode < 0) { const char* e = getenv("SNERF_GEMM_AREG"); areg_mode = e ? atoi(e) : 1; }
+        if (areg_mode && !act && g.W && (g.K == 512 || areg_mode == 2) && gemm_areg_ok(g)) {
+            hipError_t e = split32();
+            if (e != hipSuccess) return e;
+            return launch_gemm_areg(gx, st);
+        }
+    }
     {   // the pipelined full-tile kernel wherever the shape allows it (every per-point layer of the training step)
         static int full_mode = -1, pf_force = 0, mode16 = 1;
         if (full_mode < 0) {

@@ -53,6 +53,9 @@ hipError_t launch_split_weights(const float* W, int rows, int cols, bool transpo
 int gemm_rows_group_tiles(int ksteps);      // 0 = K too large for the LDS-resident weight layout (caller falls back to fp32 MFMA)
 hipError_t launch_gemm_bf16x3(const GemmX& g, hipStream_t st);
 hipError_t launch_gemm_rows16(const GemmX& gx, int aol_mode, int act_mode, dim3 grid, size_t lds, hipStream_t st, int nt16 = 8);      // gemm16.hip
+// gemm_areg.hip: K = 256 / 512 with the activations resident in AGPRs and the weights streamed through the LDS ring (the reference's default width)
+bool gemm_areg_ok(const GemmX& g);
+hipError_t launch_gemm_areg(const GemmX& g, hipStream_t st);
 // bf16x3 weight gradient: dW[n_out, n_in] (ld ldw) += alpha * dZ[M, n_out]^T In[M, n_in]   (fp32 atomics over M-chunks)
 // optional BatchNorm backward folded into the weight-gradient kernel (dZ holds dL/dY on entry, dL/dZ on exit; needs n_in <= 256)
 struct WgradBN {
