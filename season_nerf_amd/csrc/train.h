@@ -55,6 +55,7 @@ hipError_t launch_gemm_bf16x3(const GemmX& g, hipStream_t st);
 hipError_t launch_gemm_rows16(const GemmX& gx, int aol_mode, int act_mode, dim3 grid, size_t lds, hipStream_t st, int nt16 = 8);      // gemm16.hip
 // gemm_areg.hip: K = 256 / 512 with the activations resident in AGPRs and the weights streamed through the LDS ring (the reference's default width)
 bool gemm_areg_ok(const GemmX& g);
+hipError_t launch_areg_split_weights(const float* W, int rows, int cols, bool transpose, uint16_t* frag, int n_tiles, int ksteps, hipStream_t st);      // k-major stream
 hipError_t launch_gemm_areg(const GemmX& g, hipStream_t st);
 // bf16x3 weight gradient: dW[n_out, n_in] (ld ldw) += alpha * dZ[M, n_out]^T In[M, n_in]   (fp32 atomics over M-chunks)
 // optional BatchNorm backward folded into the weight-gradient kernel (dZ holds dL/dY on entry, dL/dZ on exit; needs n_in <= 256)

@@ -205,3 +205,51 @@ def test_w512_kernel_agprs_are_touched_only_by_the_hand_written_instructions(tmp
             assert writes > 100 and mfma_b > 100, (name, writes, mfma_b)
             seen += 1
     assert seen == 4               # variants 0..3 (3 = ray visibility)
+
+
+def test_areg_gemm_agprs_are_touched_only_by_the_hand_written_instructions(tmp_path):
+    """gemm_areg_kernel (csrc/gemm_areg.hip) keeps the 32 x N accumulator tile of a wave in AGPRs addressed BY NUMBER (v_mfma_f32_32x32x16_bf16 with
+    C / D = a[16 T : 16 T + 15], read out by v_accvgpr_read in the epilogue, both through inline asm).  The register allocator may park its own values in
+    AGPRs whenever the architectural VGPRs run short (it did, twice, while the kernel was written: an address register per table row hoisted out of the tile
+    loop, and a four-deep weight prefetch) - silently corrupting the accumulators.  So: no scratch, and no AGPR operand anywhere but in those two forms."""
+    import importlib.util
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not available")
+    spec = importlib.util.spec_from_file_location("snerf_build", os.path.join(REPO, "season_nerf_amd", "build.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    b.build()
+    seen = 0
+    for n, elf in enumerate(_device_code_objects(b.LIB)):
+        meta = {k[".name"]: k for k in _kernel_metadata(elf) if "gemm_areg_kernel" in k[".name"]}
+        if not meta:
+            continue
+        f = tmp_path / f"areg{n}.elf"
+        f.write_bytes(elf)
+        dis = subprocess.run([objdump, "-d", "--mcpu=gfx950", str(f)], capture_output=True, text=True, timeout=600).stdout
+        for name, k in meta.items():
+            assert k[".private_segment_fixed_size"] == 0 and k[".vgpr_spill_count"] == 0, (name, "scratch / spills")
+            nt, _, pfa = (int(v) for v in re.search(r"kernelILi(\d+)ELi(\d+)ELi(\d+)E", name).groups())
+            m = re.search(r"^[0-9a-f]+ <" + re.escape(name) + r">:\n(.*?)(?=^[0-9a-f]+ <|\Z)", dis, re.S | re.M)
+            assert m, name
+            reads = mfmas = 0
+            for line in m.group(1).split("\n"):
+                code = line.split("//")[0].strip()
+                if not code or not re.search(r"\ba(\d+|\[\d+:\d+\])", code):
+                    continue
+                op = code.split()[0]
+                args = code[len(op):]
+                if op == "v_accvgpr_read_b32":
+                    assert re.match(r"\s*v\d+, a\d+\s*$", args), (name, code)
+                    reads += 1
+                elif op == "v_mfma_f32_32x32x16_bf16":
+                    d, a_, b_, c_ = [x.strip() for x in args.split(",")[:4]]
+                    assert d.startswith("a[") and a_.startswith("v[") and b_.startswith("v[") and (c_ == d or c_ == "0"), (name, code)
+                    mfmas += 1
+                else:
+                    raise AssertionError(f"{name}: AGPR operand outside the hand-written forms: {code}")
+            # epilogue inside the first k-step of a row tile + the last tile's own: 2 x 16 registers per n-tile; 1 + PFA k-step bodies of 3 MFMAs per n-tile
+            assert reads == 2 * 16 * nt and mfmas == (1 + pfa) * 3 * nt, (name, reads, mfmas)
+            seen += 1
+    assert seen == 8
