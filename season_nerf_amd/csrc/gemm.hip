@@ -1106,7 +1106,9 @@ hipError_t launch_gemm_bf16x3(const GemmX& g, hipStream_t st) {
         // shape the kernel takes (also the 256-wide layers of a W = 256 network, where the column-group kernels are HBM-bound already)
         static int areg_mode = -1;
         if (areg_mode < 0) { const char* e = getenv("SNERF_GEMM_AREG"); areg_mode = e ? atoi(e) : 1; }
-        if (areg_mode && !act && g.W && (g.N == 512 || g.K > 256 || areg_mode == 2) && gemm_areg_ok(g)) {
+        static int areg_act = -1;      // the activation-backward form on it: SNERF_GEMM_AREG_ACT=0 keeps the column-group kernel for those
+        if (areg_act < 0) { const char* e = getenv("SNERF_GEMM_AREG_ACT"); areg_act = e ? atoi(e) : 1; }
+        if (areg_mode && (!act || areg_act) && g.W && (g.N == 512 || g.K > 256 || areg_mode == 2) && gemm_areg_ok(g)) {
             hipError_t e = launch_areg_split_weights(g.W, g.w_rows, g.w_cols, g.w_transpose != 0, const_cast<uint16_t*>(g.frag), g.n_tiles, g.ksteps, st);
             if (e != hipSuccess) return e;
             return launch_gemm_areg(gx, st);

@@ -18,6 +18,8 @@
 //     fragments requested one pair ahead, and between the pairs the slices of the NEXT k-step's conversion;
 //   * epilogue (bias, BatchNorm column sums, stores through a buffer descriptor: no address arithmetic, rows past M dropped by the bounds check) of row
 //     tile t inside the FIRST k-step of tile t+1: each n-tile's 16 accumulators are read out right before that k-step's first MFMA restarts them (C = 0);
+//     ACT (input gradients): the activation-backward epilogue of gemm_rows_full_kernel - times cos(2 pi (a z + b)) of the layer below, its pre-activations
+//     loaded a pair of n-tiles ahead - and the column sums sum v, sum v xhat;
 //   * one workgroup (4 waves = one per SIMD, all 512 registers) per CU, persistent over row tiles of 128 rows.
 // Same products, same k order and the same order of the three partial products per accumulator as gemm_rows_full_kernel (tools/areg_check.py).
 #include <hip/hip_runtime.h>
@@ -121,40 +123,65 @@ struct ArStream {     // the A stream of a wave: the next k-step to request
     int ks;           // k-step to request next
 };
 
-// epilogue of n-tile T of the previous row tile: accumulators read out of a[16 T ..] (the caller restarts them right after)
+// epilogue of n-tile T of the previous row tile: accumulators read out of a[16 T ..] (the caller restarts them right after).
+// ACT (input gradients): the value is dL/dH of the SineLayer below - multiplied by cos(2 pi (a z + b)) of that layer's pre-activation z (staged by the
+// caller: zs[i] = ez[row i][column]) it becomes dL/d(arg); the column sums are sum v and sum v * xhat, xhat = (z - mu) istd (see gemm_rows_full_kernel).
+template <int ACT>
 __device__ __forceinline__ void ar_epilogue(const GemmX& g, int T, const __amdgpu_buffer_rsrc_t& rs_c, int lc, int so0, int rows_left, bool on, lds_cfloat* col_l,
-                                            __attribute__((address_space(3))) float* stat_l, int r, int h) {
-    const float ab = g.alpha * col_l[32 * T + r];
+                                            __attribute__((address_space(3))) float* stat_l, int r, int h, const float* zs = nullptr) {
+    const int N = (int)g.N;
+    const float ab = ACT ? 0.f : g.alpha * col_l[32 * T + r];
+    const float ea = ACT ? stat_l[2 * N + 32 * T + r] : 0.f, eb = ACT ? stat_l[3 * N + 32 * T + r] : 0.f;
+    const float mu = ACT ? stat_l[4 * N + 32 * T + r] : 0.f, istd = ACT ? stat_l[5 * N + 32 * T + r] : 0.f;
     float s1 = 0.f, s2 = 0.f;
     switch (T) {
 #define AR_EPI(T_) case T_: {                                                                                                                              \
         _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                                                                                    \
             const int ro = (i & 3) + 8 * (i >> 2);                                                                                                          \
             const float a = ar_read(16 * T_ + i);                                                                                                           \
+            float v, w;                                                                                                                                     \
+            if (ACT) {                                                                                                                                      \
+                const float z = zs[i];                                                                                                                      \
+                v = g.alpha * a * __builtin_amdgcn_cosf(__builtin_fmaf(ea, z, eb));                                                                         \
+                w = v * ((z - mu) * istd);                                                                                                                  \
+            } else {                                                                                                                                        \
+                v = __builtin_fmaf(g.alpha, a, ab);                                                                                                         \
+                w = a;                                                                                                                                      \
+            }                                                                                                                                               \
             if (!(SNERF_ABLA & 1))                                                                                                                          \
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, __builtin_fmaf(g.alpha, a, ab)), rs_c, lc, so0 + (ro * (int)g.ldc + 32 * T_) * 4, 0); \
-            const float am = ro < rows_left ? a : 0.f;                                                                                                      \
-            s1 += am;                                                                                                                                       \
-            s2 = __builtin_fmaf(am, am, s2);                                                                                                                \
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rs_c, lc, so0 + (ro * (int)g.ldc + 32 * T_) * 4, 0);                   \
+            const bool ok = ro < rows_left;                                                                                                                 \
+            if (ACT) { s1 += ok ? v : 0.f; s2 += ok ? w : 0.f; }                                                                                            \
+            else { const float am = ok ? a : 0.f; s1 += am; s2 = __builtin_fmaf(am, am, s2); }                                                              \
         } } break;
         AR_EPI(0) AR_EPI(1) AR_EPI(2) AR_EPI(3) AR_EPI(4) AR_EPI(5) AR_EPI(6) AR_EPI(7) AR_EPI(8) AR_EPI(9) AR_EPI(10) AR_EPI(11) AR_EPI(12) AR_EPI(13) AR_EPI(14) AR_EPI(15)
 #undef AR_EPI
         default: break;
     }
-    if (g.stats) {      // BatchNorm column sums: the two lane-halves hold the same column (rows differ), the four waves too
+    if (g.stats) {      // column sums: the two lane-halves hold the same column (rows differ), the four waves too
         s1 += __shfl_xor(s1, 32);
         s2 += __shfl_xor(s2, 32);
         if (h == 0 && on) {
             __builtin_amdgcn_ds_faddf(stat_l + 32 * T + r, s1, __ATOMIC_RELAXED, __MEMORY_SCOPE_WRKGRP, false);      // ds_add_f32: a flat atomic would count in vmcnt
-            __builtin_amdgcn_ds_faddf(stat_l + g.N + 32 * T + r, s2, __ATOMIC_RELAXED, __MEMORY_SCOPE_WRKGRP, false);
+            __builtin_amdgcn_ds_faddf(stat_l + N + 32 * T + r, s2, __ATOMIC_RELAXED, __MEMORY_SCOPE_WRKGRP, false);
         }
+    }
+}
+// ACT: the pre-activations of n-tile T of the row tile at byte offset sz0 (buffer descriptor over ez; rows past M read as 0): 16 loads per lane,
+// compiler-issued - it waits for them by its own count of the vector-memory operations IT issued, which is below the true number (the hand-issued
+// DMA and A loads are invisible to it): the wait is merely conservative
+__device__ __forceinline__ void ar_load_z(const GemmX& g, const __amdgpu_buffer_rsrc_t& rs_z, int lz, int sz0, int T, float* zs) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int ro = (i & 3) + 8 * (i >> 2);
+        zs[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_z, lz, sz0 + (ro * (int)g.eld + 32 * T) * 4, 0));
     }
 }
 
 // One k-step over all NT n-tiles, in NT / 2 pairs.  On entry `cur` holds the converted operands of this k-step and `fb0` the fragments of its first pair;
 // on exit `nxt` those of the next k-step (converted here from staging slot `sx / sy`, which is refilled) and `fb0` the first pair of the next k-step.
 // FIRST: the first k-step of a row tile - every accumulator is read out (the epilogue of the previous row tile `pv`) right before it is restarted.
-template <int NT, int AOL, int PFA, bool FIRST>
+template <int NT, int AOL, int PFA, bool FIRST, int ACT = 0>
 __device__ __forceinline__ void ar_kstep(const GemmX& g, ArRing& rg, lds_char* lds, const uint8_t* stream, uint32_t stream_bytes, const u32x4& chi, const u32x4& clo,
                                          u32x4& nhi, u32x4& nlo, ArFrag& fb0, f32x4& sx, f32x4& sy, ArStream& as, int ks_next, int KS, lds_cfloat* tab_h,
                                          const ArTile& pv, lds_cfloat* col_l, __attribute__((address_space(3))) float* stat_l, int64_t n_tiles, int wave, int lane) {
@@ -164,6 +191,15 @@ __device__ __forceinline__ void ar_kstep(const GemmX& g, ArRing& rg, lds_char* l
     const int lc = (FIRST && pv.on) ? (int)((4 * h) * g.ldc + r) * 4 : (int)0x80000000;
     const int so0 = FIRST ? (int)(pv.row0 * g.ldc * 4) : 0;
     const int rows_left = (FIRST && pv.on) ? (int)(g.M - pv.row0) - 4 * h : 0;      // element i is a real row iff (i & 3) + 8 (i >> 2) < rows_left
+    // ACT: the pre-activations of the previous row tile, a pair of n-tiles ahead of the epilogue that needs them (64 staging registers)
+    const __amdgpu_buffer_rsrc_t rs_z = __builtin_amdgcn_make_buffer_rsrc((void*)(ACT ? g.ez : g.A), 0, ACT ? (int)(g.M * g.eld * 4) : 0, 0x00020000);
+    const int lz = (FIRST && ACT && pv.on) ? (int)((4 * h) * g.eld + r) * 4 : (int)0x80000000;
+    const int sz0 = (FIRST && ACT) ? (int)(pv.row0 * g.eld * 4) : 0;
+    float zt[2][2][16];
+    if (FIRST && ACT) {
+        ar_load_z(g, rs_z, lz, sz0, 0, zt[0][0]);
+        ar_load_z(g, rs_z, lz, sz0, 1, zt[0][1]);
+    }
     ArFrag fb[2];
     fb[0] = fb0;
     float a8[8];
@@ -195,8 +231,12 @@ __device__ __forceinline__ void ar_kstep(const GemmX& g, ArRing& rg, lds_char* l
             }
         }
         if (FIRST) {      // the previous row tile's n-tiles T0, T1 leave the accumulators (their last MFMAs issued >= 90 MFMAs ago)
-            ar_epilogue(g, T0, rs_c, lc, so0, rows_left, pv.on, col_l, stat_l, r, h);
-            ar_epilogue(g, T1, rs_c, lc, so0, rows_left, pv.on, col_l, stat_l, r, h);
+            if (ACT && gi + 1 < G) {
+                ar_load_z(g, rs_z, lz, sz0, T0 + 2, zt[(gi + 1) & 1][0]);
+                ar_load_z(g, rs_z, lz, sz0, T1 + 2, zt[(gi + 1) & 1][1]);
+            }
+            ar_epilogue<ACT>(g, T0, rs_c, lc, so0, rows_left, pv.on, col_l, stat_l, r, h, zt[gi & 1][0]);
+            ar_epilogue<ACT>(g, T1, rs_c, lc, so0, rows_left, pv.on, col_l, stat_l, r, h, zt[gi & 1][1]);
             asm volatile("s_nop 1" ::: "memory");      // accumulator reads -> the MFMAs that overwrite them
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -253,7 +293,7 @@ __device__ __forceinline__ void ar_kstep(const GemmX& g, ArRing& rg, lds_char* l
 
 // NT: 32-column n-tiles (8: N = 256, 16: N = 512).  AOL: activation on load from the table g.act_tab ([a | b] x 16 KS).  PFA: k-steps of A in flight
 // (divides the number of k-steps: staging slots are compile-time).
-template <int NT, int AOL, int PFA>
+template <int NT, int AOL, int PFA, int ACT = 0>
 __global__ __launch_bounds__(64 * AR_WAVES, 1) void gemm_areg_kernel(const GemmX g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     lds_char* lds = (lds_char*)smem;
@@ -272,6 +312,12 @@ __global__ __launch_bounds__(64 * AR_WAVES, 1) void gemm_areg_kernel(const GemmX
         col_l[i] = g.bias ? g.bias[i] : 0.f;
         stat_l[i] = 0.f;
         stat_l[32 * NT + i] = 0.f;
+        if (ACT) {      // [a | b | mu | istd] of the SineLayer below, behind the sums (zeros for a layer without BatchNorm: its xhat sums are defined as 0)
+            stat_l[2 * 32 * NT + i] = g.etab[i];
+            stat_l[3 * 32 * NT + i] = g.etab[g.N + i];
+            stat_l[4 * 32 * NT + i] = g.emu ? g.emu[i] : 0.f;
+            stat_l[5 * 32 * NT + i] = g.eistd ? g.eistd[i] : 0.f;
+        }
     }
     ArRing rg;
     rg.rd = 0; rg.cur = 0; rg.goff = 0;
@@ -348,7 +394,7 @@ __global__ __launch_bounds__(64 * AR_WAVES, 1) void gemm_areg_kernel(const GemmX
     ArTile pv{0, false};
     // k-steps in blocks of PFA: k-step j uses the operand set j & 1 (PFA is even) and converts staging slot (j + 1) % PFA into the other set
 #define AR_STEP(D_, FIRST_)                                                                                                                              \
-    ar_kstep<NT, AOL, PFA, FIRST_>(g, rg, lds, stream, stream_bytes, ohi[(D_) & 1], olo[(D_) & 1], ohi[((D_) + 1) & 1], olo[((D_) + 1) & 1], fb0,          \
+    ar_kstep<NT, AOL, PFA, FIRST_, ACT>(g, rg, lds, stream, stream_bytes, ohi[(D_) & 1], olo[(D_) & 1], ohi[((D_) + 1) & 1], olo[((D_) + 1) & 1], fb0,          \
                                    sx[((D_) + 1) % PFA], sy[((D_) + 1) % PFA], as, (ks0 + (D_) + 1) % KS, KS, tab_h, pv, (lds_cfloat*)col_l, stat_l, n_tiles, wave, lane);
     for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
         for (int ks0 = 0; ks0 < KS; ks0 += PFA) {
@@ -366,8 +412,14 @@ __global__ __launch_bounds__(64 * AR_WAVES, 1) void gemm_areg_kernel(const GemmX
         const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc((void*)g.C, 0, (int)(g.M * g.ldc * 4), 0x00020000);
         const int lc = (int)((4 * h) * g.ldc + r) * 4, so0 = (int)(pv.row0 * g.ldc * 4);
         const int rows_left = (int)(g.M - pv.row0) - 4 * h;
+        const __amdgpu_buffer_rsrc_t rs_z = __builtin_amdgcn_make_buffer_rsrc((void*)(ACT ? g.ez : g.A), 0, ACT ? (int)(g.M * g.eld * 4) : 0, 0x00020000);
+        const int lz = ACT ? (int)((4 * h) * g.eld + r) * 4 : 0, sz0 = ACT ? (int)(pv.row0 * g.eld * 4) : 0;
 #pragma unroll
-        for (int T = 0; T < NT; ++T) ar_epilogue(g, T, rs_c, lc, so0, rows_left, true, (lds_cfloat*)col_l, stat_l, r, h);
+        for (int T = 0; T < NT; ++T) {
+            float zs[16];
+            if (ACT) ar_load_z(g, rs_z, lz, sz0, T, zs);
+            ar_epilogue<ACT>(g, T, rs_c, lc, so0, rows_left, true, (lds_cfloat*)col_l, stat_l, r, h, zs);
+        }
     }
     // the never-consumed A loads of the stream's tail and the ring's must land before the wave ends
 #pragma unroll
@@ -375,9 +427,9 @@ __global__ __launch_bounds__(64 * AR_WAVES, 1) void gemm_areg_kernel(const GemmX
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (g.stats) {
         __syncthreads();
-        for (int i = tid; i < 32 * NT; i += 64 * AR_WAVES) {
-            atomicAdd(g.stats + i, (double)g.alpha * (double)stat_l[i]);
-            atomicAdd(g.stats + g.N + i, (double)g.alpha * (double)g.alpha * (double)stat_l[32 * NT + i]);
+        for (int i = tid; i < 32 * NT; i += 64 * AR_WAVES) {      // (ACT: the sums are of the finished values, nothing to scale)
+            atomicAdd(g.stats + i, (ACT ? 1.0 : (double)g.alpha) * (double)stat_l[i]);
+            atomicAdd(g.stats + g.N + i, (ACT ? 1.0 : (double)g.alpha * (double)g.alpha) * (double)stat_l[32 * NT + i]);
         }
     }
 }
@@ -398,7 +450,9 @@ static int areg_blocks() {
 bool gemm_areg_ok(const GemmX& g) {
     const bool aol = g.act_tab != nullptr && g.act_cols > 0;
     const bool k_ok = g.K % 16 == 0 || (g.a_padded && g.lda >= (int64_t)g.ksteps * 16);
-    return (g.N == 256 || g.N == 512) && g.n_tiles * 32 == g.N && k_ok && g.ksteps >= 8 && g.ksteps <= 64 && g.ksteps % 4 == 0 && !g.accumulate && !g.ez &&
+    const bool act = g.ez != nullptr;
+    return (g.N == 256 || g.N == 512) && g.n_tiles * 32 == g.N && k_ok && g.ksteps >= 8 && g.ksteps <= 64 && g.ksteps % 4 == 0 && !g.accumulate &&
+           (!act || (!aol && g.stats && g.etab && g.M * g.eld < (1ll << 29))) &&
            (!aol || (g.act_cols % 16 == 0 && g.act_cols <= g.ksteps * 16)) && ((uintptr_t)g.A % 16 == 0) && g.lda % 4 == 0 && g.frag != nullptr &&
            g.M * g.ldc < (1ll << 29);      // 32-bit byte offsets of the buffer stores
 }
@@ -416,20 +470,25 @@ hipError_t launch_gemm_areg(const GemmX& g, hipStream_t st) {
     if (!gemm_areg_ok(g)) return hipErrorInvalidValue;
     const bool aol = g.act_tab != nullptr && g.act_cols > 0;
     const int KS = g.ksteps;
-    const size_t lds = (size_t)AR_D * kChunkBytes + (size_t)(2 * 16 * KS + 3 * g.N) * 4;
+    const bool act = g.ez != nullptr;
+    const size_t lds = (size_t)AR_D * kChunkBytes + (size_t)(2 * 16 * KS + (act ? 7 : 3) * g.N) * 4;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     const int64_t n_tiles = (g.M + AR_ROWS - 1) / AR_ROWS;
     int grid = (int)(n_tiles < areg_blocks() ? n_tiles : areg_blocks());
     if (grid < 1) grid = 1;
-#define AR_LAUNCH(NT_, AOL_, PFA_)                                                                                               \
+#define AR_LAUNCH(NT_, AOL_, PFA_, ...)                                                                                          \
     do {                                                                                                                         \
-        auto k = gemm_areg_kernel<NT_, AOL_, PFA_>;                                                                              \
+        auto k = gemm_areg_kernel<NT_, AOL_, PFA_ __VA_OPT__(,) __VA_ARGS__>;                                                    \
         hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);               \
         if (e != hipSuccess) return e;                                                                                           \
         hipLaunchKernelGGL(k, dim3(grid), dim3(64 * AR_WAVES), lds, st, g);                                                      \
         return hipGetLastError();                                                                                                \
     } while (0)
     const bool p8 = KS % 8 == 0;
+    if (act) {      // input gradient with the activation-backward epilogue
+        if (g.N == 512) { if (p8) AR_LAUNCH(16, 0, 8, 1); else AR_LAUNCH(16, 0, 4, 1); }
+        if (p8) AR_LAUNCH(8, 0, 8, 1); else AR_LAUNCH(8, 0, 4, 1);
+    }
     if (g.N == 512) {
         if (aol) { if (p8) AR_LAUNCH(16, 1, 8); else AR_LAUNCH(16, 1, 4); }
         if (p8) AR_LAUNCH(16, 0, 8); else AR_LAUNCH(16, 0, 4);

@@ -156,7 +156,9 @@ def test_activation_on_load(shape):
                                   sc.data_ptr(), sc.numel(), tab.data_ptr(), ac, st) != 0
 
 
-@pytest.mark.parametrize("shape", [(1500, 256, 256, True), (1029, 128, 128, False), (2048, 319, 256, True), (700, 256, 12, False)])
+@pytest.mark.parametrize("shape", [(1500, 256, 256, True), (1029, 128, 128, False), (2048, 319, 256, True), (700, 256, 12, False),
+                                   # gemm_areg_kernel's activation-backward form (512-wide layers): whole and ragged row tiles, with and without BatchNorm
+                                   (1500, 512, 512, True), (2049, 512, 512, False), (1031, 256, 512, True), (40000, 512, 512, True)])
 def test_dgrad_activation_backward_epilogue(shape):
     """dgrad whose epilogue already applies the activation backward of the SineLayer below (x cos) and reduces the column sums."""
     sn, L, st = _env()
