@@ -823,6 +823,8 @@ def main():
             extra["repack_note"] = "T_NeRF.device_model() after a parameter change: D2H of the state_dict + host pack (fold, int8 error model, digits) + upload"
         if not a.no_train:
             del rho, sv, col
+            import gc
+            gc.collect()                 # the networks / engines of the rows above are cyclic garbage: collected HERE, not inside the timed steps below
             torch.cuda.empty_cache()
             try:
                 tr = bench_train(argparse.Namespace(**{**vars(a), "loss": "mse"}), standalone=False)
