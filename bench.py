@@ -573,7 +573,7 @@ def main():
     ap.add_argument("--width", type=int, default=256, choices=[256, 512], help="--workload train: fc_units (256 = BASELINE configs[2]; 512 = the reference's default)")
     ap.add_argument("--headline-only", action="store_true",
                     help="only the headline timed region (no per-mode table, seam, sweep, training step, CPU baseline): profiler passes")
-    ap.add_argument("--train-graph", action="store_true", help="--workload train: the step as one hipGraph launch (season_nerf_amd.GraphedTrainStep; MSE loss, one GPU)")
+    ap.add_argument("--train-graph", action="store_true", help="--workload train: the step as one hipGraph launch (season_nerf_amd.GraphedTrainStep; one GPU)")
     ap.add_argument("--no-aux", action="store_true", help="render workload: skip the converged-weights rows and the exact-solar pass (kernel-stats passes: they launch the "
                                                         "dominant kernel at other sizes)")
     ap.add_argument("--no-train", action="store_true", help="render workload: skip the extra training-step measurement (train_* keys)")
@@ -851,11 +851,20 @@ def main():
                 torch.cuda.empty_cache()
                 tb = bench_train(argparse.Namespace(**{**vars(a), "loss": "barron", "no_cpu_baseline": True}), standalone=False)
                 extra.update({"train_barron_ms_per_step": tb["ms_per_step"], "train_barron_final_loss": tb["final_loss"],
+                              "train_barron_host_enqueue_ms_per_step": tb["host_enqueue_ms_per_step"],
                               "train_barron_note": "same step with the Barron adaptive colour loss (configs[2] names it) and its second Adam; the loss "
                                                    "object restates robust_loss_pytorch from its published definition: parity UNPINNED (no importable "
                                                    "reference, no reference-held fixture) - a timing, not a reference-checked result"})
             except Exception as ex:
                 extra["train_barron_error"] = repr(ex)
+            try:      # ... and that step captured: the generic loss terms, both Adams (the second in torch's capturable form) in one hipGraph launch
+                gc.collect()
+                torch.cuda.empty_cache()
+                tbg = bench_train(argparse.Namespace(**{**vars(a), "loss": "barron", "train_graph": True, "no_cpu_baseline": True}), standalone=False)
+                extra.update({"train_barron_graph_ms_per_step": tbg["ms_per_step"], "train_barron_graph_host_enqueue_ms_per_step": tbg["host_enqueue_ms_per_step"],
+                              "train_barron_graph_final_loss": tbg["final_loss"]})
+            except Exception as ex:
+                extra["train_barron_graph_error"] = repr(ex)
             try:      # the reference's DEFAULT width (main_lite.py:80, fc_units = 512), MSE loss
                 torch.cuda.empty_cache()
                 t5 = bench_train(argparse.Namespace(**{**vars(a), "loss": "mse", "width": 512, "no_cpu_baseline": True}), standalone=False)

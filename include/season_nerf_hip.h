@@ -168,6 +168,12 @@ int snerf_composite_rays(int64_t n_rays, int n_samples, const float* d_top, cons
                          const float* d_rho, const float* d_col, const float* d_solar_vis, const float* d_sky,
                          int flags, const float* d_rho_prior, float trust,
                          const snerf_composite_out* out, void* stream);
+/* The same with the trust factor in DEVICE memory (one float, read when the kernel runs): a training step captured into a hipGraph
+ * replays with a trust that changes every step (trust = current_step / n_steps, Eval_Tools_2.py:243) without re-capturing. */
+int snerf_composite_rays_dt(int64_t n_rays, int n_samples, const float* d_top, const float* d_bot, const float* d_tvals,
+                            const float* d_rho, const float* d_col, const float* d_solar_vis, const float* d_sky,
+                            int flags, const float* d_rho_prior, const float* d_trust,
+                            const snerf_composite_out* out, void* stream);
 
 /* ---- one-call render: All_in_One_Eval.eval (Eval_Tools_2.py:165-252, no prior) = group network + field network +
  * compositing.  d_time is [R,4], d_sun [R,3].  d_workspace must hold snerf_render_workspace_bytes(R,S,C) bytes.
@@ -239,6 +245,10 @@ int snerf_trainer_forward_image(snerf_trainer* t, int64_t n_rays, int n_samples,
 int snerf_trainer_backward_image(snerf_trainer* t, const float* d_g_rgb, const float* d_g_albedo, const float* d_g_sky,
                                  const float* d_g_pe, const float* d_rho_prior, float trust, const float* d_g_rgb_merged,
                                  const float* d_g_albedo_merged, void* stream);
+/* The same with the trust factor in device memory (see snerf_composite_rays_dt). */
+int snerf_trainer_backward_image_dt(snerf_trainer* t, const float* d_g_rgb, const float* d_g_albedo, const float* d_g_sky,
+                                    const float* d_g_pe, const float* d_rho_prior, const float* d_trust, const float* d_g_rgb_merged,
+                                    const float* d_g_albedo_merged, void* stream);
 /* Seam B1 in train mode - `T_NeRF.forward(X, Solar_Angle, Time)` called on points with an autograd graph attached
  * (T_NeRF_net_v2.py:75-105, called so by the reference's evaluator at Eval_Tools_2.py:174-176): backward of the last
  * snerf_trainer_forward_image from gradients with respect to the PER-SAMPLE network outputs - dL/dRho [N], dL/dCol [N,3],

@@ -65,6 +65,7 @@ def lib():
     L.snerf_field_ray_visibility.argtypes = [vp, i64, i32, vp, vp, vp, i32, vp, vp]
     L.snerf_composite_rays.argtypes = [i64, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, C.c_float,
                                        C.POINTER(CompositeOut), vp]
+    L.snerf_composite_rays_dt.argtypes = [i64, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, C.POINTER(CompositeOut), vp]
     L.snerf_render_workspace_bytes.restype = C.c_size_t
     L.snerf_render_workspace_bytes.argtypes = [i64, i32, i32]
     L.snerf_render_rays.argtypes = [vp, i64, i32, vp, vp, vp, vp, vp, i32, vp, C.POINTER(FieldOut),
@@ -92,6 +93,7 @@ def lib():
     L.snerf_trainer_forward_image.argtypes = [vp, i64, i32, vp, vp, vp, vp, vp, i32, i32, C.POINTER(CompositeOut), vp, vp,
                                               C.POINTER(FieldOut), vp]
     L.snerf_trainer_backward_image.argtypes = [vp, vp, vp, vp, vp, vp, C.c_float, vp, vp, vp]
+    L.snerf_trainer_backward_image_dt.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.snerf_trainer_backward_points.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     L.snerf_trainer_forward_solar.argtypes = [vp, i64, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp]
     L.snerf_trainer_backward_solar.argtypes = [vp, vp, vp]
@@ -130,11 +132,11 @@ EXPORTS = ["snerf_last_error", "snerf_abi_version", "snerf_model_create", "snerf
            "snerf_model_finalize", "snerf_model_destroy", "snerf_model_width", "snerf_model_classes",
            "snerf_model_set_precision", "snerf_model_precision", "snerf_model_i8_estimate", "snerf_model_resolve_precision",
            "snerf_model_pack_host", "snerf_group_forward", "snerf_field_forward_points", "snerf_field_forward_rays", "snerf_field_ray_visibility",
-           "snerf_composite_rays", "snerf_composite_sweep", "snerf_render_workspace_bytes", "snerf_render_rays", "snerf_rays_from_camera", "snerf_ray_grid", "snerf_field_kernel_info",
+           "snerf_composite_rays", "snerf_composite_rays_dt", "snerf_composite_sweep", "snerf_render_workspace_bytes", "snerf_render_rays", "snerf_rays_from_camera", "snerf_ray_grid", "snerf_field_kernel_info",
            "snerf_prior_density", "snerf_surface_distance", "snerf_image_error", "snerf_transmittance",
            "snerf_linear_scratch_bytes", "snerf_linear_forward", "snerf_linear_dgrad", "snerf_linear_wgrad",
            "snerf_trainer_create", "snerf_trainer_destroy", "snerf_trainer_classes", "snerf_trainer_param_floats", "snerf_trainer_buffer_floats",
            "snerf_trainer_tensor_count", "snerf_trainer_tensor_info", "snerf_trainer_workspace_bytes", "snerf_trainer_bind", "snerf_trainer_bound_sizes",
-           "snerf_trainer_forward_image", "snerf_trainer_backward_image", "snerf_trainer_backward_points", "snerf_trainer_forward_solar",
+           "snerf_trainer_forward_image", "snerf_trainer_backward_image", "snerf_trainer_backward_image_dt", "snerf_trainer_backward_points", "snerf_trainer_forward_solar",
            "snerf_trainer_backward_solar", "snerf_trainer_zero_grad", "snerf_trainer_set_allreduce", "snerf_trainer_adam_step", "snerf_trainer_adam_step_dev", "snerf_adam_step", "snerf_trainer_debug_read",
            "snerf_loss_scratch_bytes", "snerf_loss_scratch_init", "snerf_loss_terms_forward", "snerf_loss_terms_backward"]

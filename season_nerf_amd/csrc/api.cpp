@@ -55,7 +55,7 @@ struct snerf_model {
 extern "C" {
 
 const char* snerf_last_error(void) { return g_err.c_str(); }
-int snerf_abi_version(void) { return 7; }
+int snerf_abi_version(void) { return 8; }
 
 snerf_model* snerf_model_create(int layer_width, int n_classes) {
     if (layer_width != 64 && layer_width != 256 && layer_width != 512) {
@@ -422,9 +422,9 @@ int snerf_field_ray_visibility(const snerf_model* m, int64_t n_rays, int n_sampl
     return field_launch(m, 3, a, nullptr, stream);
 }
 
-int snerf_composite_rays(int64_t n_rays, int n_samples, const float* d_top, const float* d_bot, const float* d_tvals,
-                         const float* d_rho, const float* d_col, const float* d_solar_vis, const float* d_sky,
-                         int flags, const float* d_rho_prior, float trust, const snerf_composite_out* out, void* stream) {
+static int composite_rays(int64_t n_rays, int n_samples, const float* d_top, const float* d_bot, const float* d_tvals,
+                          const float* d_rho, const float* d_col, const float* d_solar_vis, const float* d_sky,
+                          int flags, const float* d_rho_prior, float trust, const float* d_trust, const snerf_composite_out* out, void* stream) {
     if (n_rays == 0) return SNERF_OK;
     if (n_rays < 0 || n_samples < 1 || !d_top || !d_bot || !d_tvals || !d_rho || !d_col || !d_solar_vis || !d_sky || !out)
         return fail(SNERF_E_INVALID, "snerf_composite_rays: bad argument");
@@ -432,12 +432,25 @@ int snerf_composite_rays(int64_t n_rays, int n_samples, const float* d_top, cons
     a.n_rays = n_rays; a.n_samples = n_samples;
     a.top = d_top; a.bot = d_bot; a.tvals = d_tvals;
     a.rho = d_rho; a.col = d_col; a.solar_vis = d_solar_vis; a.sky = d_sky;
-    a.flags = flags; a.rho_prior = d_rho_prior; a.trust = trust;
+    a.flags = flags; a.rho_prior = d_rho_prior; a.trust = trust; a.trust_dev = d_trust;
     a.out.rgb = out->d_rgb; a.out.albedo = out->d_albedo; a.out.pv = out->d_pv; a.out.pe = out->d_pe;
     a.out.ps = out->d_ps; a.out.delta = out->d_delta; a.out.shadow = out->d_shadow; a.out.acc = out->d_acc;
     a.out.surf_loc = out->d_surf_loc; a.out.surf_dist = out->d_surf_dist;
     hipError_t e = launch_composite(a, (hipStream_t)stream);
     return e == hipSuccess ? SNERF_OK : fail_hip(e, "composite kernel launch");
+}
+
+int snerf_composite_rays(int64_t n_rays, int n_samples, const float* d_top, const float* d_bot, const float* d_tvals,
+                         const float* d_rho, const float* d_col, const float* d_solar_vis, const float* d_sky,
+                         int flags, const float* d_rho_prior, float trust, const snerf_composite_out* out, void* stream) {
+    return composite_rays(n_rays, n_samples, d_top, d_bot, d_tvals, d_rho, d_col, d_solar_vis, d_sky, flags, d_rho_prior, trust, nullptr, out, stream);
+}
+
+int snerf_composite_rays_dt(int64_t n_rays, int n_samples, const float* d_top, const float* d_bot, const float* d_tvals,
+                            const float* d_rho, const float* d_col, const float* d_solar_vis, const float* d_sky,
+                            int flags, const float* d_rho_prior, const float* d_trust, const snerf_composite_out* out, void* stream) {
+    if (d_rho_prior && !d_trust) return fail(SNERF_E_INVALID, "snerf_composite_rays_dt: d_trust is NULL");
+    return composite_rays(n_rays, n_samples, d_top, d_bot, d_tvals, d_rho, d_col, d_solar_vis, d_sky, flags, d_rho_prior, 1.f, d_trust, out, stream);
 }
 
 // workspace layout of snerf_render_rays: classes [R,C] | sky_raw [R,3] | sky [R,3] | rho [N] | sv [N] | col [N,3]

@@ -56,6 +56,7 @@ struct CompArgs {
     int flags;
     const float* rho_prior;
     float trust;
+    const float* trust_dev;       // optional: the trust factor read from device memory at run time (captured steps); overrides `trust`
     CompOutDev out;
 };
 

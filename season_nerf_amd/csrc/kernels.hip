@@ -515,7 +515,8 @@ __global__ __launch_bounds__(256) void composite_kernel(const CompArgs A) {
             c2 += ps * k2 * (sv + (1.f - sv) * sky2);
         }
         if (A.rho_prior) {
-            const float rm = in ? (rho * A.trust + A.rho_prior[idx] * (1.f - A.trust)) : 0.f;
+            const float tr = A.trust_dev ? A.trust_dev[0] : A.trust;
+            const float rm = in ? (rho * tr + A.rho_prior[idx] * (1.f - tr)) : 0.f;
             const float ym = rm * delta;
             const float incl_m = wave_incl_scan(ym, lane);
             const float excl_m = carry_m + (incl_m - ym);

@@ -21,7 +21,7 @@
 // parameter / gradient / workspace tensors).  The forward ops are functional in their tensor arguments (torch.library.register_autograd
 // attaches the backward ops to them, season_nerf_amd/training.py); the engine keeps the activations of its last forward and the BatchNorm
 // running statistics behind the handle.  `params` only ties the ops into the autograd graph of the parameters.
-//   season_nerf::train_fwd_image(trainer, top, bot, tvals, sun, time, train_bn, classic, n_classes, height_map?, trust, params[])       get_loss, image rays
+//   season_nerf::train_fwd_image(trainer, top, bot, tvals, sun, time, train_bn, classic, n_classes, height_map?, trust, trust_dev?, params[])       get_loss, image rays
 //        -> [rgb, albedo, sky, pe, rgb_merged, albedo_merged | pv, ps, delta, classes, rho, solar_vis, col, pts, adjust_col | prior terms]  Eval_Tools_2.py:165-252
 //   season_nerf::train_bwd_image(trainer, grads!, g_rgb?, g_albedo?, g_sky?, g_pe?, rho_prior?, trust, g_rgb_merged?, g_albedo_merged?) -> ()
 //   season_nerf::train_fwd_points(trainer, x, sun, time, train_bn, n_classes, params[]) -> [rho, col, solar_vis, sky, classes, adjust_col, col_raw, adjust]
@@ -292,7 +292,7 @@ Tensor prior_density(const Tensor& pts, const Tensor& delta, const Tensor& heigh
 
 std::vector<Tensor> train_fwd_image(int64_t trainer, const Tensor& top, const Tensor& bot, const Tensor& tvals, const Tensor& sun, const Tensor& time,
                                     bool train_bn, bool classic, int64_t n_classes, const c10::optional<Tensor>& height_map, double trust,
-                                    at::TensorList /*params*/) {
+                                    const c10::optional<Tensor>& trust_dev, at::TensorList /*params*/) {
     snerf_trainer* t = trainer_of(trainer, n_classes);
     check_shape(top, "top", -1, 3);
     const int64_t R = top.size(0);
@@ -317,6 +317,8 @@ std::vector<Tensor> train_fwd_image(int64_t trainer, const Tensor& top, const Te
     std::vector<Tensor> extra;
     if (height_map.has_value()) {      // DSM-prior phase (Eval_Tools_2.py:218-248): supervised density, merged density, their composites
         Tensor rs = prior_density(pts.reshape({-1, 3}), delta.reshape({-1}), *height_map, c10::nullopt).reshape({R, S, 1});
+        // trust_dev (one float on the device) replaces `trust` where a captured step needs a factor that changes between replays
+        const float* td = trust_dev.has_value() ? optptr(trust_dev, "trust_dev", 1) : nullptr;
         auto comp = [&](const Tensor& rho_t, const float* prior, float tr, int flags, Tensor* c_rgb, Tensor* c_alb, Tensor* c_pv, Tensor* c_pe, Tensor* c_ps) {
             snerf_composite_out c{};
             if (c_rgb) c.d_rgb = mptr(*c_rgb);
@@ -324,14 +326,18 @@ std::vector<Tensor> train_fwd_image(int64_t trainer, const Tensor& top, const Te
             if (c_pv) c.d_pv = mptr(*c_pv);
             if (c_pe) c.d_pe = mptr(*c_pe);
             if (c_ps) c.d_ps = mptr(*c_ps);
-            ck(snerf_composite_rays(R, (int)S, fptr(top), fptr(bot), fptr(tvals), fptr(rho_t), fptr(col), fptr(sv), fptr(sky), flags, prior, tr, &c, st),
-               "train_fwd_image (prior composites)");
+            if (prior && td)
+                ck(snerf_composite_rays_dt(R, (int)S, fptr(top), fptr(bot), fptr(tvals), fptr(rho_t), fptr(col), fptr(sv), fptr(sky), flags, prior, td, &c, st),
+                   "train_fwd_image (prior composites)");
+            else
+                ck(snerf_composite_rays(R, (int)S, fptr(top), fptr(bot), fptr(tvals), fptr(rho_t), fptr(col), fptr(sv), fptr(sky), flags, prior, tr, &c, st),
+                   "train_fwd_image (prior composites)");
         };
         Tensor pv_s = e({R, S, 1}), pe_s = e({R, S, 1}), ps_s = e({R, S, 1}), pv_m = e({R, S, 1}), pe_m = e({R, S, 1}), ps_m = e({R, S, 1});
         comp(rs, nullptr, 1.f, 0, nullptr, nullptr, &pv_s, &pe_s, &ps_s);
         rgb_m = e({R, 3}); alb_m = e({R, 3});
         comp(rho, fptr(rs), (float)trust, classic ? 1 : 0, &rgb_m, &alb_m, nullptr, nullptr, nullptr);
-        Tensor rho_m = rho * trust + rs * (1.0 - trust);
+        Tensor rho_m = td ? rho * (*trust_dev) + rs * (1.0 - *trust_dev) : rho * trust + rs * (1.0 - trust);
         comp(rho_m, nullptr, 1.f, 0, nullptr, nullptr, &pv_m, &pe_m, &ps_m);
         extra = {rs, pv_s, pe_s, ps_s, pv_m, pe_m, ps_m, rho_m};
     }
@@ -342,15 +348,20 @@ std::vector<Tensor> train_fwd_image(int64_t trainer, const Tensor& top, const Te
 
 void train_bwd_image(int64_t trainer, Tensor grads, const c10::optional<Tensor>& g_rgb, const c10::optional<Tensor>& g_albedo, const c10::optional<Tensor>& g_sky,
                      const c10::optional<Tensor>& g_pe, const c10::optional<Tensor>& rho_prior, double trust, const c10::optional<Tensor>& g_rgb_m,
-                     const c10::optional<Tensor>& g_alb_m, int64_t n_rays, int64_t n_samples) {
+                     const c10::optional<Tensor>& g_alb_m, int64_t n_rays, int64_t n_samples, const c10::optional<Tensor>& trust_dev) {
     snerf_trainer* t = trainer_of(trainer);
     check_dev_f32(grads, "grads");
     const int64_t R = n_rays, N = n_rays * n_samples;
     c10::hip::HIPGuardMasqueradingAsCUDA g(grads.device());
     const float* prior = optptr(rho_prior, "rho_prior", N);
-    ck(snerf_trainer_backward_image(t, optptr(g_rgb, "g_rgb", R * 3), optptr(g_albedo, "g_albedo", R * 3), optptr(g_sky, "g_sky", R * 3), optptr(g_pe, "g_pe", N),
-                                    prior, (float)trust, prior ? optptr(g_rgb_m, "g_rgb_merged", R * 3) : nullptr,
-                                    prior ? optptr(g_alb_m, "g_albedo_merged", R * 3) : nullptr, cur_stream(grads)), "train_bwd_image");
+    const float* gm = prior ? optptr(g_rgb_m, "g_rgb_merged", R * 3) : nullptr;
+    const float* ga = prior ? optptr(g_alb_m, "g_albedo_merged", R * 3) : nullptr;
+    if (prior && trust_dev.has_value())
+        ck(snerf_trainer_backward_image_dt(t, optptr(g_rgb, "g_rgb", R * 3), optptr(g_albedo, "g_albedo", R * 3), optptr(g_sky, "g_sky", R * 3),
+                                           optptr(g_pe, "g_pe", N), prior, optptr(trust_dev, "trust_dev", 1), gm, ga, cur_stream(grads)), "train_bwd_image");
+    else
+        ck(snerf_trainer_backward_image(t, optptr(g_rgb, "g_rgb", R * 3), optptr(g_albedo, "g_albedo", R * 3), optptr(g_sky, "g_sky", R * 3), optptr(g_pe, "g_pe", N),
+                                        prior, (float)trust, gm, ga, cur_stream(grads)), "train_bwd_image");
 }
 
 std::vector<Tensor> train_fwd_points(int64_t trainer, const Tensor& x, const Tensor& sun, const Tensor& time, bool train_bn, int64_t n_classes,
@@ -521,9 +532,9 @@ TORCH_LIBRARY(season_nerf, m) {
     m.def("loss_terms_bwd(Tensor g_vals, Tensor rgb, Tensor gt, Tensor albedo, Tensor sky, Tensor solar_vis, Tensor pv_exact, Tensor min, int world) "
           "-> (Tensor, Tensor, Tensor, Tensor)");
     m.def("train_fwd_image(int trainer, Tensor top, Tensor bot, Tensor tvals, Tensor sun, Tensor time, bool train_bn, bool classic, int n_classes, "
-          "Tensor? height_map, float trust, Tensor[] params) -> Tensor[]");
+          "Tensor? height_map, float trust, Tensor? trust_dev, Tensor[] params) -> Tensor[]");
     m.def("train_bwd_image(int trainer, Tensor(a!) grads, Tensor? g_rgb, Tensor? g_albedo, Tensor? g_sky, Tensor? g_pe, Tensor? rho_prior, float trust, "
-          "Tensor? g_rgb_merged, Tensor? g_albedo_merged, int n_rays, int n_samples) -> ()");
+          "Tensor? g_rgb_merged, Tensor? g_albedo_merged, int n_rays, int n_samples, Tensor? trust_dev=None) -> ()");
     m.def("train_fwd_points(int trainer, Tensor x, Tensor sun, Tensor time, bool train_bn, int n_classes, Tensor[] params) -> Tensor[]");
     m.def("train_bwd_points(int trainer, Tensor(a!) grads, Tensor? g_rho, Tensor? g_col, Tensor? g_solar_vis, Tensor? g_sky, Tensor? g_classes, "
           "int n_points, int n_classes) -> ()");

@@ -665,9 +665,9 @@ int snerf_trainer_forward_image(snerf_trainer* t, int64_t n_rays, int n_samples,
 // in t->d_sv_raw [N].  d_g_classes (optional, [R,C]) is added to the class-probability gradient.
 static int network_backward_image(snerf_trainer* t, bool classic, const float* d_g_classes, hipStream_t st);
 
-int snerf_trainer_backward_image(snerf_trainer* t, const float* d_g_rgb, const float* d_g_albedo, const float* d_g_sky,
-                                 const float* d_g_pe, const float* d_rho_prior, float trust, const float* d_g_rgb_merged,
-                                 const float* d_g_albedo_merged, void* stream) {
+static int backward_image(snerf_trainer* t, const float* d_g_rgb, const float* d_g_albedo, const float* d_g_sky,
+                          const float* d_g_pe, const float* d_rho_prior, float trust, const float* d_trust, const float* d_g_rgb_merged,
+                          const float* d_g_albedo_merged, void* stream) {
     if (!t || !t->ws) return snerf_set_error(SNERF_E_STATE, "trainer not bound");
     CtxGuard ctx(t);
     hipStream_t st = (hipStream_t)stream;
@@ -677,12 +677,25 @@ int snerf_trainer_backward_image(snerf_trainer* t, const float* d_g_rgb, const f
     CompBwdArgs cb{};
     cb.n_rays = R; cb.n_samples = S; cb.top = P.top; cb.bot = P.bot; cb.rho = P.rho; cb.col = P.col; cb.sv = P.sv; cb.sky = P.sky;
     cb.g_rgb = d_g_rgb; cb.g_albedo = d_g_albedo; cb.g_pe = d_g_pe; cb.d_rho = t->d_rho; cb.d_col = t->d_col; cb.d_sky = t->d_sky;
-    cb.rho_prior = d_rho_prior; cb.trust = trust; cb.g_rgb_m = d_g_rgb_merged; cb.g_albedo_m = d_g_albedo_merged;
+    cb.rho_prior = d_rho_prior; cb.trust = trust; cb.trust_dev = d_trust; cb.g_rgb_m = d_g_rgb_merged; cb.g_albedo_m = d_g_albedo_merged;
     const bool classic = (t->img_flags & 1) != 0;
     cb.classic = classic ? 1 : 0; cb.d_sv = t->d_sv_raw;       // dL/dSolar_Vis, turned into dL/d(raw) in place below
     HIPCK(launch_composite_bwd(cb, st));
     if (d_g_sky) HIPCK(launch_copy_cols(d_g_sky, 3, t->d_sky, 3, R, 3, true, st));
     return network_backward_image(t, classic, nullptr, st);
+}
+
+int snerf_trainer_backward_image(snerf_trainer* t, const float* d_g_rgb, const float* d_g_albedo, const float* d_g_sky,
+                                 const float* d_g_pe, const float* d_rho_prior, float trust, const float* d_g_rgb_merged,
+                                 const float* d_g_albedo_merged, void* stream) {
+    return backward_image(t, d_g_rgb, d_g_albedo, d_g_sky, d_g_pe, d_rho_prior, trust, nullptr, d_g_rgb_merged, d_g_albedo_merged, stream);
+}
+
+int snerf_trainer_backward_image_dt(snerf_trainer* t, const float* d_g_rgb, const float* d_g_albedo, const float* d_g_sky,
+                                    const float* d_g_pe, const float* d_rho_prior, const float* d_trust, const float* d_g_rgb_merged,
+                                    const float* d_g_albedo_merged, void* stream) {
+    if (d_rho_prior && !d_trust) return snerf_set_error(SNERF_E_INVALID, "snerf_trainer_backward_image_dt: d_trust is NULL");
+    return backward_image(t, d_g_rgb, d_g_albedo, d_g_sky, d_g_pe, d_rho_prior, 1.f, d_trust, d_g_rgb_merged, d_g_albedo_merged, stream);
 }
 
 // Seam B1 in train mode (T_NeRF.forward called on points with autograd, T_NeRF_net_v2.py:75-105): backward from gradients with

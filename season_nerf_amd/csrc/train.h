@@ -166,6 +166,7 @@ struct CompBwdArgs {
     // Rendered_Col_Merged / merged Albedo_Color.  The solar factor always comes from the un-merged PS.
     const float* rho_prior;                     // [N] or NULL
     float trust;
+    const float* trust_dev;                     // optional device-resident trust (captured steps); overrides `trust`
     const float *g_rgb_m, *g_albedo_m;          // [R,3] or NULL
     float *d_rho, *d_col, *d_sky;               // [N], [N,3], [R,3] (d_sky is overwritten)
     // classic solar model (Solar_Type_2, Eval_Tools_2.py:211-212): Rendered_Col = sum PS*Col*(SV + (1-SV)*Sky) per sample;

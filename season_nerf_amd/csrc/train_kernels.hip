@@ -648,7 +648,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const CompBwdArgs A)
     const float delta = __fdiv_rn(__fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz))), (float)S);
     const float sky[3] = {A.sky[r * 3], A.sky[r * 3 + 1], A.sky[r * 3 + 2]};
     const bool prior = A.rho_prior != nullptr;
-    const float tr = A.trust;
+    const float tr = A.trust_dev ? A.trust_dev[0] : A.trust;
     // ---- pass 1: forward sums (albedo, merged albedo, u)
     float alb[3] = {0.f, 0.f, 0.f}, albm[3] = {0.f, 0.f, 0.f}, u = 0.f, carry = 0.f, carry_m = 0.f;
     for (int base = 0; base < S; base += 64) {

@@ -286,7 +286,10 @@ class T_NeRF(nn.Module):
 
     def height_map_on(self, dev):
         """The DSM height map the module was built with (HM=...), float64 on `dev` (Supervised_Sample, T_NeRF_net_v2.py:175-181)."""
-        if self._hm_dev is None or self._hm_dev.device != torch.device(dev):
+        dev = torch.device(dev)
+        if dev.type == "cuda" and dev.index is None:           # "cuda" and "cuda:0" must hit the same cached copy (a captured step may not upload)
+            dev = torch.device("cuda", torch.cuda.current_device())
+        if self._hm_dev is None or self._hm_dev.device != dev:
             self._hm_dev = self.hm.to(device=dev, dtype=torch.float64).contiguous()
         if self._hm_dev.dim() != 2:
             raise ValueError("Supervised_Sample needs the 2-D height map the module was built with (HM=...)")

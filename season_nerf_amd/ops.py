@@ -72,7 +72,7 @@ def _register_fakes():
         return torch.empty_like(rgb), torch.empty_like(albedo), torch.empty_like(sky), torch.empty_like(solar_vis)
 
     @reg("season_nerf::train_fwd_image")
-    def _(trainer, top, bot, tvals, sun, time, train_bn, classic, n_classes, height_map, trust, params):
+    def _(trainer, top, bot, tvals, sun, time, train_bn, classic, n_classes, height_map, trust, trust_dev, params):
         R, S, C = top.shape[0], tvals.numel(), n_classes
         e = top.new_empty
         m3 = (R, 3) if height_map is not None else (0,)

@@ -150,8 +150,12 @@ class GraphedTrainStep:
     sun rays, in the reference's order: seeded runs reproduce the eager step's draws), uploads them, refreshes Adam's scalars (learning rate of
     the schedule, bias corrections: device-resident, `FusedAdam.make_capturable`) and launches the graph.
 
-    Limits (checked): the default training configuration only - MSE colour loss, solar rays on, default solar model, no DSM prior (its trust
-    factor is a per-step kernel argument), fused Adam, no process group (the collectives are issued from Python).  Fixed ray count.
+    Covered: the reference's default run - solar rays on, default solar model, fused Adam - in all of its phases: MSE colour loss (the five loss terms
+    of ONE fused kernel) or Barron's adaptive loss (the generic loss terms in torch ops; the second Adam on the loss object's alpha / scale switches
+    to torch's capturable form: step count and learning rate in device tensors, the OneCycle schedule fills the latter before each replay), with or
+    without the DSM prior of phase 1 (its trust factor current_step / n_steps sits in ONE device float the composite kernels read at run time -
+    snerf_composite_rays_dt / snerf_trainer_backward_image_dt - refreshed before each replay).
+    Limits (checked): Solar_Type_2, a torch optimiser on the network, or a process group (the collectives are issued from Python).  Fixed ray count.
 
         step = GraphedTrainStep(tool, example_batch)
         for k in range(n): loss = step(batch_k, k)          # loss: the step's LossDict (device tensors, not read back)
@@ -167,8 +171,10 @@ class GraphedTrainStep:
         from . import parallel
         ev = tool.eval_tool
         a = ev.args
-        if not (tool.fused_adam and ev.use_MSE_loss and a.Use_Solar and not a.Solar_Type_2 and not ev.use_prior):
-            return "only the default training configuration (fused Adam, MSE loss, solar rays, default solar model, no prior)"
+        if not (tool.fused_adam and a.Use_Solar and not a.Solar_Type_2):
+            return "only the default training configuration (fused Adam, solar rays, default solar model)"
+        if not ev.use_MSE_loss and (tool.optim2 is None or any(not p.is_cuda for p in tool._ada_params)):
+            return "the adaptive loss needs its parameters on the GPU and their optimiser (Net_tool.optim2)"
         if parallel.data_parallel():
             return "not under torch.distributed (the data-parallel exchanges are issued from Python)"
         return None
@@ -188,7 +194,7 @@ class GraphedTrainStep:
         self.R, self.S = data_dict["Top"].shape[0], a.n_samples
         e = lambda *sh: torch.empty(*sh, device=dev)
         self.data = {k: e(*data_dict[k].shape) for k in ("Top", "Bot", "Sun_Angle", "Time_Encoded", "GT_Color")}
-        self.tv = {"tv_image": e(self.S), "tv_solar": e(self.S)}
+        self.tv = {"tv_image": e(self.S), "tv_solar": e(self.S), "trust": e(1) if ev.use_prior else None}
         self.sol = (e(self.R, 3), e(self.R, 3), e(self.R, 3), e(self.R, 4))
         self._gen = ev.solar_creation_tool
         self.warmup, self.calls, self.graph, self.loss = int(warmup), 0, None, None
@@ -207,14 +213,38 @@ class GraphedTrainStep:
     def _body(self):
         tool, ev = self.tool, self.ev
         tool.optim.zero_grad()
-        loss = ev.get_loss(self.data, self.net, 0, train_mode=True)
-        loss.total().backward()
+        if tool.optim2 is not None:
+            tool.optim2.zero_grad()
+        loss = ev.get_loss(self.data, self.net, 0, train_mode=True)       # the step number reaches the kernels through self.tv["trust"], not through this 0
+        if getattr(loss, "vec", None) is not None:
+            total = loss.total()
+        else:
+            total = 0
+            for k in loss:
+                total = total + loss[k][0] * loss[k][1]
+        total.backward()
         tool.optim.step()
+        if tool.optim2 is not None:
+            tool.optim2.step()
         return loss
+
+    @staticmethod
+    def _torch_adam_capturable(opt, dev):
+        """torch.optim.Adam -> its capturable form in place: learning rate and step counts as device tensors (what `capturable=True` would have
+        built), moments untouched.  Eager steps keep working afterwards."""
+        for g in opt.param_groups:
+            g["capturable"] = True
+            if not torch.is_tensor(g["lr"]):
+                g["lr"] = torch.tensor(float(g["lr"]), dtype=torch.float32, device=dev)
+        for st in opt.state.values():
+            if "step" in st and st["step"].device != dev:
+                st["step"] = st["step"].to(device=dev, dtype=torch.float32)
 
     def _capture(self):
         tool, ev = self.tool, self.ev
         tool.optim.make_capturable()
+        if tool.optim2 is not None:
+            self._torch_adam_capturable(tool.optim2, self.dev)
         ev.static_inputs = self.tv
         ev.solar_creation_tool = lambda n, include_times=True: self.sol + (None,)
         import gc
@@ -239,16 +269,27 @@ class GraphedTrainStep:
         tool = self.tool
         if self.calls < self.warmup:                   # eager steps first: the engine, its scratch and every cached constant exist before the capture
             self.calls += 1
-            return tool.train_step(data_dict, current_step)
+            loss = tool.train_step(data_dict, current_step)
+            if getattr(loss, "vec", None) is None:
+                # The generic terms carry the autograd graph of this eager step, and with it the gradient accumulators of the loss object's parameters - created
+                # on the stream current NOW (the legacy default stream).  Autograd runs an accumulator on the stream it was created on: one that is still alive at
+                # capture time would pull the default stream into the capture (a segfault in hipStreamEndCapture on ROCm 7.2).  Hand out detached values, so the
+                # graph dies here and the captured backward creates its accumulators on the capture stream.
+                loss = tool.last_loss = {k: [v[0].detach() if torch.is_tensor(v[0]) else v[0], v[1]] for k, v in loss.items()}
+            return loss
         if data_dict["Top"].shape[0] != self.R:
             raise ValueError(f"GraphedTrainStep: captured for {self.R} rays, got {data_dict['Top'].shape[0]}")
         self._load(data_dict)
+        if self.tv["trust"] is not None:               # Eval_Tools_2.py:243: trust = current_step / n_steps, read by the kernels from this one float
+            self.tv["trust"].copy_(self._training._to_dev(torch.tensor([current_step / self.ev.n_steps], dtype=torch.float32), self.dev))
         if self.graph is None:
             self._capture()
         tool.optim.set_hyper()
         self.graph.replay()
         self.net.invalidate_packed()
         tool.sched.step()
+        if tool.sched2 is not None:
+            tool.sched2.step()                         # fills optim2's device-resident learning rate for the next replay
         loss = self._snapshot() if self.keep else self.loss
         tool._log("Training/", loss, current_step)
         if tool.writer is not None and current_step % tool.log_every == 0:       # as train_step logs it
@@ -260,6 +301,8 @@ class GraphedTrainStep:
     def _snapshot(self):
         """A LossDict of this step's values that the next replay does not overwrite (clone of the 5-float vector)."""
         src = self.loss
+        if getattr(src, "vec", None) is None:          # the generic terms (adaptive loss, prior phase): one small clone per term
+            return {k: [v[0].detach().clone() if torch.is_tensor(v[0]) else v[0], v[1].detach().clone() if torch.is_tensor(v[1]) else v[1]] for k, v in src.items()}
         vec = src.vec.detach().clone()
         out = type(src)()
         for i, k in enumerate(src.names):

@@ -298,7 +298,7 @@ def _register_autograd():
 
     def setup_image(ctx, inputs, output):
         setup(ctx, inputs, output, "image")
-        ctx.trust = float(inputs[10])
+        ctx.trust, ctx.trust_dev = float(inputs[10]), inputs[11]      # trust_dev: one device float (captured steps), never differentiated
         ctx.rs = output[15] if len(output) > 15 else None          # the DSM-prior density of this forward
         ctx.R, ctx.S = inputs[1].shape[0], inputs[3].numel()
 
@@ -308,7 +308,7 @@ def _register_autograd():
         eng.attach_grads()
         merged = ctx.rs is not None
         ops.train_bwd_image(ctx.trainer, eng.grads, g[0], g[1], g[2], g[3], ctx.rs, ctx.trust if merged else 1.0, g[4] if merged else None,
-                            g[5] if merged else None, ctx.R, ctx.S)
+                            g[5] if merged else None, ctx.R, ctx.S, ctx.trust_dev if merged else None)
         return ctx.no_grads
 
     def setup_points(ctx, inputs, output):
@@ -357,11 +357,11 @@ def _train_ops(eng, params_need_grad=True, kind="image"):
     return _ops()
 
 
-def _image_pass(eng, top, bot, tv, sun, tim, train_bn, height_map, trust):
+def _image_pass(eng, top, bot, tv, sun, tim, train_bn, height_map, trust, trust_dev=None):
     """T_NeRF.forward (train mode) + compositing on R rays.  Differentiable: Rendered_Col, Albedo_Color, Sky_Col (per ray), PE and -
     in the DSM-prior phase - Rendered_Col_Merged and the merged Albedo_Color; everything else comes back detached."""
     r = _train_ops(eng).train_fwd_image(eng.handle, top, bot, tv, sun, tim, bool(train_bn), bool(eng.classic_solar), eng.net.n_classes,
-                                        height_map, float(trust), eng.param_list)
+                                        height_map, float(trust), trust_dev, eng.param_list)
     return list(r[:6]) + [t.detach() for t in r[6:]]
 
 
@@ -543,7 +543,7 @@ def eval_train(ev, data_dict, net, train_mode, current_step=0):
     tv = static["tv_image"] if static is not None else _to_dev(sample_parameters(S, eval_mode=not train_mode), dev)
     eng.classic_solar = bool(ev.use_classic_solar)            # Solar_Type_2: per-sample shading, Solar_Vis carries gradient
     res = _image_pass(eng, top, bot, tv, sun, tim, net.training, net.height_map_on(dev) if ev.use_prior else None,
-                      current_step / ev.n_steps if ev.use_prior else 1.0)
+                      current_step / ev.n_steps if ev.use_prior else 1.0, static.get("trust") if (static is not None and ev.use_prior) else None)
     rgb, alb, sky, pe, rgb_m, alb_m, pv, ps, dl, cls, rho, sv, col, pts, adjc = res[:15]
     _after_train_forward(net)
     Cn = net.n_classes
@@ -580,7 +580,7 @@ def eval_rho_only_train(ev, data_dict, net, train_mode, current_step=0):
     sv, pv, pe, sky_raw, rho, pts, dl = _solar_pass(eng, top, bot, tv, sun, net.training)
     _after_train_forward(net)
     if ev.use_prior:                                              # Eval_Tools_2.py:319-334
-        trust = current_step / ev.n_steps
+        trust = static["trust"] if (static is not None and static.get("trust") is not None) else current_step / ev.n_steps      # captured: one device float
         p2, d2 = pts.reshape(-1, 3), dl.reshape(-1, 1)
         rs = net.Supervised_Sample(p2, d2, outside=rho.detach().reshape(-1))      # outside the cube: the network's own density
         rho_m = (rho * trust + rs.reshape(R, S, 1) * (1 - trust)).contiguous()

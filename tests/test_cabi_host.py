@@ -34,7 +34,7 @@ def test_exports_match_header(lib):
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
     import season_nerf_amd as sn
     assert sorted(sn._lib.EXPORTS) == declared
-    assert lib.snerf_abi_version() == 7
+    assert lib.snerf_abi_version() == 8
 
 
 def test_custom_op_library_registers_without_a_gpu():

@@ -217,14 +217,14 @@ def test_training_ops_validate_and_fake():
     d = {k: v.cuda() for k, v in data.items()}
     tv = sn.sample_parameters(S, eval_mode=True).cuda()
     with pytest.raises(RuntimeError, match="NULL trainer"):
-        o.train_fwd_image(0, d["Top"], d["Bot"], tv, d["Sun_Angle"], d["Time_Encoded"], True, False, 4, None, 1.0, eng.param_list)
+        o.train_fwd_image(0, d["Top"], d["Bot"], tv, d["Sun_Angle"], d["Time_Encoded"], True, False, 4, None, 1.0, None, eng.param_list)
     with pytest.raises(RuntimeError, match="float32"):
-        o.train_fwd_image(eng.handle, d["Top"].double(), d["Bot"], tv, d["Sun_Angle"], d["Time_Encoded"], True, False, 4, None, 1.0, eng.param_list)
+        o.train_fwd_image(eng.handle, d["Top"].double(), d["Bot"], tv, d["Sun_Angle"], d["Time_Encoded"], True, False, 4, None, 1.0, None, eng.param_list)
     with pytest.raises(RuntimeError, match=r"\[24,3\]|sun"):
         o.train_fwd_solar(eng.handle, d["Top"], d["Bot"], tv, d["Sun_Angle"][:5], True, eng.param_list)
     with pytest.raises(RuntimeError, match="g_rgb"):
         o.train_bwd_image(eng.handle, eng.grads, torch.zeros(5, 3, device="cuda"), None, None, None, None, 1.0, None, None, R, S)
-    args = (eng.handle, d["Top"], d["Bot"], tv, d["Sun_Angle"], d["Time_Encoded"], True, False, 4, None, 1.0, eng.param_list)
+    args = (eng.handle, d["Top"], d["Bot"], tv, d["Sun_Angle"], d["Time_Encoded"], True, False, 4, None, 1.0, None, eng.param_list)
     torch.library.opcheck(o.train_fwd_image.default, args, test_utils=("test_schema", "test_faketensor"))
     torch.library.opcheck(o.train_fwd_solar.default, (eng.handle, d["Top"], d["Bot"], tv, d["Sun_Angle"], True, eng.param_list),
                           test_utils=("test_schema", "test_faketensor"))

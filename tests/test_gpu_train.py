@@ -554,7 +554,7 @@ def test_backward_survives_engine_eviction():
 
 
 @pytest.mark.parametrize("fixture,graphed", [("trajectory_W64.npz", False), ("trajectory_W64.npz", True), ("trajectory_W256.npz", False), ("trajectory_W256.npz", True),
-                                             ("trajectory_prior_W64.npz", False), ("trajectory_classic_W64.npz", False)])
+                                             ("trajectory_prior_W64.npz", False), ("trajectory_prior_W64.npz", True), ("trajectory_classic_W64.npz", False)])
 def test_training_follows_the_reference_trajectory(golden_dir, fixture, graphed):
     """40 CONSECUTIVE steps of the reference's own training loop (tools/make_trajectory_golden.py: mg_run_NeRF.py:288-326 with the optimiser / OneCycleLR of
     Net_Tool_2.py:111-130 on fixed batches of a synthetic scene, host RNGs seeded once) replayed through season_nerf_amd.Net_tool with the same seeds: the RNG
@@ -562,7 +562,8 @@ def test_training_follows_the_reference_trajectory(golden_dir, fixture, graphed)
     backward, fused Adam, the schedule and the BatchNorm running statistics - every step against the reference's loss dict.  Rounding differences compound through
     Adam, so the band widens with the step count; a wrong schedule, moment, draw order or statistic leaves it within a few steps.
     graphed: the same 40 steps with the step captured once and replayed as one hipGraph launch (trainer.GraphedTrainStep) from step 2 on - the captured step against
-    the REFERENCE, learning-rate schedule and bias corrections through device memory included.
+    the REFERENCE, learning-rate schedule and bias corrections through device memory included; in the DSM-prior phase the trust factor too (one device float,
+    refreshed before each replay).
     Fixtures: W = 64 (40 steps), W = 256 (24 steps: the benchmark's width; of the large tensors only the norms are stored), and 16 steps of the DSM-prior phase
     (use_prior: supervised density, merged renderings, Alpha_Adjust, trust = step / n_steps, Eval_Tools_2.py:218-248,413-420), and 16 steps with the classic solar
     model (Solar_Type_2: per-sample shading, Solar_Correction_2 with gradient, :211-212,366-370)."""

@@ -119,14 +119,20 @@ def test_phase_switch_and_lr_trajectory(golden_dir):
 
 
 @pytest.mark.gpu
-def test_graphed_train_step_follows_the_eager_step():
+@pytest.mark.parametrize("use_mse,prior", [(True, False), (False, False), (True, True), (False, True)])
+def test_graphed_train_step_follows_the_eager_step(use_mse, prior):
     """trainer.GraphedTrainStep: the training step (mg_run_NeRF.py:288-326) captured once and replayed as one hipGraph launch per step must BE the
     eager step: same host draws (jitter, random sun rays: seeded alike), same loss values, same parameters after eight steps under the OneCycleLR
     schedule (the learning rate and Adam's bias corrections reach the captured Adam kernel through device memory) - to the noise of atomically
-    reduced gradients."""
+    reduced gradients.
+    All four configurations of the reference's run: MSE / Barron's adaptive loss (its alpha and scale have their own Adam and schedule, captured in
+    torch's capturable form: they must end where the eager ones end) x free phase / DSM-prior phase (trust = step / n_steps changes every step:
+    the captured composite kernels read it from one device float)."""
     import season_nerf_amd as sn
     from oracle import season_nerf_oracle as orc
+    from season_nerf_amd.adaptive_loss import AdaptiveLossFunction
     W, R, S, n_steps = 64, 96, 32, 8
+    hm = np.random.Generator(np.random.PCG64(3)).uniform(-0.8, 0.6, (24, 24))
     WC, H4 = np.array([41.29, -95.9, 300.0]), np.array([[310.0, 12.0, 0.0, -11650.0], [-9.0, 240.0, 0.0, 23390.0], [0.0, 0.0, 0.01, -3.0], [0, 0, 0, 1.0]])
     rng = np.random.Generator(np.random.PCG64(5))
     t = lambda a: torch.tensor(a, dtype=torch.float32, device="cuda")
@@ -139,13 +145,17 @@ def test_graphed_train_step_follows_the_eager_step():
                         "GT_Color": t(rng.uniform(0, 1, (R, 3)))})
 
     def run(graphed):
-        net = sn.T_NeRF(W, 4)
+        net = sn.T_NeRF(W, 4, HM=hm) if prior else sn.T_NeRF(W, 4)
         net.load_state_dict(orc.init_weights(W, 4, 7, bn_stats="identity"))
         net = net.cuda().train()
-        args = SimpleNamespace(n_samples=S, Use_Reg=True, Solar_Type_2=False, Use_MSE_loss=True, Use_Solar=True, sc_lambda=0.03, number_low_frequency_cases=4)
-        ev = sn.All_in_One_Eval(args, torch.device("cuda"), 10, False, None, H4, WC)
-        tool = sn.Net_tool(net, ev, 3e-4, total_steps=n_steps + 1, writer=None)   # (a large rate lets Adam amplify the rounding noise of the atomics into the losses)
+        args = SimpleNamespace(n_samples=S, Use_Reg=True, Solar_Type_2=False, Use_MSE_loss=use_mse, Use_Solar=True, sc_lambda=0.03, number_low_frequency_cases=4)
+        mk = lambda dims, s0, slo: AdaptiveLossFunction(dims, torch.float32, "cuda", alpha_hi=2.99, alpha_init=2.0, scale_init=s0, scale_lo=slo)
+        ada = None if use_mse else ([mk(3, .03, .01), mk(1, .5, .05)] if prior else mk(3, .03, .01))       # as Net_Tool_2.py:69-82 builds them
+        ev = sn.All_in_One_Eval(args, torch.device("cuda"), 10, prior, ada, H4, WC)
+        tool = sn.Net_tool(net, ev, 3e-4, total_steps=n_steps + 1, lr_alpha_scale=30.0, writer=None)   # (a large rate lets Adam amplify the rounding noise of the atomics into the losses)
+        assert (tool.optim2 is None) == use_mse
         step = sn.GraphedTrainStep(tool, batches[0], warmup=2) if graphed else None
+        ada0 = [p.detach().clone() for p in tool._ada_params]
         np.random.seed(11); torch.manual_seed(11)
         losses = []
         for k in range(n_steps):
@@ -153,11 +163,16 @@ def test_graphed_train_step_follows_the_eager_step():
             losses.append({n: float(v[0]) for n, v in loss.items()})
         if graphed:
             assert step.graph is not None and step.calls == n_steps
-        return losses, {k: v.detach().clone() for k, v in net.state_dict().items()}, tool.sched.get_last_lr()[0]
+        lr2 = None if use_mse else float(tool.optim2.param_groups[0]["lr"])
+        return losses, {k: v.detach().clone() for k, v in net.state_dict().items()}, (tool.sched.get_last_lr()[0], lr2), [(p.detach().clone(), p0) for p, p0 in zip(tool._ada_params, ada0)]
 
-    le, pe, lre = run(False)
-    lg, pg, lrg = run(True)
-    assert lre == lrg
+    le, pe, lre, ae = run(False)
+    lg, pg, lrg, ag = run(True)
+    assert lre[0] == lrg[0] and (use_mse or lrg[1] == pytest.approx(lre[1], rel=1e-6))       # the second schedule's rate: a device float in the captured run
+    assert len(ae) == (0 if use_mse else (4 if prior else 2))
+    for (a, a0), (b, _) in zip(ae, ag):       # alpha / scale latents: moved by Adam steps of ~lr2 each, the same way in both runs
+        moved = float((a - a0).abs().max())
+        assert moved > 1e-3 and float((a - b).abs().max()) <= 0.03 * moved, (a0, a, b)
     for k in range(n_steps):
         for n, v in le[k].items():
             assert abs(lg[k][n] - v) <= 2e-4 * max(abs(v), 1e-3), (k, n, lg[k][n], v)
@@ -176,7 +191,9 @@ def test_graphed_train_step_follows_the_eager_step():
     assert moved > 0 and diff < 0.02 * moved, (diff, moved)
     for k, v in pe.items():
         if "running" in k:
-            assert float((pg[k] - v).abs().max()) <= 5e-3 * max(float(v.abs().max()), 1e-2), k
+            # (the running means follow the gradient-free biases in front of BatchNorm, which Adam moves by rounding noise: 4e-3 of the largest mean with
+            # the adaptive loss, whose gradients are ~500x those of the MSE loss at scale 0.03)
+            assert float((pg[k] - v).abs().max()) <= (5e-3 if use_mse else 1.5e-2) * max(float(v.abs().max()), 1e-2), k
 
 
 @pytest.mark.gpu
@@ -228,7 +245,7 @@ def test_graphed_steps_without_readback_keep_their_own_adam_scalars():
 
 @pytest.mark.gpu
 def test_driver_with_use_graph_switches_to_the_captured_step():
-    """T_NeRF_Net_Tool(..., use_graph=True): 12 steps - phase 1 (DSM prior: not capturable, eager) then phase 4, whose first two steps run eagerly and
+    """T_NeRF_Net_Tool(..., use_graph=True): 20 steps - phase 1 (DSM prior, 4 steps) then phase 4; in each phase the first two steps run eagerly and
     the rest as one hipGraph launch each; a new phase (new evaluator / optimisers) drops the captured step.  The learning rate follows the same
     OneCycleLR trajectory as the eager driver, Adam's step count too, and the loss keeps falling through the switch."""
     import season_nerf_amd as sn
@@ -243,19 +260,19 @@ def test_driver_with_use_graph_switches_to_the_captured_step():
     WC, H4 = np.array([41.29, -95.9, 300.0]), np.array([[310.0, 12.0, 0.0, -11650.0], [-9.0, 240.0, 0.0, 23390.0], [0.0, 0.0, 0.01, -3.0], [0, 0, 0, 1.0]])
     out = {}
     for use_graph in (False, True):
-        args = _args(12, n_saves=5, use_mse=True)
+        args = _args(20, n_saves=5, use_mse=True)
         tool = sn.T_NeRF_Net_Tool(args, hm, hm, "cuda", H4, WC, get_data=lambda eval_mode: data, use_graph=use_graph)
         tool.network.load_state_dict(orc.init_weights(64, 4, 1))
         np.random.seed(3); torch.manual_seed(3)
         lrs, steps, colour, graphed = [], [], [], []
-        for s_ in range(12):
+        for s_ in range(20):
             tool.step()
             lrs.append(tool.sched.get_last_lr()[0])
             steps.append(tool.network._param_store.adam_steps)
             colour.append(float(tool.last_loss["Color"][0]))
             graphed.append(tool._graphed is not None and tool._graphed.graph is not None)
         out[use_graph] = (lrs, steps, colour, graphed)
-    assert out[False][3] == [False] * 12
-    assert out[True][3] == [False] * 4 + [True] * 8          # steps 0-1: prior phase; 2-3: eager warm-up of the new phase; from step 4 on: replays
+    assert out[False][3] == [False] * 20
+    assert out[True][3] == [False] * 2 + [True] * 2 + [False] * 2 + [True] * 14      # steps 0-3: prior phase (2 eager + 2 replays); 4-5: eager warm-up of the new phase; then replays
     assert out[True][0] == out[False][0] and out[True][1] == out[False][1]
     np.testing.assert_allclose(out[True][2], out[False][2], rtol=2e-3)
