@@ -12,7 +12,7 @@ import season_nerf_amd as sn
 
 dev = torch.device("cuda")
 R, S = bench.R, bench.S
-net = sn.T_NeRF(256, 4)
+net = sn.T_NeRF(int(os.environ.get("SOAK_WIDTH", "256")), 4)      # SOAK_WIDTH=512: the reference's default width (tools/power_under.py runs both)
 net.load_state_dict(sn.synthetic_state_dict(net, 0, bn_stats="identity"))
 net = net.to(dev).train()
 args = SimpleNamespace(n_samples=S, Use_Reg=True, Solar_Type_2=False, Use_MSE_loss=True, Use_Solar=True, sc_lambda=0.03, number_low_frequency_cases=4)
@@ -22,7 +22,7 @@ d = bench.synth(0, dev)
 # a learnable target: colour = a smooth function of where the ray hits z = 0
 mid = 0.5 * (d["Top"] + d["Bot"])
 d["GT_Color"] = torch.stack([0.5 + 0.4 * torch.sin(3 * mid[:, 0]), 0.5 + 0.4 * torch.cos(2 * mid[:, 1]), 0.5 + 0.3 * torch.sin(mid[:, 0] + mid[:, 1])], 1)
-n_g, n_e = 1000, 300
+n_g, n_e = int(os.environ.get("SOAK_GRAPHED", "1000")), int(os.environ.get("SOAK_EAGER", "300"))
 tool = sn.Net_tool(net, ev, 3e-4, total_steps=n_g + n_e + 8, writer=None)
 step = sn.GraphedTrainStep(tool, d, warmup=3)
 mem, col = [], []
