@@ -20,7 +20,11 @@
 //     tile t inside the FIRST k-step of tile t+1: each n-tile's 16 accumulators are read out right before that k-step's first MFMA restarts them (C = 0);
 //     ACT (input gradients): the activation-backward epilogue of gemm_rows_full_kernel - times cos(2 pi (a z + b)) of the layer below, its pre-activations
 //     loaded a pair of n-tiles ahead - and the column sums sum v, sum v xhat;
-//   * one workgroup (4 waves = one per SIMD, all 512 registers) per CU, persistent over row tiles of 128 rows.
+//   * one workgroup (4 waves = one per SIMD, all 512 registers) per CU, persistent over row tiles of 128 rows;
+//   * HV = 2 (the forward forms at N = 512): EIGHT waves - waves w and w + 4 share a row group and own a column half each (128 AGPRs, 128 architectural
+//     registers), convert every k-step of A once between them (16 rows each) and exchange the bf16 operands through LDS behind the ring's barriers.  The
+//     second wave fills the matrix pipe (MFMAs alone: 277 us instead of 380) - and the kernel as a whole does not move, because every complete build of it
+//     runs at the package power limit (tools/areg_power.py): -4 % with activation on load, 0 without.
 // Same products, same k order and the same order of the three partial products per accumulator as gemm_rows_full_kernel (tools/areg_check.py).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
