@@ -7,12 +7,49 @@
 //   * the k-order permutation of the register-resident chain and the row maps of the head layers;
 //   * the bf16 hi/lo split  w = hi + lo  (hi = RNE bf16(w), lo = RNE bf16(w - hi)).
 // Pure host code: no HIP calls, usable (and unit-tested) on a machine without a GPU.
+#include <atomic>
+#include <cstdlib>
+#include <mutex>
+#include <thread>
 #include "pack.h"
 
 #include <cmath>
 #include <cstring>
 
 namespace snerf {
+
+// The layers of a program pack independently (disjoint regions of the stream and the tables): a few host threads take them from a counter.  A re-pack after
+// a parameter change sits in front of every in-loop validation render (bench.py `repack_ms`); SNERF_PACK_THREADS=1 packs serially.
+template <class F>
+static bool parallel_layers(int L, std::string* err, F fn) {
+    static int cap = -1;
+    if (cap < 0) {
+        const char* e = getenv("SNERF_PACK_THREADS");
+        const unsigned hw = std::thread::hardware_concurrency();
+        cap = e ? atoi(e) : (int)(hw ? (hw < 8 ? hw : 8) : 1);
+        if (cap < 1) cap = 1;
+    }
+    const int T = cap < L ? cap : L;
+    std::atomic<int> next{0};
+    std::atomic<bool> ok{true};
+    std::mutex mu;
+    auto work = [&]() {
+        for (;;) {
+            const int l = next.fetch_add(1);
+            if (l >= L || !ok.load()) break;
+            std::string e;
+            if (!fn(l, &e)) {
+                std::lock_guard<std::mutex> g(mu);
+                if (ok.exchange(false)) *err = e;
+            }
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; ++t) th.emplace_back(work);
+    work();
+    for (auto& t : th) t.join();
+    return ok.load();
+}
 
 static inline uint16_t bf16_rne(float f) {
     uint32_t u;
@@ -147,7 +184,7 @@ bool pack_program(const Weights& w, int prog, int W, int C, bool fold_bn, Packed
     const int L = prog_layers(prog);
     out->stream.assign((size_t)prog_chunks(prog, W, C) * kChunkBytes, 0);
     out->bias.assign((size_t)prog_bias_floats(prog, W, C), 0.f);
-    for (int l = 0; l < L; ++l) {
+    return parallel_layers(L, err, [&](int l, std::string* err) {
         const LayerShape s = prog_layer(prog, W, C, l);
         Dense d;
         if (!dense_layer(w, prog, W, C, l, fold_bn, &d, err)) return false;
@@ -184,8 +221,8 @@ bool pack_program(const Weights& w, int prog, int W, int C, bool fold_bn, Packed
                     }
                 }
             }
-    }
-    return true;
+        return true;
+    });
 }
 
 // ---- int8-digit format (program.h, FMT_I8) ----------------------------------------------------------------
@@ -201,7 +238,7 @@ bool pack_program_i8(const Weights& w, int prog, int W, int C, bool fold_bn, Pac
     const int L = prog_layers(prog);
     out->stream.assign((size_t)prog_chunks(prog, W, C, FMT_I8) * kChunkBytes, 0);
     out->bias.assign((size_t)prog_table_floats(prog, W, C), 0.f);
-    for (int l = 0; l < L; ++l) {
+    return parallel_layers(L, err, [&](int l, std::string* err) {
         const LayerShape s = prog_layer(prog, W, C, l, FMT_I8);
         Dense d;
         if (!dense_layer(w, prog, W, C, l, fold_bn, &d, err)) return false;
@@ -267,8 +304,8 @@ bool pack_program_i8(const Weights& w, int prog, int W, int C, bool fold_bn, Pac
                                 (rr >= 0 && dd < rdims && rbase + dd < d.k) ? (float)d.W[(size_t)rr * d.k + rbase + dd] : 0.f;
                     }
         }
-    }
-    return true;
+        return true;
+    });
 }
 
 // ---- error model of the int8-digit format ------------------------------------------------------------------
@@ -290,40 +327,64 @@ static bool estimate_program(const Weights& w, int prog, int W, int C, std::vect
     out_var->assign(L, {});
     const double qa = 1.0 / (12.0 * 32767.0 * 32767.0);       // variance of an activation's rounding, in units of [-1,1]^2
     const double lb = 5461.5 / (32767.0 * 32767.0);           // E[b^2] of a uniformly distributed low activation digit, same units
+    // Pass 1, layers in parallel: everything a layer's own weights contribute (their rounding, the activations' rounding through them, the dropped L x b
+    // product) and its accumulator bound.  Pass 2, in layer order and cheap: the error the INPUT activations already carry, through the weights.
+    std::vector<Dense> dense(L);
+    std::vector<std::vector<double>> own(L);
+    std::vector<long long> bound_l(L, 0);
+    std::vector<int> n_hidden_l(L, 0);
+    if (!parallel_layers(L, err, [&](int l, std::string* err) {
+            const LayerShape s = prog_layer(prog, W, C, l, FMT_I8);
+            Dense& d = dense[l];
+            if (!dense_layer(w, prog, W, C, l, /*fold_bn=*/true, &d, err)) return false;
+            const int f0 = kind_features(s.kind0, s.ks0, FMT_I8);
+            const int rk = raw_kind(s), rdims = raw_dims(rk), rbase = (rk != IN_NONE && rk == s.kind1 && rk != s.kind0) ? f0 : 0;
+            auto is_raw_col = [&](int c) { return rk != IN_NONE && c >= rbase && c < rbase + rdims; };
+            n_hidden_l[l] = s.kind0 == IN_H ? (f0 < d.k ? f0 : d.k) : 0;          // columns [0, n_hidden) are hidden activations
+            own[l].assign(d.n, 0.0);
+            for (int n = 0; n < d.n; ++n) {
+                const double* row = d.W.data() + (size_t)n * d.k;
+                double mx = 0.0;
+                for (int c = 0; c < d.k; ++c) if (!is_raw_col(c)) mx = std::fmax(mx, std::fabs(row[c]));
+                const double sn = mx > 0.0 ? mx / 32512.0 : 1.0;
+                double v = 0.0;
+                long long sT = 0, sL = 0;
+                for (int c = 0; c < d.k; ++c) {
+                    if (is_raw_col(c)) continue;                                       // fp32 path: no digits
+                    const long long q = std::llround(row[c] / sn);
+                    const long long T = (q + 128) >> 8, Lq = q - 256 * T;
+                    sT += T < 0 ? -T : T; sL += Lq < 0 ? -Lq : Lq;
+                    const double dw = row[c] - sn * (double)q;                         // this weight's rounding error, exactly
+                    v += 0.5 * dw * dw                                                 // times an activation of mean square 1/2
+                       + row[c] * row[c] * qa                                          // the activation's rounding through the weight
+                       + sn * sn * (double)(Lq * Lq) * lb;                             // the dropped L x b product
+                }
+                // |M| <= 128 sum|T|, |X| <= 128 sum(|T| + |L|)   (digits in [-128, 127])
+                const long long bound = 256LL * 128LL * sT + 128LL * (sT + sL);
+                if (bound > bound_l[l]) bound_l[l] = bound;
+                own[l][n] = v;
+            }
+            return true;
+        }))
+        return false;
     for (int l = 0; l < L; ++l) {
         const LayerShape s = prog_layer(prog, W, C, l, FMT_I8);
-        Dense d;
-        if (!dense_layer(w, prog, W, C, l, /*fold_bn=*/true, &d, err)) return false;
+        const Dense& d = dense[l];
         const int f0 = kind_features(s.kind0, s.ks0, FMT_I8);
         const int rk = raw_kind(s), rdims = raw_dims(rk), rbase = (rk != IN_NONE && rk == s.kind1 && rk != s.kind0) ? f0 : 0;
         auto is_raw_col = [&](int c) { return rk != IN_NONE && c >= rbase && c < rbase + rdims; };
         const int src = hidden_source(prog, l);
-        const int n_hidden = s.kind0 == IN_H ? (f0 < d.k ? f0 : d.k) : 0;          // columns [0, n_hidden) are hidden activations
         const std::vector<double>* ein = src >= 0 ? &(*out_var)[src] : nullptr;
+        const int nh = ein ? (n_hidden_l[l] < (int)ein->size() ? n_hidden_l[l] : (int)ein->size()) : 0;
         std::vector<double>& ev = (*out_var)[l];
         ev.assign(d.n, 0.0);
         double sum = 0.0;
+        if (bound_l[l] > *acc_bound) *acc_bound = bound_l[l];
         for (int n = 0; n < d.n; ++n) {
             const double* row = d.W.data() + (size_t)n * d.k;
-            double mx = 0.0;
-            for (int c = 0; c < d.k; ++c) if (!is_raw_col(c)) mx = std::fmax(mx, std::fabs(row[c]));
-            const double sn = mx > 0.0 ? mx / 32512.0 : 1.0;
-            double v = 0.0;
-            long long sT = 0, sL = 0;
-            for (int c = 0; c < d.k; ++c) {
-                if (is_raw_col(c)) continue;                                       // fp32 path: no digits
-                const long long q = std::llround(row[c] / sn);
-                const long long T = (q + 128) >> 8, Lq = q - 256 * T;
-                sT += T < 0 ? -T : T; sL += Lq < 0 ? -Lq : Lq;
-                const double dw = row[c] - sn * (double)q;                         // this weight's rounding error, exactly
-                v += 0.5 * dw * dw                                                 // times an activation of mean square 1/2
-                   + row[c] * row[c] * qa                                          // the activation's rounding through the weight
-                   + sn * sn * (double)(Lq * Lq) * lb;                             // the dropped L x b product
-                if (c < n_hidden && ein && c < (int)ein->size()) v += row[c] * row[c] * (*ein)[c];
-            }
-            // |M| <= 128 sum|T|, |X| <= 128 sum(|T| + |L|)   (digits in [-128, 127])
-            const long long bound = 256LL * 128LL * sT + 128LL * (sT + sL);
-            if (bound > *acc_bound) *acc_bound = bound;
+            double v = own[l][n];
+            for (int c = 0; c < nh; ++c)
+                if (!is_raw_col(c)) v += row[c] * row[c] * (*ein)[c];
             // sine layer: d sin(2 pi z) = 2 pi cos(.) dz, mean square of the cosine 1/2
             ev[n] = s.out_kind == OUT_SIN ? (2.0 * M_PI) * (2.0 * M_PI) * 0.5 * v : v;
             sum += ev[n];

@@ -237,9 +237,17 @@ class T_NeRF(nn.Module):
         want = self.precision
         _ops()
         m = torch.classes.season_nerf.Model(W, self.n_classes, want)
-        for k, v in self.state_dict().items():
-            if v.is_floating_point():
-                m.set_tensor(k, v.detach().float().cpu().contiguous())
+        # ONE device-to-host copy for the whole state (a copy per tensor is ~70 synchronous transfers: 2-3 ms of the re-pack every in-loop validation render pays)
+        items = [(k, v.detach()) for k, v in self.state_dict().items() if v.is_floating_point()]
+        if items and all(v.is_cuda for _, v in items):
+            flat = torch.cat([v.reshape(-1).float() for _, v in items]).cpu()
+            off = 0
+            for k, v in items:
+                m.set_tensor(k, flat[off:off + v.numel()].reshape(v.shape))
+                off += v.numel()
+        else:
+            for k, v in items:
+                m.set_tensor(k, v.float().cpu().contiguous())
         v = m.i8_estimate()
         self._estimate = {"head_rms": v[0:4], "hidden_rms": v[4], "worst": v[5], "rgb_pred": v[6], "budget": v[7], "acc_bound": int(v[8]), "ok": bool(v[9])}
         r = m.resolve()
