@@ -1,8 +1,8 @@
 #!/bin/bash
-# usage (GPU box): tools/trace_gaps.sh  - kernel trace of the training bench: busy time vs span of the timed steps, gap histogram
+# usage (GPU box): tools/trace_gaps.sh [extra bench.py arguments, e.g. --train-graph]  - kernel trace of the training bench: busy time vs span of the timed steps, gap histogram
 cd /tmp && export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT (the repo root on the GPU box)}"
 out=gpurun_out/gaps; rm -rf $out; mkdir -p $out
-rocprofv3 --kernel-trace --output-format csv -d $out/tr -- python3 bench.py --workload train --steps 4 --warmup 2 --no-cpu-baseline > $out/log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $out/tr -- python3 bench.py --workload train --steps 6 --warmup 3 --no-cpu-baseline "$@" > $out/log 2>&1
 f=$(find $out/tr -name "*kernel_trace.csv" | head -1)
 python3 - "$f" <<'PY'
 import csv, sys
@@ -21,6 +21,11 @@ if len(adam) >= 5:
     import collections
     h = collections.Counter(min(int(g / 1000), 20) for g in pos)
     print("gap histogram (us: count/step):", {k: round(v / 4, 1) for k, v in sorted(h.items())})
+    per = collections.defaultdict(lambda: [0, 0])
+    for s_, e_, n_ in seg:
+        per[n_][0] += 1; per[n_][1] += e_ - s_
+    for n_, (c_, t_) in sorted(per.items(), key=lambda kv: -kv[1][1])[:8]:
+        print(f"  {n_:52s} {c_/4:6.1f} per step  {t_/c_/1e3:8.1f} us")
     big = sorted(((g, seg[i][2], seg[i + 1][2]) for i, g in enumerate(gaps) if g > 8000), reverse=True)[:12]
     for g, a_, b_ in big: print(f"  {g/1e3:7.1f} us between {a_} -> {b_}")
 PY
