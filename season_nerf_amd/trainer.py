@@ -199,16 +199,32 @@ class GraphedTrainStep:
         self._gen = ev.solar_creation_tool
         self.warmup, self.calls, self.graph, self.loss = int(warmup), 0, None, None
 
-    def _load(self, data_dict):
-        """Host draws in the reference's order (image jitter, sun rays, sun-ray jitter: Eval_Tools_2.py:169,349,301) + uploads into the fixed buffers."""
+    def _load(self, data_dict, current_step, with_hyper):
+        """Host draws in the reference's order (image jitter, sun rays, sun-ray jitter: Eval_Tools_2.py:169,349,301) + uploads into the fixed buffers.
+        What the HOST produces per step - both jitter vectors, the four sun-ray arrays, the prior's trust factor, Adam's six scalars - travels as ONE upload
+        through the pinned ring and is dealt out to the fixed buffers by one multi-tensor copy kernel: eight uploads, each with a device-to-device copy behind
+        it and each waiting for the one before it, cost the GPU ~0.4 ms between two replays (tools/graph_replay_probe.py)."""
         tr = self._training
         for k, dst in self.data.items():
             dst.copy_(tr._to_dev(data_dict[k], self.dev))
-        self.tv["tv_image"].copy_(tr._to_dev(tr.sample_parameters(self.S, eval_mode=False), self.dev))
+        tvi = tr.sample_parameters(self.S, eval_mode=False)
         st, en, vec, stime, _ = self._gen(self.R, include_times=True)
-        for dst, src in zip(self.sol, (st, en, vec, stime)):
-            dst.copy_(tr._to_dev(src, self.dev))
-        self.tv["tv_solar"].copy_(tr._to_dev(tr.sample_parameters(self.S, eval_mode=False, include_end_pt=True), self.dev))
+        tvs = tr.sample_parameters(self.S, eval_mode=False, include_end_pt=True)
+        parts = [(self.tv["tv_image"], tvi)] + list(zip(self.sol, (st, en, vec, stime))) + [(self.tv["tv_solar"], tvs)]
+        if self.tv["trust"] is not None:               # Eval_Tools_2.py:243: trust = current_step / n_steps, read by the kernels from this one float
+            parts.append((self.tv["trust"], torch.tensor([current_step / self.ev.n_steps], dtype=torch.float32)))
+        if with_hyper:
+            parts.append((self.tool.optim.hyper, torch.tensor(self.tool.optim.next_hyper(), dtype=torch.float32)))
+        if any(torch.is_tensor(s) and s.is_cuda for _, s in parts):      # (a generator that draws on the device: nothing to pack)
+            for dst, src in parts:
+                dst.copy_(tr._to_dev(src, self.dev))
+            return
+        packed = tr._to_dev(torch.cat([torch.as_tensor(s, dtype=torch.float32).reshape(-1) for _, s in parts]), self.dev)
+        off, srcs = 0, []
+        for dst, _ in parts:
+            srcs.append(packed[off:off + dst.numel()].view(dst.shape))
+            off += dst.numel()
+        torch._foreach_copy_([d for d, _ in parts], srcs)
 
     def _body(self):
         tool, ev = self.tool, self.ev
@@ -279,12 +295,11 @@ class GraphedTrainStep:
             return loss
         if data_dict["Top"].shape[0] != self.R:
             raise ValueError(f"GraphedTrainStep: captured for {self.R} rays, got {data_dict['Top'].shape[0]}")
-        self._load(data_dict)
-        if self.tv["trust"] is not None:               # Eval_Tools_2.py:243: trust = current_step / n_steps, read by the kernels from this one float
-            self.tv["trust"].copy_(self._training._to_dev(torch.tensor([current_step / self.ev.n_steps], dtype=torch.float32), self.dev))
-        if self.graph is None:
+        first = self.graph is None
+        self._load(data_dict, current_step, with_hyper=not first)
+        if first:                                      # (the capture creates the device vector of Adam's scalars: filled on its own this once)
             self._capture()
-        tool.optim.set_hyper()
+            tool.optim.set_hyper()
         self.graph.replay()
         self.net.invalidate_packed()
         tool.sched.step()

@@ -688,18 +688,23 @@ class FusedAdam(torch.optim.Optimizer):
         self.hyper = torch.zeros(6, device=store.dev)
         return self
 
-    def set_hyper(self):
-        """Upload the scalars of the NEXT Adam step (param_groups' lr / betas / eps, step count + 1) - stream-ordered, no sync."""
+    def next_hyper(self):
+        """Advance the step count and return the six scalars of that Adam step [lr, beta1, beta2, eps, 1 - beta1^t, 1 - beta2^t] as host floats."""
         g = self.param_groups[0]
         store = self.net._param_store
         store.adam_steps += 1
         t = store.adam_steps
         b1, b2 = g["betas"]
+        return [float(g["lr"]), b1, b2, g["eps"], 1.0 - b1 ** t, 1.0 - b2 ** t]
+
+    def set_hyper(self):
+        """Upload the scalars of the NEXT Adam step (param_groups' lr / betas / eps, step count + 1) - stream-ordered, no sync."""
+        store = self.net._param_store
         # ADVICE r4 (high): a single pinned buffer rewritten every step races with its own asynchronous DMA - the copy reads the
         # pinned memory when it EXECUTES, and the host runs several steps ahead of the GPU, so step k's Adam kernel could see the
         # scalars of step k+1..k+5.  The six floats go through the event-guarded ring of pinned slots instead (a slot is rewritten
         # only after the copy that read it has executed), then device -> device into the fixed vector the captured kernel reads.
-        h = torch.tensor([float(g["lr"]), b1, b2, g["eps"], 1.0 - b1 ** t, 1.0 - b2 ** t], dtype=torch.float32)
+        h = torch.tensor(self.next_hyper(), dtype=torch.float32)
         self.hyper.copy_(_RING.upload(h, store.dev), non_blocking=True)
 
     def state_dict(self):
