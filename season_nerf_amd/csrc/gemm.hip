@@ -1008,6 +1008,13 @@ hipError_t launch_wgrad_bf16x3(float* dZ, int64_t ldz, const float* In, int64_t 
         g.z = bn->z; g.ldzz = bn->ldz; g.bn_gamma = bn->gamma; g.bn_mu = bn->mu; g.bn_istd = bn->istd; g.bn_sdy = bn->sdy; g.bn_sdyx = bn->sdyx;
         g.bn_inv_m = bn->inv_m; g.bias_alpha = bn->bias_alpha; g.dbias = bn->dbias;
     }
+    {
+        static int log_shapes = -1;      // SNERF_LOG_WGRAD=1: one line per launch (which layers end up on which block shape)
+        if (log_shapes < 0) { const char* e = getenv("SNERF_LOG_WGRAD"); log_shapes = (e && e[0] == '1') ? 1 : 0; }
+        if (log_shapes)
+            fprintf(stderr, "wgrad M=%lld n_out=%d n_in=%d ldz=%lld ldi=%lld ta=%d tb=%d full=%d bn=%d in_tab=%d grid=(%lld,%d,%d) rows/block=%lld partial=%d\n", (long long)M, n_out, n_in,
+                    (long long)ldz, (long long)ldi, ta, tb, (int)full, bn ? 1 : 0, in_tab ? in_cols : 0, (long long)bx, by, bz, (long long)rows, g.partial ? 1 : 0);
+    }
     hipError_t e;
     if (full) e = bn ? launch_wgrad_as<true, true, 2, 4>(g, grid, st) : launch_wgrad_as<true, false, 2, 4>(g, grid, st);
     else if (ta == 2 && tb == 4) e = bn ? launch_wgrad_as<false, true, 2, 4>(g, grid, st) : launch_wgrad_as<false, false, 2, 4>(g, grid, st);
