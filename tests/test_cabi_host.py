@@ -567,3 +567,44 @@ def test_network_class_resolves_its_precision_on_the_host():
     with torch.no_grad():
         net.G_NeRF_net.fc2.norm.running_var.mul_(1e-6)       # BatchNorm gain x1000: far outside the bound
     assert net.resolved_precision == "bf16x3"
+
+
+def test_threaded_pack_is_the_serial_pack():
+    """pack.cpp packs the layers of a program on a few host threads (disjoint regions of the stream and the tables) and runs the per-weight pass of the int8
+    error model in parallel: both programs' streams and tables, the int8 stream and the estimate must be what SNERF_PACK_THREADS=1 produces (the switch is
+    read once per process: two children).  A missing tensor is still reported from inside a worker."""
+    import subprocess
+    import sys
+    code = r'''
+import ctypes as C, hashlib, sys, numpy as np
+sys.path.insert(0, %r)
+from season_nerf_amd import _lib
+from oracle import season_nerf_oracle as orc
+lib = _lib.lib()
+for W in (64, 256):
+    sd = orc.init_weights(W, 4, 3)
+    m = lib.snerf_model_create(W, 4)
+    keep = {}
+    for k, v in sd.items():
+        if v.is_floating_point():
+            keep[k] = np.ascontiguousarray(v.numpy(), dtype=np.float32).ravel()
+            assert lib.snerf_model_set_tensor(m, k.encode(), keep[k].ctypes.data, keep[k].size) == 0
+    assert lib.snerf_model_set_precision(m, 2) == 0
+    h = hashlib.sha256()
+    for prog in (0, 1, 2):
+        ns, nb = C.c_size_t(), C.c_size_t()
+        assert lib.snerf_model_pack_host(m, prog, None, C.byref(ns), None, C.byref(nb)) == 0
+        s, b = np.zeros(ns.value, np.uint8), np.zeros(nb.value, np.float32)
+        assert lib.snerf_model_pack_host(m, prog, s.ctypes.data, C.byref(ns), b.ctypes.data, C.byref(nb)) == 0
+        h.update(s.tobytes()); h.update(b.tobytes())
+    print(W, h.hexdigest())
+m = lib.snerf_model_create(64, 4)
+n = C.c_size_t()
+print("missing", lib.snerf_model_pack_host(m, 0, None, C.byref(n), None, None), b"missing tensor" in lib.snerf_last_error())
+''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),)
+    outs = []
+    for threads in ("1", "8"):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SNERF_PACK_THREADS=threads), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(r.stdout)
+    assert outs[0] == outs[1] and "missing -2 True" in outs[0] and len(outs[0].split()) >= 6, outs
