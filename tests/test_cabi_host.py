@@ -597,7 +597,9 @@ for W in (64, 256):
         s, b = np.zeros(ns.value, np.uint8), np.zeros(nb.value, np.float32)
         assert lib.snerf_model_pack_host(m, prog, s.ctypes.data, C.byref(ns), b.ctypes.data, C.byref(nb)) == 0
         h.update(s.tobytes()); h.update(b.tobytes())
-    print(W, h.hexdigest())
+    e = _lib.I8Estimate()
+    assert lib.snerf_model_i8_estimate(m, C.byref(e)) == 0
+    print(W, h.hexdigest(), "%.9e %.9e %d" % (e.rgb_pred, e.hidden_rms, e.acc_bound))
 m = lib.snerf_model_create(64, 4)
 n = C.c_size_t()
 print("missing", lib.snerf_model_pack_host(m, 0, None, C.byref(n), None, None), b"missing tensor" in lib.snerf_last_error())
@@ -607,4 +609,5 @@ print("missing", lib.snerf_model_pack_host(m, 0, None, C.byref(n), None, None), 
         r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SNERF_PACK_THREADS=threads), capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(r.stdout)
-    assert outs[0] == outs[1] and "missing -2 True" in outs[0] and len(outs[0].split()) >= 6, outs
+    # (the estimate's pass over the inputs' own error runs in layer order in both; its per-weight pass sums per row, so not a digit differs)
+    assert outs[0] == outs[1] and "missing -2 True" in outs[0] and len(outs[0].split()) >= 12, outs
