@@ -599,7 +599,7 @@ for W in (64, 256):
         h.update(s.tobytes()); h.update(b.tobytes())
     e = _lib.I8Estimate()
     assert lib.snerf_model_i8_estimate(m, C.byref(e)) == 0
-    print(W, h.hexdigest(), "%.9e %.9e %d" % (e.rgb_pred, e.hidden_rms, e.acc_bound))
+    print(W, h.hexdigest(), "%%.9e %%.9e %%d" %% (e.rgb_pred, e.hidden_rms, e.acc_bound))
 m = lib.snerf_model_create(64, 4)
 n = C.c_size_t()
 print("missing", lib.snerf_model_pack_host(m, 0, None, C.byref(n), None, None), b"missing tensor" in lib.snerf_last_error())
