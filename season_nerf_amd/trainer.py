@@ -248,7 +248,6 @@ class GraphedTrainStep:
     def _torch_adam_capturable(opt, dev):
         """torch.optim.Adam -> its capturable form in place: learning rate and step counts as device tensors (what `capturable=True` would have
         built), moments untouched.  Eager steps keep working afterwards."""
-        # (every value is written by a KERNEL - torch.full, clone - not by the copy engine: the first reader is a kernel node of the graph, see DESIGN 5.4c)
         for g in opt.param_groups:
             g["capturable"] = True
             if not torch.is_tensor(g["lr"]):
