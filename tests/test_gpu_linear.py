@@ -34,7 +34,9 @@ FWD = [  # M, K (n_in), N (n_out), lda, ldc
     (1, 16, 16, 16, 16), (65, 7, 5, 7, 5),
     # gemm_areg_kernel (csrc/gemm_areg.hip: accumulators in AGPRs, A and weights streamed; N = 256 / 512, K in 16-k steps, their number a multiple of 4):
     # whole and ragged row tiles, padded leading dimensions, 8 / 4 k-steps of A in flight (K / 16 a multiple of 8 or only of 4), more rows than one CU takes
-    (1177, 512, 256, 516, 260), (3001, 320, 256, 320, 256), (2049, 576, 512, 576, 512), (640, 256, 512, 256, 512), (40000, 512, 512, 512, 512), (129, 128, 512, 132, 512)]
+    (1177, 512, 256, 516, 260), (3001, 320, 256, 320, 256), (2049, 576, 512, 576, 512), (640, 256, 512, 256, 512), (40000, 512, 512, 512, 512), (129, 128, 512, 132, 512),
+    # the two-waves-per-SIMD form (N = 512): fewer rows than a wave pair shares, one row, exactly one tile
+    (1, 512, 512, 512, 512), (17, 256, 512, 256, 516), (128, 512, 512, 512, 512)]
 
 
 @pytest.mark.parametrize("precision", [1, 0])
@@ -121,7 +123,7 @@ def test_linear_argument_errors():
 ACT = [  # M, K, N, lda, act_cols   (In5-like concat input: transformed leading columns + raw tail; thin head; K = 128)
     (1300, 319, 256, 320, 256), (2048, 256, 256, 256, 256), (777, 128, 3, 128, 128), (1025, 156, 128, 156, 128), (64, 16, 16, 16, 8),
     # gemm_areg_kernel: table over all of K, and over the leading 512 of 576 columns (the [h | PE] concat input of fc5 at the reference's default width)
-    (1300, 512, 512, 512, 512), (3333, 576, 512, 576, 512), (900, 320, 256, 320, 256), (700, 256, 512, 260, 256)]
+    (1300, 512, 512, 512, 512), (3333, 576, 512, 576, 512), (900, 320, 256, 320, 256), (700, 256, 512, 260, 256), (15, 512, 512, 512, 512), (1, 256, 512, 256, 256)]
 
 
 @pytest.mark.parametrize("shape", ACT)
