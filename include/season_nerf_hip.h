@@ -49,8 +49,10 @@ int snerf_model_classes(const snerf_model* m);
 
 /* Arithmetic of the fused per-point (field) network; set before snerf_model_finalize.  The reference computes in fp32
  * (plain torch, T_NeRF_net_v2.py:75-105); the north-star bar is 1e-4 relative on RGB / depth against it.
- *   SNERF_PREC_BF16X3  3-term error-compensated bf16 MFMA products, fp32 accumulate: RGB ~3e-6, per-sample outputs ~1e-5 (C-ABI default)
- *   SNERF_PREC_BF16    one bf16 MFMA per product (first layer keeps 3 terms): RGB 2-3e-3 - outside the bar, "fast" mode
+ *   SNERF_PREC_BF16X3  3-term error-compensated bf16 MFMA products, fp32 accumulate: RGB ~3e-6, per-sample outputs ~1e-5 (C-ABI default);
+ *                      widths 64 / 256: one wave per 32 points (csrc/kernels.hip); width 512, the reference's default (main_lite.py:80):
+ *                      every layer's K split over a pair of waves (csrc/kernels_ks.hip)
+ *   SNERF_PREC_BF16    one bf16 MFMA per product (first layer keeps 3 terms): RGB 2-3e-3 - outside the bar, "fast" mode (widths 64 / 256)
  *   SNERF_PREC_I8X3    16-bit fixed point in two int8 digits on the int8 MFMA pipe, exact integer accumulation:
  *                      RGB ~2e-5, per-sample outputs ~1e-4; any input range (the raw coordinates of the encodings enter in fp32)
  *   SNERF_PREC_AUTO    SNERF_PREC_I8X3 where the packed weights clear its pack-time error bound (snerf_model_i8_estimate),
@@ -86,14 +88,14 @@ typedef struct snerf_i8_estimate {
 } snerf_i8_estimate;
 int snerf_model_i8_estimate(snerf_model* m, snerf_i8_estimate* out);
 /* Packs on the host if that has not happened yet and returns the precision the model runs in (SNERF_PREC_AUTO resolved),
- * or a negative SNERF_E_* code.  SNERF_E_INVALID with width 512 means: the int8 bound failed and no other fused kernel
- * exists at that width (the host falls back to the layer-wise engine). */
+ * or a negative SNERF_E_* code (SNERF_E_INVALID: the mode asked for has no kernel at this width - SNERF_PREC_BF16 at 512). */
 int snerf_model_resolve_precision(snerf_model* m);
 
 /* Host-only packing (no GPU): sizes and bytes of the packed programs, for tests and offline tooling.
  * program 0 = per-point field network, 1 = per-group (time/sun) network (bf16 hi/lo fragment pairs + bias table);
  * program 2 = the field network in the int8-digit format (T/L digit fragment pairs + per-row [scale | bias] tables),
- * only under SNERF_PREC_I8X3.  Buffers may be NULL to query sizes. */
+ * only under SNERF_PREC_I8X3; program 3 = the field network's bf16 pairs in the K-split order of the width-512 kernel
+ * (csrc/program.h ks_*: a permutation of program 0's pairs, same bias table), width 512 only.  Buffers may be NULL to query sizes. */
 int snerf_model_pack_host(snerf_model* m, int program, uint8_t* stream_out, size_t* stream_bytes,
                           float* bias_out, size_t* bias_floats);
 

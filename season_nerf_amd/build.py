@@ -14,14 +14,15 @@ REPO = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(REPO, "build", "obj")
 LIB = os.path.join(HERE, "libseason_nerf_hip.so")
-SOURCES = ["kernels.hip", "kernels_i8.hip", "kernels_i8x2.hip", "kernels_i8_w512.hip", "api.cpp", "pack.cpp", "gemm.hip", "gemm16.hip", "gemm_areg.hip", "train_kernels.hip", "train.cpp", "dsm.hip"]
-HEADERS = ["gemm_common.h", "kernels.h", "mlp_device.h", "mlp_i8_device.h", "pack.h", "program.h", "train.h", os.path.join("..", "..", "include", "season_nerf_hip.h")]
+SOURCES = ["kernels.hip", "kernels_i8.hip", "kernels_i8x2.hip", "kernels_i8_w512.hip", "kernels_ks.hip", "api.cpp", "pack.cpp", "gemm.hip", "gemm16.hip", "gemm_areg.hip", "train_kernels.hip", "train.cpp", "dsm.hip"]
+HEADERS = ["gemm_common.h", "kernels.h", "mlp_device.h", "mlp_bf16_device.h", "mlp_i8_device.h", "pack.h", "program.h", "train.h", os.path.join("..", "..", "include", "season_nerf_hip.h")]
 FLAGS = ["-std=c++17", "-O3", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off",
          "-mllvm", "-amdgpu-mfma-vgpr-form=1",    # MFMA accumulators in VGPRs: no v_accvgpr_read per epilogue element
          "-Wno-unused-command-line-argument"]
 
 
 EXTRA = {"kernels_i8_w512.hip": ["-mllvm", "-pragma-unroll-threshold=1000000"],      # per-source flags
+         "kernels_ks.hip": ["-mllvm", "-pragma-unroll-threshold=1000000"],           # (a 512 -> 512 layer is 256 pairs per wave, fully unrolled)
          "gemm_areg.hip": ["-mllvm", "-pragma-unroll-threshold=1000000"]}           # (its 32 k-steps per n-tile must unroll: register numbers are immediates)
 INCLUDED = {"kernels_i8_w512.hip": ["kernels_i8.hip"]}                               # sources a source #includes
 

@@ -40,6 +40,7 @@ struct snerf_model {
     bool finalized = false;
     Packed host[2];
     Packed host_i8;                  // field program in the int8-digit format (precision SNERF_PREC_I8X3 only)
+    Packed host_ks;                  // field program in the K-split order of kernels_ks.hip (W = 512 under SNERF_PREC_BF16X3)
     // Widths without a bf16 group kernel (512): the per-ray networks (time -> class softmax, sun -> sky colour: one row per ray,
     // 1/S of the field network's work) run layer by layer in exact fp32 (v_mfma_f32_32x32x2_f32, csrc/gemm.hip) - their error is
     // not averaged over a ray's samples, so they get the full precision.  Device copy of the five layers' fp32 weights:
@@ -49,6 +50,8 @@ struct snerf_model {
     float* d_bias[2] = {nullptr, nullptr};
     uint8_t* d_stream_i8 = nullptr;
     float* d_table_i8 = nullptr;
+    uint8_t* d_stream_ks = nullptr;
+    float* d_bias_ks = nullptr;
     int n_cu = 0;
 };
 
@@ -60,7 +63,7 @@ int snerf_abi_version(void) { return 8; }
 snerf_model* snerf_model_create(int layer_width, int n_classes) {
     if (layer_width != 64 && layer_width != 256 && layer_width != 512) {
         fail(SNERF_E_INVALID, "layer_width " + std::to_string(layer_width) +
-                                  " has no compiled kernel (built widths: 64, 256; 512 under SNERF_PREC_I8X3)");
+                                  " has no compiled kernel (built widths: 64, 256, 512)");
         return nullptr;
     }
     if (n_classes < 1 || n_classes > kMaxClasses) {
@@ -126,6 +129,7 @@ int snerf_model_set_tensor(snerf_model* m, const char* key, const float* host_da
 }
 
 static bool bf16_width(int W) { return W == 64 || W == 256; }     // widths the bf16 kernels (kernels.hip) are instantiated for
+static bool ks_width(int W) { return W == 512; }                  // ... the K-split bf16x3 field kernel (kernels_ks.hip): the reference's default width
 
 static int pack_both(snerf_model* m, bool want_bf16_field = false) {
     if (!m->resolved) {          // SNERF_PREC_AUTO: int8 digits where their error bound holds for these weights
@@ -143,8 +147,16 @@ static int pack_both(snerf_model* m, bool want_bf16_field = false) {
             return fail(SNERF_E_INVALID, "SNERF_PREC_I8X3: a weight row of this model can overflow the int32 accumulators (bound " +
                                              std::to_string((long long)e.acc_bound) + " >= 2^31); use SNERF_PREC_AUTO or SNERF_PREC_BF16X3");
     }
-    if (!bf16_width(m->W) && m->precision != SNERF_PREC_I8X3)
-        return fail(SNERF_E_INVALID, "layer_width " + std::to_string(m->W) + " has a fused kernel only under SNERF_PREC_I8X3");
+    if (!bf16_width(m->W) && m->precision != SNERF_PREC_I8X3 && !(ks_width(m->W) && m->precision == SNERF_PREC_BF16X3))
+        return fail(SNERF_E_INVALID, "layer_width " + std::to_string(m->W) + " has fused kernels only under SNERF_PREC_I8X3 and SNERF_PREC_BF16X3");
+    if (ks_width(m->W) && (m->precision == SNERF_PREC_BF16X3 || want_bf16_field) && (m->host_ks.stream.empty() || (want_bf16_field && m->host[PROG_FIELD].stream.empty()))) {
+        std::string err;
+        Packed tmp, ks;
+        if (!pack_program(m->w, PROG_FIELD, m->W, m->C, /*fold_bn=*/true, &tmp, &err) || !permute_program_ks(tmp, m->W, m->C, &ks, &err))
+            return fail(err.rfind("missing", 0) == 0 ? SNERF_E_MISSING : SNERF_E_INVALID, err);
+        m->host_ks = std::move(ks);
+        if (want_bf16_field) m->host[PROG_FIELD] = std::move(tmp);      // the canonical order, on request only (snerf_model_pack_host)
+    }
     for (int p = 0; p < 2; ++p) {
         if (!bf16_width(m->W)) break;
         if (!m->host[p].stream.empty()) continue;
@@ -174,12 +186,14 @@ int snerf_model_resolve_precision(snerf_model* m) {
 
 int snerf_model_pack_host(snerf_model* m, int program, uint8_t* stream_out, size_t* stream_bytes, float* bias_out,
                           size_t* bias_floats) {
-    if (!m || program < 0 || program > 2) return fail(SNERF_E_INVALID, "snerf_model_pack_host: bad argument");
+    if (!m || program < 0 || program > 3) return fail(SNERF_E_INVALID, "snerf_model_pack_host: bad argument");
     if (program == 2 && m->precision != SNERF_PREC_I8X3)
         return fail(SNERF_E_STATE, "program 2 (int8-digit field network) exists only under SNERF_PREC_I8X3");
-    int rc = pack_both(m, program == PROG_FIELD);
+    if (program == 3 && !ks_width(m->W)) return fail(SNERF_E_STATE, "program 3 (K-split bf16 field network) exists only at width 512");
+    if (program == PROG_GROUP && !bf16_width(m->W)) return fail(SNERF_E_STATE, "the per-ray networks have no packed program at this width (they run layer by layer in fp32)");
+    int rc = pack_both(m, program == PROG_FIELD || program == 3);
     if (rc) return rc;
-    const Packed& P = program == 2 ? m->host_i8 : m->host[program];
+    const Packed& P = program == 3 ? m->host_ks : program == 2 ? m->host_i8 : m->host[program];
     if (stream_bytes) *stream_bytes = P.stream.size();
     if (bias_floats) *bias_floats = P.bias.size();
     if (stream_out) std::memcpy(stream_out, P.stream.data(), P.stream.size());
@@ -201,9 +215,16 @@ int snerf_model_finalize(snerf_model* m) {
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(SNERF_E_HIP, std::string("this library is built for gfx950 only, device is ") + prop.gcnArchName);
     m->n_cu = prop.multiProcessorCount;
+    if (m->precision == SNERF_PREC_BF16X3 && ks_width(m->W)) {
+        const Packed& P = m->host_ks;
+        if ((e = hipMalloc((void**)&m->d_stream_ks, P.stream.size())) != hipSuccess) return fail_hip(e, "hipMalloc");
+        if ((e = hipMalloc((void**)&m->d_bias_ks, P.bias.size() * 4)) != hipSuccess) return fail_hip(e, "hipMalloc");
+        if ((e = hipMemcpy(m->d_stream_ks, P.stream.data(), P.stream.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail_hip(e, "hipMemcpy");
+        if ((e = hipMemcpy(m->d_bias_ks, P.bias.data(), P.bias.size() * 4, hipMemcpyHostToDevice)) != hipSuccess) return fail_hip(e, "hipMemcpy");
+    }
     for (int p = 0; p < 2; ++p) {
         const Packed& P = m->host[p];
-        if (P.stream.empty()) continue;
+        if (P.stream.empty() || !bf16_width(m->W)) continue;
         if ((e = hipMalloc((void**)&m->d_stream[p], P.stream.size())) != hipSuccess) return fail_hip(e, "hipMalloc");
         if ((e = hipMalloc((void**)&m->d_bias[p], P.bias.size() * 4)) != hipSuccess) return fail_hip(e, "hipMalloc");
         if ((e = hipMemcpy(m->d_stream[p], P.stream.data(), P.stream.size(), hipMemcpyHostToDevice)) != hipSuccess)
@@ -254,6 +275,8 @@ void snerf_model_destroy(snerf_model* m) {
     }
     if (m->d_stream_i8) (void)hipFree(m->d_stream_i8);
     if (m->d_table_i8) (void)hipFree(m->d_table_i8);
+    if (m->d_stream_ks) (void)hipFree(m->d_stream_ks);
+    if (m->d_bias_ks) (void)hipFree(m->d_bias_ks);
     if (m->d_group_f32) (void)hipFree(m->d_group_f32);
     delete m;
 }
@@ -335,7 +358,9 @@ int snerf_group_forward(const snerf_model* m, int64_t n_groups, const float* d_t
 }
 
 static int field_launch(const snerf_model* m, int variant, MlpArgs& a, const snerf_field_out* out, void* stream) {
-    if (variant < 0 || variant > 3) return fail(SNERF_E_INVALID, "variant must be 0, 1 or 2");
+    // variant 3 (ray visibility) is reachable through snerf_field_ray_visibility only, which sets everything the RaySum epilogue dereferences
+    if (variant < 0 || variant > 3 || (variant == 3 && !(a.out.vis && a.top && a.bot && a.tvals && !a.points)))
+        return fail(SNERF_E_INVALID, "variant must be 0, 1 or 2 (3, ray visibility, only through snerf_field_ray_visibility)");
     if (variant == 3 && m->precision == SNERF_PREC_BF16) return fail(SNERF_E_INVALID, "ray visibility: not available in the bf16 fast mode");
     a.stream = m->d_stream[PROG_FIELD];
     a.stream_bytes = (uint32_t)field_variant_chunks(m->W, m->C, variant) * kChunkBytes;
@@ -361,6 +386,12 @@ static int field_launch(const snerf_model* m, int variant, MlpArgs& a, const sne
         static const bool one_wave = getenv("SNERF_I8_ONE_WAVE") != nullptr;
         if (m->W <= 256 && !one_wave) e = launch_mlp_i8x2(m->W, variant, a, m->n_cu, (hipStream_t)stream);
         else e = launch_mlp_i8(PROG_FIELD, m->W, variant, a, m->n_cu, (hipStream_t)stream);
+    } else if (ks_width(m->W)) {
+        a.stream = m->d_stream_ks;
+        a.stream_bytes = (uint32_t)field_variant_chunks_ks(m->W, m->C, variant) * kChunkBytes;
+        a.bias = m->d_bias_ks;
+        a.bias_floats = (int)m->host_ks.bias.size();
+        e = launch_mlp_ks(m->W, variant, a, m->n_cu, (hipStream_t)stream);
     } else {
         e = launch_mlp(PROG_FIELD, m->W, variant, m->precision == SNERF_PREC_BF16, a, m->n_cu, (hipStream_t)stream);
     }
@@ -591,13 +622,15 @@ int snerf_field_kernel_info(const snerf_model* m, int64_t n_points, int* grid, i
     const bool i8 = m->precision == SNERF_PREC_I8X3;
     static const bool one_wave = getenv("SNERF_I8_ONE_WAVE") != nullptr;         // the A/B switch field_launch honours
     const bool two_waves = i8 && m->W <= 256 && !one_wave;    // kernels_i8x2.hip: 512 threads, 256 points per tile
-    const int tile = two_waves ? 256 : mlp_tile_points();
+    const bool ks = !i8 && ks_width(m->W);                    // kernels_ks.hip: 64 points per tile (two wave pairs)
+    const int tile = two_waves ? 256 : ks ? mlp_ks_tile_points() : mlp_tile_points();
     const int64_t tiles = (n_points + tile - 1) / tile;
     const int ncu = m->n_cu ? m->n_cu : 256;
     if (grid) *grid = (int)(tiles < ncu ? tiles : ncu);
     if (block) *block = two_waves ? 512 : 256;
     if (lds_bytes) {
         if (i8) *lds_bytes = (m->W > 256 ? 5 : 7) * kChunkBytes + (int)m->host_i8.bias.size() * 4;
+        else if (ks) *lds_bytes = mlp_ks_lds_bytes((int)m->host_ks.bias.size());
         else *lds_bytes = mlp_lds_bytes((int)m->host[PROG_FIELD].bias.size());
     }
     return SNERF_OK;

@@ -102,6 +102,10 @@ hipError_t launch_mlp(int prog, int W, int variant, bool fast, const MlpArgs& a,
 hipError_t launch_mlp_i8(int prog, int W, int variant, const MlpArgs& a, int n_cu, hipStream_t st);      // kernels_i8.hip
 int field_variant_chunks_i8(int W, int C, int variant);
 hipError_t launch_mlp_i8x2(int W, int variant, const MlpArgs& a, int n_cu, hipStream_t st);                // kernels_i8x2.hip (W <= 256)
+hipError_t launch_mlp_ks(int W, int variant, const MlpArgs& a, int n_cu, hipStream_t st);                // kernels_ks.hip (W = 512, bf16x3, K split over wave pairs)
+int field_variant_chunks_ks(int W, int C, int variant);
+int mlp_ks_lds_bytes(int bias_floats);
+int mlp_ks_tile_points();
 hipError_t launch_composite(const CompArgs& a, hipStream_t st);
 // dsm.hip
 hipError_t launch_prior_density(int64_t n, const float* pts, const float* delta, const double* hm, int hx, int hy, const float* outside,

@@ -1,0 +1,377 @@
+// Fused bf16x3 field kernel of the reference's DEFAULT width (main_lite.py:80, opt2.py:79: fc_units = 512): the chain of kernels.hip with the
+// K dimension of every layer split over a PAIR of waves (round 6).
+//
+// Why a second structure.  At W = 512 the activations of 32 points are 2 x 256 registers per lane (input + output of a 512 -> 512 layer as bf16
+// hi / lo fragments): more than a wave owns.  Here two waves (on two SIMDs) share 32 points.  Wave `a` (0 / 1) of a pair
+//   * holds the K-half `a` of every hidden activation (features [256 a, 256 a + 256): 16 k-steps = 128 registers, as a W = 256 wave does),
+//   * OWNS the output blocks a*NBH .. a*NBH + NBH - 1 of every layer (they are exactly its K-half of the next layer),
+//   * multiplies its K-half against ALL output blocks: an "F" phase (a block the partner owns: the fp32 partial sums go to the partner through
+//     4 KiB of LDS) and an "O" phase (a block it owns: the partner's partial sums are added in front of the bias / sin / split epilogue).
+// Both waves walk F(i), O(i), i = 0 .. NBH-1 in step: while one forms the partial sums of block i for its partner, the partner forms the partial
+// sums of block NBH + i for it.  The exchange needs no synchronisation of its own - it is ordered by the weight ring's barriers: a partial
+// written in the first k-steps of an O phase is read by the partner in the first k-step of its NEXT F phase, >= 2 ring steps later, and
+// overwritten one phase after that.  The encodings (PE(pos) of fc1 / fc5, PE(sun) of fc_solar_1) enter on the OWN blocks only, in full, so the
+// first layer needs no exchange at all.  The raw heads (one block) are symmetric: both waves add the partner's half and both hold the result.
+// Epilogue work (sin + split) exists in every second phase only: per MFMA half the vector work of the W = 256 kernel.
+//
+// Weight stream (pack.cpp pack_program_ks): the pairs of the canonical bf16 stream in the order each wave consumes them, a 16 KiB chunk =
+// 4 pairs for parity 0 | 4 pairs for parity 1; every chunk is read by two waves (one per pair), i.e. the L2 -> LDS stream per point is twice
+// the W = 256 kernel's (64 points share a chunk, not 128) - the price of the width; the ring (7 slots, 5 in flight) is unchanged.
+#include "mlp_bf16_device.h"
+
+namespace snerf {
+
+constexpr int KS_TILE_PTS = 64;                       // points per workgroup tile: 2 wave pairs x 32
+constexpr int KS_PAR_PAIRS = 4;                       // pairs per parity and chunk
+constexpr int KS_PAR_BYTES = KS_PAR_PAIRS * kPairBytes;   // 8 KiB
+constexpr int KS_XBUF_BYTES = 4096;                   // one 32 x 32 fp32 block of partial sums
+static_assert(kChunkPairs == 2 * KS_PAR_PAIRS, "a chunk holds 4 pairs per parity");
+
+// LDS: ring | bias table | 32 zero floats (bias of the partner's half of a raw head) | 4 exchange buffers (pair, parity)
+__host__ __device__ constexpr int ks_lds_bytes(int bias_floats) { return RING_BYTES + (bias_floats + 32) * 4 + 4 * KS_XBUF_BYTES; }
+
+struct KsCtx {
+    lds_char* lds;            // ring base
+    uint32_t par_off;         // a * 8 KiB: this wave's half of every chunk
+    lds_char* xw;             // exchange buffer this wave writes (read by the partner)
+    lds_char* xr;             // ... the partner writes
+};
+
+__device__ __forceinline__ void xbuf_write(lds_char* xw, const f32x16& v, int lane) {
+    __attribute__((address_space(3))) f32x4* p = (__attribute__((address_space(3))) f32x4*)(xw + lane * 16);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) p[q * 64] = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+}
+__device__ __forceinline__ f32x16 xbuf_read(lds_char* xr, int lane) {
+    lds_cf32x4* p = (lds_cf32x4*)(xr + lane * 16);
+    f32x16 v;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 t = p[q * 64];
+        v[4 * q] = t[0]; v[4 * q + 1] = t[1]; v[4 * q + 2] = t[2]; v[4 * q + 3] = t[3];
+    }
+    return v;
+}
+// phase A of the epilogue with the partner's partial sums added in front of the sine
+__device__ __forceinline__ void epi_A2(const f32x16& acc, const f32x16& part, int e, EpiTmp& t) {
+    t.v0 = sin2pi(acc[2 * e] + part[2 * e]);
+    t.v1 = sin2pi(acc[2 * e + 1] + part[2 * e + 1]);
+}
+
+// One layer over a wave pair.  NBH own (= foreign) blocks per wave, KSH k-steps of this wave's K-half of the hidden input (0: none - the layer
+// reads an encoding only and needs no exchange), KSX k-steps of an encoding that enter the own blocks in full.  bias_own: bias rows of the own blocks.
+template <int NBH, int KSH, int KSX>
+__device__ __forceinline__ void run_layer_ks(Ring& rg, const uint8_t* stream, uint32_t stream_bytes, const KsCtx& cx, lds_cfloat* bias_own,
+                                             const Frag* in0, const Frag* in1, Frag* out, int wave, int lane) {
+    constexpr bool EX = KSH > 0;
+    constexpr int KO = KSH + KSX;                  // k-steps of an O phase
+    constexpr int SL = (EX ? KSH : 0) + KO;        // pairs per step (F + O)
+    constexpr int NP = NBH * SL;
+    static_assert(!EX || KSH >= 8, "the exchange is ordered by >= 2 ring steps per phase");
+    static_assert(KO >= 4, "the sliced epilogue needs 4 k-steps");
+    const int h = lane >> 5;
+    u32x4 fh[PF], fl[PF];
+#pragma unroll
+    for (int q = 0; q < PF; ++q) {
+        if (q % KS_PAR_PAIRS == 0) ring_step(rg, stream, stream_bytes, cx.lds, wave, lane);
+        lds_char* ap = cx.lds + rg.cur + cx.par_off + (q % KS_PAR_PAIRS) * kPairBytes + lane * 16;
+        fh[q] = *(lds_cu32x4*)ap;
+        fl[q] = *(lds_cu32x4*)(ap + kFragBytes);
+    }
+    f32x16 accF, accO[2], part;
+    EpiTmp et[8];
+    f32x16 next_init = load_bias(bias_own, 0, h);
+    // one k-step: consume pair q, prefetch pair q + PF (ring step where it opens a chunk)
+#define KS_STEP(q, ACC, BFRAG)                                                                                          \
+    {                                                                                                                   \
+        const u32x4 a_hi = fh[(q) % PF], a_lo = fl[(q) % PF];                                                           \
+        if ((q) + PF < NP) {                                                                                            \
+            if (((q) + PF) % KS_PAR_PAIRS == 0) ring_step(rg, stream, stream_bytes, cx.lds, wave, lane);                \
+            lds_char* ap = cx.lds + rg.cur + cx.par_off + (((q) + PF) % KS_PAR_PAIRS) * kPairBytes + lane * 16;         \
+            fh[(q) % PF] = *(lds_cu32x4*)ap;                                                                            \
+            fl[(q) % PF] = *(lds_cu32x4*)(ap + kFragBytes);                                                             \
+        }                                                                                                               \
+        ACC = mfma3(a_hi, a_lo, BFRAG, ACC);                                                                            \
+    }
+#define KS_SCHED()                                                                                                      \
+    {                                                                                                                   \
+        _Pragma("unroll") for (int m = 0; m < 3; ++m) {                                                                 \
+            __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);                                                        \
+            __builtin_amdgcn_sched_group_barrier(SG_DSREAD, 1, 0);                                                      \
+            __builtin_amdgcn_sched_group_barrier(SG_TRANS, 1, 0);                                                       \
+            __builtin_amdgcn_sched_group_barrier(SG_VALU, 3, 0);                                                        \
+        }                                                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                                              \
+    }
+#pragma unroll
+    for (int i = 0; i < NBH; ++i) {
+        if constexpr (EX) {
+            // ---- F phase: partial sums of the partner's block i over this wave's K-half; the epilogue of the own block i - 1 rides along
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < KSH; ++s) {
+                const int q = i * SL + s;
+                if (i > 0 && s == 0) part = xbuf_read(cx.xr, lane);       // written by the partner in the first k-steps of its last O phase
+                KS_STEP(q, acc, in0[s]);
+                if (i > 0) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int sA = 1 + (e * (KSH - 4)) / 8;
+                        if (s == sA + 2) epi_C(e, et[e], out + 2 * (i - 1));
+                        if (s == sA + 1) epi_B(e, et[e], out + 2 * (i - 1));
+                        if (s == sA) epi_A2(accO[(i - 1) & 1], part, e, et[e]);
+                    }
+                }
+                KS_SCHED();
+            }
+            accF = acc;
+        }
+        {
+            // ---- O phase: the own block i over this wave's K-half and, in full, the encoding
+            f32x16 acc = next_init;
+#pragma unroll
+            for (int s = 0; s < KO; ++s) {
+                const int q = i * SL + (EX ? KSH : 0) + s;
+                if (EX && s == 1) xbuf_write(cx.xw, accF, lane);           // in front of this k-step's ring step (if any): see the header
+                KS_STEP(q, acc, (s < KSH ? in0[s] : in1[s - KSH]));
+                if (i + 1 < NBH && s == KO - 1) next_init = load_bias(bias_own, i + 1, h);
+                if (!EX && i > 0) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int sA = 1 + (e * (KO - 4)) / 8;
+                        if (s == sA + 2) epi_C(e, et[e], out + 2 * (i - 1));
+                        if (s == sA + 1) epi_B(e, et[e], out + 2 * (i - 1));
+                        if (s == sA) epi_A(accO[(i - 1) & 1], e, et[e]);
+                    }
+                }
+                KS_SCHED();
+            }
+            accO[i & 1] = acc;
+        }
+    }
+    // ---- the last own block: nothing left to hide its epilogue behind
+    if constexpr (EX) {
+        part = xbuf_read(cx.xr, lane);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) epi_A2(accO[(NBH - 1) & 1], part, e, et[e]);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) epi_A(accO[(NBH - 1) & 1], e, et[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) epi_B(e, et[e], out + 2 * (NBH - 1));
+#pragma unroll
+    for (int e = 0; e < 8; ++e) epi_C(e, et[e], out + 2 * (NBH - 1));
+}
+
+// A raw head (one 32-row block): each wave multiplies its K-half (parity 0 starts from the bias, parity 1 from zero), both publish their half and
+// both add the partner's - symmetric, no branch; one extra workgroup barrier per head.
+template <int KSH>
+__device__ __forceinline__ f32x16 run_head_ks(Ring& rg, const uint8_t* stream, uint32_t stream_bytes, const KsCtx& cx, lds_cfloat* bias_sel,
+                                              const Frag* in0, int wave, int lane) {
+    constexpr int NP = KSH;
+    const int h = lane >> 5;
+    u32x4 fh[PF], fl[PF];
+#pragma unroll
+    for (int q = 0; q < PF; ++q) {
+        if (q % KS_PAR_PAIRS == 0) ring_step(rg, stream, stream_bytes, cx.lds, wave, lane);
+        lds_char* ap = cx.lds + rg.cur + cx.par_off + (q % KS_PAR_PAIRS) * kPairBytes + lane * 16;
+        fh[q] = *(lds_cu32x4*)ap;
+        fl[q] = *(lds_cu32x4*)(ap + kFragBytes);
+    }
+    f32x16 acc = load_bias(bias_sel, 0, h);
+#pragma unroll
+    for (int s = 0; s < KSH; ++s) {
+        KS_STEP(s, acc, in0[s]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    xbuf_write(cx.xw, acc, lane);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    const f32x16 part = xbuf_read(cx.xr, lane);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] += part[r];
+    return acc;
+}
+#undef KS_STEP
+#undef KS_SCHED
+
+template <int W, int VARIANT>
+__global__ __launch_bounds__(256, 1) void mlp_ks_kernel(const MlpArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int C_MAX = kMaxClasses;
+    constexpr int W2 = W / 2;
+    lds_char* lds = (lds_char*)smem;
+    __attribute__((address_space(3))) float* bias_lds = (__attribute__((address_space(3))) float*)(lds + RING_BYTES);
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int pair = wave >> 1, par = wave & 1;
+    const int h = lane >> 5;
+    const int C = A.n_classes;
+
+    for (int i = threadIdx.x; i < A.bias_floats + 32; i += 256) bias_lds[i] = i < A.bias_floats ? A.bias[i] : 0.f;
+    lds_cfloat* zero_bias = bias_lds + A.bias_floats;
+    KsCtx cx;
+    cx.lds = lds;
+    cx.par_off = par * KS_PAR_BYTES;
+    {
+        lds_char* xb = lds + RING_BYTES + (A.bias_floats + 32) * 4;
+        cx.xw = xb + (pair * 2 + par) * KS_XBUF_BYTES;
+        cx.xr = xb + (pair * 2 + (par ^ 1)) * KS_XBUF_BYTES;
+    }
+
+    Ring rg;
+    rg.rd = 0;
+    rg.cur = 0;
+    rg.goff = 0;
+    {
+        uint32_t wr = 0;
+#pragma unroll
+        for (int c = 0; c < RING_D - 2; ++c) {
+            dma_chunk(A.stream, rg.goff, lds, wr, wave, lane);
+            rg.goff += kChunkBytes;
+            if (rg.goff >= A.stream_bytes) rg.goff = 0;
+            wr += kChunkBytes;
+        }
+        rg.wr = wr;
+    }
+    __syncthreads();
+
+    // VARIANT 3 (ray visibility, mlp_device.h RaySum): a "tile" is a group of 2 rays (one per wave pair), walked in `passes` steps of 32 samples
+    const int64_t n_tiles = VARIANT == 3 ? (A.n + 1) / 2 : (A.n + KS_TILE_PTS - 1) / KS_TILE_PTS;
+    const int passes = VARIANT == 3 ? (A.n_samples + 31) / 32 : 1;
+    int pass = 0;
+    RaySum rs;
+    for (int64_t tile = blockIdx.x; tile < n_tiles;) {
+        const int64_t n = tile * KS_TILE_PTS + pair * 32 + (lane & 31);
+        const bool valid = n < A.n;
+        const int64_t nc = valid ? n : A.n - 1;
+        const int64_t g = VARIANT == 3 ? 0 : nc / A.group_size;
+
+        float x0, x1, x2;
+        if constexpr (VARIANT == 3) {
+            raysum_point(rs, A, tile, 2, pair, pass, lane, x0, x1, x2);
+        } else if (A.points) {
+            x0 = A.points[nc * 3]; x1 = A.points[nc * 3 + 1]; x2 = A.points[nc * 3 + 2];
+        } else {
+            const int64_t r = nc / A.n_samples;
+            const int s = (int)(nc - r * A.n_samples);
+            const float t = A.tvals[s], omt = __fsub_rn(1.f, t);
+            x0 = __fadd_rn(__fmul_rn(A.top[r * 3], omt), __fmul_rn(A.bot[r * 3], t));
+            x1 = __fadd_rn(__fmul_rn(A.top[r * 3 + 1], omt), __fmul_rn(A.bot[r * 3 + 1], t));
+            x2 = __fadd_rn(__fmul_rn(A.top[r * 3 + 2], omt), __fmul_rn(A.bot[r * 3 + 2], t));
+        }
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+        float pcls[C_MAX];
+#pragma unroll
+        for (int c = 0; c < C_MAX; ++c) pcls[c] = 0.f;
+        if constexpr (VARIANT <= 1) { s0 = A.sun[g * 3]; s1 = A.sun[g * 3 + 1]; s2 = A.sun[g * 3 + 2]; }
+        if constexpr (VARIANT == 0) {
+            if (A.classes) {
+#pragma unroll
+                for (int c = 0; c < C_MAX; ++c) if (c < C) pcls[c] = A.classes[g * C + c];
+            }
+        }
+        Frag pe[PEPOS_KS];
+        make_pe_pos(x0, x1, x2, h, pe);
+
+        constexpr int KH = W / 32, KH2 = W2 / 32;        // k-steps of this wave's K-half of a W- / W/2-wide activation
+        constexpr int NBW = W / 64, NBW2 = W2 / 64;      // own blocks of a W- / W/2-wide layer
+        static_assert(ks_layer_pairs(field_layer(W, C_MAX, F_FC1)) == NBW * PEPOS_KS && ks_layer_pairs(field_layer(W, C_MAX, F_FC2)) == NBW * 2 * KH &&
+                      ks_layer_pairs(field_layer(W, C_MAX, F_FC5)) == NBW * (2 * KH + PEPOS_KS) && ks_layer_pairs(field_layer(W, C_MAX, F_FC9)) == NBW2 * 2 * KH &&
+                      ks_layer_pairs(field_layer(W, C_MAX, F_HEAD)) == KH2 && ks_layer_pairs(field_layer(W, C_MAX, F_S1)) == NBW2 * (2 * KH2 + PESUN_KS) &&
+                      ks_layer_pairs(field_layer(W, C_MAX, F_S2)) == NBW2 * 2 * KH2 && ks_layer_pairs(field_layer(W, C_MAX, F_A1)) == NBW * 2 * KH2 &&
+                      ks_layer_pairs(field_layer(W, C_MAX, F_AC)) == KH, "kernel and packer (program.h ks_*) disagree about the stream");
+        Frag hA[KH], hB[KH];
+        // bias rows of this wave's own blocks of layer L (n_out = 64 NBH)
+#define OWNB(L, NBH) (bias_lds + prog_bias_start(PROG_FIELD, W, C_MAX, L) + par * (NBH) * 32)
+#define LAYER(L, NBH, KSHv, KSXv, IN0, IN1, OUT) run_layer_ks<NBH, KSHv, KSXv>(rg, A.stream, A.stream_bytes, cx, OWNB(L, NBH), IN0, IN1, OUT, wave, lane)
+#define HEADL(L, KSHv, IN0) run_head_ks<KSHv>(rg, A.stream, A.stream_bytes, cx, par ? zero_bias : bias_lds + prog_bias_start(PROG_FIELD, W, C_MAX, L), IN0, wave, lane)
+        LAYER(F_FC1, NBW, 0, PEPOS_KS, nullptr, pe, hA);
+        LAYER(F_FC2, NBW, KH, 0, hA, nullptr, hB);
+        LAYER(F_FC3, NBW, KH, 0, hB, nullptr, hA);
+        LAYER(F_FC4, NBW, KH, 0, hA, nullptr, hB);
+        LAYER(F_FC5, NBW, KH, PEPOS_KS, hB, pe, hA);
+        LAYER(F_FC6, NBW, KH, 0, hA, nullptr, hB);
+        LAYER(F_FC7, NBW, KH, 0, hB, nullptr, hA);
+        LAYER(F_FC8, NBW, KH, 0, hA, nullptr, hB);
+        Frag x1f[KH2];
+        LAYER(F_FC9, NBW2, KH, 0, hB, nullptr, x1f);
+        f32x16 raw = HEADL(F_HEAD, KH2, x1f);
+        const float col_r = raw[0], col_g = raw[1], col_b = raw[2], rho_raw = raw[3];
+        float sv_raw = 0.f;
+        float adj[3 * C_MAX];
+#pragma unroll
+        for (int i = 0; i < 3 * C_MAX; ++i) adj[i] = 0.f;
+        if constexpr (VARIANT <= 1) {
+            Frag ps[PESUN_KS];
+            make_pe_sun(s0, s1, s2, h, ps);
+            Frag sA[KH2], sB[KH2];
+            LAYER(F_S1, NBW2, KH2, PESUN_KS, x1f, ps, sA);
+            LAYER(F_S2, NBW2, KH2, 0, sA, nullptr, sB);
+            LAYER(F_S3, NBW2, KH2, 0, sB, nullptr, sA);
+            raw = HEADL(F_S4, KH2, sA);
+            sv_raw = raw[0];
+        }
+        if constexpr (VARIANT == 0) {
+            LAYER(F_A1, NBW, KH2, 0, x1f, nullptr, hA);
+            LAYER(F_A2, NBW, KH, 0, hA, nullptr, hB);
+            LAYER(F_A3, NBW, KH, 0, hB, nullptr, hA);
+            raw = HEADL(F_AC, KH, hA);
+#pragma unroll
+            for (int i = 0; i < 3 * C_MAX; ++i) adj[i] = raw[i];
+        }
+#undef LAYER
+#undef HEADL
+#undef OWNB
+        if constexpr (VARIANT == 3) {
+            raysum_add(rs, A, tile, 2, pair, pass, lane, rho_raw, x0, x1, x2);
+            if (++pass == passes) {
+                if (par == 0) raysum_end(rs, A, tile, 2, pair, lane);
+                pass = 0;
+                tile += gridDim.x;
+            }
+        } else {
+            if (par == 0 && h == 0 && valid) store_field_outputs<VARIANT>(A.out, n, C, x0, x1, x2, col_r, col_g, col_b, rho_raw, sv_raw, adj, pcls);
+            tile += gridDim.x;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup
+}
+
+template <int W, int VARIANT>
+static hipError_t launch_ks_t(const MlpArgs& a, int n_cu, hipStream_t st) {
+    const int lds_bytes = ks_lds_bytes(a.bias_floats);
+    if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
+    const int64_t n_tiles = VARIANT == 3 ? (a.n + 1) / 2 : (a.n + KS_TILE_PTS - 1) / KS_TILE_PTS;
+    int grid = (int)(n_tiles < n_cu ? n_tiles : n_cu);
+    if (grid < 1) grid = 1;
+    auto k = mlp_ks_kernel<W, VARIANT>;
+    hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds_bytes, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_mlp_ks(int W, int variant, const MlpArgs& a, int n_cu, hipStream_t st) {
+    if (W != 512) return hipErrorInvalidValue;
+    switch (variant) {
+        case 0: return launch_ks_t<512, 0>(a, n_cu, st);
+        case 1: return launch_ks_t<512, 1>(a, n_cu, st);
+        case 2: return launch_ks_t<512, 2>(a, n_cu, st);
+        case 3: return launch_ks_t<512, 3>(a, n_cu, st);
+    }
+    return hipErrorInvalidValue;
+}
+
+// chunks consumed per tile by a variant (the DMA stream is cyclic over exactly these); variant 3 = the layers of variant 2
+int field_variant_chunks_ks(int W, int C, int variant) {
+    const int last = variant == 0 ? (int)F_NUM : variant == 1 ? (int)F_A1 : (int)F_S1;
+    return ks_chunk_start(W, C, last);
+}
+int mlp_ks_lds_bytes(int bias_floats) { return ks_lds_bytes(bias_floats); }
+int mlp_ks_tile_points() { return KS_TILE_PTS; }
+
+}  // namespace snerf

@@ -225,6 +225,27 @@ bool pack_program(const Weights& w, int prog, int W, int C, bool fold_bn, Packed
     });
 }
 
+// ---- K-split order (program.h ks_*): what the wave pairs of kernels_ks.hip consume ---------------------------------------------
+bool permute_program_ks(const Packed& canon, int W, int C, Packed* out, std::string* err) {
+    if (W % 128 != 0) { *err = "the K-split kernel needs a width that is a multiple of 128 (got " + std::to_string(W) + ")"; return false; }
+    if (canon.stream.size() != (size_t)prog_chunks(PROG_FIELD, W, C) * kChunkBytes) { *err = "permute_program_ks: not a packed field program of this width"; return false; }
+    out->bias = canon.bias;
+    out->stream.assign((size_t)ks_chunk_start(W, C, F_NUM) * kChunkBytes, 0);
+    for (int l = 0; l < F_NUM; ++l) {
+        const LayerShape s = field_layer(W, C, l);
+        const uint8_t* src = canon.stream.data() + (size_t)prog_chunk_start(PROG_FIELD, W, C, l) * kChunkBytes;
+        uint8_t* dst = out->stream.data() + (size_t)ks_chunk_start(W, C, l) * kChunkBytes;
+        const int np = ks_layer_pairs(s);
+        for (int a = 0; a < 2; ++a)
+            for (int q = 0; q < np; ++q) {
+                const int sp = ks_pair_source(s, a, q), b = sp / 4096, ks = sp % 4096;
+                std::memcpy(dst + (size_t)(q / kKsParPairs) * kChunkBytes + (size_t)a * kKsParPairs * kPairBytes + (size_t)(q % kKsParPairs) * kPairBytes,
+                            src + (size_t)(b * s.ks() + ks) * kPairBytes, kPairBytes);
+            }
+    }
+    return true;
+}
+
 // ---- int8-digit format (program.h, FMT_I8) ----------------------------------------------------------------
 // Row n of a folded layer becomes s_n * (256 T + L): wq = round(w / s_n), s_n = max_k |w| / 32512, balanced digits
 // T = floor((wq + 128) / 256), L = wq - 256 T, both in [-128,127].  The activations arrive as q = 256 a + b + 128

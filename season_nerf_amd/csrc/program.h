@@ -139,6 +139,31 @@ __host__ __device__ constexpr int prog_table_start(int prog, int W, int C, int l
 }
 __host__ __device__ constexpr int prog_table_floats(int prog, int W, int C) { return prog_table_start(prog, W, C, prog_layers(prog)); }
 
+// ---- K-split stream of the field program (kernels_ks.hip, W = 512 bf16x3): the pairs of the bf16 stream in the order the two waves of a pair
+// consume them.  Per parity a layer is a sequence of pairs: a raw head ks0/2 of them (its K-half); a hidden layer NBH = nb/2 steps of
+// [F: ks0/2 pairs of the partner's block over the own K-half | O: ks0/2 + ks1 pairs of the own block: own K-half, then the encoding in full];
+// an encoding-only layer (fc1) NBH steps of ks0 pairs (own blocks).  A 16 KiB chunk holds 4 pairs of parity 0, then 4 pairs of parity 1.
+constexpr int kKsParPairs = kChunkPairs / 2;
+__host__ __device__ constexpr int ks_layer_pairs(const LayerShape& s) {       // pairs per parity
+    return s.out_kind == OUT_RAW ? s.ks0 / 2 : s.kind0 == IN_H ? (s.nb() / 2) * (s.ks0 + s.ks1) : (s.nb() / 2) * s.ks0;
+}
+__host__ __device__ constexpr int ks_layer_chunks(const LayerShape& s) { return (ks_layer_pairs(s) + kKsParPairs - 1) / kKsParPairs; }
+__host__ __device__ constexpr int ks_chunk_start(int W, int C, int l) {
+    int c = 0;
+    for (int i = 0; i < l; ++i) c += ks_layer_chunks(field_layer(W, C, i));
+    return c;
+}
+// canonical pair (block, k-step) behind pair q of parity a of a layer; returns block * 4096 + k-step
+__host__ __device__ constexpr int ks_pair_source(const LayerShape& s, int a, int q) {
+    if (s.out_kind == OUT_RAW) return a * (s.ks0 / 2) + q;
+    const int nbh = s.nb() / 2;
+    if (s.kind0 != IN_H) return (a * nbh + q / s.ks0) * 4096 + q % s.ks0;
+    const int ksh = s.ks0 / 2, sl = s.ks0 + s.ks1, i = q / sl, r = q % sl;
+    if (r < ksh) return ((1 - a) * nbh + i) * 4096 + a * ksh + r;                    // F phase
+    const int t = r - ksh;                                                         // O phase
+    return (a * nbh + i) * 4096 + (t < ksh ? a * ksh + t : s.ks0 + (t - ksh));
+}
+
 // accumulator register i of lane-half h  <->  row of the 32-row output block
 __host__ __device__ constexpr int acc_row(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
 

@@ -2,7 +2,7 @@
 HIP C-ABI.  Same constructor, same `state_dict` keys/shapes (SURVEY App. C - `Final_Model.nn` loads unchanged), same
 forward variants and return conventions; the arithmetic runs in the gfx950 kernels, never in PyTorch.
 
-Eval mode (`.eval()`, BatchNorm running statistics): the fused register-resident MFMA kernels (widths 64 / 256), no autograd.
+Eval mode (`.eval()`, BatchNorm running statistics): the fused register-resident MFMA kernels (widths 64 / 256 / 512), no autograd.
 Train mode (`.train()`, batch-statistics BatchNorm): every forward variant (`forward`, `forward_seperate`, `forward_full_eval`,
 `forward_Solar`, `forward_Classic_Sigma_Only`, `get_class_only`, `approx_Solar`)
 runs on the layer-wise training engine and returns tensors with an autograd graph whose backward is the engine's HIP backward
@@ -26,15 +26,17 @@ def _ops():
 
 
 OMEGA0 = 30.0
-FUSED_WIDTHS = (64, 256)      # widths with a compiled fused bf16 MFMA kernel; others run on the layer-wise fp32 engine
-FUSED_WIDTHS_I8 = (64, 256, 512)   # ... with a fused int8-digit kernel (precision "i8x3" / "auto"): the reference's default width too
+FUSED_WIDTHS = (64, 256, 512)  # widths with a compiled fused bf16x3 MFMA kernel (512, the reference's default, main_lite.py:80: K split over wave
+                               # pairs, csrc/kernels_ks.hip); others run on the layer-wise engine
+FAST_WIDTHS = (64, 256)        # ... with the one-term "bf16" fast mode
+FUSED_WIDTHS_I8 = (64, 256, 512)   # ... with a fused int8-digit kernel (precision "i8x3" / "auto")
 
 
 # ---- `auto`, second stage: a MEASURED check of the int8 digits on the device (round 5).  The pack-time error model (csrc/pack.cpp estimate_i8) is
 # analytic: against the gain ladder of tests/golden/sharp_sweep_W*.npz it is within 1.07-8x of what the GPU measures, but weights from the reference's
 # DSM-prior phase rendered 1.19x WORSE than predicted (1.05e-4 observed at a prediction of 8.8e-5: int8 digits chosen, bar missed).  So where the
-# prediction is not comfortably low the class renders a fixed probe batch in int8 digits AND in the 3-term bf16 arithmetic (fused kernel at widths
-# 64 / 256, layer-wise engine at 512) and keeps the int8 pipe only if RGB and depth agree to PROBE_ACCEPT - the error of THESE weights, not a model of it.
+# prediction is not comfortably low the class renders a fixed probe batch in int8 digits AND in the 3-term bf16 arithmetic (the fused bf16x3 kernel of
+# the width) and keeps the int8 pipe only if RGB and depth agree to PROBE_ACCEPT - the error of THESE weights, not a model of it.
 PROBE_RAYS, PROBE_SAMPLES = 1024, 96
 PROBE_SKIP_BELOW = 4e-5      # predictions this low need no probe (the model never under-predicted by more than 1.2x on any measured set)
 PROBE_ACCEPT = 5e-5          # half the 1e-4 bar: bf16x3 itself sits ~1e-5 from the reference on near-fog weights, the rest is margin for other rays
@@ -137,7 +139,7 @@ class T_NeRF(nn.Module):
     @property
     def resolved_precision(self):
         """The arithmetic the fused kernel runs in for the current weights ("auto" resolved), or None where no fused kernel serves
-        them (the layer-wise engine then does: any width outside 64 / 256 / 512, or 512 when the int8 bound fails)."""
+        them (the layer-wise engine then does: any width outside 64 / 256 / 512, or the "bf16" fast mode at 512)."""
         self._pack()
         self._probe_int8()
         return self._resolved
@@ -159,38 +161,22 @@ class T_NeRF(nn.Module):
             m8 = self._packed
             m8.finalize()
             rgb8, depth8, _, _ = ops.render_fwd(m8, top, bot, sun, tim, tv, 0, False)
-            m3 = None
-            if W in FUSED_WIDTHS:
-                m3 = torch.classes.season_nerf.Model(W, Cn, "bf16x3")
-                for k, v in self.state_dict().items():
-                    if v.is_floating_point():
-                        m3.set_tensor(k, v.detach().float().cpu().contiguous())
-                if m3.resolve() < 0:
-                    raise RuntimeError(f"season_nerf_amd: packing the bf16x3 probe model failed: {_lib.lib().snerf_last_error().decode()}")
-                m3.finalize()
-                rgb3, depth3, _, _ = ops.render_fwd(m3, top, bot, sun, tim, tv, 0, False)
-                dist3 = depth3[:, 0]
-            else:                                   # 512: no fused bf16x3 kernel - the layer-wise engine (3-term bf16 products as well) on a clone
-                from .evaluator import All_in_One_Eval
-                from types import SimpleNamespace
-                clone = T_NeRF(W, Cn)
-                clone.load_state_dict(self.state_dict())
-                clone.precision = "bf16x3"
-                clone = clone.to(dev).eval()
-                ev = All_in_One_Eval(SimpleNamespace(n_samples=PROBE_SAMPLES, Use_Reg=True, Solar_Type_2=False, Use_MSE_loss=True, Use_Solar=True, sc_lambda=0.03,
-                                                     number_low_frequency_cases=Cn), dev, 10, False, None, np.eye(4), np.zeros(3))
-                n = PROBE_RAYS // 2               # half the batch: the engine's workspace scales with the ray count
-                rgb3, _, dist3 = ev.render_summary({"Top": top[:n], "Bot": bot[:n], "Sun_Angle": sun[:n], "Time_Encoded": tim[:n]}, clone)
-                rgb8, depth8 = rgb8[:n], depth8[:n]
-                dist3 = dist3.reshape(-1)
-                del clone
+            m3 = torch.classes.season_nerf.Model(W, Cn, "bf16x3")
+            for k, v in self.state_dict().items():
+                if v.is_floating_point():
+                    m3.set_tensor(k, v.detach().float().cpu().contiguous())
+            if m3.resolve() < 0:
+                raise RuntimeError(f"season_nerf_amd: packing the bf16x3 probe model failed: {_lib.lib().snerf_last_error().decode()}")
+            m3.finalize()
+            rgb3, depth3, _, _ = ops.render_fwd(m3, top, bot, sun, tim, tv, 0, False)
+            dist3 = depth3[:, 0]
             d_rgb, d_depth = rel(rgb8, rgb3), rel(depth8[:, 0], dist3)
         keep = max(d_rgb, d_depth) <= PROBE_ACCEPT
         self._probe = {"ran": True, "rgb_dev": d_rgb, "depth_dev": d_depth, "threshold": PROBE_ACCEPT, "kept_int8": keep,
-                       "against": "bf16x3 fused kernel" if m3 is not None else "layer-wise engine (bf16x3 products)"}
+                       "against": "bf16x3 fused kernel"}
         if not keep:                                  # leave the int8 pipe: the probe's bf16x3 model is already packed and uploaded
             self.release()
-            self._packed, self._resolved = (m3, "bf16x3") if m3 is not None else (None, None)
+            self._packed, self._resolved = m3, "bf16x3"
 
     def i8_probe(self):
         """What the measured second stage of `auto` found for the current weights (None: not run - explicit precision, host-resident module, or the
@@ -251,8 +237,8 @@ class T_NeRF(nn.Module):
         v = m.i8_estimate()
         self._estimate = {"head_rms": v[0:4], "hidden_rms": v[4], "worst": v[5], "rgb_pred": v[6], "budget": v[7], "acc_bound": int(v[8]), "ok": bool(v[9])}
         r = m.resolve()
-        if r == -1 and W not in FUSED_WIDTHS and (want != "i8x3" or self._estimate["acc_bound"] < 2 ** 31):
-            return                                    # bf16 modes, or "auto" whose int8 bound failed: no such fused kernel at this width
+        if r == -1 and want == "bf16" and W not in FAST_WIDTHS:
+            return                                    # the one-term fast mode has no fused kernel at this width: layer-wise engine
         if r < 0:
             raise RuntimeError(f"season_nerf_amd: packing the model failed (code {r}): {_lib.lib().snerf_last_error().decode()}")
         self._packed, self._resolved = m, _lib.PRECISION_NAMES[r]
