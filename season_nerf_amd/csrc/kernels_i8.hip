@@ -32,13 +32,28 @@ namespace snerf {
 constexpr int AG_R0 = 0, AG_R1 = 128;      // two 128-register regions; who lives where: see the layer list of the kernel
 // register numbers are "i" operands: loop indices that are constants once the layer is unrolled (a number that did not fold
 // fails the build in the backend, it cannot reach the GPU)
+#ifdef SNERF_DBG_NOP_PARK
+#define DBG_PARK_PAD "\n\ts_nop 7"
+#else
+#define DBG_PARK_PAD ""
+#endif
+#ifdef SNERF_DBG_NOP_MFMA
+#define DBG_MFMA_PAD "\n\ts_nop 15\n\ts_nop 15"
+#else
+#define DBG_MFMA_PAD ""
+#endif
+#ifdef SNERF_DBG_EARLYCLOBBER
+#define DBG_EC "=&v"
+#else
+#define DBG_EC "=v"
+#endif
 static __device__ __forceinline__ void park(int v, int idx) {
-    asm volatile("v_accvgpr_write_b32 a[%1], %0" ::"v"(v), "i"(idx));
+    asm volatile("v_accvgpr_write_b32 a[%1], %0" DBG_PARK_PAD ::"v"(v), "i"(idx));
 }
 template <bool FIRST>
 __device__ __forceinline__ void mfma_asm(i32x16& acc, const i32x4& a, int base) {
-    if (FIRST) asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, a[%2:%3], 0" : "=v"(acc) : "v"(a), "i"(base), "i"(base + 3));
-    else asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, a[%2:%3], %0" : "+v"(acc) : "v"(a), "i"(base), "i"(base + 3));
+    if (FIRST) asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, a[%2:%3], 0" DBG_MFMA_PAD : DBG_EC(acc) : "v"(a), "i"(base), "i"(base + 3));
+    else asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, a[%2:%3], %0" DBG_MFMA_PAD : "+v"(acc) : "v"(a), "i"(base), "i"(base + 3));
 }
 template <bool FIRST>      // base: first register of the k-step (4 high-digit dwords, then 4 low-digit dwords)
 __device__ __forceinline__ void mfma_i8x3_agpr(const i32x4& aT, const i32x4& aL, Acc8& acc, int base) {
@@ -185,7 +200,11 @@ __device__ __forceinline__ void run_layer8(Ring& rg, const uint8_t* stream, uint
     }
     tab = load_tab(tab_l, NB - 1, h);
     if (RAWL) rw = load_raw(raw_l, NB - 1, h);
-    if (AG) asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");   // the last asm MFMA's result: 18 wait states before a VALU read, by hand
+    // The last asm MFMA's result: 18 wait states before a VALU read, by hand.  The pad must CARRY the accumulators ("+v"): a bare asm volatile with a
+    // memory clobber orders nothing against register-only VALU code, and hipcc hoisted the whole epilogue above it - the first elements of every
+    // layer's last block were read 3 instructions behind the MFMA that was still forming them (stale by its product, and by how far the read ran ahead:
+    // found in round 6 as launch-to-launch differences of the seasonal-adjust outputs, tools/ks_race.py; tests/test_isa_guards.py now scans the ISA).
+    if (AG) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(accs[(NB - 1) & 1].M), "+v"(accs[(NB - 1) & 1].X)::"memory");
     if (SIN) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) epi_A<RAWL>(accs[(NB - 1) & 1], tab, e, ev, &rw, rawx);

@@ -16,7 +16,8 @@
 //
 // Weight stream (pack.cpp pack_program_ks): the pairs of the canonical bf16 stream in the order each wave consumes them, a 16 KiB chunk =
 // 4 pairs for parity 0 | 4 pairs for parity 1; every chunk is read by two waves (one per pair), i.e. the L2 -> LDS stream per point is twice
-// the W = 256 kernel's (64 points share a chunk, not 128) - the price of the width; the ring (7 slots, 5 in flight) is unchanged.
+// the W = 256 kernel's (64 points share a chunk, not 128) - the price of the width; the ring (7 slots, 5 in flight) is the same, its refill spread
+// over the k-steps (ks_ring below).
 #include "mlp_bf16_device.h"
 
 namespace snerf {
@@ -37,7 +38,76 @@ struct KsCtx {
     lds_char* xr;             // ... the partner writes
 };
 
+// The ring of mlp_device.h with the refill SPREAD: a ring step (counted vmcnt + barrier) only names the chunk to fetch; its four 1 KiB pieces per
+// wave are issued one per k-step over the four k-steps up to the next ring step.  An LDS-DMA instruction holds its wave's issue for ~30 cycles:
+// four in a row behind every barrier cost this kernel - a ring step every 12 MFMAs, twice the W = 256 kernel's rate - 0.9 ms of 5.5 (the `dma_only`
+// build of tools/ks_variants.py); one per k-step hides in an MFMA's shadow.  The vmcnt count is unchanged: every piece of a chunk is issued before
+// the next ring step (the first chunk of a layer, whose ring step has one k-step to the next, flushes its last three pieces in front of it).
+struct Pend {
+    uint32_t goff, wr;        // the chunk whose pieces are being issued: offset in the global stream, LDS slot
+};
+__device__ __forceinline__ void dma_piece(const uint8_t* stream, const Pend& pd, lds_char* lds, int wave, int lane, int p) {
+#if defined(SNERF_ABLATE) && (ABL & (4 | 32))
+    return;
+#endif
+#if defined(SNERF_ABLATE) && (ABL & 256)      // timing-only: half the DMA bytes
+    if (p >= 2) return;
+#endif
+    const uint8_t* bp = stream + pd.goff + (wave + 4 * p) * kFragBytes;                          // wave-uniform
+    const uint32_t dst = (uint32_t)(uintptr_t)(lds + pd.wr + (wave + 4 * p) * kFragBytes);      // wave-uniform LDS byte address
+    const uint32_t voff = lane * 16;
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %3\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(dst), "s"(bp)
+        : "memory", "scc");
+}
+__device__ __forceinline__ void ring_step_ks(Ring& rg, Pend& pd, uint32_t stream_bytes) {
+#if defined(SNERF_ABLATE) && (ABL & 4)
+    return;
+#endif
+#if defined(SNERF_ABLATE) && (ABL & 64)
+    asm volatile("" ::: "memory");
+#else
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((RING_D - 3) * DMA_PER_WAVE) : "memory");
+#endif
+    pd.goff = rg.goff;
+    pd.wr = rg.wr;
+    rg.goff += kChunkBytes;
+#if defined(SNERF_ABLATE) && (ABL & 128)      // timing-only: the stream cycles over 64 KiB (always cache-resident)
+    if (rg.goff >= 4 * kChunkBytes) rg.goff = 0;
+#endif
+    if (rg.goff >= stream_bytes) rg.goff = 0;
+    rg.cur = rg.rd;
+    rg.rd = ring_next<RING_D>(rg.rd);
+    rg.wr = ring_next<RING_D>(rg.wr);
+}
+// k-step q of a layer of NP pairs: the ring step of chunk (q + PF) / 4 opens it where (q + PF) % 4 == 0 (q = 1, 5, 9, ...; the layer's first chunk in
+// its prologue).  Piece to issue in k-step q: q = 0 -> piece 0 of the first chunk (pieces 1..3 are flushed at q = 1); q >= 1 -> piece (q - 1) % 4 of the
+// chunk opened at k-step q - (q - 1) % 4, if that k-step had a ring step.
+template <int NP>
+__device__ __forceinline__ void ks_ring(Ring& rg, Pend& pd, const uint8_t* stream, uint32_t stream_bytes, lds_char* lds, int wave, int lane, int q) {
+    static_assert(PF == 3 && KS_PAR_PAIRS == 4, "piece schedule written for 3 pairs of prefetch, 4 pairs per chunk and parity");
+    if (q == 1) {
+        dma_piece(stream, pd, lds, wave, lane, 1);
+        dma_piece(stream, pd, lds, wave, lane, 2);
+        dma_piece(stream, pd, lds, wave, lane, 3);
+    }
+    if (q + PF < NP && (q + PF) % KS_PAR_PAIRS == 0) ring_step_ks(rg, pd, stream_bytes);
+    if (q == 0) dma_piece(stream, pd, lds, wave, lane, 0);
+    else if ((q - (q - 1) % 4) + PF < NP) dma_piece(stream, pd, lds, wave, lane, (q - 1) % 4);
+}
+
 __device__ __forceinline__ void xbuf_write(lds_char* xw, const f32x16& v, int lane) {
+#if defined(SNERF_ABLATE) && (ABL & 16)       // timing-only: no partial-sum exchange (the values stay live: the F phases must not become dead code)
+    _Pragma("unroll") for (int q = 0; q < 16; ++q) asm volatile("" ::"v"(v[q]));
+    return;
+#endif
     __attribute__((address_space(3))) f32x4* p = (__attribute__((address_space(3))) f32x4*)(xw + lane * 16);
 #pragma unroll
     for (int q = 0; q < 4; ++q) p[q * 64] = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
@@ -45,6 +115,10 @@ __device__ __forceinline__ void xbuf_write(lds_char* xw, const f32x16& v, int la
 __device__ __forceinline__ f32x16 xbuf_read(lds_char* xr, int lane) {
     lds_cf32x4* p = (lds_cf32x4*)(xr + lane * 16);
     f32x16 v;
+#if defined(SNERF_ABLATE) && (ABL & 16)
+    _Pragma("unroll") for (int q = 0; q < 16; ++q) v[q] = 0.f;
+    return v;
+#endif
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const f32x4 t = p[q * 64];
@@ -61,7 +135,7 @@ __device__ __forceinline__ void epi_A2(const f32x16& acc, const f32x16& part, in
 // One layer over a wave pair.  NBH own (= foreign) blocks per wave, KSH k-steps of this wave's K-half of the hidden input (0: none - the layer
 // reads an encoding only and needs no exchange), KSX k-steps of an encoding that enter the own blocks in full.  bias_own: bias rows of the own blocks.
 template <int NBH, int KSH, int KSX>
-__device__ __forceinline__ void run_layer_ks(Ring& rg, const uint8_t* stream, uint32_t stream_bytes, const KsCtx& cx, lds_cfloat* bias_own,
+__device__ __forceinline__ void run_layer_ks(Ring& rg, Pend& pd, const uint8_t* stream, uint32_t stream_bytes, const KsCtx& cx, lds_cfloat* bias_own,
                                              const Frag* in0, const Frag* in1, Frag* out, int wave, int lane) {
     constexpr bool EX = KSH > 0;
     constexpr int KO = KSH + KSX;                  // k-steps of an O phase
@@ -73,7 +147,7 @@ __device__ __forceinline__ void run_layer_ks(Ring& rg, const uint8_t* stream, ui
     u32x4 fh[PF], fl[PF];
 #pragma unroll
     for (int q = 0; q < PF; ++q) {
-        if (q % KS_PAR_PAIRS == 0) ring_step(rg, stream, stream_bytes, cx.lds, wave, lane);
+        if (q % KS_PAR_PAIRS == 0) ring_step_ks(rg, pd, stream_bytes);       // the layer's first chunk; its pieces go out in k-steps 0 and 1 (ks_ring)
         lds_char* ap = cx.lds + rg.cur + cx.par_off + (q % KS_PAR_PAIRS) * kPairBytes + lane * 16;
         fh[q] = *(lds_cu32x4*)ap;
         fl[q] = *(lds_cu32x4*)(ap + kFragBytes);
@@ -82,17 +156,26 @@ __device__ __forceinline__ void run_layer_ks(Ring& rg, const uint8_t* stream, ui
     EpiTmp et[8];
     f32x16 next_init = load_bias(bias_own, 0, h);
     // one k-step: consume pair q, prefetch pair q + PF (ring step where it opens a chunk)
+#if defined(SNERF_ABLATE) && (ABL & 2)        // timing-only: the A fragments stay in registers, no LDS reads
+#define KS_FRAG_READ(q) asm volatile("" : "+v"(fh[(q) % PF]), "+v"(fl[(q) % PF]));
+#else
+#define KS_FRAG_READ(q)                                                                                                 \
+    {                                                                                                                   \
+        lds_char* ap = cx.lds + rg.cur + cx.par_off + (((q) + PF) % KS_PAR_PAIRS) * kPairBytes + lane * 16;             \
+        fh[(q) % PF] = *(lds_cu32x4*)ap;                                                                                \
+        fl[(q) % PF] = *(lds_cu32x4*)(ap + kFragBytes);                                                                 \
+    }
+#endif
 #define KS_STEP(q, ACC, BFRAG)                                                                                          \
     {                                                                                                                   \
         const u32x4 a_hi = fh[(q) % PF], a_lo = fl[(q) % PF];                                                           \
-        if ((q) + PF < NP) {                                                                                            \
-            if (((q) + PF) % KS_PAR_PAIRS == 0) ring_step(rg, stream, stream_bytes, cx.lds, wave, lane);                \
-            lds_char* ap = cx.lds + rg.cur + cx.par_off + (((q) + PF) % KS_PAR_PAIRS) * kPairBytes + lane * 16;         \
-            fh[(q) % PF] = *(lds_cu32x4*)ap;                                                                            \
-            fl[(q) % PF] = *(lds_cu32x4*)(ap + kFragBytes);                                                             \
-        }                                                                                                               \
+        ks_ring<NP>(rg, pd, stream, stream_bytes, cx.lds, wave, lane, (q));                                             \
+        if ((q) + PF < NP) KS_FRAG_READ(q)                                                                              \
         ACC = mfma3(a_hi, a_lo, BFRAG, ACC);                                                                            \
     }
+#ifdef KS_NO_SCHED
+#define KS_SCHED() __builtin_amdgcn_sched_barrier(0);
+#else
 #define KS_SCHED()                                                                                                      \
     {                                                                                                                   \
         _Pragma("unroll") for (int m = 0; m < 3; ++m) {                                                                 \
@@ -103,6 +186,7 @@ __device__ __forceinline__ void run_layer_ks(Ring& rg, const uint8_t* stream, ui
         }                                                                                                               \
         __builtin_amdgcn_sched_barrier(0);                                                                              \
     }
+#endif
 #pragma unroll
     for (int i = 0; i < NBH; ++i) {
         if constexpr (EX) {
@@ -169,14 +253,14 @@ __device__ __forceinline__ void run_layer_ks(Ring& rg, const uint8_t* stream, ui
 // A raw head (one 32-row block): each wave multiplies its K-half (parity 0 starts from the bias, parity 1 from zero), both publish their half and
 // both add the partner's - symmetric, no branch; one extra workgroup barrier per head.
 template <int KSH>
-__device__ __forceinline__ f32x16 run_head_ks(Ring& rg, const uint8_t* stream, uint32_t stream_bytes, const KsCtx& cx, lds_cfloat* bias_sel,
+__device__ __forceinline__ f32x16 run_head_ks(Ring& rg, Pend& pd, const uint8_t* stream, uint32_t stream_bytes, const KsCtx& cx, lds_cfloat* bias_sel,
                                               const Frag* in0, int wave, int lane) {
     constexpr int NP = KSH;
     const int h = lane >> 5;
     u32x4 fh[PF], fl[PF];
 #pragma unroll
     for (int q = 0; q < PF; ++q) {
-        if (q % KS_PAR_PAIRS == 0) ring_step(rg, stream, stream_bytes, cx.lds, wave, lane);
+        if (q % KS_PAR_PAIRS == 0) ring_step_ks(rg, pd, stream_bytes);       // the layer's first chunk; its pieces go out in k-steps 0 and 1 (ks_ring)
         lds_char* ap = cx.lds + rg.cur + cx.par_off + (q % KS_PAR_PAIRS) * kPairBytes + lane * 16;
         fh[q] = *(lds_cu32x4*)ap;
         fl[q] = *(lds_cu32x4*)(ap + kFragBytes);
@@ -196,6 +280,7 @@ __device__ __forceinline__ f32x16 run_head_ks(Ring& rg, const uint8_t* stream, u
 }
 #undef KS_STEP
 #undef KS_SCHED
+#undef KS_FRAG_READ
 
 template <int W, int VARIANT>
 __global__ __launch_bounds__(256, 1) void mlp_ks_kernel(const MlpArgs A) {
@@ -223,6 +308,9 @@ __global__ __launch_bounds__(256, 1) void mlp_ks_kernel(const MlpArgs A) {
     }
 
     Ring rg;
+    Pend pd;
+    pd.goff = 0;
+    pd.wr = 0;
     rg.rd = 0;
     rg.cur = 0;
     rg.goff = 0;
@@ -287,8 +375,8 @@ __global__ __launch_bounds__(256, 1) void mlp_ks_kernel(const MlpArgs A) {
         Frag hA[KH], hB[KH];
         // bias rows of this wave's own blocks of layer L (n_out = 64 NBH)
 #define OWNB(L, NBH) (bias_lds + prog_bias_start(PROG_FIELD, W, C_MAX, L) + par * (NBH) * 32)
-#define LAYER(L, NBH, KSHv, KSXv, IN0, IN1, OUT) run_layer_ks<NBH, KSHv, KSXv>(rg, A.stream, A.stream_bytes, cx, OWNB(L, NBH), IN0, IN1, OUT, wave, lane)
-#define HEADL(L, KSHv, IN0) run_head_ks<KSHv>(rg, A.stream, A.stream_bytes, cx, par ? zero_bias : bias_lds + prog_bias_start(PROG_FIELD, W, C_MAX, L), IN0, wave, lane)
+#define LAYER(L, NBH, KSHv, KSXv, IN0, IN1, OUT) run_layer_ks<NBH, KSHv, KSXv>(rg, pd, A.stream, A.stream_bytes, cx, OWNB(L, NBH), IN0, IN1, OUT, wave, lane)
+#define HEADL(L, KSHv, IN0) run_head_ks<KSHv>(rg, pd, A.stream, A.stream_bytes, cx, par ? zero_bias : bias_lds + prog_bias_start(PROG_FIELD, W, C_MAX, L), IN0, wave, lane)
         LAYER(F_FC1, NBW, 0, PEPOS_KS, nullptr, pe, hA);
         LAYER(F_FC2, NBW, KH, 0, hA, nullptr, hB);
         LAYER(F_FC3, NBW, KH, 0, hB, nullptr, hA);

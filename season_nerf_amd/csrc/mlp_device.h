@@ -98,8 +98,14 @@ __device__ __forceinline__ void ring_step(Ring& rg, const uint8_t* stream, uint3
 #if defined(SNERF_ABLATE) && (ABL & 4)     // timing-only: no ring at all
     return;
 #endif
+#if defined(SNERF_ABLATE) && (ABL & 64)    // timing-only: the DMA stream without its rendezvous
+    asm volatile("" ::: "memory");
+#else
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((D - 3) * DMA_PER_WAVE) : "memory");
+#endif
+#if !(defined(SNERF_ABLATE) && (ABL & 32)) // timing-only (32): the rendezvous without the DMA stream
     dma_chunk(stream, rg.goff, lds, rg.wr, wave, lane);
+#endif
     rg.goff += kChunkBytes;
     if (rg.goff >= stream_bytes) rg.goff = 0;
     rg.cur = rg.rd;

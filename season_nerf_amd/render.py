@@ -57,7 +57,7 @@ def _exact_solar_visibility(net: T_NeRF, pts, sun_vec, S, zero_oob, chunk_rays=1
     over the S samples of each ray with the optical depth kept in registers - one float out per ray, no rho [M,S] round trip, no
     compositing launch, no scratch tensors.  The tops of a chunk are formed chunk by chunk (M = R*S can be 2.5e7 for a 512 x 512 x 96
     image: 300 MB of tops at once would cost more memory than the whole render).  A network without a fused kernel (a width outside
-    64 / 256 / 512, or 512 when the int8 bound fails) composes the same quantity from the layer-wise density and a transmittance scan."""
+    64 / 256 / 512, or the one-term "bf16" mode) composes the same quantity from the layer-wise density and a transmittance scan."""
     dev = pts.device
     M = pts.shape[0]
     tv = sample_parameters_on(dev, S, eval_mode=True, include_end_pt=True)

@@ -463,8 +463,7 @@ def _estimate(lib, m):
 def test_auto_precision_follows_the_error_bound(lib, W):
     """Weights of the init law clear the bound and run in int8 digits (so do the really-trained fixtures: test_trained_fixtures_clear_the_bound);
     synthetic families with per-row outliers (x4, x16), heavy tails or a mix of gains and outliers do not - since round 4's refit on really
-    trained weights the guard is conservative for them - and are routed to bf16x3 (512: no bf16 kernel -> SNERF_E_INVALID, the host falls back
-    to the layer-wise engine)."""
+    trained weights the guard is conservative for them - and are routed to bf16x3 (at 512: the K-split kernel of csrc/kernels_ks.hip, round 6)."""
     AUTO, I8, BF3 = 3, 2, 0
     for kind, want in [("init", I8), ("outlier4", BF3), ("laplace", BF3), ("outlier16", BF3), ("trained", BF3)]:
         sd = orc.init_weights(W, 4, 0) if kind == "init" else orc.stress_weights(W, 4, 0, kind)
@@ -475,13 +474,13 @@ def test_auto_precision_follows_the_error_bound(lib, W):
         if kind == "init":
             assert 5e-5 < e.rgb_pred < 9.5e-5 and max(e.head_rms) == pytest.approx(e.worst)
         r = lib.snerf_model_resolve_precision(m)
-        if want == BF3 and W == 512:
-            assert r == -1 and b"512" in lib.snerf_last_error()
-        else:
-            assert r == want and lib.snerf_model_precision(m) == want
-            ns = C.c_size_t()
-            assert lib.snerf_model_pack_host(m, 2, None, C.byref(ns), None, None) == (0 if want == I8 else -4)
+        assert r == want and lib.snerf_model_precision(m) == want
+        ns = C.c_size_t()
+        assert lib.snerf_model_pack_host(m, 2, None, C.byref(ns), None, None) == (0 if want == I8 else -4)
         lib.snerf_model_destroy(m)
+    m = _host_model(lib, W, orc.init_weights(W, 4, 0), 1)          # the one-term fast mode: widths 64 / 256 only
+    assert lib.snerf_model_resolve_precision(m) == (1 if W != 512 else -1)
+    lib.snerf_model_destroy(m)
 
 
 @pytest.mark.parametrize("W", [64, 256, 512])
@@ -557,9 +556,11 @@ def test_network_class_resolves_its_precision_on_the_host():
     net512.load_state_dict(orc.init_weights(512, 4, 0))
     assert net512.resolved_precision == "i8x3"
     net512.load_state_dict(orc.stress_weights(512, 4, 0, "outlier16"))
-    assert net512.resolved_precision is None and not net512.fused       # layer-wise engine
+    assert net512.resolved_precision == "bf16x3" and net512.fused       # the K-split kernel (round 6; the layer-wise engine before)
     net512.precision = "bf16x3"
-    assert not net512.fused
+    assert net512.fused
+    net512.precision = "bf16"
+    assert not net512.fused                                             # the fast mode has no kernel at 512: layer-wise engine
     # a buffer replaced by Module._apply (.double().float()) is still tracked
     net.load_state_dict(orc.init_weights(256, 4, 0))
     assert net.resolved_precision == "i8x3"
@@ -611,3 +612,65 @@ print("missing", lib.snerf_model_pack_host(m, 0, None, C.byref(n), None, None), 
         outs.append(r.stdout)
     # (the estimate's pass over the inputs' own error runs in layer order in both; its per-weight pass sums per row, so not a digit differs)
     assert outs[0] == outs[1] and "missing -2 True" in outs[0] and len(outs[0].split()) >= 12, outs
+
+
+def _ks_sequence(shape, a):
+    """Independent restatement of the order wave `a` of a pair consumes the (block, k-step) pairs of a layer in (csrc/kernels_ks.hip header):
+    shape = (n_blocks, ks_hidden, ks_encoding, raw_head, encoding_only)."""
+    nb, ksh_full, ksx, raw, enc_only = shape
+    if raw:
+        return [(0, a * (ksh_full // 2) + s) for s in range(ksh_full // 2)]
+    nbh = nb // 2
+    if enc_only:
+        return [(a * nbh + i, s) for i in range(nbh) for s in range(ksx)]
+    ksh, seq = ksh_full // 2, []
+    for i in range(nbh):
+        seq += [((1 - a) * nbh + i, a * ksh + s) for s in range(ksh)]                       # F: the partner's block over the own K-half
+        seq += [(a * nbh + i, a * ksh + s) for s in range(ksh)] + [(a * nbh + i, ksh_full + s) for s in range(ksx)]   # O: own block, own K-half, then the encoding
+    return seq
+
+
+def test_ksplit_stream_is_a_permutation_of_the_bf16_pairs(lib):
+    """Width 512, bf16x3 (round 6): program 3 (the stream the K-split kernel reads) holds exactly the pairs of the canonical bf16 field program
+    (program 0, itself pinned by test_packed_stream_reproduces_the_network at the other widths), each once, in the order the two waves of a pair
+    consume them - 4 pairs of parity 0, then 4 of parity 1 per 16 KiB chunk, every layer on a chunk boundary; same bias table."""
+    W, Cn = 512, 4
+    m = _host_model(lib, W, orc.init_weights(W, Cn, 5), 0)
+    def fetch(prog):
+        ns, nb = C.c_size_t(), C.c_size_t()
+        assert lib.snerf_model_pack_host(m, prog, None, C.byref(ns), None, C.byref(nb)) == 0, lib.snerf_last_error()
+        st, bi = np.zeros(ns.value, np.uint8), np.zeros(nb.value, np.float32)
+        assert lib.snerf_model_pack_host(m, prog, st.ctypes.data_as(C.POINTER(C.c_uint8)), C.byref(ns), bi.ctypes.data_as(C.POINTER(C.c_float)), C.byref(nb)) == 0
+        return st, bi
+    canon, bias0 = fetch(0)
+    ks, bias3 = fetch(3)
+    assert np.array_equal(bias0, bias3) and len(ks) % 16384 == 0
+    W2, PP, PS = W // 2, 4, 2
+    # (n_blocks, hidden k-steps, encoding k-steps, raw head, encoding only) per field layer, program.h field_layer
+    shapes = [(W // 32, 0, PP, False, True)] + [(W // 32, W // 16, 0, False, False)] * 3 + [(W // 32, W // 16, PP, False, False)] + [(W // 32, W // 16, 0, False, False)] * 3 + \
+             [(W2 // 32, W // 16, 0, False, False), (1, W2 // 16, 0, True, False), (W2 // 32, W2 // 16, PS, False, False)] + [(W2 // 32, W2 // 16, 0, False, False)] * 2 + \
+             [(1, W2 // 16, 0, True, False), (W // 32, W2 // 16, 0, False, False)] + [(W // 32, W // 16, 0, False, False)] * 2 + [(1, W // 16, 0, True, False)]
+    co = ko = 0
+    seen = 0
+    for sh in shapes:
+        nb, ksh, ksx, raw, enc = sh
+        kst = ksx if enc else ksh + ksx
+        n_pairs = nb * kst
+        seq = [_ks_sequence(sh, a) for a in (0, 1)]
+        assert len(seq[0]) == len(seq[1]) and sorted(seq[0] + seq[1]) == [(b, k) for b in range(nb) for k in range(kst)]      # every pair exactly once
+        chunks = -(-len(seq[0]) // 4)
+        used = np.zeros(chunks * 16384, bool)
+        for a in (0, 1):
+            for q, (b, k) in enumerate(seq[a]):
+                src = co + (b * kst + k) * 2048
+                dst = ko + (q // 4) * 16384 + a * 8192 + (q % 4) * 2048
+                assert np.array_equal(ks[dst:dst + 2048], canon[src:src + 2048]), (sh, a, q)
+                used[dst - ko:dst - ko + 2048] = True
+                seen += 1
+        assert not ks[ko:ko + chunks * 16384][~used].any()                                      # padding is zero
+        co += -(-n_pairs // 8) * 16384
+        ko += chunks * 16384
+    assert co == len(canon) and ko == len(ks) and seen * 2048 <= len(ks)
+    assert lib.snerf_model_pack_host(m, 1, None, None, None, None) < 0                           # the per-ray networks have no packed program at 512
+    lib.snerf_model_destroy(m)
+
