@@ -22,6 +22,7 @@ own fp32 arithmetic is from exact on these weights; tests print it next to their
 
     python tools/make_sharp_golden.py scaled 64 256 512
     python tools/make_sharp_golden.py prior 64 400 200
+    python tools/make_sharp_golden.py converged 64 12000 6
 """
 import os
 import sys
@@ -204,6 +205,75 @@ def gen_prior(W, n_prior, n_free, batch=512, S=96):
     print("wrote", path, os.path.getsize(path) // 1024, "KiB; mean max-PS per ray", float(out["max_ps"].mean()))
 
 
+def gen_converged(W, n_total, hours, target=0.3, batch=512, S=96):
+    """tests/golden/converged_W{W}.npz: the reference's own schedule (Net_Tool_2.py:23-33, main_lite.py:44-47: the first 20 % of the steps under
+    the DSM prior, learning mode 1, the rest free, mode 4; a fresh Adam + OneCycleLR per phase, Net_Tool_2.py:111-130) on the synthetic scene, checked every 250
+    steps with the reference's own eval on held-out rays and STOPPED in the free phase once the mean max-PS per ray reaches `target` (or at `hours` of wall
+    clock): surfaces that training produced, not a scaled density head.  Stored as prior_trained: state_dict, trajectory, the reference's eval, the oracle in float64."""
+    import make_trained_golden as mt
+    torch.manual_seed(3000 + W)
+    np.random.seed(3000 + W)
+    n = 96
+    gx, gy = np.meshgrid(np.linspace(-1, 1, n), np.linspace(-1, 1, n), indexing="ij")
+    hm = mt.height(gx, gy)
+    net = T_NeRF(W, 4, HM=hm)
+    r = net.load_state_dict(orc.init_weights(W, 4, 41), strict=True)
+    assert not r.missing_keys and not r.unexpected_keys
+    net.train(True)
+    in_cube = lambda d: ((d["Top"].abs() <= 1).all(1) & (d["Bot"].abs() <= 1).all(1))
+    cull = lambda d: {k: v[in_cube(d)] for k, v in d.items()}
+    pool = cull(mt.make_scene(12, 4096, 7))
+    npool = pool["Top"].shape[0]
+    held = cull(mt.make_scene(4, 32, 99))
+    held = {k: v[:48] for k, v in held.items()}
+    more = mg.synth_rays(64, 902)
+    data_h = {k: torch.cat([held[k], more[k]], 0) for k in held}
+    rng = np.random.Generator(np.random.PCG64(5))
+    lr = 10 ** (-4.86) * 3                                   # main_lite.py:75
+    n_prior = int(round(0.2 * n_total))
+    traj, checks, t0, done = [], [], time.time(), False
+    for phase, n_steps, prior in ((1, n_prior, True), (4, n_total - n_prior, False)):
+        ev = All_in_One_Eval(mg.args_ns(S), torch.device("cpu"), n_steps, prior, None, H4, WC)
+        opt = torch.optim.Adam(net.parameters(), lr=lr)
+        sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=lr, total_steps=n_steps, base_momentum=0.85, max_momentum=0.95, cycle_momentum=False)
+        for step in range(n_steps):                          # mg_run_NeRF.py:288-326
+            sel = torch.tensor(rng.choice(npool, batch, replace=False))
+            data = {k: v[sel] for k, v in pool.items()}
+            opt.zero_grad()
+            loss = ev.get_loss(data, net, step, True)
+            total = 0
+            for k in loss:
+                total = total + loss[k][0] * loss[k][1]
+            total.backward()
+            opt.step()
+            sched.step()
+            traj.append([phase, float(total), float(loss["Color"][0])])
+            if step % 250 == 249 or step == n_steps - 1:
+                net.train(False)
+                mps = float(ref_eval(net, data_h, S)["PS"].max(1).values.mean())
+                net.train(True)
+                checks.append([phase, step, mps, time.time() - t0])
+                print(f"W{W} phase {phase} step {step:5d} total {float(total):.5f} colour {float(loss['Color'][0]):.5f} held-out mean max-PS {mps:.3f} ({time.time() - t0:.0f} s)", flush=True)
+                if phase == 4 and (mps >= target or time.time() - t0 > hours * 3600):
+                    done = True
+                    break
+        if done:
+            break
+    net.train(False)
+    out = {"W": W, "C": 4, "S": S, "n_total": n_total, "loss_trajectory": np.asarray(traj), "checks": np.asarray(checks), "hm": hm}
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    for k, v in sd.items():
+        out["sd_" + k] = v.cpu().numpy()
+    for k, v in data_h.items():
+        out["in_" + k] = f32(v)
+    r = ref_eval(net, data_h, S)
+    eval_record(out, r)
+    oracle64(out, sd, data_h, S)
+    path = os.path.join(mg.OUT, f"converged_W{W}.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB; mean max-PS per ray", float(out["max_ps"].mean()), "steps", len(traj))
+
+
 def gen_sweep(W, S=96, gains=(1, 2, 4, 8, 16, 32, 64, 128, 256)):
     """tests/golden/sharp_sweep_W{W}.npz: the reference's eval (RGB, albedo, depth, max-PS) of the trained fixture's weights for a LADDER of density-head
     gains, fog (g = 1) to hard surfaces (g = 256): what the pack-time error model of the int8 digits is validated against (tools/sharp_modes.py)."""
@@ -239,6 +309,8 @@ def main():
             gen_sweep(W)
     elif mode == "prior":
         gen_prior(int(ARGV[1]), int(ARGV[2]), int(ARGV[3]) if len(ARGV) > 3 else 0)
+    elif mode == "converged":          # width, total steps of the schedule, wall-clock cap in hours
+        gen_converged(int(ARGV[1]), int(ARGV[2]), float(ARGV[3]) if len(ARGV) > 3 else 6.0)
     else:
         raise SystemExit(__doc__)
 
