@@ -448,7 +448,8 @@ int snerf_field_ray_visibility(const snerf_model* m, int64_t n_rays, int n_sampl
     a.tvals = d_tvals;
     a.n_samples = n_samples;
     a.group_size = 1;
-    a.ray_flags = flags & 2;
+    static const bool no_early_out = getenv("SNERF_RAYVIS_NO_EARLY_OUT") != nullptr;      // A/B switch: walk every pass of every ray (mlp_device.h raysum_saturated)
+    a.ray_flags = (flags & 2) | (no_early_out ? 4 : 0);
     a.out.vis = d_vis;
     return field_launch(m, 3, a, nullptr, stream);
 }
@@ -629,7 +630,7 @@ int snerf_field_kernel_info(const snerf_model* m, int64_t n_points, int* grid, i
     if (grid) *grid = (int)(tiles < ncu ? tiles : ncu);
     if (block) *block = two_waves ? 512 : 256;
     if (lds_bytes) {
-        if (i8) *lds_bytes = (m->W > 256 ? 5 : 7) * kChunkBytes + (int)m->host_i8.bias.size() * 4;
+        if (i8) *lds_bytes = (m->W > 256 ? 5 : 7) * kChunkBytes + (int)m->host_i8.bias.size() * 4 + kVoteBytes;
         else if (ks) *lds_bytes = mlp_ks_lds_bytes((int)m->host_ks.bias.size());
         else *lds_bytes = mlp_lds_bytes((int)m->host[PROG_FIELD].bias.size());
     }

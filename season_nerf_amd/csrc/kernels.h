@@ -16,6 +16,8 @@ struct snerf_field_out_dev {
     float* vis;               // VARIANT 3 only: [n_rays] exp(-sum_{j < S-1} rho_j delta_j), one value per ray
 };
 
+constexpr int kVoteBytes = 64;    // LDS behind every fused kernel's image: one float per wave for the ray-visibility early-out vote (mlp_device.h raysum_saturated)
+
 struct MlpArgs {
     const uint8_t* stream;     // packed fragment stream (device)
     uint32_t stream_bytes;     // bytes consumed per tile = length of the cyclic DMA stream
@@ -41,7 +43,7 @@ struct MlpArgs {
     uint32_t debug;            // only read by -DSNERF_ABLATE builds
     // VARIANT 3 (ray visibility: the density-only program with the sum over a ray's samples kept in registers): n = rays, every wave
     // owns one ray of a group of `waves per workgroup` rays and walks its samples 32 at a time
-    int ray_flags;             // bit 1: a sample outside [-1,1]^3 contributes nothing (mg_Img_Eval.py:42,65-66)
+    int ray_flags;             // bit 1: a sample outside [-1,1]^3 contributes nothing (mg_Img_Eval.py:42,65-66); bit 2: no early-out (A/B)
 };
 
 struct CompOutDev {

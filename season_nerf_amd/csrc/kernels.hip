@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpArgs A) {
             // ---- output non-linearities (T_NeRF_net_v2.py:91-98), lane-half 0 holds the head rows
             if constexpr (VARIANT == 3) {
                 raysum_add(rs, A, tile, 4, wave, pass, lane, rho_raw, x0, x1, x2);
-                if (++pass == passes) {
+                if (++pass == passes || raysum_saturated(rs, A, tile * 4 + wave, wave, 4, lane, (__attribute__((address_space(3))) float*)(bias_lds + A.bias_floats))) {
                     raysum_end(rs, A, tile, 4, wave, lane);
                     pass = 0;
                     tile += gridDim.x;
@@ -667,7 +667,7 @@ hipError_t launch_ray_grid(const RayGridArgs& a, hipStream_t st) {
 // launchers
 template <int PROG, int W, int VARIANT, bool FAST = false>
 static hipError_t launch_mlp_t(const MlpArgs& a, int n_cu, hipStream_t st) {
-    const int lds_bytes = RING_BYTES + a.bias_floats * 4;
+    const int lds_bytes = RING_BYTES + a.bias_floats * 4 + kVoteBytes;
     const int64_t n_tiles = VARIANT == 3 ? (a.n + 3) / 4 : (a.n + TILE_PTS - 1) / TILE_PTS;
     int grid = (int)(n_tiles < n_cu ? n_tiles : n_cu);
     if (grid < 1) grid = 1;
@@ -697,7 +697,7 @@ hipError_t launch_mlp(int prog, int W, int variant, bool fast, const MlpArgs& a,
     return hipErrorInvalidValue;
 }
 
-int mlp_lds_bytes(int bias_floats) { return RING_BYTES + bias_floats * 4; }
+int mlp_lds_bytes(int bias_floats) { return RING_BYTES + bias_floats * 4 + kVoteBytes; }
 int mlp_tile_points() { return TILE_PTS; }
 const char* mlp_kernel_name() { return "mlp_kernel"; }
 

@@ -400,7 +400,7 @@ __global__ __launch_bounds__(256, 1) void mlp_i8_kernel(const MlpArgs A) {
 #undef LAYER_RAW
         if constexpr (VARIANT == 3) {
             raysum_add(rs, A, tile, 4, wave, pass, lane, rho_raw, x0, x1, x2);
-            if (++pass == passes) {
+            if (++pass == passes || raysum_saturated(rs, A, tile * 4 + wave, wave, 4, lane, (__attribute__((address_space(3))) float*)(tab_lds + A.bias_floats))) {
                 raysum_end(rs, A, tile, 4, wave, lane);
                 pass = 0;
                 tile += gridDim.x;
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(256, 1) void mlp_i8_kernel(const MlpArgs A) {
 
 template <int PROG, int W, int VARIANT>
 static hipError_t launch_mlp_i8_t(const MlpArgs& a, int n_cu, hipStream_t st) {
-    const int lds_bytes = ring_depth8(W) * kChunkBytes + a.bias_floats * 4;
+    const int lds_bytes = ring_depth8(W) * kChunkBytes + a.bias_floats * 4 + kVoteBytes;
     const int64_t n_tiles = VARIANT == 3 ? (a.n + 3) / 4 : (a.n + TILE_PTS - 1) / TILE_PTS;
     int grid = (int)(n_tiles < n_cu ? n_tiles : n_cu);
     if (grid < 1) grid = 1;

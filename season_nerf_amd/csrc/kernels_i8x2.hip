@@ -465,7 +465,7 @@ __device__ __forceinline__ void field_tiles2(const MlpArgs& A, Ring2& rg, lds_ch
 #undef LAYER_RAW
         if constexpr (VARIANT == 3) {
             raysum_add(rs, A, tile, NW2, wave, pass, lane, rho_raw, x0, x1, x2);
-            if (++pass == passes) {
+            if (++pass == passes || raysum_saturated(rs, A, tile * NW2 + wave, wave, NW2, lane, (__attribute__((address_space(3))) float*)(tab_lds + A.bias_floats))) {
                 raysum_end(rs, A, tile, NW2, wave, lane);
                 pass = 0;
                 tile += gridDim.x;
@@ -481,7 +481,7 @@ __device__ __forceinline__ void field_tiles2(const MlpArgs& A, Ring2& rg, lds_ch
 
 template <int W, int VARIANT>
 static hipError_t launch_mlp_i8x2_t(const MlpArgs& a, int n_cu, hipStream_t st) {
-    const int lds_bytes = RING2_D * kChunkBytes + a.bias_floats * 4;
+    const int lds_bytes = RING2_D * kChunkBytes + a.bias_floats * 4 + kVoteBytes;
     const int64_t n_tiles = VARIANT == 3 ? (a.n + NW2 - 1) / NW2 : (a.n + TILE2 - 1) / TILE2;
     int grid = (int)(n_tiles < n_cu ? n_tiles : n_cu);
     if (grid < 1) grid = 1;

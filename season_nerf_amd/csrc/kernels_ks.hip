@@ -29,7 +29,7 @@ constexpr int KS_XBUF_BYTES = 4096;                   // one 32 x 32 fp32 block 
 static_assert(kChunkPairs == 2 * KS_PAR_PAIRS, "a chunk holds 4 pairs per parity");
 
 // LDS: ring | bias table | 32 zero floats (bias of the partner's half of a raw head) | 4 exchange buffers (pair, parity)
-__host__ __device__ constexpr int ks_lds_bytes(int bias_floats) { return RING_BYTES + (bias_floats + 32) * 4 + 4 * KS_XBUF_BYTES; }
+__host__ __device__ constexpr int ks_lds_bytes(int bias_floats) { return RING_BYTES + (bias_floats + 32) * 4 + 4 * KS_XBUF_BYTES + kVoteBytes; }
 
 struct KsCtx {
     lds_char* lds;            // ring base
@@ -306,6 +306,7 @@ __global__ __launch_bounds__(256, 1) void mlp_ks_kernel(const MlpArgs A) {
         cx.xw = xb + (pair * 2 + par) * KS_XBUF_BYTES;
         cx.xr = xb + (pair * 2 + (par ^ 1)) * KS_XBUF_BYTES;
     }
+    __attribute__((address_space(3))) float* vote_lds = (__attribute__((address_space(3))) float*)(lds + RING_BYTES + (A.bias_floats + 32) * 4 + 4 * KS_XBUF_BYTES);
 
     Ring rg;
     Pend pd;
@@ -416,7 +417,7 @@ __global__ __launch_bounds__(256, 1) void mlp_ks_kernel(const MlpArgs A) {
 #undef OWNB
         if constexpr (VARIANT == 3) {
             raysum_add(rs, A, tile, 2, pair, pass, lane, rho_raw, x0, x1, x2);
-            if (++pass == passes) {
+            if (++pass == passes || raysum_saturated(rs, A, tile * 2 + pair, wave, 4, lane, vote_lds)) {      // both waves of a pair hold the same sum and vote alike
                 if (par == 0) raysum_end(rs, A, tile, 2, pair, lane);
                 pass = 0;
                 tile += gridDim.x;

@@ -180,6 +180,26 @@ __device__ __forceinline__ void raysum_add(RaySum& q, const MlpArgs& A, int64_t 
     const bool on = s < A.n_samples - 1 && !((A.ray_flags & 2) && oob);
     q.sum += on ? __fmul_rn(softplus_f(rho_raw), delta) : 0.f;
 }
+// Early-out (round 6): behind a surface the optical depth only grows, and exp(-18) = 1.5e-8 is below the last bit of a visibility - once EVERY ray of the
+// workgroup's group has passed 18, the ray's remaining passes (whole evaluations of the density network) change no result by more than that.  The vote is
+// workgroup-wide because the waves share the weight ring: all of them skip the same passes, at a pass boundary, where the cyclic stream stands at its
+// start either way.  Consecutive secondary rays start at consecutive samples of one primary ray, so a group saturates together.  `vote`: one LDS float per wave
+// (kVoteBytes behind each kernel's LDS image); the store is drained and the barrier passed by all waves before the loads; the next vote is a whole pass later.
+constexpr float kSaturatedDepth = 18.f;
+// `ray`: the ray this wave walks; `slot` / `n_slots`: this wave's vote word and how many the workgroup casts
+__device__ __forceinline__ bool raysum_saturated(const RaySum& q, const MlpArgs& A, int64_t ray, int slot, int n_slots, int lane,
+                                                 __attribute__((address_space(3))) float* vote) {
+    if (A.ray_flags & 4) return false;                        // A/B switch (SNERF_RAYVIS_NO_EARLY_OUT=1): every pass of every ray
+    float v = q.sum;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (ray >= A.n) v = 1e30f;                                // a ray past the end never holds the group back
+    if (lane == 0) vote[slot] = v;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    bool all = true;
+    for (int w = 0; w < n_slots; ++w) all = all && vote[w] > kSaturatedDepth;
+    return all;
+}
 __device__ __forceinline__ void raysum_end(RaySum& q, const MlpArgs& A, int64_t group, int waves, int wave, int lane) {
     float v = q.sum;
 #pragma unroll
