@@ -66,7 +66,9 @@ def _exact_solar_visibility(net: T_NeRF, pts, sun_vec, S, zero_oob, chunk_rays=1
     vis = torch.empty(M, device=dev)
     fused = net.fused and net.resolved_precision != "bf16"
     if not fused:
-        chunk_rays = min(chunk_rays, 1 << 16)
+        # the layer-wise engine keeps every layer's [points x width] array of a chunk: ~32 of them, 4 bytes each - size the chunk to ~12 GB of workspace
+        # (round 6: the fixed 65 536-ray chunk of round 5 asked for 435 GB at width 512 and S = 96; nothing above 24 x 20 x 96 had ever run through here)
+        chunk_rays = min(chunk_rays, 1 << 16, max(64, int(12e9 / (128.0 * net.layer_width)) // S))
     flags = 2 if zero_oob else 0
     for i in range(0, M, chunk_rays):
         j = min(M, i + chunk_rays)

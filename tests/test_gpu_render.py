@@ -434,3 +434,73 @@ def test_exact_solar_image_64x64x96_vs_oracle(golden_dir):
     dev8 = np.abs(np.asarray(d8["Exact_Solar"])[:, :, 0] - ex)
     print(f"  exact solar 64x64x96: int8 digits vs bf16x3 max abs {dev8.max():.2e}, mean {dev8.mean():.2e}")
     assert dev8.max() < 5e-3
+
+
+# ---------------------------------------------------------------------------------------------------------------- round 6
+def test_layerwise_visibility_across_its_chunk_boundary():
+    """VERDICT r5 #2c: a network WITHOUT a fused kernel (width 128) composes the exact-solar visibility from the layer-wise density and a transmittance scan
+    (render._visibility_layerwise), in chunks sized to the engine's workspace (round 6: ~12 GB; the fixed 65 536-ray chunks of round 5 could not be allocated at
+    width 512).  More rays than one chunk holds, against forced small chunks and against the oracle: the chunk boundary changes nothing."""
+    import season_nerf_amd as sn
+    from season_nerf_amd import render as R_
+    W, S = 128, 24
+    sd = orc.init_weights(W, 4, 8)
+    sd["G_NeRF_net.fc10Sigma.weight"] = sd["G_NeRF_net.fc10Sigma.weight"] * 24          # some opacity: visibilities spread over (0, 1)
+    net = sn.T_NeRF(W, 4)
+    net.load_state_dict(sd)
+    net = net.to("cuda").eval()
+    assert not net.fused
+    per_chunk = min(1 << 16, max(64, int(12e9 / (128.0 * W)) // S))
+    M = per_chunk + 1777                                                                 # one full chunk + a ragged one
+    rng = np.random.Generator(np.random.PCG64(6))
+    pts = torch.tensor(rng.uniform(-0.95, 0.95, (M, 3)), dtype=torch.float32, device="cuda")
+    WC, H4 = np.array([41.29, -95.9, 300.0]), np.array([[310.0, 12.0, 0.0, -11650.0], [-9.0, 240.0, 0.0, 23390.0], [0.0, 0.0, 0.01, -3.0], [0, 0, 0, 1.0]])
+    sunv = orc.world_angle_2_local_vec(40, 120, WC, H4)
+    sun_d = torch.tensor(sunv, dtype=torch.float32, device="cuda")
+    one = R_._exact_solar_visibility(net, pts, sun_d, S, zero_oob=True, sun64=sunv)
+    many = R_._exact_solar_visibility(net, pts, sun_d, S, zero_oob=True, sun64=sunv, chunk_rays=5000)
+    d = float((one - many).abs().max())
+    print(f"  layer-wise visibility, {M} rays: default chunks ({per_chunk} rays) vs 5000-ray chunks: max abs diff {d:.1e}; spread {float(one.min()):.3f} .. {float(one.max()):.3f}")
+    assert d <= 1e-6 and float(one.std()) > 0.05
+    idx = torch.cat([torch.arange(0, M, 997), torch.arange(per_chunk - 3, per_chunk + 3)])   # scattered rays and the ones either side of the boundary
+    want = orc.exact_solar_visibility(sd, pts[idx].cpu(), sunv, S, path_b=True)
+    close("layer-wise visibility vs oracle", one[idx].cpu().numpy(), want.numpy(), rtol=1e-4, atol=3e-5)
+
+
+def test_exact_solar_at_the_default_width(golden_dir):
+    """The reference's default configuration (main_lite.py:80 fc_units = 512; Quick_Run.py:62 / mg_Img_Eval.py:96 exact solar on) on weights with surfaces
+    (sharp_W512: `auto` -> bf16x3 = the K-split kernel, VARIANT 3): a 32 x 32 x 96 render with include_exact_solar=True - 98 304 secondary rays, 49 152 wave-pair
+    groups - against the oracle's restatement of mg_Img_Eval.py:57-70 on scattered pixels, and the kernel against its own composition (density-only pass + scan)."""
+    import season_nerf_amd as sn
+    from season_nerf_amd import render as R_
+    g = dict(np.load(os.path.join(golden_dir, "sharp_W512.npz"), allow_pickle=False))
+    t = dict(np.load(os.path.join(golden_dir, str(g["source"])), allow_pickle=False))
+    head = ("G_NeRF_net.fc10Sigma.weight", "G_NeRF_net.fc10Sigma.bias")
+    sd = {k[3:]: torch.tensor(v) * (float(g["g"]) if k[3:] in head else 1.0) for k, v in t.items() if k.startswith("sd_")}
+    net = sn.T_NeRF(512, 4)
+    net.load_state_dict(sd)
+    net = net.to("cuda").eval()
+    assert net.resolved_precision == "bf16x3" and net.fused
+    WC, H4 = np.array([41.29, -95.9, 300.0]), np.array([[310.0, 12.0, 0.0, -11650.0], [-9.0, 240.0, 0.0, 23390.0], [0.0, 0.0, 0.01, -3.0], [0, 0, 0, 1.0]])
+    size, view, sun, tf = (32, 32, 96), (80, 0), (30, 90), 0.25
+    d = sn.component_render_by_dir(net, view, sun, tf, size, WC, H4, torch.device("cuda"), include_exact_solar=True)
+    ex = np.asarray(d["Exact_Solar"])[:, :, 0]
+    assert ex.shape == (1024, 96) and 0.05 < float((ex < 0.5).mean()) < 0.95
+    sunv = orc.world_angle_2_local_vec(sun[0], sun[1], WC, H4)
+    rays = np.arange(5, 1024, 127)
+    want = orc.exact_solar_visibility(sd, torch.tensor(np.asarray(d["World_Points"])[rays]).float(), sunv, 96, path_b=True).reshape(len(rays), 96).numpy()
+    close("Exact_Solar W=512 32x32x96 (scattered rays)", ex[rays], want, rtol=1e-4, atol=3e-5)
+    # the kernel against its own composition: S that is not a multiple of 32, rays that are not a multiple of the group size
+    rng = np.random.Generator(np.random.PCG64(9))
+    for S in (33, 100):
+        R = 203
+        top = torch.tensor(np.concatenate([rng.uniform(-1, 1, (R, 2)), np.ones((R, 1))], 1), dtype=torch.float32, device="cuda")
+        bot = torch.tensor(np.concatenate([rng.uniform(-1, 1, (R, 2)), -np.ones((R, 1))], 1), dtype=torch.float32, device="cuda")
+        tv = sn.sample_parameters(S, eval_mode=True).cuda()
+        vis = torch.ops.season_nerf.ray_visibility(net.op_model(), top, bot, tv, 0)
+        pts = (top[:, None, :] * (1 - tv[None, :, None]) + bot[:, None, :] * tv[None, :, None]).reshape(-1, 3).contiguous()
+        rho = net.forward_Classic_Sigma_Only(pts).reshape(R, S)
+        ref = torch.exp(-(rho[:, :-1] * ((top - bot).norm(dim=1, keepdim=True) / S)).sum(1))
+        dd = float((vis - ref).abs().max())
+        print(f"  W=512 ray_visibility S={S}: max abs dev from its composition {dd:.1e}")
+        assert dd < 2e-6
