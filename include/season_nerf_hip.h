@@ -59,7 +59,7 @@ int snerf_model_classes(const snerf_model* m);
  *                      SNERF_PREC_BF16X3 otherwise; resolved when the weights are packed (snerf_model_resolve_precision or
  *                      snerf_model_finalize), after which snerf_model_precision reports the mode chosen
  * The per-group network (class softmax, sky colour: one row per ray, its error is not averaged over a ray's samples) runs in
- * BF16X3 at the widths that have that kernel (64, 256) and layer by layer in exact fp32 at 512, whatever the mode. */
+ * BF16X3 at every width, whatever the mode (512: on the wave-pair structure of csrc/kernels_ks.hip; exact fp32 layer by layer in rounds 3-5). */
 #define SNERF_PREC_BF16X3 0
 #define SNERF_PREC_BF16 1
 #define SNERF_PREC_I8X3 2
@@ -95,7 +95,8 @@ int snerf_model_resolve_precision(snerf_model* m);
  * program 0 = per-point field network, 1 = per-group (time/sun) network (bf16 hi/lo fragment pairs + bias table);
  * program 2 = the field network in the int8-digit format (T/L digit fragment pairs + per-row [scale | bias] tables),
  * only under SNERF_PREC_I8X3; program 3 = the field network's bf16 pairs in the K-split order of the width-512 kernel
- * (csrc/program.h ks_*: a permutation of program 0's pairs, same bias table), width 512 only.  Buffers may be NULL to query sizes. */
+ * (csrc/program.h ks_*: a permutation of program 0's pairs, same bias table), program 4 = program 1's pairs in that order; 3 and 4: width 512 only.
+ * Buffers may be NULL to query sizes. */
 int snerf_model_pack_host(snerf_model* m, int program, uint8_t* stream_out, size_t* stream_bytes,
                           float* bias_out, size_t* bias_floats);
 

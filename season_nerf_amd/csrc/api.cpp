@@ -41,6 +41,7 @@ struct snerf_model {
     Packed host[2];
     Packed host_i8;                  // field program in the int8-digit format (precision SNERF_PREC_I8X3 only)
     Packed host_ks;                  // field program in the K-split order of kernels_ks.hip (W = 512 under SNERF_PREC_BF16X3)
+    Packed host_ksg;                 // per-ray (group) program in the same order: W = 512 under every precision (round 6; exact fp32 layer by layer before)
     // Widths without a bf16 group kernel (512): the per-ray networks (time -> class softmax, sun -> sky colour: one row per ray,
     // 1/S of the field network's work) run layer by layer in exact fp32 (v_mfma_f32_32x32x2_f32, csrc/gemm.hip) - their error is
     // not averaged over a ray's samples, so they get the full precision.  Device copy of the five layers' fp32 weights:
@@ -52,6 +53,8 @@ struct snerf_model {
     float* d_table_i8 = nullptr;
     uint8_t* d_stream_ks = nullptr;
     float* d_bias_ks = nullptr;
+    uint8_t* d_stream_ksg = nullptr;
+    float* d_bias_ksg = nullptr;
     int n_cu = 0;
 };
 
@@ -157,6 +160,14 @@ static int pack_both(snerf_model* m, bool want_bf16_field = false) {
         m->host_ks = std::move(ks);
         if (want_bf16_field) m->host[PROG_FIELD] = std::move(tmp);      // the canonical order, on request only (snerf_model_pack_host)
     }
+    if (ks_width(m->W) && m->host_ksg.stream.empty()) {            // the per-ray networks of width 512: bf16x3 on the wave-pair structure, whatever the field's mode
+        std::string err;
+        Packed tmp, ks;
+        if (!pack_program(m->w, PROG_GROUP, m->W, m->C, /*fold_bn=*/true, &tmp, &err) || !permute_program_ks(tmp, m->W, m->C, &ks, &err, PROG_GROUP))
+            return fail(err.rfind("missing", 0) == 0 ? SNERF_E_MISSING : SNERF_E_INVALID, err);
+        m->host_ksg = std::move(ks);
+        m->host[PROG_GROUP] = std::move(tmp);                         // the canonical order, for snerf_model_pack_host
+    }
     for (int p = 0; p < 2; ++p) {
         if (!bf16_width(m->W)) break;
         if (!m->host[p].stream.empty()) continue;
@@ -186,14 +197,14 @@ int snerf_model_resolve_precision(snerf_model* m) {
 
 int snerf_model_pack_host(snerf_model* m, int program, uint8_t* stream_out, size_t* stream_bytes, float* bias_out,
                           size_t* bias_floats) {
-    if (!m || program < 0 || program > 3) return fail(SNERF_E_INVALID, "snerf_model_pack_host: bad argument");
+    if (!m || program < 0 || program > 4) return fail(SNERF_E_INVALID, "snerf_model_pack_host: bad argument");
     if (program == 2 && m->precision != SNERF_PREC_I8X3)
         return fail(SNERF_E_STATE, "program 2 (int8-digit field network) exists only under SNERF_PREC_I8X3");
     if (program == 3 && !ks_width(m->W)) return fail(SNERF_E_STATE, "program 3 (K-split bf16 field network) exists only at width 512");
-    if (program == PROG_GROUP && !bf16_width(m->W)) return fail(SNERF_E_STATE, "the per-ray networks have no packed program at this width (they run layer by layer in fp32)");
+    if (program == 4 && !ks_width(m->W)) return fail(SNERF_E_STATE, "program 4 (K-split per-ray networks) exists only at width 512");
     int rc = pack_both(m, program == PROG_FIELD || program == 3);
     if (rc) return rc;
-    const Packed& P = program == 3 ? m->host_ks : program == 2 ? m->host_i8 : m->host[program];
+    const Packed& P = program == 4 ? m->host_ksg : program == 3 ? m->host_ks : program == 2 ? m->host_i8 : m->host[program];
     if (stream_bytes) *stream_bytes = P.stream.size();
     if (bias_floats) *bias_floats = P.bias.size();
     if (stream_out) std::memcpy(stream_out, P.stream.data(), P.stream.size());
@@ -221,6 +232,13 @@ int snerf_model_finalize(snerf_model* m) {
         if ((e = hipMalloc((void**)&m->d_bias_ks, P.bias.size() * 4)) != hipSuccess) return fail_hip(e, "hipMalloc");
         if ((e = hipMemcpy(m->d_stream_ks, P.stream.data(), P.stream.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail_hip(e, "hipMemcpy");
         if ((e = hipMemcpy(m->d_bias_ks, P.bias.data(), P.bias.size() * 4, hipMemcpyHostToDevice)) != hipSuccess) return fail_hip(e, "hipMemcpy");
+    }
+    if (ks_width(m->W)) {
+        const Packed& P = m->host_ksg;
+        if ((e = hipMalloc((void**)&m->d_stream_ksg, P.stream.size())) != hipSuccess) return fail_hip(e, "hipMalloc");
+        if ((e = hipMalloc((void**)&m->d_bias_ksg, P.bias.size() * 4)) != hipSuccess) return fail_hip(e, "hipMalloc");
+        if ((e = hipMemcpy(m->d_stream_ksg, P.stream.data(), P.stream.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail_hip(e, "hipMemcpy");
+        if ((e = hipMemcpy(m->d_bias_ksg, P.bias.data(), P.bias.size() * 4, hipMemcpyHostToDevice)) != hipSuccess) return fail_hip(e, "hipMemcpy");
     }
     for (int p = 0; p < 2; ++p) {
         const Packed& P = m->host[p];
@@ -277,6 +295,8 @@ void snerf_model_destroy(snerf_model* m) {
     if (m->d_table_i8) (void)hipFree(m->d_table_i8);
     if (m->d_stream_ks) (void)hipFree(m->d_stream_ks);
     if (m->d_bias_ks) (void)hipFree(m->d_bias_ks);
+    if (m->d_stream_ksg) (void)hipFree(m->d_stream_ksg);
+    if (m->d_bias_ksg) (void)hipFree(m->d_bias_ksg);
     if (m->d_group_f32) (void)hipFree(m->d_group_f32);
     delete m;
 }
@@ -339,11 +359,14 @@ int snerf_group_forward(const snerf_model* m, int64_t n_groups, const float* d_t
     if (rc) return rc;
     if (n_groups == 0) return SNERF_OK;
     if (n_groups < 0 || !d_time || !d_sun) return fail(SNERF_E_INVALID, "snerf_group_forward: bad argument");
-    if (m->d_group_f32) return group_forward_f32(m, n_groups, d_time, d_sun, d_classes, d_sky_raw, d_sky, (hipStream_t)stream);
+    // width 512: the wave-pair kernel (bf16x3, as the per-ray networks of the other widths); SNERF_GROUP_F32=1: the exact-fp32 layer-wise form of rounds 3-5 (A/B)
+    static const bool group_f32 = getenv("SNERF_GROUP_F32") != nullptr;
+    if (m->d_group_f32 && (group_f32 || !m->d_stream_ksg)) return group_forward_f32(m, n_groups, d_time, d_sun, d_classes, d_sky_raw, d_sky, (hipStream_t)stream);
     MlpArgs a{};
-    a.stream = m->d_stream[PROG_GROUP];
-    a.stream_bytes = (uint32_t)m->host[PROG_GROUP].stream.size();
-    a.bias = m->d_bias[PROG_GROUP];
+    const bool ks = ks_width(m->W);
+    a.stream = ks ? m->d_stream_ksg : m->d_stream[PROG_GROUP];
+    a.stream_bytes = ks ? (uint32_t)group_chunks_ks(m->W, m->C) * kChunkBytes : (uint32_t)m->host[PROG_GROUP].stream.size();
+    a.bias = ks ? m->d_bias_ksg : m->d_bias[PROG_GROUP];
     a.bias_floats = (int)m->host[PROG_GROUP].bias.size();
     a.n = n_groups;
     a.n_classes = m->C;
@@ -353,7 +376,8 @@ int snerf_group_forward(const snerf_model* m, int64_t n_groups, const float* d_t
     a.g_classes = d_classes;
     a.g_sky_raw = d_sky_raw;
     a.g_sky = d_sky;
-    hipError_t e = launch_mlp(PROG_GROUP, m->W, 0, false, a, m->n_cu, (hipStream_t)stream);      // bf16x3: its cost is 1/S of the field network's
+    hipError_t e = ks ? launch_mlp_ks_group(m->W, a, m->n_cu, (hipStream_t)stream)
+                      : launch_mlp(PROG_GROUP, m->W, 0, false, a, m->n_cu, (hipStream_t)stream);      // bf16x3: its cost is 1/S of the field network's
     return e == hipSuccess ? SNERF_OK : fail_hip(e, "group kernel launch");
 }
 

@@ -105,7 +105,9 @@ hipError_t launch_mlp_i8(int prog, int W, int variant, const MlpArgs& a, int n_c
 int field_variant_chunks_i8(int W, int C, int variant);
 hipError_t launch_mlp_i8x2(int W, int variant, const MlpArgs& a, int n_cu, hipStream_t st);                // kernels_i8x2.hip (W <= 256)
 hipError_t launch_mlp_ks(int W, int variant, const MlpArgs& a, int n_cu, hipStream_t st);                // kernels_ks.hip (W = 512, bf16x3, K split over wave pairs)
+hipError_t launch_mlp_ks_group(int W, const MlpArgs& a, int n_cu, hipStream_t st);                         // ... its per-ray (time / sun) networks
 int field_variant_chunks_ks(int W, int C, int variant);
+int group_chunks_ks(int W, int C);
 int mlp_ks_lds_bytes(int bias_floats);
 int mlp_ks_tile_points();
 hipError_t launch_composite(const CompArgs& a, hipStream_t st);

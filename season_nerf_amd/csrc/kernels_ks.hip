@@ -142,7 +142,8 @@ __device__ __forceinline__ void run_layer_ks(Ring& rg, Pend& pd, const uint8_t* 
     constexpr int SL = (EX ? KSH : 0) + KO;        // pairs per step (F + O)
     constexpr int NP = NBH * SL;
     static_assert(!EX || KSH >= 8, "the exchange is ordered by >= 2 ring steps per phase");
-    static_assert(KO >= 4, "the sliced epilogue needs 4 k-steps");
+    constexpr bool PIPE = KO >= 4;                 // the sliced epilogue needs 4 k-steps; a two-step encoding layer (per-ray networks) runs it in one piece
+    static_assert(PIPE || !EX, "only an encoding-only layer may be that short");
     const int h = lane >> 5;
     u32x4 fh[PF], fl[PF];
 #pragma unroll
@@ -224,10 +225,16 @@ __device__ __forceinline__ void run_layer_ks(Ring& rg, Pend& pd, const uint8_t* 
                 if (!EX && i > 0) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        const int sA = 1 + (e * (KO - 4)) / 8;
-                        if (s == sA + 2) epi_C(e, et[e], out + 2 * (i - 1));
-                        if (s == sA + 1) epi_B(e, et[e], out + 2 * (i - 1));
-                        if (s == sA) epi_A(accO[(i - 1) & 1], e, et[e]);
+                        if (PIPE) {
+                            const int sA = 1 + (e * (KO - 4)) / 8;
+                            if (s == sA + 2) epi_C(e, et[e], out + 2 * (i - 1));
+                            if (s == sA + 1) epi_B(e, et[e], out + 2 * (i - 1));
+                            if (s == sA) epi_A(accO[(i - 1) & 1], e, et[e]);
+                        } else if (s == 0) {
+                            epi_A(accO[(i - 1) & 1], e, et[e]);
+                            epi_B(e, et[e], out + 2 * (i - 1));
+                            epi_C(e, et[e], out + 2 * (i - 1));
+                        }
                     }
                 }
                 KS_SCHED();
@@ -429,6 +436,114 @@ __global__ __launch_bounds__(256, 1) void mlp_ks_kernel(const MlpArgs A) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup
 }
+
+// The per-ray networks at this width (time -> class softmax, T_NeRF_net_v2.py:77-78,160-163; sun -> sky colour, G_NeRF.py:110-111) on the same wave-pair
+// structure: one "point" per ray, 64 rays per tile.  Until round 6 they ran layer by layer in exact fp32 - five GEMM launches and seven small kernels,
+// ~0.3 ms in front of every width-512 render step; bf16x3 is what the per-ray networks of the other widths run in (never int8 digits: their error is
+// per ray, not averaged over a ray's samples).
+template <int W>
+__global__ __launch_bounds__(256, 1) void mlp_ks_group_kernel(const MlpArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int C_MAX = kMaxClasses;
+    lds_char* lds = (lds_char*)smem;
+    __attribute__((address_space(3))) float* bias_lds = (__attribute__((address_space(3))) float*)(lds + RING_BYTES);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int pair = wave >> 1, par = wave & 1;
+    const int h = lane >> 5;
+    const int C = A.n_classes;
+    for (int i = threadIdx.x; i < A.bias_floats + 32; i += 256) bias_lds[i] = i < A.bias_floats ? A.bias[i] : 0.f;
+    lds_cfloat* zero_bias = bias_lds + A.bias_floats;
+    KsCtx cx;
+    cx.lds = lds;
+    cx.par_off = par * KS_PAR_BYTES;
+    {
+        lds_char* xb = lds + RING_BYTES + (A.bias_floats + 32) * 4;
+        cx.xw = xb + (pair * 2 + par) * KS_XBUF_BYTES;
+        cx.xr = xb + (pair * 2 + (par ^ 1)) * KS_XBUF_BYTES;
+    }
+    Ring rg;
+    Pend pd;
+    pd.goff = 0;
+    pd.wr = 0;
+    rg.rd = 0;
+    rg.cur = 0;
+    rg.goff = 0;
+    {
+        uint32_t wr = 0;
+#pragma unroll
+        for (int c = 0; c < RING_D - 2; ++c) {
+            dma_chunk(A.stream, rg.goff, lds, wr, wave, lane);
+            rg.goff += kChunkBytes;
+            if (rg.goff >= A.stream_bytes) rg.goff = 0;
+            wr += kChunkBytes;
+        }
+        rg.wr = wr;
+    }
+    __syncthreads();
+    const int64_t n_tiles = (A.n + KS_TILE_PTS - 1) / KS_TILE_PTS;
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t n = tile * KS_TILE_PTS + pair * 32 + (lane & 31);
+        const bool valid = n < A.n;
+        const int64_t nc = valid ? n : A.n - 1;
+        const float t0 = A.time[nc * 4], t1 = A.time[nc * 4 + 1];
+        const float s0 = A.sun[nc * 3], s1 = A.sun[nc * 3 + 1], s2 = A.sun[nc * 3 + 2];
+        constexpr int KH = W / 32, W4P = pad32(W / 4), KH4 = W4P / 32, NBW = W / 64, NB4 = W4P / 64;
+        static_assert(ks_layer_pairs(group_layer(W, C_MAX, G_T1)) == NBW * PETIME_KS && ks_layer_pairs(group_layer(W, C_MAX, G_T2)) == NBW * 2 * KH &&
+                      ks_layer_pairs(group_layer(W, C_MAX, G_CL)) == KH && ks_layer_pairs(group_layer(W, C_MAX, G_K1)) == NB4 * PESUN_KS &&
+                      ks_layer_pairs(group_layer(W, C_MAX, G_K2)) == KH4, "kernel and packer (program.h ks_*) disagree about the stream");
+#define OWNB(L, NBH) (bias_lds + prog_bias_start(PROG_GROUP, W, C_MAX, L) + par * (NBH) * 32)
+#define LAYER(L, NBH, KSHv, KSXv, IN0, IN1, OUT) run_layer_ks<NBH, KSHv, KSXv>(rg, pd, A.stream, A.stream_bytes, cx, OWNB(L, NBH), IN0, IN1, OUT, wave, lane)
+#define HEADL(L, KSHv, IN0) run_head_ks<KSHv>(rg, pd, A.stream, A.stream_bytes, cx, par ? zero_bias : bias_lds + prog_bias_start(PROG_GROUP, W, C_MAX, L), IN0, wave, lane)
+        Frag pt[PETIME_KS];
+        make_pe_time(t0, t1, h, pt);
+        Frag hA[KH], hB[KH];
+        LAYER(G_T1, NBW, 0, PETIME_KS, nullptr, pt, hA);
+        LAYER(G_T2, NBW, KH, 0, hA, nullptr, hB);
+        f32x16 raw = HEADL(G_CL, KH, hB);
+        float logit[C_MAX];
+#pragma unroll
+        for (int c = 0; c < C_MAX; ++c) logit[c] = raw[c];
+        Frag ps[PESUN_KS];
+        make_pe_sun(s0, s1, s2, h, ps);
+        Frag kA[KH4];
+        LAYER(G_K1, NB4, 0, PESUN_KS, nullptr, ps, kA);
+        raw = HEADL(G_K2, KH4, kA);
+#undef LAYER
+#undef HEADL
+#undef OWNB
+        if (par == 0 && h == 0 && valid) {
+            float m = -3.0e38f;
+#pragma unroll
+            for (int c = 0; c < C_MAX; ++c) if (c < C) m = fmaxf(m, logit[c]);
+            float e[C_MAX], sum = 0.f;
+#pragma unroll
+            for (int c = 0; c < C_MAX; ++c) { e[c] = c < C ? expf(logit[c] - m) : 0.f; sum += e[c]; }
+#pragma unroll
+            for (int c = 0; c < C_MAX; ++c) if (c < C && A.g_classes) A.g_classes[n * C + c] = e[c] / sum;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                if (A.g_sky_raw) A.g_sky_raw[n * 3 + k] = raw[k];
+                if (A.g_sky) A.g_sky[n * 3 + k] = sigmoid_f(raw[k]);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup
+}
+
+hipError_t launch_mlp_ks_group(int W, const MlpArgs& a, int n_cu, hipStream_t st) {
+    if (W != 512) return hipErrorInvalidValue;
+    const int lds_bytes = ks_lds_bytes(a.bias_floats);
+    const int64_t n_tiles = (a.n + KS_TILE_PTS - 1) / KS_TILE_PTS;
+    int grid = (int)(n_tiles < n_cu ? n_tiles : n_cu);
+    if (grid < 1) grid = 1;
+    auto k = mlp_ks_group_kernel<512>;
+    hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds_bytes, st, a);
+    return hipGetLastError();
+}
+int group_chunks_ks(int W, int C) { return ks_chunk_start_g(W, C, G_NUM); }
 
 template <int W, int VARIANT>
 static hipError_t launch_ks_t(const MlpArgs& a, int n_cu, hipStream_t st) {

@@ -226,15 +226,17 @@ bool pack_program(const Weights& w, int prog, int W, int C, bool fold_bn, Packed
 }
 
 // ---- K-split order (program.h ks_*): what the wave pairs of kernels_ks.hip consume ---------------------------------------------
-bool permute_program_ks(const Packed& canon, int W, int C, Packed* out, std::string* err) {
-    if (W % 128 != 0) { *err = "the K-split kernel needs a width that is a multiple of 128 (got " + std::to_string(W) + ")"; return false; }
-    if (canon.stream.size() != (size_t)prog_chunks(PROG_FIELD, W, C) * kChunkBytes) { *err = "permute_program_ks: not a packed field program of this width"; return false; }
+bool permute_program_ks(const Packed& canon, int W, int C, Packed* out, std::string* err, int prog) {
+    if (W % 256 != 0) { *err = "the K-split kernels need a width that is a multiple of 256 (got " + std::to_string(W) + ")"; return false; }
+    if (canon.stream.size() != (size_t)prog_chunks(prog, W, C) * kChunkBytes) { *err = "permute_program_ks: not a packed program of this kind and width"; return false; }
+    const int L = prog_layers(prog);
+    auto start = [&](int l) { return prog == PROG_FIELD ? ks_chunk_start(W, C, l) : ks_chunk_start_g(W, C, l); };
     out->bias = canon.bias;
-    out->stream.assign((size_t)ks_chunk_start(W, C, F_NUM) * kChunkBytes, 0);
-    for (int l = 0; l < F_NUM; ++l) {
-        const LayerShape s = field_layer(W, C, l);
-        const uint8_t* src = canon.stream.data() + (size_t)prog_chunk_start(PROG_FIELD, W, C, l) * kChunkBytes;
-        uint8_t* dst = out->stream.data() + (size_t)ks_chunk_start(W, C, l) * kChunkBytes;
+    out->stream.assign((size_t)start(L) * kChunkBytes, 0);
+    for (int l = 0; l < L; ++l) {
+        const LayerShape s = prog_layer(prog, W, C, l);
+        const uint8_t* src = canon.stream.data() + (size_t)prog_chunk_start(prog, W, C, l) * kChunkBytes;
+        uint8_t* dst = out->stream.data() + (size_t)start(l) * kChunkBytes;
         const int np = ks_layer_pairs(s);
         for (int a = 0; a < 2; ++a)
             for (int q = 0; q < np; ++q) {

@@ -29,7 +29,7 @@ struct Packed {
 
 bool pack_program(const Weights& w, int prog, int W, int C, bool fold_bn, Packed* out, std::string* err);
 // K-split order of a packed bf16 FIELD program (program.h ks_*; kernels_ks.hip): a permutation of `canon.stream`'s pairs, the bias table unchanged
-bool permute_program_ks(const Packed& canon, int W, int C, Packed* out, std::string* err);
+bool permute_program_ks(const Packed& canon, int W, int C, Packed* out, std::string* err, int prog = PROG_FIELD);
 // int8-digit format (FMT_I8): stream of T/L digit fragment pairs, `bias` = per-row [scale | bias] tables
 bool pack_program_i8(const Weights& w, int prog, int W, int C, bool fold_bn, Packed* out, std::string* err);
 

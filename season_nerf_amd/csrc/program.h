@@ -153,6 +153,11 @@ __host__ __device__ constexpr int ks_chunk_start(int W, int C, int l) {
     for (int i = 0; i < l; ++i) c += ks_layer_chunks(field_layer(W, C, i));
     return c;
 }
+__host__ __device__ constexpr int ks_chunk_start_g(int W, int C, int l) {      // the per-ray (group) program in the same order
+    int c = 0;
+    for (int i = 0; i < l; ++i) c += ks_layer_chunks(group_layer(W, C, i));
+    return c;
+}
 // canonical pair (block, k-step) behind pair q of parity a of a layer; returns block * 4096 + k-step
 __host__ __device__ constexpr int ks_pair_source(const LayerShape& s, int a, int q) {
     if (s.out_kind == OUT_RAW) return a * (s.ks0 / 2) + q;

@@ -179,8 +179,14 @@ class GraphedTrainStep:
             return "not under torch.distributed (the data-parallel exchanges are issued from Python)"
         return None
 
-    def __init__(self, tool, data_dict, warmup=3, keep=False):
+    def __init__(self, tool, data_dict, warmup=3, keep=False, check_every=64):
         from . import training
+        # check_every: every that many replays the parameters, Adam's moments and (adaptive loss) the loss object's parameters and moments are tested for
+        # non-finite values ON THE DEVICE (one reduction, its flag copied to pinned memory without a sync and read one period later).  A hit disables the graph:
+        # the step falls back to the eager path, with a warning.  The capture of the generic-loss phases (Barron, DSM prior) is EXPERIMENTAL: two sibling
+        # variants of it - the step's inputs as views of one storage, the packed upload on a second stream - produced NaN moments for a reason that was
+        # bisected but not found; the form that ships passed every soak, which bounds a rate, not an absence.  0 = no check.
+        self.check_every, self._flag_dev, self._flag_host, self._flag_event, self.disabled = int(check_every), None, None, None, None
         if int(warmup) < 1:      # the capture may not allocate or upload: the engine, its scratch and LossDict's weight vector must exist already
             raise ValueError("GraphedTrainStep: warmup must be >= 1 (the eager steps create every buffer the captured step uses)")
         self.keep = bool(keep)
@@ -230,7 +236,9 @@ class GraphedTrainStep:
         tool, ev = self.tool, self.ev
         tool.optim.zero_grad()
         if tool.optim2 is not None:
-            tool.optim2.zero_grad()
+            # in place: the gradients of the loss object's parameters exist since the eager warm-up steps and keep their addresses - the capture allocates
+            # none of them and no replay depends on what a freed block of the graph's pool held
+            tool.optim2.zero_grad(set_to_none=False)
         loss = ev.get_loss(self.data, self.net, 0, train_mode=True)       # the step number reaches the kernels through self.tv["trust"], not through this 0
         if getattr(loss, "vec", None) is not None:
             total = loss.total()
@@ -281,8 +289,36 @@ class GraphedTrainStep:
             ev.static_inputs = None
             ev.solar_creation_tool = self._gen
 
+    def _finite_check(self):
+        """Delayed, asynchronous: read the flag of the PREVIOUS check (its copy has long executed), then enqueue the next one."""
+        if self._flag_event is not None and self._flag_event.query():
+            if float(self._flag_host[0]) != 0.0:
+                import warnings
+                self.disabled = ("non-finite parameters or Adam moments after a captured step (checked every %d replays): the step runs eagerly from here on; "
+                                 "the values are already in the parameters - restore a checkpoint" % self.check_every)
+                warnings.warn("GraphedTrainStep: " + self.disabled)
+                return
+            self._flag_event = None
+        if self._flag_event is None:
+            store = self.net._param_store
+            ts = [store.params, store.adam_m, store.adam_v] if hasattr(store, "params") else [store.adam_m, store.adam_v]
+            if self.tool.optim2 is not None:
+                for p_ in self.tool._ada_params:
+                    ts.append(p_.detach().reshape(-1))
+                for st in self.tool.optim2.state.values():
+                    ts += [st[k].reshape(-1) for k in ("exp_avg", "exp_avg_sq") if k in st]
+            bad = sum((~torch.isfinite(t)).any().to(torch.float32) for t in ts)
+            if self._flag_host is None:
+                self._flag_host = torch.zeros(1).pin_memory()
+                self._flag_event = None
+            self._flag_host.copy_(bad.reshape(1), non_blocking=True)
+            self._flag_event = torch.cuda.Event()
+            self._flag_event.record()
+
     def __call__(self, data_dict, current_step=0):
         tool = self.tool
+        if self.disabled:
+            return tool.train_step(data_dict, current_step)
         if self.calls < self.warmup:                   # eager steps first: the engine, its scratch and every cached constant exist before the capture
             self.calls += 1
             loss = tool.train_step(data_dict, current_step)
@@ -301,6 +337,8 @@ class GraphedTrainStep:
             self._capture()
             tool.optim.set_hyper()
         self.graph.replay()
+        if self.check_every > 0 and (self.calls - self.warmup) % self.check_every == self.check_every - 1:
+            self._finite_check()
         self.net.invalidate_packed()
         tool.sched.step()
         if tool.sched2 is not None:

@@ -671,6 +671,11 @@ def test_ksplit_stream_is_a_permutation_of_the_bf16_pairs(lib):
         co += -(-n_pairs // 8) * 16384
         ko += chunks * 16384
     assert co == len(canon) and ko == len(ks) and seen * 2048 <= len(ks)
-    assert lib.snerf_model_pack_host(m, 1, None, None, None, None) < 0                           # the per-ray networks have no packed program at 512
+    # the per-ray networks (program 1 canonical, program 4 K-split): the same pairs, each once (T1 / K1 read an encoding only: own blocks, two k-steps)
+    g0, gb0 = fetch(1)
+    g4, gb4 = fetch(4)
+    assert np.array_equal(gb0, gb4)
+    pairs = lambda st: sorted(bytes(st[o:o + 2048]) for o in range(0, len(st), 2048) if st[o:o + 2048].any())
+    assert pairs(g0) == pairs(g4) and len(pairs(g4)) > 280
     lib.snerf_model_destroy(m)
 

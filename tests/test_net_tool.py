@@ -276,3 +276,45 @@ def test_driver_with_use_graph_switches_to_the_captured_step():
     assert out[True][3] == [False] * 2 + [True] * 2 + [False] * 2 + [True] * 14      # steps 0-3: prior phase (2 eager + 2 replays); 4-5: eager warm-up of the new phase; then replays
     assert out[True][0] == out[False][0] and out[True][1] == out[False][1]
     np.testing.assert_allclose(out[True][2], out[False][2], rtol=2e-3)
+
+
+@pytest.mark.gpu
+def test_graphed_step_checks_its_state_and_falls_back_to_eager():
+    """the captured step tests the parameters, Adam's moments and the adaptive loss object's state for non-finite values on the device every
+    `check_every` replays (asynchronous, read one period later) and, on a hit, warns and runs eagerly from then on.  A healthy Barron run never trips it;
+    a moment poisoned by hand does, two periods later at most."""
+    import warnings
+    import season_nerf_amd as sn
+    from oracle import season_nerf_oracle as orc
+    from season_nerf_amd.adaptive_loss import AdaptiveLossFunction
+    W, R, S = 64, 64, 24
+    WC, H4 = np.array([41.29, -95.9, 300.0]), np.array([[310.0, 12.0, 0.0, -11650.0], [-9.0, 240.0, 0.0, 23390.0], [0.0, 0.0, 0.01, -3.0], [0, 0, 0, 1.0]])
+    rng = np.random.Generator(np.random.PCG64(15))
+    t = lambda a: torch.tensor(a, dtype=torch.float32, device="cuda")
+    sun = rng.uniform(0.1, 1, (R, 3)); sun /= np.linalg.norm(sun, axis=1, keepdims=True)
+    batch = {"Top": t(np.concatenate([rng.uniform(-1, 1, (R, 2)), np.ones((R, 1))], 1)), "Bot": t(np.concatenate([rng.uniform(-1, 1, (R, 2)), -np.ones((R, 1))], 1)),
+             "Sun_Angle": t(sun), "Time_Encoded": t(np.tile([1.0, 0.0, 0.0, 1.0], (R, 1))), "GT_Color": t(rng.uniform(0, 1, (R, 3)))}
+    net = sn.T_NeRF(W, 4)
+    net.load_state_dict(orc.init_weights(W, 4, 7, bn_stats="identity"))
+    net = net.cuda().train()
+    args = SimpleNamespace(n_samples=S, Use_Reg=True, Solar_Type_2=False, Use_MSE_loss=False, Use_Solar=True, sc_lambda=0.03, number_low_frequency_cases=4)
+    ada = AdaptiveLossFunction(3, torch.float32, "cuda", alpha_hi=2.99, alpha_init=2.0, scale_init=.03, scale_lo=.01)
+    ev = sn.All_in_One_Eval(args, torch.device("cuda"), 10, False, ada, H4, WC)
+    tool = sn.Net_tool(net, ev, 1e-4, total_steps=64, lr_alpha_scale=30.0, writer=None)
+    step = sn.GraphedTrainStep(tool, batch, warmup=2, check_every=3)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                      # a healthy run: no warning in 2 eager + 12 replayed steps (4 checks)
+        for k in range(14):
+            step(batch, k)
+        torch.cuda.synchronize()
+    assert step.graph is not None and not step.disabled
+    net._param_store.adam_v[5] = float("nan")               # poison one second moment: Adam turns it into a NaN parameter at the next replay
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        for k in range(14, 24):
+            step(batch, k)
+            torch.cuda.synchronize()
+    assert step.disabled and any("non-finite" in str(x.message) for x in w), (step.disabled, [str(x.message) for x in w])
+    n = step.calls
+    step(batch, 24)                                          # eager from here on: the call count of the captured path no longer moves
+    assert step.calls == n

@@ -269,7 +269,7 @@ def gen_converged(W, n_total, hours, target=0.3, batch=512, S=96):
     r = ref_eval(net, data_h, S)
     eval_record(out, r)
     oracle64(out, sd, data_h, S)
-    path = os.path.join(mg.OUT, f"converged_W{W}.npz")
+    path = os.path.join(mg.OUT, f"converged_W{W}{os.environ.get('SNERF_CONVERGED_TAG', '')}.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path) // 1024, "KiB; mean max-PS per ray", float(out["max_ps"].mean()), "steps", len(traj))
 

@@ -75,8 +75,10 @@ def main():
             if dominant(r["Name"]):
                 avg = float(r["AverageNs"])
                 rec.append(f"{r['Name'][:80]}: calls {r['Calls']}, AverageNs {avg:.0f}, MinNs {r['MinNs']}, MaxNs {r['MaxNs']}\n"
-                           f"  frac = {FLOP / 1e9:.1f} GFLOP / {avg / 1e6:.4f} ms / 2.5e15 = {FLOP / (avg * 1e-9) / 2.5e15:.4f}   "
-                           f"(bench.json roofline: kernel_ms {bench['roofline']['kernel_ms']:.4f}, frac {bench['roofline']['frac']:.4f})")
+                           f"  {FLOP / 1e9:.1f} GFLOP / {avg / 1e6:.4f} ms = {FLOP / (avg * 1e-9) / 1e12:.1f} TFLOP/s: frac {FLOP / (avg * 1e-9) / 5.0e15:.4f} of the int8 peak (5 Pop/s), "
+                           f"{FLOP / (avg * 1e-9) / 2.5e15:.4f} of the bf16 peak   "
+                           f"(bench.json roofline: kernel_ms {bench['roofline']['kernel_ms']:.4f}, frac {bench['roofline']['frac']:.4f} of peak {bench['roofline']['peak']:.0f}, "
+                           f"frac_of_bf16_peak {bench['roofline'].get('frac_of_bf16_peak', float('nan')):.4f})")
     shutil.rmtree(d, ignore_errors=True)
     open(os.path.join(out, "recompute.txt"), "w").write("\n".join(rec) + "\n")
     # PMC passes
@@ -97,7 +99,7 @@ def main():
                    "FETCH_SIZE_KB": tot["FETCH_SIZE"], "WRITE_SIZE_KB": tot["WRITE_SIZE"],
                    "correction": "gfx950: FETCH_SIZE counts 64 B per 128 B request on wide coalesced streams -> x2 (MI355X_MICROARCH.md, HBM)",
                    "bytes_per_launch": (2 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024.0}, open(os.path.join(out, "traffic.json"), "w"), indent=1)
-    if "--no-train" not in sys.argv:
+    if "--no-train" not in sys.argv and "--only" not in sys.argv:
         with open(os.path.join(out, "train_bench.json"), "w") as f:
             subprocess.call(["python3", "bench.py", "--workload", "train"], stdout=f, stderr=open(os.path.join(out, "train_bench.err"), "w"), cwd=REPO)
         d = os.path.join(out, "prof_train")
@@ -150,7 +152,13 @@ def main():
     for aux, match, counters in (("sweep", "sweep_kernel", ["SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_INSTS_VALU", "GRBM_GUI_ACTIVE"]),
                                  ("w512", "mlp_i8_kernel", ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_INSTS_MFMA", "SQ_LDS_BANK_CONFLICT", "GRBM_GUI_ACTIVE"]),
                                  # the exact-solar pass at 256 x 256 x 96 (6.3e6 secondary rays through the ray-visibility variant of the field kernel)
-                                 ("exact_solar", "mlp_i8x2_kernel<256, 3>", ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_INSTS_MFMA", "SQ_LDS_BANK_CONFLICT", "GRBM_GUI_ACTIVE"])):
+                                 ("exact_solar", "mlp_i8x2_kernel<256, 3>", ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_INSTS_MFMA", "SQ_LDS_BANK_CONFLICT", "GRBM_GUI_ACTIVE"]),
+                                 # round 6: the bf16x3 kernel of width 512 (K split over wave pairs) on the benchmark's rays, and the reference's DEFAULT render
+                                 # configuration - width 512, converged (sharp) weights, exact solar - through its ray-visibility variant
+                                 ("w512_bf16x3", "mlp_ks_kernel<512, 0>", ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_INSTS_MFMA", "SQ_LDS_BANK_CONFLICT", "GRBM_GUI_ACTIVE"]),
+                                 ("exact_solar_w512", "mlp_ks_kernel<512, 3>", ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_INSTS_MFMA", "SQ_LDS_BANK_CONFLICT", "GRBM_GUI_ACTIVE"])):
+        if "--only" in sys.argv and aux not in sys.argv[sys.argv.index("--only") + 1].split(","):
+            continue
         kargs = ["--aux-kernel", aux, "--steps", "6"]
         with open(os.path.join(out, aux + "_bench.json"), "w") as f:
             subprocess.call(["python3", "bench.py"] + kargs, stdout=f, stderr=subprocess.DEVNULL, cwd=REPO)
