@@ -887,6 +887,13 @@ def main():
                 torch.cuda.synchronize()
                 tp.append((time.perf_counter() - t1) * 1e3)
             extra["repack_ms"] = min(tp)
+            net._probe_memo = None                   # ... and with the measured second stage of `auto` (the int8-vs-bf16x3 probe renders) not reused from the last pack
+            net.invalidate_packed()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            net.device_model()
+            torch.cuda.synchronize()
+            extra["repack_with_probe_ms"] = (time.perf_counter() - t1) * 1e3
             extra["repack_note"] = "T_NeRF.device_model() after a parameter change: D2H of the state_dict + host pack (fold, int8 error model, digits) + upload"
         if not a.no_train:
             del rho, sv, col

@@ -466,6 +466,14 @@ static Tensor loss_scratch(const Tensor& like) {
     return s;
 }
 
+// Create (and initialise) the reduction scratch of the CURRENT stream now: a captured step calls this on its capture stream BEFORE the capture begins, so that
+// the capture neither allocates it from the graph's private pool nor records its initialisation as a node that re-runs on every replay.
+void loss_scratch_prepare(const Tensor& like) {
+    check_dev_f32(like, "like");
+    c10::hip::HIPGuardMasqueradingAsCUDA g(like.device());
+    (void)loss_scratch(like);
+}
+
 // ---- scalar loss terms of a training step (get_loss, Eval_Tools_2.py:340-420, default configuration) ---------------------------------
 // loss_terms(rgb, gt, albedo, sky, solar_vis, pv_exact, pe, albedo_min_global?, world) -> (vals[5], min[6]: the minima + the rows that own them);  loss_terms_bwd: the gradients
 std::tuple<Tensor, Tensor> loss_terms(const Tensor& rgb, const Tensor& gt, const Tensor& albedo, const Tensor& sky, const Tensor& sv, const Tensor& pv,
@@ -527,6 +535,7 @@ TORCH_LIBRARY(season_nerf, m) {
     m.def("trainer_adam_step_(int trainer, Tensor(a!) params, Tensor grads, float lr, float beta1, float beta2, float eps, int step) -> ()");
     m.def("trainer_adam_step_dev_(int trainer, Tensor(a!) params, Tensor grads, Tensor hyper) -> ()");
     m.def("trainer_zero_grad_(int trainer, Tensor(a!) grads) -> ()");
+    m.def("loss_scratch_prepare(Tensor like) -> ()");
     m.def("loss_terms(Tensor rgb, Tensor gt, Tensor albedo, Tensor sky, Tensor solar_vis, Tensor pv_exact, Tensor pe, Tensor? albedo_min_global, int world) "
           "-> (Tensor, Tensor)");
     m.def("loss_terms_bwd(Tensor g_vals, Tensor rgb, Tensor gt, Tensor albedo, Tensor sky, Tensor solar_vis, Tensor pv_exact, Tensor min, int world) "
@@ -552,6 +561,7 @@ TORCH_LIBRARY_IMPL(season_nerf, CUDA, m) {      // "CUDA" is the dispatch key of
     m.impl("trainer_adam_step_", trainer_adam_step_);
     m.impl("trainer_adam_step_dev_", trainer_adam_step_dev_);
     m.impl("trainer_zero_grad_", trainer_zero_grad_);
+    m.impl("loss_scratch_prepare", loss_scratch_prepare);
     m.impl("loss_terms", loss_terms);
     m.impl("loss_terms_bwd", loss_terms_bwd);
     m.impl("fused_adam_", fused_adam_);

@@ -22,13 +22,12 @@ namespace snerf {
 // a parameter change sits in front of every in-loop validation render (bench.py `repack_ms`); SNERF_PACK_THREADS=1 packs serially.
 template <class F>
 static bool parallel_layers(int L, std::string* err, F fn) {
-    static int cap = -1;
-    if (cap < 0) {
+    static const int cap = [] {                    // initialised once, thread-safely (two Python threads may pack at the same time)
         const char* e = getenv("SNERF_PACK_THREADS");
         const unsigned hw = std::thread::hardware_concurrency();
-        cap = e ? atoi(e) : (int)(hw ? (hw < 8 ? hw : 8) : 1);
-        if (cap < 1) cap = 1;
-    }
+        const int c = e ? atoi(e) : (int)(hw ? (hw < 8 ? hw : 8) : 1);
+        return c < 1 ? 1 : c;
+    }();
     const int T = cap < L ? cap : L;
     std::atomic<int> next{0};
     std::atomic<bool> ok{true};
@@ -38,7 +37,15 @@ static bool parallel_layers(int L, std::string* err, F fn) {
             const int l = next.fetch_add(1);
             if (l >= L || !ok.load()) break;
             std::string e;
-            if (!fn(l, &e)) {
+            bool good = false;
+            try {                                  // an exception in a worker thread (bad_alloc in a layer's buffers) must become an error, not std::terminate
+                good = fn(l, &e);
+            } catch (const std::exception& ex) {
+                e = std::string("packing layer ") + std::to_string(l) + ": " + ex.what();
+            } catch (...) {
+                e = "packing layer " + std::to_string(l) + ": unknown exception";
+            }
+            if (!good) {
                 std::lock_guard<std::mutex> g(mu);
                 if (ok.exchange(false)) *err = e;
             }

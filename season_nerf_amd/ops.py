@@ -63,6 +63,10 @@ def _register_fakes():
     def _(pts, delta, height_map, outside):
         return pts.new_empty(pts.shape[0], 1)
 
+    @reg("season_nerf::loss_scratch_prepare")
+    def _(like):
+        return None
+
     @reg("season_nerf::loss_terms")
     def _(rgb, gt, albedo, sky, solar_vis, pv_exact, pe, albedo_min_global, world):
         return rgb.new_empty(5), rgb.new_empty(6)

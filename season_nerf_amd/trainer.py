@@ -281,7 +281,14 @@ class GraphedTrainStep:
             gc.collect()
             gc.disable()
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
+            # the capture runs on a stream of ours: whatever is keyed by stream (the loss kernels' reduction scratch, csrc/ops.cpp loss_scratch) is created and
+            # initialised on it BEFORE the capture - nothing of it comes from the graph's private pool, no initialisation is recorded as a node
+            self._stream = torch.cuda.Stream(device=self.dev)
+            self._stream.wait_stream(torch.cuda.current_stream(self.dev))
+            with torch.cuda.stream(self._stream):
+                torch.ops.season_nerf.loss_scratch_prepare(self.data["Top"])
+            torch.cuda.current_stream(self.dev).wait_stream(self._stream)
+            with torch.cuda.graph(self.graph, stream=self._stream):
                 self.loss = self._body()
         finally:
             if gc_was_on:
