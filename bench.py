@@ -501,7 +501,7 @@ def bench_train(a, standalone=True):
     sol = fwd_bytes(trunk + heads + solar) + bwd_bytes(solar, False)
     hbm_bytes = 4.0 * R * S * (img + sol)
     lname = "Barron adaptive loss" if barron else "MSE loss"
-    traffic = None      # HBM bytes per step from the committed PMC passes of this same command (tools/train_traffic.sh)
+    traffic = None      # HBM bytes per step from the committed PMC passes of this same command (tools/profile_round.py)
     try:
         traffic = json.load(open(_profile_file("train_traffic.json")))["bytes_per_step"]
     except Exception:
