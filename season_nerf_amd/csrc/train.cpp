@@ -388,6 +388,10 @@ static int sine_bwd(snerf_trainer* t, const LayerP& L, Act D, Act Z, Act In, int
     // column sums in t->bn_stats.  below / fused_below: the same offer for the layer that will consume dIn.
     const int C = L.n_out;
     if (fused_below) *fused_below = false;
+    // EXPERIMENT (never on by default): the inter-layer gradient as bf16.  Rounds dL/dY (as the dgrad above would have stored it) and, behind the
+    // weight-gradient kernel, dL/dZ (as it would be written back) to bf16 precision in place: the accuracy side of the idea on the real kernels.
+    static const bool dy_bf16 = getenv("SNERF_TRAIN_DY_BF16") != nullptr;
+    if (dy_bf16 && pre_activated) HIPCK(launch_round_bf16(D.p, D.ld, M, C, st));
     if (L.bn) {
         float *mean = bnslot + 2 * t->W, *istd = bnslot + 3 * t->W;
         float *sdy = t->bn_bwd, *sdyx = t->bn_bwd + t->W;
@@ -412,6 +416,7 @@ static int sine_bwd(snerf_trainer* t, const LayerP& L, Act D, Act Z, Act In, int
             // D holds dL/dY: the dZ sweep rides in the weight-gradient kernel (dY -> dZ in registers, written back in place)
             WgradBN bn{Z.p, Z.ld, t->params + L.g, mean, istd, sdy, sdyx, 1.f / (float)Mg, 30.f, t->grads + L.b};
             HIPCK(linear_wgrad(t, L, D.p, D.ld, In, M, 30.f, st, &bn));
+            if (dy_bf16) HIPCK(launch_round_bf16(D.p, D.ld, M, C, st));
             if (dIn.p) HIPCK(linear_dgrad(t, L, D.p, D.ld, M, dIn.p, dIn.ld, n_in_cols, 30.f, accumulate_in, st, below, fused_below));
             return SNERF_OK;
         }

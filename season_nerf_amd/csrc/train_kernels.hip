@@ -864,6 +864,23 @@ __global__ void copy_cols_kernel(const float* src, int64_t ld_src, float* dst, i
         if (acc) dst[r * ld_dst + c] += v; else dst[r * ld_dst + c] = v;
     }
 }
+// Experiment switch only (SNERF_TRAIN_DY_BF16=1, train.cpp sine_bwd): round an fp32 array to bf16 precision IN PLACE - what storing the inter-layer gradient
+// as bf16 would do to its values, without the kernels that would read it as such (the byte saving is priced from the layer table, not measured here).
+__global__ void round_bf16_kernel(float* p, int64_t ld, int64_t M, int C) {
+    const int64_t total = M * C;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / C;
+        float* q = p + r * ld + (i - r * C);
+        *q = (float)(__bf16)*q;
+    }
+}
+hipError_t launch_round_bf16(float* p, int64_t ld, int64_t M, int C, hipStream_t st) {
+    if (M <= 0 || C <= 0) return hipSuccess;
+    int64_t b = (M * C + 255) / 256;
+    if (b > 8192) b = 8192;
+    hipLaunchKernelGGL(round_bf16_kernel, dim3((unsigned)b), dim3(256), 0, st, p, ld, M, C);
+    return hipGetLastError();
+}
 hipError_t launch_copy_cols(const float* src, int64_t ld_src, float* dst, int64_t ld_dst, int64_t M, int C, bool accumulate, hipStream_t st) {
     LAUNCH_1D(copy_cols_kernel, M * C, st, src, ld_src, dst, ld_dst, M, C, accumulate ? 1 : 0);
     return hipGetLastError();
