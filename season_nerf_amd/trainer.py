@@ -289,7 +289,14 @@ class GraphedTrainStep:
             # the eager step by 1-4 % from the 4th replay on, in 3 runs of 4; a kernel on the capture stream WITHOUT the waits: 0 of 4; a first capture: never.
             # SNERF_GRAPH_PREPARE=waitonly|nowait|dummy|1 re-creates the variants (tools/graph_wait_probe.py); the default does none of it.
             mode = os.environ.get("SNERF_GRAPH_PREPARE", "0")
-            if mode != "0":
+            if mode in ("cs_waits_cur", "cur_waits_cs", "other"):        # one direction only / the same pair of waits with a stream that is NOT the capture stream
+                cur, cs = torch.cuda.current_stream(self.dev), (torch.cuda.Stream(device=self.dev) if mode == "other" else ctx.capture_stream)
+                if mode != "cur_waits_cs":
+                    cs.wait_stream(cur)
+                if mode != "cs_waits_cur":
+                    cur.wait_stream(cs)
+                self._other = cs
+            elif mode != "0":
                 cs = ctx.capture_stream
                 if mode != "nowait":
                     cs.wait_stream(torch.cuda.current_stream(self.dev))

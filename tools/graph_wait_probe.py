@@ -9,14 +9,16 @@ on, in most runs.  Variants (trainer.GraphedTrainStep._capture, SNERF_GRAPH_PREP
     nowait    a small kernel on cs, no waits
     dummy     waits + a small kernel on cs
     1         waits + the loss scratch created on cs (what ADVICE r5 asked for, and how this was found)
-usage (GPU box): python3 tools/graph_wait_probe.py [runs per variant, default 6]"""
+    cs_waits_cur / cur_waits_cs   one of the two waits only;   other   both waits, with a fresh stream that is NOT the capture stream
+usage (GPU box): python3 tools/graph_wait_probe.py [runs per variant, default 6] [comma-separated variants]"""
 import os
 import subprocess
 import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 6
-for mode in ("0", "nowait", "waitonly", "dummy", "1"):
+modes = sys.argv[2].split(",") if len(sys.argv) > 2 else ("0", "nowait", "waitonly", "dummy", "1")
+for mode in modes:
     fails = 0
     for _ in range(n):
         r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_net_tool.py", "-x", "-q", "-m", "gpu", "-k", "driver_with_use_graph"], cwd=REPO,
