@@ -25,7 +25,8 @@ _EPS = float(np.finfo(np.float32).eps)            # the package clamps |alpha-2|
 
 def general_loss(x, alpha, scale):
     """rho(x, alpha, c) (eq. 1) in the numerically safe form: b = |alpha-2|+eps, d = alpha +- eps."""
-    z = (x / scale) ** 2
+    z = x / scale
+    z = z * z                                  # not `** 2`: its backward copies through the runtime's memcpy (training._sq)
     b = torch.abs(alpha - 2) + _EPS
     d = torch.where(alpha >= 0, alpha + _EPS, alpha - _EPS)
     return (b / d) * (torch.pow(z / b + 1.0, 0.5 * d) - 1.0)
@@ -83,8 +84,10 @@ def log_base_partition_function(alpha):
     u = torch.clamp(alpha, 0.0, float(a[-1])) / h
     i = torch.clamp(u.detach().floor().long(), 0, len(a) - 2)
     f = u - i
-    h00 = (1 + 2 * f) * (1 - f) ** 2
-    h10 = f * (1 - f) ** 2
+    g = 1 - f
+    g2 = g * g                                 # (not `** 2`: training._sq)
+    h00 = (1 + 2 * f) * g2
+    h10 = f * g2
     h01 = f * f * (3 - 2 * f)
     h11 = f * f * (f - 1)
     return h00 * va[i] + h10 * h * sa[i] + h01 * va[i + 1] + h11 * h * sa[i + 1]

@@ -874,6 +874,28 @@ __global__ void round_bf16_kernel(float* p, int64_t ld, int64_t M, int C) {
         *q = (float)(__bf16)*q;
     }
 }
+// The engine's own fill and copy (train.cpp snerf_zero_async / snerf_copy_async: no runtime memory operations inside a step): 16 bytes per lane where the
+// addresses allow, a scalar tail.
+__global__ void fill_zero_kernel(float* __restrict__ p, int64_t n) {
+    const int64_t n4 = (((uintptr_t)p & 15) == 0) ? n / 4 : 0;
+    const int64_t t0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, step = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = t0; i < n4; i += step) ((float4*)p)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t i = n4 * 4 + t0; i < n; i += step) p[i] = 0.f;
+}
+hipError_t launch_fill_zero(float* p, int64_t n, hipStream_t st) {
+    LAUNCH_1D(fill_zero_kernel, (n + 3) / 4, st, p, n);
+    return hipGetLastError();
+}
+__global__ void copy_f32_kernel(float* __restrict__ d, const float* __restrict__ s, int64_t n) {
+    const int64_t n4 = (((((uintptr_t)d) | ((uintptr_t)s)) & 15) == 0) ? n / 4 : 0;
+    const int64_t t0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, step = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = t0; i < n4; i += step) ((float4*)d)[i] = ((const float4*)s)[i];
+    for (int64_t i = n4 * 4 + t0; i < n; i += step) d[i] = s[i];
+}
+hipError_t launch_copy_f32(float* d, const float* s, int64_t n, hipStream_t st) {
+    LAUNCH_1D(copy_f32_kernel, (n + 3) / 4, st, d, s, n);
+    return hipGetLastError();
+}
 hipError_t launch_round_bf16(float* p, int64_t ld, int64_t M, int C, hipStream_t st) {
     if (M <= 0 || C <= 0) return hipSuccess;
     int64_t b = (M * C + 255) / 256;

@@ -183,9 +183,9 @@ class GraphedTrainStep:
         from . import training
         # check_every: every that many replays the parameters, Adam's moments and (adaptive loss) the loss object's parameters and moments are tested for
         # non-finite values ON THE DEVICE (one reduction, its flag copied to pinned memory without a sync and read one period later).  A hit disables the graph:
-        # the step falls back to the eager path, with a warning.  The capture of the generic-loss phases (Barron, DSM prior) is EXPERIMENTAL: two sibling
-        # variants of it - the step's inputs as views of one storage, the packed upload on a second stream - produced NaN moments for a reason that was
-        # bisected but not found; the form that ships passed every soak, which bounds a rate, not an absence.  0 = no check.
+        # the step falls back to the eager path, with a warning.  0 = no check.  (Rounds 4-6 saw captured steps produce garbage moments; round 6 found the cause -
+        # hipGraph MEMCPY / MEMSET nodes under the runtime's AQL packet capture, DESIGN 5.4c - and removed every such node from the step
+        # (tests/test_gpu_graph_nodes.py); the check stays as the cheap net under a torch or ROCm update that brings one back.)
         self.check_every, self._flag_dev, self._flag_host, self._flag_event, self.disabled = int(check_every), None, None, None, None
         if int(warmup) < 1:      # the capture may not allocate or upload: the engine, its scratch and LossDict's weight vector must exist already
             raise ValueError("GraphedTrainStep: warmup must be >= 1 (the eager steps create every buffer the captured step uses)")
@@ -282,13 +282,17 @@ class GraphedTrainStep:
             gc.disable()
             self.graph = torch.cuda.CUDAGraph()
             import os
+            dump = os.environ.get("SNERF_GRAPH_DUMP")        # a path: the captured graph as a DOT file (node kinds: tests/test_gpu_graph_nodes.py)
+            if dump:
+                self.graph.enable_debug_mode()
             ctx = torch.cuda.graph(self.graph)           # torch's own capture stream
-            # NOTHING may touch the capture stream from here.  Round 6 tried to create the loss kernels' stream-keyed scratch on it before the capture
-            # and found a two-line trigger of the failure family DESIGN 5.4c could not explain: an event wait between the current stream and the capture stream
-            # in front of the SECOND capture of a process (`cs.wait_stream(cur); cur.wait_stream(cs)`, no kernel needed) makes the new graph's replays drift from
-            # the eager step by 1-4 % from the 4th replay on, in 3 runs of 4; a kernel on the capture stream WITHOUT the waits: 0 of 4; a first capture: never.
-            # SNERF_GRAPH_PREPARE=waitonly|nowait|dummy|1 re-creates the variants (tools/graph_wait_probe.py); the default does none of it.
-            mode = os.environ.get("SNERF_GRAPH_PREPARE", "0")
+            # The loss kernels' reduction scratch is keyed by stream (csrc/ops.cpp): create the capture stream's one NOW, on that stream, so that the capture
+            # allocates nothing and the scratch does not pin a block of this graph's private pool after the graph is gone.  Round 6 first tried this
+            # while the engine still issued hipMemcpyAsync / hipMemsetAsync inside the step and found that ANY event wait between the current stream and another in
+            # front of a process's second capture made the new graph's replays drift (tools/graph_wait_probe.py: 3-4 runs of 6 for the variants below) - one more face
+            # of the MEMCPY / MEMSET-node defect.  With kernel nodes only every variant is 0 of 6.  SNERF_GRAPH_PREPARE keeps the variants for the
+            # reproduction (with SNERF_TRAIN_MEMOPS=1): 0 = nothing touches the capture stream | waitonly | nowait | dummy | cs_waits_cur | cur_waits_cs | other.
+            mode = os.environ.get("SNERF_GRAPH_PREPARE", "1")
             if mode in ("cs_waits_cur", "cur_waits_cs", "other"):        # one direction only / the same pair of waits with a stream that is NOT the capture stream
                 cur, cs = torch.cuda.current_stream(self.dev), (torch.cuda.Stream(device=self.dev) if mode == "other" else ctx.capture_stream)
                 if mode != "cur_waits_cs":
@@ -310,6 +314,8 @@ class GraphedTrainStep:
                     torch.cuda.current_stream(self.dev).wait_stream(cs)
             with ctx:
                 self.loss = self._body()
+            if dump:
+                self.graph.debug_dump(dump)
         finally:
             if gc_was_on:
                 gc.enable()

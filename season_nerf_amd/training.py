@@ -591,6 +591,13 @@ def eval_rho_only_train(ev, data_dict, net, train_mode, current_step=0):
     return {"PE": pe, "PV_Exact": pv, "Solar_Vis": sv, "Sky_Col": sky_raw.unsqueeze(1).expand(R, S, 3)}
 
 
+def _sq(x):
+    """x squared as x * x.  `x ** 2` has the same value, but its backward (PowBackward0) evaluates `x.pow(1)`, which torch turns into a contiguous
+    device-to-device copy_ = hipMemcpyAsync = a MEMCPY node inside a captured step - the node kind the captured step must not hold (csrc/train.cpp
+    snerf_copy_async).  The gradient is the same number: g * x + g * x = (2 x) g exactly."""
+    return x * x
+
+
 def albedo_min_loss(albedo, group=None):
     """`Albedo_Color` of Eval_Tools_2.py:374-379: sum over the three channels of (1 - a / 0.2)^2 where a = min over the batch's rays of
     the albedo < 0.2, divided by the number of rays.  The reference selects with boolean indexing (a device->host sync per step);
@@ -601,7 +608,7 @@ def albedo_min_loss(albedo, group=None):
     (FusedAdam / allreduce_gradients) is the global-batch gradient f'(a) / R_global."""
     from . import parallel
     alb_min, _ = torch.min(albedo, 0)
-    hinge = lambda a: torch.sum(torch.where(a < .2, (1. - a / .2) ** 2, torch.zeros_like(a)))
+    hinge = lambda a: torch.sum(torch.where(a < .2, _sq(1. - a / .2), torch.zeros_like(a)))
     n_local = albedo.shape[0]
     if not parallel.data_parallel(group):
         return hinge(alb_min) / n_local
@@ -616,14 +623,14 @@ def get_loss(ev, data_dict, net, current_step, train_mode):
     n_rays = data_dict["Top"].shape[0]
     Loss = {}
     weight = {"Color": 1.0, "Solar_Correction": args.sc_lambda, "Alpha_Adjust": 1.}
-    mse = lambda a, b: torch.mean((a - b) ** 2)
+    mse = lambda a, b: torch.mean(_sq(a - b))
     out = ev.eval(data_dict, net, current_step, train_mode)
     if args.Use_Solar:
         starts, ends, vec, stime, _ = ev.solar_creation_tool(n_rays, include_times=True)
         so = ev.eval_Rho_Only({"Top": starts, "Bot": ends, "Sun_Angle": vec, "Time_Encoded": stime}, net, train_mode, current_step)
         if _fused_loss_ok(ev, args, out, so):
             return _fused_loss(ev, net, out, so, data_dict["GT_Color"].to(dev), weight)
-        Loss["Solar_Correction"] = [torch.mean(torch.sum((so["Solar_Vis"] - so["PV_Exact"].detach()) ** 2, 1)), weight["Solar_Correction"]]
+        Loss["Solar_Correction"] = [torch.mean(torch.sum(_sq(so["Solar_Vis"] - so["PV_Exact"].detach()), 1)), weight["Solar_Correction"]]
         absorb = torch.mean(1 - torch.sum(so["PE"].detach() * so["PV_Exact"].detach() * so["Solar_Vis"], 1))
         Loss["Solar_Correction_2"] = [absorb.detach() if not args.Solar_Type_2 else absorb, weight["Solar_Correction"]]
         if not args.Solar_Type_2:
@@ -632,7 +639,7 @@ def get_loss(ev, data_dict, net, current_step, train_mode):
             store = getattr(net, "_param_store", None)
             alb_loss = albedo_min_loss(out["Albedo_Color"], store.bn_sync[0] if (store is not None and store.bn_sync is not None) else None)
             x = (out["Sky_Col"] - .5) / .5
-            sk = torch.sum(torch.where(x > 0, x ** 2, torch.zeros_like(x))) / x.numel()
+            sk = torch.sum(torch.where(x > 0, _sq(x), torch.zeros_like(x))) / x.numel()
             if ev.use_prior:
                 sk = sk.detach()
             Loss["Sky_Color_Var"] = [sk, weight["Solar_Correction"]]
