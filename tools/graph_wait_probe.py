@@ -1,14 +1,16 @@
-"""GPU: the smallest known trigger of the captured training step's unexplained failure family.
+"""GPU: the event-wait trigger of the captured training step's failure family - history; the cause is hipGraph MEMSET nodes under the runtime's
+packet capture (tools/graph_memop_repro.py), which the engine no longer issues.  With SNERF_TRAIN_MEMOPS=1 (the engine's old hipMemcpyAsync / hipMemsetAsync
+calls back) this reproduces what round 6 first saw:
 
 The driver test `tests/test_net_tool.py::test_driver_with_use_graph_switches_to_the_captured_step` captures the step twice in one process (DSM-prior phase, then
-the free phase) and compares 20 steps with the eager driver.  With NOTHING between the two captures it passes every time.  With an event wait between the current
-stream and torch's capture stream in front of a capture - two lines, no kernel - the second graph's replays drift from the eager step by 1-4 % from its 4th replay
-on, in most runs.  Variants (trainer.GraphedTrainStep._capture, SNERF_GRAPH_PREPARE):
-    0         shipped: nothing touches the capture stream
+the free phase) and compares 20 steps with the eager driver at the level of the losses.  With an event wait between the current stream and torch's capture stream
+in front of a capture - two lines, no kernel - the second graph's replays drift from the eager step by 1-4 % from its 4th replay on, in most runs (waitonly 4 of 6,
+dummy 3 of 6, 1: 3 of 6).  With kernel nodes only every variant is 0 of 6.  Variants (trainer.GraphedTrainStep._capture, SNERF_GRAPH_PREPARE):
+    0         nothing touches the capture stream
     waitonly  cs.wait_stream(cur); cur.wait_stream(cs)
     nowait    a small kernel on cs, no waits
     dummy     waits + a small kernel on cs
-    1         waits + the loss scratch created on cs (what ADVICE r5 asked for, and how this was found)
+    1         waits + the loss scratch created on cs (the default since the cause was removed)
     cs_waits_cur / cur_waits_cs   one of the two waits only;   other   both waits, with a fresh stream that is NOT the capture stream
 usage (GPU box): python3 tools/graph_wait_probe.py [runs per variant, default 6] [comma-separated variants]"""
 import os
