@@ -733,10 +733,9 @@ static hipError_t launch_wreg(const GemmX& gx, int aol_mode, int act_mode, hipSt
 
 // shapes the (experimental) register-resident-weight kernel takes: N = 256 or 128 output columns, K = 256
 bool gemm_wreg_ok(const GemmX& gx) {
-    static int mode = -1;
     // opt-in (SNERF_GEMM_WREG=1): measured equal to gemm_rows16_kernel in the forward (213 against 200-224 us per 256 -> 256 layer) and
     // slower with the activation-backward epilogue (282 against 236 us) - see DESIGN 5.4 for what the per-stage barrier costs
-    if (mode < 0) { const char* e = getenv("SNERF_GEMM_WREG"); mode = (e && e[0] == '1') ? 1 : 0; if (SNERF_ABLW) mode = 1; }
+    static const int mode = [] { const char* e = getenv("SNERF_GEMM_WREG"); if (SNERF_ABLW) return 1; return (e && e[0] == '1') ? 1 : 0; }();
     const int KS32 = gx.ksteps / 2;
     return mode && gx.W && KS32 == 8 && gx.ksteps == 16 && (gx.N == 256 || gx.N == 128) && gx.N == (int64_t)gx.n_tiles * 32;
 }
