@@ -282,9 +282,6 @@ class GraphedTrainStep:
             gc.disable()
             self.graph = torch.cuda.CUDAGraph()
             import os
-            dump = os.environ.get("SNERF_GRAPH_DUMP")        # a path: the captured graph as a DOT file (node kinds: tests/test_gpu_graph_nodes.py)
-            if dump:
-                self.graph.enable_debug_mode()
             ctx = torch.cuda.graph(self.graph)           # torch's own capture stream
             # The loss kernels' reduction scratch is keyed by stream (csrc/ops.cpp): create the capture stream's one NOW, on that stream, so that the capture
             # allocates nothing and the scratch does not pin a block of this graph's private pool after the graph is gone.  Round 6 first tried this
@@ -314,8 +311,6 @@ class GraphedTrainStep:
                     torch.cuda.current_stream(self.dev).wait_stream(cs)
             with ctx:
                 self.loss = self._body()
-            if dump:
-                self.graph.debug_dump(dump)
         finally:
             if gc_was_on:
                 gc.enable()
