@@ -980,7 +980,7 @@ hipError_t launch_wgrad_bf16x3(float* dZ, int64_t ldz, const float* In, int64_t 
     g.in_tab = in_tab; g.in_cols = in_tab ? in_cols : 0; g.in_tab_stride = in_tab_stride > 0 ? in_tab_stride : g.in_cols;
     g.dZ = dZ; g.In = In; g.dW = dW; g.M = M; g.ldz = ldz; g.ldi = ldi; g.ldw = ldw; g.n_out = n_out; g.n_in = n_in; g.alpha = alpha;
     // the workgroup's block of dW: 128 TA x 64 TB - the 128-wide layers get blocks of their own size (SNERF_WGRAD_SMALL=0: always 256 x 256)
-        static const int small_blocks = [] { const char* e = getenv("SNERF_WGRAD_SMALL"); return (e && e[0] == '0') ? 0 : 1; }();
+    static const int small_blocks = [] { const char* e = getenv("SNERF_WGRAD_SMALL"); return (e && e[0] == '0') ? 0 : 1; }();
     const int ta = (small_blocks && n_out <= 128) ? 1 : 2, tb = (small_blocks && n_in <= 128) ? 2 : 4;
     const int bo = 128 * ta, bi = 64 * tb;
     const int by = (n_out + bo - 1) / bo, bz = (n_in + bi - 1) / bi;
@@ -994,7 +994,7 @@ hipError_t launch_wgrad_bf16x3(float* dZ, int64_t ldz, const float* In, int64_t 
     g.reverse = stream_direction(M);
     const bool full = n_out % 256 == 0 && n_in % 256 == 0;
     const dim3 grid((unsigned)bx, by, bz);
-        static const int two_stage = [] { const char* e = getenv("SNERF_WGRAD_ATOMIC"); return (e && e[0] == '1') ? 0 : 1; }();
+    static const int two_stage = [] { const char* e = getenv("SNERF_WGRAD_ATOMIC"); return (e && e[0] == '1') ? 0 : 1; }();
     // (a few row blocks, or a thin layer whose blocks are mostly empty: the atomics are cheap enough)
     if (two_stage && bx >= 8 && 2 * (int64_t)(n_out < bo ? n_out : bo) * (n_in < bi ? n_in : bi) >= (int64_t)bo * bi) {
         g.partial = wgrad_scratch(st, (size_t)bx * by * bz * 8 * ta * tb * 1024);
@@ -1006,7 +1006,7 @@ hipError_t launch_wgrad_bf16x3(float* dZ, int64_t ldz, const float* In, int64_t 
         g.bn_inv_m = bn->inv_m; g.bias_alpha = bn->bias_alpha; g.dbias = bn->dbias;
     }
     {
-                static const int log_shapes = [] { const char* e = getenv("SNERF_LOG_WGRAD"); return (e && e[0] == '1') ? 1 : 0; }();      // SNERF_LOG_WGRAD=1: one line per launch (which layers end up on which block shape)
+        static const int log_shapes = [] { const char* e = getenv("SNERF_LOG_WGRAD"); return (e && e[0] == '1') ? 1 : 0; }();      // SNERF_LOG_WGRAD=1: one line per launch (which layers end up on which block shape)
         if (log_shapes)
             fprintf(stderr, "wgrad M=%lld n_out=%d n_in=%d ldz=%lld ldi=%lld ta=%d tb=%d full=%d bn=%d in_tab=%d grid=(%lld,%d,%d) rows/block=%lld partial=%d\n", (long long)M, n_out, n_in,
                     (long long)ldz, (long long)ldi, ta, tb, (int)full, bn ? 1 : 0, in_tab ? in_cols : 0, (long long)bx, by, bz, (long long)rows, g.partial ? 1 : 0);
@@ -1107,8 +1107,8 @@ hipError_t launch_gemm_bf16x3(const GemmX& g, hipStream_t st) {
     };
     {   // the reference's default width (512-wide layers): accumulators in AGPRs, A and weights streamed (gemm_areg.hip).  SNERF_GEMM_AREG=0 off, =2 every
         // shape the kernel takes (also the 256-wide layers of a W = 256 network, where the column-group kernels are HBM-bound already)
-                static const int areg_mode = [] { const char* e = getenv("SNERF_GEMM_AREG"); return e ? atoi(e) : 1; }();
-                static const int areg_act = [] { const char* e = getenv("SNERF_GEMM_AREG_ACT"); return e ? atoi(e) : 1; }();      // the activation-backward form on it: SNERF_GEMM_AREG_ACT=0 keeps the column-group kernel for those
+        static const int areg_mode = [] { const char* e = getenv("SNERF_GEMM_AREG"); return e ? atoi(e) : 1; }();
+        static const int areg_act = [] { const char* e = getenv("SNERF_GEMM_AREG_ACT"); return e ? atoi(e) : 1; }();      // the activation-backward form on it: SNERF_GEMM_AREG_ACT=0 keeps the column-group kernel for those
         if (areg_mode && (!act || areg_act) && g.W && (g.N == 512 || g.K > 256 || areg_mode == 2) && gemm_areg_ok(g)) {
             hipError_t e = launch_areg_split_weights(g.W, g.w_rows, g.w_cols, g.w_transpose != 0, const_cast<uint16_t*>(g.frag), g.n_tiles, g.ksteps, st);
             if (e != hipSuccess) return e;
@@ -1151,7 +1151,7 @@ hipError_t launch_gemm_bf16x3(const GemmX& g, hipStream_t st) {
             }
             // the K = 320 layer ([fc4 | PE]: 64-column groups, four of them read every A row): its forward on the same kernel, whose quad-coalesced
             // A loads cost the vector-memory path half of what the lane-per-row operand layout of the 32x32x16 form does
-                        static const int mode16_k320 = [] { const char* e = getenv("SNERF_GEMM16_K320"); return (e && e[0] == '0') ? 0 : 1; }();
+            static const int mode16_k320 = [] { const char* e = getenv("SNERF_GEMM16_K320"); return (e && e[0] == '0') ? 0 : 1; }();
             if (mode16 && mode16_k320 && g.W && k32 && ntf == 2 && !act && g.n_tiles % 2 == 0 && (!aol || g.act_cols % 32 == 0) && lds_f + 128 * 4 <= 160 * 1024) {
                 return launch_gemm_rows16(gx, aol_mode, 0, grid_f, lds_f + 128 * 4, st, 4);
             }

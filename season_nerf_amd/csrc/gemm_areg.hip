@@ -619,7 +619,7 @@ hipError_t launch_gemm_areg(const GemmX& g, hipStream_t st) {
     const bool aol = g.act_tab != nullptr && g.act_cols > 0;
     const int KS = g.ksteps;
     const bool act = g.ez != nullptr;
-        static const int hv = [] { const char* e = getenv("SNERF_AREG_HV"); return e ? atoi(e) : 2; }();      // SNERF_AREG_HV=1: the one-wave-per-SIMD form at N = 512 too (A/B)
+    static const int hv = [] { const char* e = getenv("SNERF_AREG_HV"); return e ? atoi(e) : 2; }();      // SNERF_AREG_HV=1: the one-wave-per-SIMD form at N = 512 too (A/B)
     // (not for the activation-backward form: with its pre-activation staging the 128 architectural registers of a wave overflow by four - hipcc would park
     // them in the accumulators' AGPRs - and the forward's gain, -4 % with activation on load, 0 without, would not pay for a third staging scheme)
     const bool two = g.N == 512 && hv >= 2 && !act;

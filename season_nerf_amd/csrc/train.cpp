@@ -282,7 +282,7 @@ static hipError_t linear_dgrad(snerf_trainer* t, const LayerP& L, const float* d
                                int n_cols, float alpha, bool accumulate, hipStream_t st, const ActBelow* below = nullptr,
                                bool* fused = nullptr) {
     if (fused) *fused = false;
-        static const int thin = [] { const char* e = getenv("SNERF_THIN_DGRAD"); return (e && e[0] == '0') ? 0 : 1; }();
+    static const int thin = [] { const char* e = getenv("SNERF_THIN_DGRAD"); return (e && e[0] == '0') ? 0 : 1; }();
     if (thin && t->gemm_mode == 1 && M >= 1024 && L.n_out <= 4) {      // a thin head: a rank-K update of dIn, streamed (exact fp32)
         ThinDgradArgs a{};
         a.D = dZ; a.ldd = ldz; a.W = t->params + L.w; a.ldw = L.n_in; a.C = dIn; a.ldc = ld_in; a.M = M; a.K = L.n_out; a.N = n_cols;
