@@ -330,6 +330,13 @@ static hipError_t linear_wgrad(snerf_trainer* t, const LayerP& L, float* dZ, int
                                const WgradBN* bn = nullptr) {
     const float* In = InA.p;
     const int64_t ld_in = InA.ld;
+    static const int thin = [] { const char* e = getenv("SNERF_THIN_WGRAD"); return (e && e[0] == '0') ? 0 : 1; }();
+    if (thin && !bn && t->gemm_mode == 1 && M >= 1024 && L.n_out <= 4) {      // a thin head: K x n_in sums, streamed over the input (exact fp32)
+        ThinWgradArgs a{};
+        a.D = dZ; a.ldd = ldz; a.In = In; a.ldi = ld_in; a.M = M; a.K = L.n_out; a.N = L.n_in; a.alpha = alpha;
+        a.dW = t->grads + L.w; a.ldw = L.n_in; a.tab = InA.tab; a.tab_cols = InA.tab ? InA.cols : 0; a.tab_stride = a.tab_cols;
+        if (thin_wgrad_ok(a)) return launch_thin_wgrad(a, st);
+    }
     if (t->gemm_mode == 1 && M >= 1024) {
         if (bn && L.n_in > 256) {
             // the activation-on-load table covers the first tc input columns: each launch gets its window of it ([a | b], b at distance tc)
@@ -947,6 +954,13 @@ int snerf_linear_wgrad(int64_t n_points, int n_in, int n_out, const float* d_gra
     if (d_act_tab && (precision != 1 || act_cols < 1 || act_cols > n_in))
         return snerf_set_error(SNERF_E_INVALID, "snerf_linear_wgrad: activation on load needs the bf16x3 path and 1 <= act_cols <= n_in");
     if (precision == 1) {
+        if (n_out <= 4 && n_points >= 1024) {      // the thin heads' stream, as the training engine routes them (linear_wgrad)
+            ThinWgradArgs a{};
+            a.D = d_grad_out; a.ldd = ld_go; a.In = d_in; a.ldi = ld_in; a.M = n_points; a.K = n_out; a.N = n_in; a.alpha = alpha;
+            a.dW = d_grad_weight; a.ldw = n_in; a.tab = d_act_tab; a.tab_cols = d_act_tab ? act_cols : 0; a.tab_stride = a.tab_cols;
+            static const int thin = [] { const char* e = getenv("SNERF_THIN_WGRAD"); return (e && e[0] == '0') ? 0 : 1; }();
+            if (thin && thin_wgrad_ok(a)) { HIPCK(launch_thin_wgrad(a, st)); return SNERF_OK; }
+        }
         HIPCK(launch_wgrad_bf16x3(const_cast<float*>(d_grad_out), ld_go, d_in, ld_in, n_points, n_out, n_in, alpha, d_grad_weight, n_in, st, d_act_tab, act_cols));      // read-only without the BatchNorm option
         return SNERF_OK;
     }

@@ -122,6 +122,18 @@ struct ThinDgradArgs {     // input gradient of a head with K <= 4 outputs as a 
 };
 bool thin_dgrad_ok(const ThinDgradArgs& a);
 hipError_t launch_thin_dgrad(const ThinDgradArgs& a, hipStream_t st);
+struct ThinWgradArgs {     // weight gradient of a head with K <= 4 outputs as a stream over its input (train_kernels.hip: thin_wgrad_kernel)
+    const float* D;        // [M, ldd]: dL/d(head output), K leading columns
+    const float* In;       // [M, ldi], N columns: the head's input - or, for the first tab_cols columns, its stored pre-activation (activation on load)
+    float* dW;             // [K, ldw] += alpha * D^T In  (fp32 atomics: one add per block, output and input column)
+    int64_t M, ldd, ldi, ldw;
+    int K, N;
+    float alpha;
+    const float* tab;      // optional [a | b] table: In[:, c] = sin(2 pi (a[c] z + b[c])) for c < tab_cols, b at distance tab_stride
+    int tab_cols, tab_stride;
+};
+bool thin_wgrad_ok(const ThinWgradArgs& a);
+hipError_t launch_thin_wgrad(const ThinWgradArgs& a, hipStream_t st);
 
 // BatchNorm finalize: mean = sum/M, var = m2/M, istd; EMA of running stats (momentum 0.01, unbiased var)
 hipError_t launch_bn_finalize(const float* colsum, const float* m2, int64_t M, int C, float* mean, float* istd,

@@ -109,6 +109,36 @@ def test_linear_wgrad(shape, precision):
     assert float((dW.double() - ref).abs().max()) / scale < TOL[precision] * 3        # split-K fp32 atomics on top
 
 
+THIN = [  # M, n_in, n_out, ld_go, ld_in, offset of the gradient's first column, act_cols (0: none)   - the heads of the network: K <= 4 outputs, >= 1024 rows
+    (5000, 128, 3, 4, 128, 0, 0), (5000, 128, 1, 4, 128, 3, 0), (4096, 64, 3, 3, 64, 0, 0), (1024, 256, 4, 4, 256, 0, 0), (393216, 128, 1, 1, 128, 0, 0),
+    (3001, 128, 3, 4, 132, 0, 128), (2050, 128, 1, 4, 128, 3, 96), (1025, 12, 2, 2, 12, 0, 0)]
+
+
+@pytest.mark.parametrize("shape", THIN)
+def test_thin_head_wgrad(shape):
+    """The weight gradient of a head with at most four outputs runs as a stream over its input (thin_wgrad_kernel: exact fp32 FMAs, one atomic add per
+    block and element), with the gradient read as 16-byte rows where its address allows (the colour head) and as scalars where not (the density head:
+    column 3 of the same [N, 4] buffer), and with the activation applied on load over the leading columns."""
+    sn, L, st = _env()
+    M, n_in, n_out, ld_go, ld_in, off, ac = shape
+    g = torch.Generator(device="cpu").manual_seed(M + n_in + n_out)
+    dZ = torch.randn(M, ld_go, generator=g).cuda()
+    X = (torch.randn(M, ld_in, generator=g) * (4 if ac else 1)).cuda()
+    base = torch.randn(n_out, n_in, generator=g).cuda()
+    dW = base.clone()
+    Hd = X[:, :n_in].double().clone()
+    tab = None
+    if ac:
+        a_, b_ = (torch.rand(ac, generator=g) * 0.2 + 0.05).double(), torch.randn(ac, generator=g).double()
+        tab = torch.stack([a_, b_]).float().cuda().contiguous()
+        Hd[:, :ac] = torch.sin(2 * np.pi * (tab[0].double() * Hd[:, :ac] + tab[1].double()))
+    dz = dZ.reshape(-1)[off:]
+    sn._lib.check(L.snerf_linear_wgrad(M, n_in, n_out, dz.data_ptr(), ld_go, X.data_ptr(), ld_in, 0.5, dW.data_ptr(), 1, tab.data_ptr() if ac else None, ac, st), "linear_wgrad")
+    cols = torch.stack([dZ.reshape(-1)[off + k::ld_go][:M] for k in range(n_out)], 1).double()      # (the last row of an offset view is short by `off`: M rows exist for off + k < ld_go)
+    prod = 0.5 * (cols.T @ Hd)
+    assert float((dW.double() - (base.double() + prod)).abs().max()) / float(prod.abs().max()) < 2e-5
+
+
 def test_linear_argument_errors():
     sn, L, st = _env()
     a = torch.zeros(8, 8, device="cuda")
