@@ -959,6 +959,8 @@ static float* wgrad_scratch(hipStream_t st, size_t floats) {
     return b.p;
 }
 
+float* gemm_partial_scratch(hipStream_t st, size_t floats) { return wgrad_scratch(st, floats); }      // (train_kernels.hip: the thin heads' two-stage sums)
+
 template <bool FULL, bool BNZ, int TA, int TB>
 static hipError_t launch_wgrad_as(const WgradX& g, dim3 grid, hipStream_t st) {
     static bool done = false;

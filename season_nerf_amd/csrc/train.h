@@ -125,13 +125,15 @@ hipError_t launch_thin_dgrad(const ThinDgradArgs& a, hipStream_t st);
 struct ThinWgradArgs {     // weight gradient of a head with K <= 4 outputs as a stream over its input (train_kernels.hip: thin_wgrad_kernel)
     const float* D;        // [M, ldd]: dL/d(head output), K leading columns
     const float* In;       // [M, ldi], N columns: the head's input - or, for the first tab_cols columns, its stored pre-activation (activation on load)
-    float* dW;             // [K, ldw] += alpha * D^T In  (fp32 atomics: one add per block, output and input column)
+    float* dW;             // [K, ldw] += alpha * D^T In  (two stages: per-block sums in `partial`, then one reduction kernel - deterministic)
+    float* partial;        // [blocks, K * N] scratch (set by the launcher)
     int64_t M, ldd, ldi, ldw;
     int K, N;
     float alpha;
     const float* tab;      // optional [a | b] table: In[:, c] = sin(2 pi (a[c] z + b[c])) for c < tab_cols, b at distance tab_stride
     int tab_cols, tab_stride;
 };
+float* gemm_partial_scratch(hipStream_t st, size_t floats);      // gemm.hip: the calling trainer's pre-carved partial-sum scratch (or the stream's own)
 bool thin_wgrad_ok(const ThinWgradArgs& a);
 hipError_t launch_thin_wgrad(const ThinWgradArgs& a, hipStream_t st);
 

@@ -353,7 +353,8 @@ hipError_t launch_thin_dgrad(const ThinDgradArgs& a, hipStream_t st) {
 // K x N is at most 4 x 1024 numbers: the MFMA kernel spends a 128 x 64 block of accumulators per workgroup on it, gathers D with 4 live lanes of 64 and
 // reached 53 % of the copy rate over In at 4096 x 96 (74 us per launch, 7 launches per step).  Like the input gradient of these heads (thin_dgrad_kernel)
 // it is a stream, not a GEMM: a thread owns four input columns and a row phase, keeps its K x 4 sums in registers (exact fp32 FMAs), U rows in flight;
-// the row phases of a block meet in LDS, and the block leaves ONE atomic add per output and column.
+// the row phases of a block meet in LDS, the block leaves its K x N sums in the partial-sum scratch and a second small kernel adds the blocks up in a fixed
+// order (as the two-stage reduction of the MFMA weight-gradient kernel does: no atomics, the same bits every step).
 template <bool ACT>
 __global__ __launch_bounds__(256) void thin_wgrad_kernel(const ThinWgradArgs A, int C4, int cpt, int rows_per_block) {
     __shared__ float red[256][16];
@@ -374,7 +375,7 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(const ThinWgradArgs A, 
     for (int k = 0; k < 4; ++k)
 #pragma unroll
         for (int q = 0; q < 4; ++q) acc[k][q] = 0.f;
-    constexpr int U = 4;
+    constexpr int U = 8;
     const bool vec_d = (A.ldd & 3) == 0 && ((uintptr_t)A.D & 15) == 0;      // the K values of a row as one 16-byte load (columns past K: dropped below)
     const int64_t n_chunks = (A.M + rows_per_block - 1) / rows_per_block;
     if (live) {
@@ -420,13 +421,41 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(const ThinWgradArgs A, 
         for (int q = 0; q < 4; ++q) red[threadIdx.x][k * 4 + q] = acc[k][q];
     __syncthreads();
     if (tr == 0 && live) {
-        for (int k = 0; k < A.K; ++k)
+        float* out = A.partial + (int64_t)blockIdx.x * A.K * A.N;
+        for (int k = 0; k < A.K; ++k) {
+            f32x4_t v;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 float s = 0.f;
                 for (int p = 0; p < rows_pass; ++p) s += red[p * cpt + tc][k * 4 + q];
-                atomicAdd(A.dW + (int64_t)k * A.ldw + tc * 4 + q, A.alpha * s);
+                v[q] = s;
             }
+            *(f32x4_t*)(out + k * A.N + tc * 4) = v;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void thin_wgrad_reduce_kernel(const float* __restrict__ partial, int blocks, int K, int N, float* dW, int64_t ldw, float alpha) {
+    // 32 elements of dW per workgroup, 8 threads per element: thread (e, seg) adds the blocks seg, seg + 8, ... (8 loads in flight), LDS adds the 8 segments
+    __shared__ float red[8][32];
+    const int el = threadIdx.x & 31, seg = threadIdx.x >> 5;
+    const int e = blockIdx.x * 32 + el;
+    const int64_t KN = (int64_t)K * N;
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (e < KN) {
+        int b = seg;
+        for (; b + 56 < blocks; b += 64) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s[u] += partial[(int64_t)(b + 8 * u) * KN + e];
+        }
+        for (; b < blocks; b += 8) s[0] += partial[(int64_t)b * KN + e];
+    }
+    red[seg][el] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    __syncthreads();
+    if (seg == 0 && e < KN) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t += red[q][el];
+        dW[(int64_t)(e / N) * ldw + e % N] += alpha * t;
     }
 }
 bool thin_wgrad_ok(const ThinWgradArgs& a) {
@@ -439,11 +468,15 @@ hipError_t launch_thin_wgrad(const ThinWgradArgs& a, hipStream_t st) {
     const int C4 = a.N / 4;
     int cpt = 1;
     while (cpt < C4) cpt <<= 1;
-    const int rpb = 4 * 4 * (256 / cpt);                    // one round of U = 4 rows per row phase, four rounds per chunk
+    const int rpb = 8 * 2 * (256 / cpt);                    // two rounds of U = 8 rows per row phase and chunk
     int64_t blocks = (a.M + rpb - 1) / rpb;
-    if (blocks > 512) blocks = 512;                         // two resident blocks per CU: 512 atomic adds per element of dW at most
-    if (a.tab && a.tab_cols > 0) hipLaunchKernelGGL((thin_wgrad_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, st, a, C4, cpt, rpb);
-    else hipLaunchKernelGGL((thin_wgrad_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, st, a, C4, cpt, rpb);
+    if (blocks > 512) blocks = 512;                         // two resident blocks per CU: 512 partial rows for the second stage
+    ThinWgradArgs b = a;
+    b.partial = gemm_partial_scratch(st, (size_t)blocks * a.K * a.N);
+    if (!b.partial) return hipErrorOutOfMemory;
+    if (a.tab && a.tab_cols > 0) hipLaunchKernelGGL((thin_wgrad_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, st, b, C4, cpt, rpb);
+    else hipLaunchKernelGGL((thin_wgrad_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, st, b, C4, cpt, rpb);
+    hipLaunchKernelGGL(thin_wgrad_reduce_kernel, dim3((unsigned)((a.K * a.N + 31) / 32)), dim3(256), 0, st, b.partial, (int)blocks, a.K, a.N, a.dW, a.ldw, a.alpha);
     return hipGetLastError();
 }
 
