@@ -249,12 +249,14 @@ def test_checkpoint_resume(golden_dir, tmp_path):
     assert float((w3 - want[key]).abs().mean()) > 20 * max(resumed, 1e-6)
 
 
-def test_ragged_batch_vs_oracle():
+@pytest.mark.parametrize("shape", [(64, 4, 33, 37), (64, 1, 33, 37), (64, 5, 41, 29), (256, 3, 30, 41), (64, 2, 600, 2), (128, 4, 35, 33)])
+def test_ragged_batch_vs_oracle(shape):
     """33 rays x 37 samples = 1221 points: not a multiple of the 32-row wave tile, the 256-row workgroup tile or the 32-point
     wgrad stage - the fused bf16x3 pipeline (masked tiles, clamped gathers, in-place BatchNorm dZ on a partial stage) against the
-    oracle's autograd."""
+    oracle's autograd.  Also: one, two, three and five classes (the class-mixing backward and the thin heads' streams at other widths of the
+    adjust / class layers), two samples per ray, and a width without a fused inference kernel (128)."""
     import season_nerf_amd as sn
-    W, C, R, S = 64, 4, 33, 37
+    W, C, R, S = shape
     sd = orc.init_weights(W, C, 9, bn_stats="identity")
     net = sn.T_NeRF(W, C)
     net.load_state_dict(sd)
