@@ -204,17 +204,34 @@ def _internal_render_device(net, top, bot, sunv, time_frac, S, device, include_e
     st = net._stream()
     tv = sample_parameters_on(dev, S, eval_mode=True, include_end_pt=True)
     sun1, tim1 = _f32(np.asarray(sunv, dtype=np.float64).reshape(1, 3), dev), _f32(encode_time(time_frac).reshape(1, 4), dev)
-    cls, _, sky = net._groups(tim1, sun1)                                  # one (time, sun) group for the whole image
     e = lambda *s: torch.empty(*s, device=dev)
     rho, sv, col_raw, adj, pts = e(R, S, 1), e(R, S, 1), e(R, S, 3), e(R, S, Cn, 3), e(R, S, 3)
     dl = e(R, S, 1)
-    if R > 0:
+    if not net.fused:
+        # A width without a fused kernel (anything but 64 / 256 / 512): the same dict from the layer-wise engine's per-point pass, in chunks of ~1M points.
+        # The sample points are formed as the kernels form them (top * (1 - t) + bot * t, separately rounded products).
+        sky = cls = None
+        per = max(1, (1 << 20) // S)
+        for i in range(0, max(R, 1), per):
+            j = min(i + per, R)
+            n = max(j - i, 1) * S if R > 0 else 1
+            p = (top[i:j, None, :] * (1.0 - tv)[None, :, None] + bot[i:j, None, :] * tv[None, :, None]) if R > 0 else torch.zeros(1, 1, 3, device=dev)
+            o = net.forward_seperate(p.reshape(-1, 3), sun1.expand(n, 3), tim1.expand(n, 4))
+            if sky is None:
+                sky, cls = o[3][:1].contiguous(), o[4][:1].contiguous()
+            if R > 0:
+                rho[i:j], col_raw[i:j], sv[i:j] = o[0].reshape(j - i, S, 1), o[1].reshape(j - i, S, 3), o[2].reshape(j - i, S, 1)
+                adj[i:j], pts[i:j] = o[5].reshape(j - i, S, Cn, 3), p
+    else:
+        cls, _, sky = net._groups(tim1, sun1)                              # one (time, sun) group for the whole image
+    if R > 0 and net.fused:
         fo = _lib.FieldOut(d_rho=rho.data_ptr(), d_solar_vis=sv.data_ptr(), d_col_raw=col_raw.data_ptr(),
                            d_adjust=adj.data_ptr(), d_points=pts.data_ptr())
         model = net.device_model()
         # one (sun, time) group for all rays: rays_per_group = R
         _lib.check(L.snerf_field_forward_rays(model, 0, R, S, top.data_ptr(), bot.data_ptr(), tv.data_ptr(), R, sun1.data_ptr(),
                                               cls.data_ptr(), C.byref(fo), st), "field_forward_rays")
+    if R > 0:
         z3 = torch.zeros(R, S, 3, device=dev)
         sky_r = sky.expand(R, 3).contiguous()
         co = _lib.CompositeOut(d_delta=dl.data_ptr())

@@ -504,3 +504,34 @@ def test_exact_solar_at_the_default_width(golden_dir):
         dd = float((vis - ref).abs().max())
         print(f"  W=512 ray_visibility S={S}: max abs dev from its composition {dd:.1e}")
         assert dd < 2e-6
+
+
+@pytest.mark.parametrize("W,C", [(128, 3), (96, 4)])
+def test_renderers_at_a_width_without_a_fused_kernel(golden_dir, W, C):
+    """fc_units is free in the reference (main_lite.py:80); only 64 / 256 / 512 have fused kernels here.  Any other multiple of four renders through the
+    layer-wise engine: renderer B's per-sample dict (component_render_by_dir, non-square image, exact solar on) and renderer A's images and DSM against the
+    oracle."""
+    import season_nerf_amd as sn
+    g = dict(np.load(os.path.join(golden_dir, "render_W64_s2.npz"), allow_pickle=False))
+    sd = orc.init_weights(W, C, 21 + C)
+    net = sn.T_NeRF(W, C)
+    net.load_state_dict(sd)
+    net = net.to("cuda").eval()
+    assert not net.fused
+    size = (5, 9, 33)
+    d = sn.component_render_by_dir(net, (75, 40), (35, 100), 0.3, size, g["WC"], g["H"], torch.device("cuda"), include_exact_solar=True)
+    ref = orc.render_by_dir(sd, (75, 40), (35, 100), 0.3, size, g["WC"], g["H"])
+    for k in ("World_Points", "Deltas", "Rho", "Base_Col", "Est_Solar_Vis", "Sky_Col", "Output_class", "Adjust_col"):
+        close(k, d[k], ref[k], rtol=1e-4, atol=3e-5)
+    sunv = orc.world_angle_2_local_vec(35, 100, g["WC"], g["H"])
+    vis = orc.exact_solar_visibility(sd, torch.tensor(ref["World_Points"]).float(), sunv, size[2], path_b=True).numpy()
+    close("Exact_Solar", np.asarray(d["Exact_Solar"]).reshape(-1), vis, rtol=1e-4, atol=2e-5)
+    assert "Shadow_Mask_Exact" in sn.get_imgs_from_Img_Dict(d, size, False)
+    args = SimpleNamespace(n_samples=96, Use_Reg=True, Solar_Type_2=False, Use_MSE_loss=True, Use_Solar=True, sc_lambda=0.03, number_low_frequency_cases=C)
+    qr = sn.Quick_Run_Net(net, args, g["WC"], g["H"], torch.device("cuda"), use_full_solar=False)
+    imgs, mask = qr.render_img((60, 30), (45, 120), 0.25, 9)
+    rimgs, rmask, _ = orc.quick_run_render(sd, (60, 30), (45, 120), 0.25, 9, g["WC"], g["H"])
+    assert (mask == rmask).all()
+    close("Col_Img", imgs["Col_Img"], rimgs["Col_Img"])
+    close("Shadow_Mask", imgs["Shadow_Mask"], rimgs["Shadow_Mask"])
+    close("DSM", qr.get_DSM((8, 8)), orc.quick_run_dsm(sd, (8, 8), g["WC"], g["H"]), rtol=1e-4, atol=2e-5)
