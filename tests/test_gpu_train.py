@@ -249,7 +249,7 @@ def test_checkpoint_resume(golden_dir, tmp_path):
     assert float((w3 - want[key]).abs().mean()) > 20 * max(resumed, 1e-6)
 
 
-@pytest.mark.parametrize("shape", [(64, 4, 33, 37), (64, 1, 33, 37), (64, 5, 41, 29), (256, 3, 30, 41), (64, 2, 600, 2), (128, 4, 35, 33)])
+@pytest.mark.parametrize("shape", [(64, 4, 33, 37), (64, 1, 33, 37), (64, 5, 41, 29), (256, 3, 30, 41), (64, 2, 600, 2), (128, 4, 35, 33), (100, 4, 35, 33), (36, 2, 40, 30), (520, 4, 35, 33)])
 def test_ragged_batch_vs_oracle(shape):
     """33 rays x 37 samples = 1221 points: not a multiple of the 32-row wave tile, the 256-row workgroup tile or the 32-point
     wgrad stage - the fused bf16x3 pipeline (masked tiles, clamped gathers, in-place BatchNorm dZ on a partial stage) against the
