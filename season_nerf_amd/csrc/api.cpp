@@ -473,7 +473,8 @@ int snerf_field_ray_visibility(const snerf_model* m, int64_t n_rays, int n_sampl
     a.n_samples = n_samples;
     a.group_size = 1;
     static const bool no_early_out = getenv("SNERF_RAYVIS_NO_EARLY_OUT") != nullptr;      // A/B switch: walk every pass of every ray (mlp_device.h raysum_saturated)
-    a.ray_flags = (flags & 2) | (no_early_out ? 4 : 0);
+    static const bool sun_side_first = getenv("SNERF_RAYVIS_SUN_FIRST") != nullptr;      // A/B switch: the passes in the order before round 6's reversal
+    a.ray_flags = (flags & 2) | (no_early_out ? 4 : 0) | (sun_side_first ? 8 : 0);
     a.out.vis = d_vis;
     return field_launch(m, 3, a, nullptr, stream);
 }

@@ -43,7 +43,7 @@ struct MlpArgs {
     uint32_t debug;            // only read by -DSNERF_ABLATE builds
     // VARIANT 3 (ray visibility: the density-only program with the sum over a ray's samples kept in registers): n = rays, every wave
     // owns one ray of a group of `waves per workgroup` rays and walks its samples 32 at a time
-    int ray_flags;             // bit 1: a sample outside [-1,1]^3 contributes nothing (mg_Img_Eval.py:42,65-66); bit 2: no early-out (A/B)
+    int ray_flags;             // bit 1: a sample outside [-1,1]^3 contributes nothing (mg_Img_Eval.py:42,65-66); bit 2: no early-out (A/B); bit 3: passes from the sun side inwards (the order before round 6's reversal, A/B)
 };
 
 struct CompOutDev {

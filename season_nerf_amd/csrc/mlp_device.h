@@ -147,13 +147,18 @@ __device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-
 struct RaySum {
     float sum;                      // running optical depth of this lane's samples (lives across the ray's passes)
 };
+// Which 32 samples the p-th pass of a ray evaluates.  The secondary ray runs from `top` (where it leaves the cube towards the sun, t = 0) to `bot` (the point
+// whose visibility is asked for, t = 1); the passes walk it FROM THE POINT OUTWARDS: block ceil(S / 32) - 1 first.  The sum does not care about the order, the
+// early-out below does: matter that shadows a point of a real scene is the ground / the building the point sits in, i.e. next to the point, and a ray that
+// meets it in its first pass is finished after one evaluation of the network instead of three (ray_flags bit 3 = the old order, sun side first: A/B).
+__device__ __forceinline__ int raysum_block(const MlpArgs& A, int p) { return (A.ray_flags & 8) ? p : (A.n_samples + 31) / 32 - 1 - p; }
 // sample position of this lane in pass p (misc.py:234-247: top (1 - t) + bot t, two roundings + one add).  The ray's end points are re-read
 // every pass (cached loads before the MFMA chain) and once more after it for the segment length: nothing but `sum` lives across the chain.
 __device__ __forceinline__ void raysum_point(RaySum& q, const MlpArgs& A, int64_t group, int waves, int wave, int p, int lane, float& x0, float& x1, float& x2) {
     const int64_t ray = group * waves + wave;
     const int64_t r = ray < A.n ? ray : A.n - 1;
     if (p == 0) q.sum = 0.f;
-    const int s = p * 32 + (lane & 31);
+    const int s = raysum_block(A, p) * 32 + (lane & 31);
     const float t = A.tvals[s < A.n_samples ? s : A.n_samples - 1], omt = __fsub_rn(1.f, t);
     x0 = __fadd_rn(__fmul_rn(A.top[r * 3], omt), __fmul_rn(A.bot[r * 3], t));
     x1 = __fadd_rn(__fmul_rn(A.top[r * 3 + 1], omt), __fmul_rn(A.bot[r * 3 + 1], t));
@@ -169,7 +174,7 @@ __device__ __forceinline__ void raysum_add(RaySum& q, const MlpArgs& A, int64_t 
     const int64_t r = ray < A.n ? ray : A.n - 1;
     const float dx = A.top[r * 3] - A.bot[r * 3], dy = A.top[r * 3 + 1] - A.bot[r * 3 + 1], dz = A.top[r * 3 + 2] - A.bot[r * 3 + 2];
     const float delta = __fdiv_rn(__fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz))), (float)A.n_samples);
-    const int s = p * 32 + (lane & 31);
+    const int s = raysum_block(A, p) * 32 + (lane & 31);
     {   // the sample position again (the registers that held it during the chain are long gone: fewer values live across it)
         const float t = A.tvals[s < A.n_samples ? s : A.n_samples - 1], omt = __fsub_rn(1.f, t);
         x0 = __fadd_rn(__fmul_rn(A.top[r * 3], omt), __fmul_rn(A.bot[r * 3], t));
