@@ -251,6 +251,30 @@ SIGMA_FLOP_PER_SAMPLE = 2 * 524800.0          # trunk fc1..fc9 + density head, W
 SIGMA_FLOP_PER_SAMPLE_512 = 2 * 2030848.0     # the same at W = 512: 63 x 512 + 6 x 512^2 + 575 x 512 + 512 x 256 + 256
 
 
+def renderer_a_row(dev, net):
+    """Renderer A (Quick_Run_Net.render_img, exact solar on - its default in the reference, Quick_Run.py:62) for one 256 x 256 x 96 image, end to end (ray grid,
+    primary render, secondary rays, the three images back on the host): as it ships - samples without compositing weight get no secondary ray - and with a
+    secondary ray for every sample (`skip_weightless=None`, the reference's loop)."""
+    import time
+    from types import SimpleNamespace
+    import season_nerf_amd as sn
+    WC, H4 = np.array([41.29, -95.9, 300.0]), np.array([[310.0, 12.0, 0.0, -11650.0], [-9.0, 240.0, 0.0, 23390.0], [0.0, 0.0, 0.01, -3.0], [0, 0, 0, 1.0]])
+    eargs = SimpleNamespace(n_samples=S, Use_Reg=True, Solar_Type_2=False, Use_MSE_loss=True, Use_Solar=True, sc_lambda=0.03, number_low_frequency_cases=NC)
+    row = {"image": "256x256x96, view (70, 20), sun (40, 110)", "precision_resolved": net.resolved_precision}
+    for key, skip in (("ms", 1e-9), ("ms_every_sample", None)):
+        qr = sn.Quick_Run_Net(net, eargs, WC, H4, dev, use_full_solar=True, skip_weightless=skip)
+        qr.render_img((70, 20), (40, 110), 0.3, 48)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        qr.render_img((70, 20), (40, 110), 0.3, 256)
+        torch.cuda.synchronize()
+        row[key] = (time.perf_counter() - t0) * 1e3
+        if skip is not None:
+            walked, of = qr.eval_tool.last_exact_solar_rays
+            row["secondary_rays_walked"], row["secondary_rays"] = walked, of
+    return row
+
+
 def exact_solar_bench(dev, net, sizes=((256, 256, 96), (512, 512, 96)), layerwise_too=False):
     """The exact-solar pass (Eval_Tools_2.py:255-295 / mg_Img_Eval.py:57-70; the DEFAULT of both reference renderers): for every sample of every
     primary ray a secondary ray towards the sun, S density-only evaluations each - R S^2 in all - as `season_nerf::ray_visibility` launches
@@ -822,6 +846,7 @@ def main():
             ns.load_state_dict(sd_s)
             ns = ns.to(dev).eval()
             late["exact_solar_converged"] = exact_solar_bench(dev, ns, sizes=((256, 256, 96),))
+            late["renderer_a_converged"] = renderer_a_row(dev, ns)
             del ns
         except Exception as ex:
             late["exact_solar_error"] = repr(ex)
@@ -834,7 +859,9 @@ def main():
             sd5, _, _ = sharp_state_dict(512)
             n5 = sn.T_NeRF(512, NC)
             n5.load_state_dict(sd5)
-            late["exact_solar_converged_w512"] = exact_solar_bench(dev, n5.to(dev).eval(), sizes=((256, 256, 96),), layerwise_too=True)
+            n5 = n5.to(dev).eval()
+            late["exact_solar_converged_w512"] = exact_solar_bench(dev, n5, sizes=((256, 256, 96),), layerwise_too=True)
+            late["renderer_a_converged_w512"] = renderer_a_row(dev, n5)
             del n5
         except Exception as ex:
             late["exact_solar_w512_error"] = repr(ex)

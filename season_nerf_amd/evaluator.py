@@ -168,10 +168,16 @@ class All_in_One_Eval:
         est = Network._field_points(1, pts, sun_m.contiguous(), None, ["d_solar_vis"])["d_solar_vis"].reshape(M, 1)
         return exact, est
 
-    def eval_exact_solar(self, data_dict, Network, current_step, train_mode):
+    def eval_exact_solar(self, data_dict, Network, current_step, train_mode, skip_weightless=None):
         """Eval_Tools_2.py:273-295: `eval` with `Solar_Vis` replaced by the exact visibility from secondary sun rays (one per
         sample, O(R S^2) density evaluations - all rays batched into sigma-only launches instead of the reference's per-ray
-        Python loop); adds `Est_Solar_Vis` and `Col_Adj`, recomputes `Rendered_Col`."""
+        Python loop); adds `Est_Solar_Vis` and `Col_Adj`, recomputes `Rendered_Col`.
+
+        `skip_weightless` (not in the reference; default None = every sample, the reference's per-sample arrays): a float w - samples whose compositing
+        weight PS is below w get NO secondary ray and keep the network's own estimate in `Solar_Vis` / `Col_Adj`.  Everything a renderer derives from this dict
+        is a PS-weighted sum over the samples of a ray (`Rendered_Col`, the shadow masks), so the images change by at most S * w; the per-sample arrays are
+        then NOT the reference's at the skipped samples.  `Quick_Run_Net` (images only) uses 1e-9: on a converged scene the samples behind the first opaque
+        surface - 40-50 % of them - weigh nothing."""
         from .render import _exact_solar_visibility
         out = self.eval(data_dict, Network, current_step, train_mode)
         R, S = out["PS"].shape[0], self.args.n_samples
@@ -180,7 +186,15 @@ class All_in_One_Eval:
             return out
         (sun,) = Network._prep(data_dict["Sun_Angle"])
         sun_e = sun.unsqueeze(1).expand(R, S, 3).reshape(-1, 3)
-        vis = _exact_solar_visibility(Network, out["sample_pts"].reshape(-1, 3).to(sun.device), sun_e, S, zero_oob=False)
+        pts = out["sample_pts"].reshape(-1, 3).to(sun.device)
+        if skip_weightless is not None:
+            keep = torch.nonzero(out["PS"].reshape(-1) >= float(skip_weightless)).reshape(-1)      # (one sync: the count sizes the launch)
+            vis = out["Est_Solar_Vis"].reshape(-1).clone()
+            if keep.numel():
+                vis[keep] = _exact_solar_visibility(Network, pts.index_select(0, keep), sun_e.index_select(0, keep), S, zero_oob=False)
+            self.last_exact_solar_rays = (int(keep.numel()), R * S)      # (diagnostic: secondary rays walked, of)
+        else:
+            vis = _exact_solar_visibility(Network, pts, sun_e, S, zero_oob=False)
         sv = vis.reshape(R, S, 1)
         out["Solar_Vis"] = sv
         sky = out["Sky_Col"]

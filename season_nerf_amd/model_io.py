@@ -49,6 +49,6 @@ def render_novel_view(model_location, view_el_az, sun_el_az, time, output_size=(
     net = net.to(device).eval()
     tf = parse_time(time) if isinstance(time, str) else float(time)
     raw = component_render_by_dir(net, view_el_az, sun_el_az, tf, tuple(output_size), W2C=geo.get("W2C"), W2L_H=geo.get("W2L_H"),
-                                  include_exact_solar=exact_shadow, device=device)
+                                  include_exact_solar=exact_shadow, device=device, skip_weightless=1e-9)      # images only (render.component_render_by_dir)
     imgs = get_imgs_from_Img_Dict(raw, tuple(output_size), False)
     return imgs["Season_Adj_Img"] * imgs["Shadow_Adjust"], imgs

@@ -118,7 +118,10 @@ def _ray_grid(mode, rows, cols, params, device, lo=0, hi=None, want_pixels=False
 # ------------------------------------------------------------------------------------------------ path A
 class Quick_Run_Net:
     def __init__(self, network, args, world_center_LLA, World_2_Local_H, device, max_input_size=50000, use_tqdm=False,
-                 use_full_solar=True):
+                 use_full_solar=True, *, skip_weightless=1e-9):
+        # skip_weightless (keyword-only, not in the reference): this class returns IMAGES - PS-weighted sums over the samples of a ray - so a sample whose
+        # weight is below it gets no secondary sun ray (All_in_One_Eval.eval_exact_solar): the images move by < 96 * 1e-9; None = every sample.
+        self.skip_weightless = skip_weightless
         self.eval_tool = All_in_One_Eval(args, device, 5, False, False, World_2_Local_H, world_center_LLA)
         self.network = network
         self.world_center_LLA = world_center_LLA
@@ -151,7 +154,7 @@ class Quick_Run_Net:
 
     def _eval(self, d, exact):
         if exact and d["Top"].shape[0] > 0:
-            return self.eval_tool.eval_exact_solar(d, self.network, -1, False)      # Quick_Run.py:184-186
+            return self.eval_tool.eval_exact_solar(d, self.network, -1, False, skip_weightless=self.skip_weightless)      # Quick_Run.py:184-186
         return self.eval_tool.eval(d, self.network, -1, False)
 
     def render_img(self, camera_el_and_az, solar_el_and_az, time_frac, out_img_size, region=None):
@@ -194,7 +197,7 @@ class ImgDict(dict):
     dev = None
 
 
-def _internal_render_device(net, top, bot, sunv, time_frac, S, device, include_exact_solar):
+def _internal_render_device(net, top, bot, sunv, time_frac, S, device, include_exact_solar, skip_weightless=None):
     """`_internal_render` (mg_Img_Eval.py:17-72) on device tensors: rays top/bot [R,3] (fp32, device), ONE sun vector
     (float64 numpy [3]) and ONE time for the whole image; returns the per-sample device tensors of the reference's dict."""
     dev = torch.device(device)
@@ -234,27 +237,37 @@ def _internal_render_device(net, top, bot, sunv, time_frac, S, device, include_e
     if R > 0:
         z3 = torch.zeros(R, S, 3, device=dev)
         sky_r = sky.expand(R, 3).contiguous()
-        co = _lib.CompositeOut(d_delta=dl.data_ptr())
+        ps = e(R, S, 1) if (include_exact_solar and skip_weightless is not None) else None
+        co = _lib.CompositeOut(d_delta=dl.data_ptr(), d_ps=ps.data_ptr() if ps is not None else None)
         _lib.check(L.snerf_composite_rays(R, S, top.data_ptr(), bot.data_ptr(), tv.data_ptr(), rho.data_ptr(), z3.data_ptr(),
                                           sv.data_ptr(), sky_r.data_ptr(), 2, None, 1.0, C.byref(co), st), "composite_rays")
     devd = {"top": top, "bot": bot, "tv": tv, "World_Points": pts, "Deltas": dl, "Rho": rho, "Base_Col": col_raw,
             "Est_Solar_Vis": sv, "Sky": sky[0].contiguous(), "Class": cls[0].contiguous(), "Adjust_col": adj}
     if include_exact_solar:
         sun_d = _f32(sunv, dev)
-        devd["Exact_Solar"] = (_exact_solar_visibility(net, pts.reshape(-1, 3), sun_d, S, zero_oob=True, sun64=sunv).reshape(R, S, 1)
-                               if R > 0 else e(0, S, 1))
+        if R > 0 and skip_weightless is not None:
+            # images only (every image of this dict is a PS-weighted sum over the samples of a ray): samples that weigh less than `skip_weightless` get no
+            # secondary ray and keep the network's estimate - on a converged scene 80 % of them (evaluator.All_in_One_Eval.eval_exact_solar)
+            keep = torch.nonzero(ps.reshape(-1) >= float(skip_weightless)).reshape(-1)
+            ex = sv.reshape(-1).clone()
+            if keep.numel():
+                ex[keep] = _exact_solar_visibility(net, pts.reshape(-1, 3).index_select(0, keep), sun_d, S, zero_oob=True, sun64=sunv)
+            devd["Exact_Solar"] = ex.reshape(R, S, 1)
+        else:
+            devd["Exact_Solar"] = (_exact_solar_visibility(net, pts.reshape(-1, 3), sun_d, S, zero_oob=True, sun64=sunv).reshape(R, S, 1)
+                                   if R > 0 else e(0, S, 1))
     return devd
 
 
 def _render_by_dir_device(net, view_el_az, sun_el_az, time_frac, out_img_size, W2C, W2L_H, device, include_exact_solar,
-                          ray_range=None):
+                          ray_range=None, skip_weightless=None):
     """ray_range=(lo, hi): render only rays lo..hi-1 of the row-major H*W grid (a rank's tile in a sharded render)."""
     Hh, Ww, S = out_img_size
     v = world_angle_2_local_vec(view_el_az[0], view_el_az[1], W2C, W2L_H)
     sunv = world_angle_2_local_vec(sun_el_az[0], sun_el_az[1], W2C, W2L_H)
     lo, hi = (0, Hh * Ww) if ray_range is None else ray_range
     top, bot, _ = _ray_grid(0, Hh, Ww, v / v[2], device, lo, hi)          # mg_Img_Eval.py:99-104 on the GPU (no culling on this path)
-    return _internal_render_device(net, top, bot, sunv, time_frac, S, device, include_exact_solar)
+    return _internal_render_device(net, top, bot, sunv, time_frac, S, device, include_exact_solar, skip_weightless)
 
 
 def _to_img_dict(d, the_network, S, include_exact_solar):
@@ -271,7 +284,7 @@ def _to_img_dict(d, the_network, S, include_exact_solar):
     return res
 
 
-def component_render_by_P(the_network, a_P_img, out_img_size: tuple, device, max_batch_size=150000, include_exact_solar=True):
+def component_render_by_P(the_network, a_P_img, out_img_size: tuple, device, max_batch_size=150000, include_exact_solar=True, *, skip_weightless=None):
     """mg_Img_Eval.py:74-94: render through a camera.  `a_P_img` is the reference's projective-image object (duck-typed:
     `.img.shape`, `.invert_P(rows, cols, h)`, `.sun_el_and_az_vec`, `.get_year_frac()`): pixel grid -> rays by its own float64
     `invert_P` (out_h x out_w solves on the host), rays leaving the cube dropped, then the same device render as by-direction.
@@ -312,7 +325,7 @@ def component_render_by_P(the_network, a_P_img, out_img_size: tuple, device, max
             idx = np.nonzero(inside)[0]
             tops_d, bots_d, src_pix = _f32(ends[0][idx], dev), _f32(ends[1][idx], dev), XY[idx]
         d = _internal_render_device(the_network, tops_d, bots_d, np.asarray(a_P_img.sun_el_and_az_vec, dtype=np.float64), a_P_img.get_year_frac(), S, device,
-                                    include_exact_solar)
+                                    include_exact_solar, skip_weightless)
         res = _to_img_dict(d, the_network, S, include_exact_solar)
         res["Image_Points_in_GT_Img"] = src_pix
         res["Image_Points"] = np.stack([idx // Ww, idx % Ww], 1)
@@ -320,13 +333,16 @@ def component_render_by_P(the_network, a_P_img, out_img_size: tuple, device, max
 
 
 def component_render_by_dir(the_network, view_el_az, sun_el_az, time_frac, out_img_size: tuple, W2C, W2L_H, device,
-                            max_batch_size=150000, include_exact_solar=True):
+                            max_batch_size=150000, include_exact_solar=True, *, skip_weightless=None):
     """mg_Img_Eval.py:96-115.  Returns the reference's dict of float64 arrays (World_Points, Deltas, Rho, Base_Col,
-    Est_Solar_Vis, Sky_Col, Output_class, Adjust_col[, Exact_Solar], Image_Points)."""
+    Est_Solar_Vis, Sky_Col, Output_class, Adjust_col[, Exact_Solar], Image_Points).
+    `skip_weightless` (keyword-only, not in the reference; default None = the reference's per-sample `Exact_Solar`): a float w - samples whose compositing weight
+    is below w get no secondary sun ray and carry the network's estimate in `Exact_Solar`.  Every image `get_imgs_from_Img_Dict*` forms is a weighted sum over a
+    ray's samples, so images move by < S * w while a converged scene needs a fifth of the secondary rays (`render_novel_view` and the sweep pipeline pass 1e-9)."""
     with torch.no_grad():
         Hh, Ww, S = out_img_size
         d = _render_by_dir_device(the_network, view_el_az, sun_el_az, time_frac, out_img_size, W2C, W2L_H, device,
-                                  include_exact_solar)
+                                  include_exact_solar, skip_weightless=skip_weightless)
         res = _to_img_dict(d, the_network, S, include_exact_solar)
         res["Image_Points"] = np.stack(np.meshgrid(np.arange(Hh), np.arange(Ww), indexing="ij"), -1).reshape([-1, 2])
     return res
@@ -428,14 +444,14 @@ def get_imgs_from_Img_Dict_t_step(Img_Dict, out_img_size: tuple, class_vecs_arra
 
 
 def season_sweep_tile(the_network, view_el_az, sun_el_az, time_fracs, out_img_size: tuple, W2C, W2L_H, device, ray_range=None,
-                      include_exact_solar=False, render_time_frac=None):
+                      include_exact_solar=False, render_time_frac=None, skip_weightless=1e-9):
     """One rank's share of `render_season_sweep`: rays ray_range = (lo, hi) of the row-major H x W grid (None: all of them) through the
     component render, the class vectors of all `time_fracs` and the sweep kernel -> [T, hi - lo, 3] on the GPU.  The tiles of
     `parallel.shard_bounds(H * W, world)` concatenated along the ray axis ARE the whole image (tests/test_gpu_fullsize.py)."""
     with torch.no_grad():
         tf0 = time_fracs[0] if render_time_frac is None else render_time_frac
         d = _render_by_dir_device(the_network, view_el_az, sun_el_az, tf0, out_img_size, W2C, W2L_H, device, include_exact_solar,
-                                  ray_range=ray_range)
+                                  ray_range=ray_range, skip_weightless=skip_weightless)      # (images only: the weightless samples' secondary rays are not walked)
         times = _f32(np.stack([encode_time(t) for t in time_fracs]), d["Rho"].device)
         cls = the_network.get_class_only(times)
         return _sweep(d, cls.cpu().numpy(), "Exact_Solar" if include_exact_solar else "Est_Solar_Vis")["shaded"]

@@ -535,3 +535,38 @@ def test_renderers_at_a_width_without_a_fused_kernel(golden_dir, W, C):
     close("Col_Img", imgs["Col_Img"], rimgs["Col_Img"])
     close("Shadow_Mask", imgs["Shadow_Mask"], rimgs["Shadow_Mask"])
     close("DSM", qr.get_DSM((8, 8)), orc.quick_run_dsm(sd, (8, 8), g["WC"], g["H"]), rtol=1e-4, atol=2e-5)
+
+
+def test_weightless_samples_get_no_secondary_ray(golden_dir):
+    """`skip_weightless` (not in the reference): every image the renderers return is a PS-weighted sum over the samples of a ray, so a sample whose compositing
+    weight is below 1e-9 needs no secondary sun ray.  On weights with surfaces that is most of them: the images of renderer A (where it is the default) and of
+    renderer B (opt-in; `render_novel_view` and the sweep pipeline pass it) stay within 1e-6 of the every-sample render while a fraction of the secondary rays is
+    walked; the per-sample `Exact_Solar` of renderer B is the every-sample value wherever the weight is not negligible.  Renderer A's default against the
+    REFERENCE's images: test_renderers_on_weights_with_surfaces above."""
+    sn, gs, sd, net = sharp_net(golden_dir)
+    gi = {"WC": gs["WC"], "H": gs["H"]}
+    args = SimpleNamespace(n_samples=96, Use_Reg=True, Solar_Type_2=False, Use_MSE_loss=True, Use_Solar=True, sc_lambda=0.03, number_low_frequency_cases=int(gs["C"]))
+    out = {}
+    for skip in (None, 1e-9):
+        qr = sn.Quick_Run_Net(net, args, gi["WC"], gi["H"], torch.device("cuda"), use_full_solar=True, skip_weightless=skip)
+        out[skip] = qr.render_img((70, 20), (40, 110), 0.3, 24)
+        if skip is not None:
+            walked, of = qr.eval_tool.last_exact_solar_rays
+            print(f"  renderer A: {walked} of {of} secondary rays walked")
+            assert 0 < walked < 0.6 * of
+    assert (out[None][1] == out[1e-9][1]).all()
+    for k in out[None][0]:
+        close("A " + k, out[1e-9][0][k], out[None][0][k], rtol=0, atol=1e-6)
+    assert sn.Quick_Run_Net(net, args, gi["WC"], gi["H"], torch.device("cuda")).skip_weightless == 1e-9            # the default of renderer A
+    size = (9, 7, 96)
+    a = sn.component_render_by_dir(net, (75, 40), (35, 100), 0.3, size, gi["WC"], gi["H"], torch.device("cuda"), include_exact_solar=True)
+    b = sn.component_render_by_dir(net, (75, 40), (35, 100), 0.3, size, gi["WC"], gi["H"], torch.device("cuda"), include_exact_solar=True, skip_weightless=1e-9)
+    ia, ib = sn.get_imgs_from_Img_Dict(a, size, True), sn.get_imgs_from_Img_Dict(b, size, True)
+    for k in ia:
+        if isinstance(ia[k], np.ndarray) and ia[k].dtype.kind == "f":
+            close("B " + k, ib[k], ia[k], rtol=0, atol=1e-6)
+    same = np.isclose(np.asarray(a["Exact_Solar"]), np.asarray(b["Exact_Solar"]), rtol=0, atol=1e-7)
+    est = np.isclose(np.asarray(b["Exact_Solar"]), np.asarray(b["Est_Solar_Vis"]), rtol=0, atol=0)
+    assert (same | est).all() and 0.05 < same.mean()              # a walked ray gives the every-sample value; a skipped sample carries the network's estimate
+    for k in ("Rho", "Base_Col", "Est_Solar_Vis", "Deltas"):
+        assert np.array_equal(np.asarray(a[k]), np.asarray(b[k]))
