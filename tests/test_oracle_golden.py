@@ -279,16 +279,18 @@ def test_eval_on_really_trained_weights(golden_dir, W):
     close(loc, g["eval_surf_loc"], **loose); close(dist, g["eval_surf_dist"], **loose)
 
 
-def test_eval_after_the_references_whole_schedule(golden_dir):
+@pytest.mark.parametrize("name,steps,lo,hi", [("trained12k_W64.npz", 12000, 0.05, 0.1), ("trained40k_W64.npz", 40000, 0.08, 0.12)])
+def test_eval_after_the_references_whole_schedule(golden_dir, name, steps, lo, hi):
     """Round 6: the reference's own schedule end to end at W = 64 - 20 % of 12 000 steps under the DSM prior (learning mode 1), the rest free
     (mode 4), a fresh Adam + OneCycleLR per phase (Net_Tool_2.py:23-33,111-130; tools/make_sharp_golden.py converged) - checked with the reference's eval every
     250 steps.  What it produced in 74 CPU-minutes is recorded, not dressed up: the colour loss fell 18x and the density stayed fog (mean max-PS per ray 0.070,
-    flat from step 1 500 on).  The oracle follows the reference on these weights as on the others."""
-    g = load(golden_dir, "trained12k_W64.npz")
+    flat from step 1 500 on).  The same schedule at 40 000 steps (3.9 CPU-hours): colour loss 100x down, mean max-PS 0.094, flat from step ~20 000 on.  The oracle
+    follows the reference on these weights as on the others."""
+    g = load(golden_dir, name)
     traj, checks = g["loss_trajectory"], g["checks"]
-    assert len(traj) == 12000 and int((traj[:, 0] == 1).sum()) == 2400
+    assert len(traj) == steps and int((traj[:, 0] == 1).sum()) == steps // 5
     assert traj[-100:, 2].mean() < 0.1 * traj[:100, 2].mean()
-    assert 0.05 < float(g["max_ps"].mean()) < 0.1 and checks[-1, 2] < 0.3          # the stop criterion (0.3) was never met: the schedule ran out first
+    assert lo < float(g["max_ps"].mean()) < hi and checks[-1, 2] < 0.3          # the stop criterion (0.3) was never met: the schedule ran out first
     sd = trained_state_dict(g)
     with torch.no_grad():
         r = orc.eval_rays(sd, rays_of(g), int(g["S"]), train_mode=False)
