@@ -192,9 +192,86 @@ class Quick_Run_Net:
 
 # ------------------------------------------------------------------------------------------------ path B
 class ImgDict(dict):
-    """The float64 numpy dict of the reference (`_internal_render`, mg_Img_Eval.py:17-72) plus, under `.dev`, the fp32
-    device tensors it was copied from, so the image-assembly functions below run on the GPU without re-upload."""
+    """The float64 numpy dict of the reference (`_internal_render`, mg_Img_Eval.py:17-72) plus, under `.dev`, the fp32 device tensors it comes from, so
+    the image-assembly functions below run on the GPU without re-upload.
+
+    The per-sample arrays are LAZY: a 256 x 256 x 96 render is ~1.1 GB of float64 on the host (points, colours, C x 3 adjustments per sample) and costs as
+    much wall time to copy and widen as the render itself (292 against 284 ms at W = 256), while the usual consumers - `get_imgs_from_Img_Dict*`,
+    `render_novel_view`, the sweeps - read the device tensors.  An array is made on its first access (`d[k]`, `.get`, `.items()`, `.values()`, `dict(d)`, pickling,
+    equality); `k in d`, `len(d)`, `.keys()` and iteration over the keys do not need it."""
     dev = None
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self._lazy = {}                          # key -> zero-argument function that makes the float64 array
+
+    def _lazy_set(self, key, make):
+        self._lazy[key] = make
+        dict.__setitem__(self, key, None)        # the key exists from now on (order, `in`, len); its value is made on first access
+
+    def _make(self, key):
+        make = self._lazy.pop(key, None)
+        if make is not None:
+            dict.__setitem__(self, key, make())
+
+    def _make_all(self):
+        for k in list(self._lazy):
+            self._make(k)
+
+    def __getitem__(self, key):
+        self._make(key)
+        return dict.__getitem__(self, key)
+
+    def __iter__(self):                          # (also what makes dict(d), {**d} and f(**d) go through keys() + __getitem__ instead of copying the raw table)
+        return iter(list(dict.keys(self)))
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+    def __setitem__(self, key, value):
+        self._lazy.pop(key, None)
+        dict.__setitem__(self, key, value)
+
+    def update(self, *a, **kw):
+        for k, v in dict(*a, **kw).items():
+            self[k] = v
+
+    def setdefault(self, key, default=None):
+        if key not in self:
+            self[key] = default
+        return self[key]
+
+    def __delitem__(self, key):
+        self._lazy.pop(key, None)
+        dict.__delitem__(self, key)
+
+    def pop(self, key, *default):
+        self._make(key)
+        return dict.pop(self, key, *default)
+
+    def items(self):
+        self._make_all()
+        return dict.items(self)
+
+    def values(self):
+        self._make_all()
+        return dict.values(self)
+
+    def copy(self):
+        self._make_all()
+        c = ImgDict(dict.items(self))
+        c.dev = self.dev
+        return c
+
+    def __eq__(self, other):
+        self._make_all()
+        return dict.__eq__(self, other)
+
+    __hash__ = None
+
+    def __reduce__(self):                        # pickling / copy.deepcopy: a plain dict of arrays (the device tensors stay behind)
+        self._make_all()
+        return (dict, (dict(dict.items(self)),))
 
 
 def _internal_render_device(net, top, bot, sunv, time_frac, S, device, include_exact_solar, skip_weightless=None):
@@ -275,11 +352,11 @@ def _to_img_dict(d, the_network, S, include_exact_solar):
     f = lambda t: t.cpu().numpy().astype(np.float64)
     res = ImgDict()
     for k in ["World_Points", "Deltas", "Rho", "Base_Col", "Est_Solar_Vis", "Adjust_col"]:
-        res[k] = f(d[k])
-    res["Sky_Col"] = np.broadcast_to(f(d["Sky"]).reshape(1, 1, 3), (R, S, 3)).copy()
-    res["Output_class"] = np.broadcast_to(f(d["Class"]).reshape(1, 1, Cn), (R, S, Cn)).copy()
+        res._lazy_set(k, lambda k=k: f(d[k]))
+    res._lazy_set("Sky_Col", lambda: np.broadcast_to(f(d["Sky"]).reshape(1, 1, 3), (R, S, 3)).copy())
+    res._lazy_set("Output_class", lambda: np.broadcast_to(f(d["Class"]).reshape(1, 1, Cn), (R, S, Cn)).copy())
     if include_exact_solar:
-        res["Exact_Solar"] = f(d["Exact_Solar"])
+        res._lazy_set("Exact_Solar", lambda: f(d["Exact_Solar"]))
     res.dev = d
     return res
 
