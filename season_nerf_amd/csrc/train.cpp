@@ -28,11 +28,14 @@ static bool train_memops() {
     return on;
 }
 static hipError_t snerf_zero_async(void* p, int value, size_t bytes, hipStream_t st) {
-    if (train_memops() || value != 0 || bytes % 4 != 0 || ((uintptr_t)p & 3)) return hipMemsetAsync(p, value, bytes, st);
+    if (train_memops()) return hipMemsetAsync(p, value, bytes, st);
+    if (value != 0) return hipErrorInvalidValue;                     // (the engine only ever zeroes)
+    if (bytes % 4 != 0 || ((uintptr_t)p & 3)) return snerf::launch_fill_zero_bytes(p, bytes, st);
     return snerf::launch_fill_zero((float*)p, (int64_t)(bytes / 4), st);
 }
 static hipError_t snerf_copy_async(void* d, const void* s_, size_t bytes, hipStream_t st) {
-    if (train_memops() || bytes % 4 != 0 || (((uintptr_t)d | (uintptr_t)s_) & 3)) return hipMemcpyAsync(d, s_, bytes, hipMemcpyDeviceToDevice, st);
+    if (train_memops()) return hipMemcpyAsync(d, s_, bytes, hipMemcpyDeviceToDevice, st);
+    if (bytes % 4 != 0 || (((uintptr_t)d | (uintptr_t)s_) & 3)) return snerf::launch_copy_bytes(d, s_, bytes, st);
     return snerf::launch_copy_f32((float*)d, (const float*)s_, (int64_t)(bytes / 4), st);
 }
 

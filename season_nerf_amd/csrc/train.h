@@ -199,6 +199,8 @@ hipError_t launch_sigmoid_bwd(const float* y, const float* dy, float* dx, int64_
 hipError_t launch_colsum(const float* X, int64_t M, int C, int64_t ld, float alpha, float* out, hipStream_t st);
 // concat-free helpers
 hipError_t launch_copy_cols(const float* src, int64_t ld_src, float* dst, int64_t ld_dst, int64_t M, int C, bool accumulate, hipStream_t st);
+hipError_t launch_fill_zero_bytes(void* p, size_t bytes, hipStream_t st);
+hipError_t launch_copy_bytes(void* d, const void* s, size_t bytes, hipStream_t st);
 hipError_t launch_copy_f32(float* d, const float* s, int64_t n, hipStream_t st);            // the engine's device-to-device copy and zero-fill: kernels, so that a
 hipError_t launch_fill_zero(float* p, int64_t n, hipStream_t st);                          // captured step holds no hipGraph memory-operation node (train.cpp)
 hipError_t launch_round_bf16(float* p, int64_t ld, int64_t M, int C, hipStream_t st);      // experiment switch SNERF_TRAIN_DY_BF16 only

@@ -1029,6 +1029,20 @@ hipError_t launch_copy_f32(float* d, const float* s, int64_t n, hipStream_t st) 
     LAUNCH_1D(copy_f32_kernel, (n + 3) / 4, st, d, s, n);
     return hipGetLastError();
 }
+__global__ void fill_zero_bytes_kernel(unsigned char* p, int64_t n) {      // (odd sizes / addresses: the engine has none today; no path falls back to the runtime's memset)
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = 0;
+}
+__global__ void copy_bytes_kernel(unsigned char* __restrict__ d, const unsigned char* __restrict__ s, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) d[i] = s[i];
+}
+hipError_t launch_fill_zero_bytes(void* p, size_t bytes, hipStream_t st) {
+    LAUNCH_1D(fill_zero_bytes_kernel, (int64_t)bytes, st, (unsigned char*)p, (int64_t)bytes);
+    return hipGetLastError();
+}
+hipError_t launch_copy_bytes(void* d, const void* s, size_t bytes, hipStream_t st) {
+    LAUNCH_1D(copy_bytes_kernel, (int64_t)bytes, st, (unsigned char*)d, (const unsigned char*)s, (int64_t)bytes);
+    return hipGetLastError();
+}
 hipError_t launch_round_bf16(float* p, int64_t ld, int64_t M, int C, hipStream_t st) {
     if (M <= 0 || C <= 0) return hipSuccess;
     int64_t b = (M * C + 255) / 256;

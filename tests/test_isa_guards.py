@@ -308,8 +308,7 @@ def test_areg_gemm_agprs_are_touched_only_by_the_hand_written_instructions(tmp_p
 def test_no_runtime_memory_operation_can_reach_a_captured_step():
     """a hipMemsetAsync / hipMemcpyAsync inside a captured training step is a hipGraph MEMSET / MEMCPY node, and MEMSET nodes replay wrongly on ROCm 7.2
     (tools/graph_memset_min.py).  Every copy and fill of the engine goes through the two wrappers of csrc/train.cpp, which launch kernels; the only stream-ordered
-    runtime memory operations left in the C++ / HIP sources are the two fall-backs inside those wrappers (reached with SNERF_TRAIN_MEMOPS=1 or a size that is not a
-    multiple of four bytes - the engine has none).  The graph-level guard on the GPU is tests/test_gpu_graph_nodes.py; this one fails at the source, without a GPU."""
+    runtime memory operations left in the C++ / HIP sources are the two calls inside those wrappers behind SNERF_TRAIN_MEMOPS=1 (the reproduction switch).  The graph-level guard on the GPU is tests/test_gpu_graph_nodes.py; this one fails at the source, without a GPU."""
     import glob
     import re
     csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "season_nerf_amd", "csrc")
@@ -321,4 +320,4 @@ def test_no_runtime_memory_operation_can_reach_a_captured_step():
             code = line.split("//")[0]
             if re.search(r"\bhip(Memset|Memcpy)\w*Async\s*\(", code):
                 hits.append((os.path.basename(f), n, code.strip()))
-    assert len(hits) == 2 and all(h[0] == "train.cpp" and "train_memops()" in h[2] for h in hits), hits
+    assert len(hits) == 2 and all(h[0] == "train.cpp" and h[2].startswith("if (train_memops()) return hip") for h in hits), hits
