@@ -21,8 +21,9 @@
 // runtime memory operation becomes a hipGraph MEMCPY / MEMSET node, and on ROCm 7.2 (graph nodes recorded as AQL packets, DEBUG_CLR_GRAPH_PACKET_CAPTURE
 // default on) replays of a graph that holds such nodes computed garbage once eager work of the same process (a save point's validation, a second capture)
 // had run between them: gradients of 1e5..1e36 in whole layers, Adam moments to match - the failure family rounds 4-6 chased.  With kernel
-// nodes only, 0 of 12 driver runs differ from the eager run; with the memory operations back (SNERF_TRAIN_MEMOPS=1, kept for the reproduction:
-// tools/graph_wait_probe4.py) 9 of 9 do; with the memory operations AND packet capture off, 0 of 6.
+// nodes only, 0 of 68 driver runs differ from the eager run; with the memory operations back (SNERF_TRAIN_MEMOPS=1, kept for the reproduction:
+// tools/graph_wait_probe4.py) 29 of 29 do; with the memory operations AND packet capture off, 0 of 6.  The defect is the runtime's and reproduces without any
+// code of this repository: tools/graph_memset_min.py (25 lines), profiles/r6/graph_memop_repro.txt.
 static bool train_memops() {
     static const bool on = [] { const char* e = getenv("SNERF_TRAIN_MEMOPS"); return e && e[0] == '1'; }();
     return on;
