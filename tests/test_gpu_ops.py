@@ -326,3 +326,47 @@ def test_optimiser_step_runs_on_the_ops():
         torch.ops.season_nerf.trainer_adam_step_(eng.handle, eng.params[:10], eng.grads[:10], 1e-3, 0.9, 0.999, 1e-8, 1)
     with pytest.raises(RuntimeError, match="live training engine"):
         torch.ops.season_nerf.trainer_zero_grad_(12345678, eng.grads)
+
+
+@pytest.mark.parametrize("W,precision", [(256, "i8x3"), (256, "bf16x3"), (512, "bf16x3")])
+def test_inference_ops_replay_from_a_captured_graph(W, precision):
+    """The render step (per-ray networks + field kernel + compositing), the exact-solar pass and a per-point forward captured once with torch.cuda.graph and
+    replayed on new inputs copied into the static buffers: bit-identical to the eager ops.  A serving loop can hold its step in a hipGraph - the inference
+    entry points launch kernels only (no hipMemcpyAsync / hipMemsetAsync: the node kinds that replay wrongly on ROCm 7.2), allocate through
+    torch's allocator and read nothing from the host."""
+    import season_nerf_amd as sn
+    o = ops()
+    m = owned_model(W, 4, 5, precision)
+    R, S = 257, 48
+    g = torch.Generator(device="cpu").manual_seed(W)
+    def batch():
+        top = torch.cat([torch.rand(R, 2, generator=g) * 2 - 1, torch.ones(R, 1)], 1).cuda()
+        bot = torch.cat([torch.rand(R, 2, generator=g) * 2 - 1, -torch.ones(R, 1)], 1).cuda()
+        sun = torch.nn.functional.normalize(torch.rand(R, 3, generator=g) + 0.1, dim=1).cuda()
+        return top, bot, sun, (torch.rand(R, 4, generator=g) * 2 - 1).cuda()
+    tv = sn.sample_parameters(S, eval_mode=True).cuda()
+    static = [t.clone() for t in batch()]
+    def step():
+        rgb, depth, alb, per = o.render_fwd(m, static[0], static[1], static[2], static[3], tv, 0, True)
+        vis = o.ray_visibility(m, static[0], static[1], tv, 0)
+        grp = o.group_fwd(m, static[3], static[2])                        # class probabilities, raw sky, sky per ray
+        pts = o.points_fwd(m, static[1], static[2], grp[0], 1, 0)
+        return [rgb, depth, alb, vis] + list(per) + list(grp) + list(pts)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        step()
+    torch.cuda.current_stream().wait_stream(s)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        outs = step()
+    for _ in range(3):
+        new = batch()
+        for d, n in zip(static, new):
+            d.copy_(n)
+        graph.replay()
+        torch.cuda.synchronize()
+        got = [t.clone() for t in outs]
+        want = step()
+        torch.cuda.synchronize()
+        assert len(got) == len(want) and all(torch.equal(a, b) for a, b in zip(got, want))
