@@ -22,7 +22,7 @@ own fp32 arithmetic is from exact on these weights; tests print it next to their
 
     python tools/make_sharp_golden.py scaled 64 256 512
     python tools/make_sharp_golden.py prior 64 400 200
-    python tools/make_sharp_golden.py converged 64 12000 6
+    python tools/make_sharp_golden.py converged 64 12000 6          (74 CPU-minutes -> trained12k_W64.npz;  `converged 64 40000 8`: 3.9 CPU-hours -> trained40k_W64.npz)
 """
 import os
 import sys
@@ -206,7 +206,7 @@ def gen_prior(W, n_prior, n_free, batch=512, S=96):
 
 
 def gen_converged(W, n_total, hours, target=0.3, batch=512, S=96):
-    """tests/golden/converged_W{W}.npz: the reference's own schedule (Net_Tool_2.py:23-33, main_lite.py:44-47: the first 20 % of the steps under
+    """tests/golden/trained{n_total / 1000}k_W{W}.npz: the reference's own schedule (Net_Tool_2.py:23-33, main_lite.py:44-47: the first 20 % of the steps under
     the DSM prior, learning mode 1, the rest free, mode 4; a fresh Adam + OneCycleLR per phase, Net_Tool_2.py:111-130) on the synthetic scene, checked every 250
     steps with the reference's own eval on held-out rays and STOPPED in the free phase once the mean max-PS per ray reaches `target` (or at `hours` of wall
     clock): surfaces that training produced, not a scaled density head.  Stored as prior_trained: state_dict, trajectory, the reference's eval, the oracle in float64."""
@@ -269,7 +269,7 @@ def gen_converged(W, n_total, hours, target=0.3, batch=512, S=96):
     r = ref_eval(net, data_h, S)
     eval_record(out, r)
     oracle64(out, sd, data_h, S)
-    path = os.path.join(mg.OUT, f"converged_W{W}{os.environ.get('SNERF_CONVERGED_TAG', '')}.npz")
+    path = os.path.join(mg.OUT, f"trained{n_total // 1000}k_W{W}.npz")          # trained12k_W64.npz, trained40k_W64.npz: the committed fixtures
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path) // 1024, "KiB; mean max-PS per ray", float(out["max_ps"].mean()), "steps", len(traj))
 
