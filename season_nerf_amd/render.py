@@ -12,6 +12,7 @@ per-sample runs on the GPU.
 """
 import ctypes as C
 import math
+import os
 
 import numpy as np
 import torch
@@ -191,6 +192,14 @@ class Quick_Run_Net:
 
 
 # ------------------------------------------------------------------------------------------------ path B
+def _skip_default(v):
+    """`skip_weightless="default"` of renderer B: SNERF_SKIP_WEIGHTLESS from the environment (a float), else None (a secondary ray for every sample)."""
+    if v != "default":
+        return v
+    e = os.environ.get("SNERF_SKIP_WEIGHTLESS")
+    return float(e) if e else None
+
+
 class ImgDict(dict):
     """The float64 numpy dict of the reference (`_internal_render`, mg_Img_Eval.py:17-72) plus, under `.dev`, the fp32 device tensors it comes from, so
     the image-assembly functions below run on the GPU without re-upload.
@@ -361,7 +370,7 @@ def _to_img_dict(d, the_network, S, include_exact_solar):
     return res
 
 
-def component_render_by_P(the_network, a_P_img, out_img_size: tuple, device, max_batch_size=150000, include_exact_solar=True, *, skip_weightless=None):
+def component_render_by_P(the_network, a_P_img, out_img_size: tuple, device, max_batch_size=150000, include_exact_solar=True, *, skip_weightless="default"):
     """mg_Img_Eval.py:74-94: render through a camera.  `a_P_img` is the reference's projective-image object (duck-typed:
     `.img.shape`, `.invert_P(rows, cols, h)`, `.sun_el_and_az_vec`, `.get_year_frac()`): pixel grid -> rays by its own float64
     `invert_P` (out_h x out_w solves on the host), rays leaving the cube dropped, then the same device render as by-direction.
@@ -402,7 +411,7 @@ def component_render_by_P(the_network, a_P_img, out_img_size: tuple, device, max
             idx = np.nonzero(inside)[0]
             tops_d, bots_d, src_pix = _f32(ends[0][idx], dev), _f32(ends[1][idx], dev), XY[idx]
         d = _internal_render_device(the_network, tops_d, bots_d, np.asarray(a_P_img.sun_el_and_az_vec, dtype=np.float64), a_P_img.get_year_frac(), S, device,
-                                    include_exact_solar, skip_weightless)
+                                    include_exact_solar, _skip_default(skip_weightless))
         res = _to_img_dict(d, the_network, S, include_exact_solar)
         res["Image_Points_in_GT_Img"] = src_pix
         res["Image_Points"] = np.stack([idx // Ww, idx % Ww], 1)
@@ -410,16 +419,17 @@ def component_render_by_P(the_network, a_P_img, out_img_size: tuple, device, max
 
 
 def component_render_by_dir(the_network, view_el_az, sun_el_az, time_frac, out_img_size: tuple, W2C, W2L_H, device,
-                            max_batch_size=150000, include_exact_solar=True, *, skip_weightless=None):
+                            max_batch_size=150000, include_exact_solar=True, *, skip_weightless="default"):
     """mg_Img_Eval.py:96-115.  Returns the reference's dict of float64 arrays (World_Points, Deltas, Rho, Base_Col,
     Est_Solar_Vis, Sky_Col, Output_class, Adjust_col[, Exact_Solar], Image_Points).
-    `skip_weightless` (keyword-only, not in the reference; default None = the reference's per-sample `Exact_Solar`): a float w - samples whose compositing weight
+    `skip_weightless` (keyword-only, not in the reference; default: the environment's SNERF_SKIP_WEIGHTLESS if set - a maintainer whose call sites only form images
+    sets it to 1e-9 once - else None = the reference's per-sample `Exact_Solar`): a float w - samples whose compositing weight
     is below w get no secondary sun ray and carry the network's estimate in `Exact_Solar`.  Every image `get_imgs_from_Img_Dict*` forms is a weighted sum over a
     ray's samples, so images move by < S * w while a converged scene needs a fifth of the secondary rays (`render_novel_view` and the sweep pipeline pass 1e-9)."""
     with torch.no_grad():
         Hh, Ww, S = out_img_size
         d = _render_by_dir_device(the_network, view_el_az, sun_el_az, time_frac, out_img_size, W2C, W2L_H, device,
-                                  include_exact_solar, skip_weightless=skip_weightless)
+                                  include_exact_solar, skip_weightless=_skip_default(skip_weightless))
         res = _to_img_dict(d, the_network, S, include_exact_solar)
         res["Image_Points"] = np.stack(np.meshgrid(np.arange(Hh), np.arange(Ww), indexing="ij"), -1).reshape([-1, 2])
     return res
