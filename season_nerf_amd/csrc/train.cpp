@@ -752,6 +752,34 @@ int snerf_trainer_backward_points(snerf_trainer* t, const float* d_g_rho, const 
     return network_backward_image(t, d_g_solar_vis != nullptr, d_g_classes, st);
 }
 
+// The colour head (3 outputs) and the density head (1) read the same input X1 and their output gradients sit side by side in d_head [N, 4]: ONE stream over X1
+// for both weight gradients and ONE read-modify-write of dX1 for both input gradients (K = 4, row 3 of the weights / of the result at the density head's
+// address) instead of two of each.  Returns false - nothing launched - where the streams do not apply (SNERF_FUSED_HEADS=0, small batches, exact-fp32 mode).
+static bool heads_bwd_fused(snerf_trainer* t, const Act& X1, int64_t N, const ActBelow* below, bool* fused_below, hipStream_t st) {
+    static const int on = [] { const char* e = getenv("SNERF_FUSED_HEADS"); return (e && e[0] == '0') ? 0 : 1; }();
+    const LayerP &Lc = t->layers[L_COL], &Ls_ = t->layers[L_SIG];
+    if (fused_below) *fused_below = false;
+    if (!on || t->gemm_mode != 1 || N < 1024 || Lc.n_out != 3 || Ls_.n_out != 1 || Lc.n_in != Ls_.n_in) return false;
+    ThinWgradArgs w{};
+    w.D = t->d_head; w.ldd = 4; w.In = X1.p; w.ldi = X1.ld; w.M = N; w.K = 4; w.N = Lc.n_in; w.alpha = 1.f;
+    w.dW = t->grads + Lc.w; w.ldw = Lc.n_in; w.dW3 = t->grads + Ls_.w; w.tab = X1.tab; w.tab_cols = X1.tab ? X1.cols : 0; w.tab_stride = w.tab_cols;
+    ThinDgradArgs a{};
+    a.D = t->d_head; a.ldd = 4; a.W = t->params + Lc.w; a.W3 = t->params + Ls_.w; a.ldw = Lc.n_in; a.C = t->dX1.p; a.ldc = t->W2; a.M = N; a.K = 4; a.N = Lc.n_in;
+    a.accumulate = 1; a.alpha = 1.f;
+    const bool act = below && below->tab && below->L->n_out == Lc.n_in;
+    if (act) {
+        a.ez = below->Z.p; a.eld = below->Z.ld; a.etab = below->tab; a.stats = t->bn_stats;
+        if (below->L->bn) { a.emu = below->bnslot + 2 * t->W; a.eistd = below->bnslot + 3 * t->W; }
+    }
+    if (!thin_wgrad_ok(w) || !thin_dgrad_ok(a)) return false;
+    if (launch_thin_wgrad(w, st) != hipSuccess) return false;
+    if (launch_colsum(t->d_head, N, 3, 4, 1.f, t->grads + Lc.b, st) != hipSuccess) return false;
+    if (launch_colsum(t->d_head + 3, N, 1, 4, 1.f, t->grads + Ls_.b, st) != hipSuccess) return false;
+    if (launch_thin_dgrad(a, st) != hipSuccess) return false;
+    if (act && fused_below) *fused_below = true;
+    return true;
+}
+
 static int network_backward_image(snerf_trainer* t, bool classic, const float* d_g_classes, hipStream_t st) {
     snerf_trainer::Pass& P = t->img;
     const int W = t->W, W2 = t->W2, W4 = t->W4, C = t->C, S = t->S;
@@ -782,8 +810,10 @@ static int network_backward_image(snerf_trainer* t, bool classic, const float* d
     // also applies fc9's activation backward in its epilogue
     const ActBelow b9{&Ls[L_FC9], P.Zc8, tab_of(8), P.bn + 7 * 4 * W};
     bool pre9 = false;
-    RC(plain_bwd(t, Ls[L_COL], t->d_head, 4, X1, N, t->dX1.p, W2, true, st));
-    RC(plain_bwd(t, Ls[L_SIG], t->d_head + 3, 4, X1, N, t->dX1.p, W2, true, st, classic ? nullptr : &b9, classic ? nullptr : &pre9));
+    if (!heads_bwd_fused(t, X1, N, classic ? nullptr : &b9, classic ? nullptr : &pre9, st)) {
+        RC(plain_bwd(t, Ls[L_COL], t->d_head, 4, X1, N, t->dX1.p, W2, true, st));
+        RC(plain_bwd(t, Ls[L_SIG], t->d_head + 3, 4, X1, N, t->dX1.p, W2, true, st, classic ? nullptr : &b9, classic ? nullptr : &pre9));
+    }
     if (classic) {      // the solar-visibility branch carries gradient from the image (G_NeRF.py:100-108), on into X1
         const ActBelow s3{&Ls[L_S3], P.Zs[2], tab_of(14), nullptr}, s2{&Ls[L_S2], P.Zs[1], tab_of(13), nullptr}, s1{&Ls[L_S1], P.Zs[0], tab_of(12), nullptr};
         RC(plain_bwd(t, Ls[L_S4], t->d_sv_raw, 1, P.Hsc[2], N, t->dA.p, W2, false, st, &s3, &pre));

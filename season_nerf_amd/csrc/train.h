@@ -109,6 +109,7 @@ hipError_t launch_colreduce(const ColArgs& a, hipStream_t st);
 struct ThinDgradArgs {     // input gradient of a head with K <= 4 outputs as a stream over C (train_kernels.hip: thin_dgrad_kernel)
     const float* D;        // [M, ldd]: dL/d(head output), K leading columns
     const float* W;        // [K, ldw]: the head's weights (row k = output k)
+    const float* W3;       // optional: row 3 lives here instead (two heads in one launch: colour rows 0..2, density row 3)
     float* C;              // [M, ldc], N columns
     int64_t M, ldd, ldw, ldc;
     int K, N, accumulate;
@@ -127,6 +128,7 @@ struct ThinWgradArgs {     // weight gradient of a head with K <= 4 outputs as a
     const float* In;       // [M, ldi], N columns: the head's input - or, for the first tab_cols columns, its stored pre-activation (activation on load)
     float* dW;             // [K, ldw] += alpha * D^T In  (two stages: per-block sums in `partial`, then one reduction kernel - deterministic)
     float* partial;        // [blocks, K * N] scratch (set by the launcher)
+    float* dW3;            // optional: row 3 of the result goes here instead (two heads in one launch)
     int64_t M, ldd, ldi, ldw;
     int K, N;
     float alpha;

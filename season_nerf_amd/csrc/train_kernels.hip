@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256) void thin_dgrad_kernel(const ThinDgradArgs A, 
 #pragma unroll
     for (int k = 0; k < KMAX; ++k)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) w[k][q] = (live && k < A.K) ? A.W[(int64_t)k * A.ldw + tc * 4 + q] : 0.f;
+        for (int q = 0; q < 4; ++q) w[k][q] = (live && k < A.K) ? ((k == 3 && A.W3) ? A.W3[tc * 4 + q] : A.W[(int64_t)k * A.ldw + tc * 4 + q]) : 0.f;
     float ea[4] = {0.f, 0.f, 0.f, 0.f}, eb[4] = {0.f, 0.f, 0.f, 0.f}, mu[4] = {0.f, 0.f, 0.f, 0.f}, is[4] = {0.f, 0.f, 0.f, 0.f};
     if (ACT && live) {
 #pragma unroll
@@ -434,7 +434,7 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(const ThinWgradArgs A, 
         }
     }
 }
-__global__ __launch_bounds__(256) void thin_wgrad_reduce_kernel(const float* __restrict__ partial, int blocks, int K, int N, float* dW, int64_t ldw, float alpha) {
+__global__ __launch_bounds__(256) void thin_wgrad_reduce_kernel(const float* __restrict__ partial, int blocks, int K, int N, float* dW, int64_t ldw, float alpha, float* dW3) {
     // 32 elements of dW per workgroup, 8 threads per element: thread (e, seg) adds the blocks seg, seg + 8, ... (8 loads in flight), LDS adds the 8 segments
     __shared__ float red[8][32];
     const int el = threadIdx.x & 31, seg = threadIdx.x >> 5;
@@ -455,7 +455,8 @@ __global__ __launch_bounds__(256) void thin_wgrad_reduce_kernel(const float* __r
         float t = 0.f;
 #pragma unroll
         for (int q = 0; q < 8; ++q) t += red[q][el];
-        dW[(int64_t)(e / N) * ldw + e % N] += alpha * t;
+        float* out = (dW3 && e / N == 3) ? dW3 + e % N : dW + (int64_t)(e / N) * ldw + e % N;
+        *out += alpha * t;
     }
 }
 bool thin_wgrad_ok(const ThinWgradArgs& a) {
@@ -476,7 +477,7 @@ hipError_t launch_thin_wgrad(const ThinWgradArgs& a, hipStream_t st) {
     if (!b.partial) return hipErrorOutOfMemory;
     if (a.tab && a.tab_cols > 0) hipLaunchKernelGGL((thin_wgrad_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, st, b, C4, cpt, rpb);
     else hipLaunchKernelGGL((thin_wgrad_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, st, b, C4, cpt, rpb);
-    hipLaunchKernelGGL(thin_wgrad_reduce_kernel, dim3((unsigned)((a.K * a.N + 31) / 32)), dim3(256), 0, st, b.partial, (int)blocks, a.K, a.N, a.dW, a.ldw, a.alpha);
+    hipLaunchKernelGGL(thin_wgrad_reduce_kernel, dim3((unsigned)((a.K * a.N + 31) / 32)), dim3(256), 0, st, b.partial, (int)blocks, a.K, a.N, a.dW, a.ldw, a.alpha, a.dW3);
     return hipGetLastError();
 }
 
