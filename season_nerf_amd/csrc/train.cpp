@@ -521,8 +521,19 @@ static int forward_pass(snerf_trainer* t, snerf_trainer::Pass& P, bool solar, in
         RC(sine_fwd(t, Ls[L_FC1 + l], In, N, zof(l), P.H[l], P.bn + (l - 1) * 4 * W, train_bn, st, tab_of(l)));
     }
     const Act X1 = P.Hc[8];
-    RC(plain_fwd(t, Ls[L_COL], X1, N, P.head.p, 4, st));
-    RC(plain_fwd(t, Ls[L_SIG], X1, N, P.head.p + 3, 4, st));
+    {   // colour (3) and density (1) heads: one stream over X1 for both where it applies (thin_fwd_kernel), else one row GEMM each
+        static const int fused = [] { const char* e = getenv("SNERF_FUSED_HEADS"); return (e && e[0] == '0') ? 0 : 1; }();
+        ThinFwdArgs f{};
+        f.In = X1.p; f.ldi = X1.ld; f.M = N; f.K = 4; f.N = Ls[L_COL].n_in; f.alpha = 1.f; f.Out = P.head.p; f.ldo = 4;
+        f.W = t->params + Ls[L_COL].w; f.ldw = Ls[L_COL].n_in; f.W3 = t->params + Ls[L_SIG].w; f.bias = t->params + Ls[L_COL].b; f.bias3 = t->params + Ls[L_SIG].b;
+        f.tab = X1.tab; f.tab_cols = X1.tab ? X1.cols : 0; f.tab_stride = f.tab_cols;
+        if (fused && t->gemm_mode == 1 && N >= 1024 && Ls[L_COL].n_out == 3 && Ls[L_SIG].n_out == 1 && Ls[L_SIG].n_in == f.N && thin_fwd_ok(f)) {
+            HIPCK(launch_thin_fwd(f, st));
+        } else {
+            RC(plain_fwd(t, Ls[L_COL], X1, N, P.head.p, 4, st));
+            RC(plain_fwd(t, Ls[L_SIG], X1, N, P.head.p + 3, 4, st));
+        }
+    }
     // solar visibility branch (G_NeRF.py:100-108)
     HIPCK(launch_pe_small(sun, 3, 3, 4, R, P.pe_sun, 28, st));
     if (!aol) HIPCK(launch_copy_cols(X1.p, X1.ld, P.In_s1.p, P.In_s1.ld, N, W2, false, st));
@@ -923,6 +934,13 @@ int snerf_linear_forward(int64_t n_points, int n_in, int n_out, const float* d_i
     if (n_points == 0) return SNERF_OK;
     if (!d_in || !d_weight || !d_out || ld_in < n_in || ld_out < n_out) return snerf_set_error(SNERF_E_INVALID, "snerf_linear_forward: bad argument");
     hipStream_t st = (hipStream_t)stream;
+    if (precision == 1 && n_out <= 4 && n_points >= 1024 && d_bias && !d_stats) {      // a thin head: the stream the training engine uses for the colour + density heads
+        ThinFwdArgs f{};
+        f.In = d_in; f.ldi = ld_in; f.M = n_points; f.K = n_out; f.N = n_in; f.alpha = alpha; f.Out = d_out; f.ldo = ld_out;
+        f.W = d_weight; f.ldw = n_in; f.bias = d_bias; f.tab = d_act_tab; f.tab_cols = d_act_tab ? act_cols : 0; f.tab_stride = f.tab_cols;
+        static const int fused = [] { const char* e = getenv("SNERF_FUSED_HEADS"); return (e && e[0] == '0') ? 0 : 1; }();
+        if (fused && thin_fwd_ok(f)) { HIPCK(launch_thin_fwd(f, st)); return SNERF_OK; }
+    }
     if (linear_mode(precision, n_points, n_in, n_out)) {
         if (!d_scratch || scratch_bytes < snerf_linear_scratch_bytes(n_out, n_in)) return snerf_set_error(SNERF_E_INVALID, "snerf_linear_forward: scratch too small");
         GemmX x{};

@@ -123,6 +123,21 @@ struct ThinDgradArgs {     // input gradient of a head with K <= 4 outputs as a 
 };
 bool thin_dgrad_ok(const ThinDgradArgs& a);
 hipError_t launch_thin_dgrad(const ThinDgradArgs& a, hipStream_t st);
+struct ThinFwdArgs {       // forward of heads with K <= 4 outputs in all as one stream over their common input (train_kernels.hip: thin_fwd_kernel)
+    const float* In;       // [M, ldi], N columns (the first tab_cols of them stored as pre-activations: activation on load)
+    const float* W;        // [K, ldw] rows 0..K-1 - row 3 at W3 if set (colour head rows 0..2, density head row 3)
+    const float* W3;
+    const float* bias;     // [K] - element 3 at bias3 if set
+    const float* bias3;
+    float* Out;            // [M, ldo]: Out[m, k] = alpha * (sum_n In[m, n] W[k, n] + bias[k])
+    int64_t M, ldi, ldw, ldo;
+    int K, N;
+    float alpha;
+    const float* tab;
+    int tab_cols, tab_stride;
+};
+bool thin_fwd_ok(const ThinFwdArgs& a);
+hipError_t launch_thin_fwd(const ThinFwdArgs& a, hipStream_t st);
 struct ThinWgradArgs {     // weight gradient of a head with K <= 4 outputs as a stream over its input (train_kernels.hip: thin_wgrad_kernel)
     const float* D;        // [M, ldd]: dL/d(head output), K leading columns
     const float* In;       // [M, ldi], N columns: the head's input - or, for the first tab_cols columns, its stored pre-activation (activation on load)

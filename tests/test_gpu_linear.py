@@ -139,6 +139,32 @@ def test_thin_head_wgrad(shape):
     assert float((dW.double() - (base.double() + prod)).abs().max()) / float(prod.abs().max()) < 2e-5
 
 
+@pytest.mark.parametrize("shape", [(5000, 128, 3, 128, 4, 0), (5000, 128, 1, 132, 1, 0), (1024, 32, 4, 32, 4, 0), (393216, 128, 4, 128, 4, 128), (2050, 256, 2, 256, 5, 96), (1025, 12, 3, 12, 3, 0)])
+def test_thin_head_forward(shape):
+    """Heads with at most four outputs run as a stream over their input (thin_fwd_kernel): exact fp32 FMAs, the lanes of a row reduced by shuffles, with and
+    without the activation on load; against float64."""
+    sn, L, st = _env()
+    M, n_in, n_out, ld_in, ld_out, ac = shape
+    g = torch.Generator(device="cpu").manual_seed(M + n_in + n_out)
+    X = (torch.randn(M, ld_in, generator=g) * (4 if ac else 1)).cuda()
+    Wt = (torch.randn(n_out, n_in, generator=g) / np.sqrt(n_in)).cuda()
+    b = torch.randn(n_out, generator=g).cuda()
+    Hd = X[:, :n_in].double().clone()
+    tab = None
+    if ac:
+        a_, b_ = (torch.rand(ac, generator=g) * 0.2 + 0.05).double(), torch.randn(ac, generator=g).double()
+        tab = torch.stack([a_, b_]).float().cuda().contiguous()
+        Hd[:, :ac] = torch.sin(2 * np.pi * (tab[0].double() * Hd[:, :ac] + tab[1].double()))
+    out = torch.full((M, ld_out), 7.0, device="cuda")
+    sc = _scratch(L, n_out, n_in)
+    sn._lib.check(L.snerf_linear_forward(M, n_in, n_out, X.data_ptr(), ld_in, Wt.data_ptr(), b.data_ptr(), 1.5, out.data_ptr(), ld_out, None, 1,
+                                         sc.data_ptr(), sc.numel(), tab.data_ptr() if ac else None, ac, st), "linear_forward")
+    ref = 1.5 * (Hd @ Wt.double().T + b.double())
+    err = float((out[:, :n_out].double() - ref).abs().max()) / float(ref.abs().max())
+    assert err < (2e-5 if ac else 2e-6), err                    # (activation on load: the hardware sine's ~1e-6 argument error times the weights)
+    assert bool((out[:, n_out:] == 7.0).all())                  # columns past n_out untouched
+
+
 def test_linear_argument_errors():
     sn, L, st = _env()
     a = torch.zeros(8, 8, device="cuda")

@@ -510,14 +510,21 @@ def test_sibling_forwards_train_mode_gradients_vs_oracle():
         assert abs(float(loss) - ref_loss) <= 2e-6 * l1, (case, float(loss), ref_loss, l1)
         params = dict(net.named_parameters())
         gmax = max(float(v.abs().max()) for v in ref.values())
-        worst = 0.0
+        worst, worst_k = 0.0, None
         for k, gr in ref.items():
             if float(gr.abs().max()) == 0.0:
                 assert params[k].grad is None or float(params[k].grad.abs().max()) <= 1e-6 * gmax, (case, k)
                 continue
             got = params[k].grad.cpu()
-            worst = max(worst, float((got - gr).abs().max()) / max(float(gr.abs().max()), 1e-3 * gmax))
-        print(f"  {case}: loss {float(loss):.6f} (oracle {ref_loss:.6f}), worst relative gradient error {worst:.2e}")
+            if k.endswith(".linear.bias") and k.replace(".linear.bias", ".norm.weight") in ref:
+                # a bias in front of BatchNorm has an exactly-zero gradient (the batch mean is subtracted): the oracle holds rounding noise there and so do
+                # we - both must be negligible, not equal (as in test_full_size_training_step_vs_reference)
+                assert float(gr.abs().max()) < 1e-5 * gmax and float(got.abs().max()) < 1e-5 * gmax, (case, k, float(gr.abs().max()), float(got.abs().max()))
+                continue
+            e_ = float((got - gr).abs().max()) / max(float(gr.abs().max()), 1e-3 * gmax)
+            if e_ > worst:
+                worst, worst_k = e_, k
+        print(f"  {case}: loss {float(loss):.6f} (oracle {ref_loss:.6f}), worst relative gradient error {worst:.2e} ({worst_k})")
         assert worst < 5e-4, (case, worst)
 
 
