@@ -466,6 +466,13 @@ static int sine_bwd(snerf_trainer* t, const LayerP& L, Act D, Act Z, Act In, int
 
 // plain Linear (heads): Out[M, n_out] = In W^T + b
 static int plain_fwd(snerf_trainer* t, const LayerP& L, Act In, int64_t M, float* Out, int64_t ldo, hipStream_t st) {
+    static const int thin = [] { const char* e = getenv("SNERF_FUSED_HEADS"); return (e && e[0] == '0') ? 0 : 1; }();
+    if (thin && t->gemm_mode == 1 && M >= 1024 && L.n_out <= 4) {      // a head with at most four outputs: a stream over its input (thin_fwd_kernel), not a 32-column MFMA tile
+        ThinFwdArgs f{};
+        f.In = In.p; f.ldi = In.ld; f.M = M; f.K = L.n_out; f.N = L.n_in; f.alpha = 1.f; f.Out = Out; f.ldo = ldo;
+        f.W = t->params + L.w; f.ldw = L.n_in; f.bias = t->params + L.b; f.tab = In.tab; f.tab_cols = In.tab ? In.cols : 0; f.tab_stride = f.tab_cols;
+        if (thin_fwd_ok(f)) { HIPCK(launch_thin_fwd(f, st)); return SNERF_OK; }
+    }
     HIPCK(linear_fwd(t, L, In, M, Out, ldo, 1.f, nullptr, st));
     return SNERF_OK;
 }

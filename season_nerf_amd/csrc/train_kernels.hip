@@ -398,13 +398,26 @@ __global__ __launch_bounds__(256) void thin_fwd_kernel(const ThinFwdArgs A, int 
 #pragma unroll
                 for (int q = 0; q < 4; ++q) p[k] = __builtin_fmaf(w[k][q], x[u][q], p[k]);
             }
-            for (int o = cpt >> 1; o > 0; o >>= 1) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) p[k] += __shfl_xor(p[k], o, 64);
-            }
             const int64_t r = rb + (int64_t)u * rows_pass;
-            if (tc == 0 && r < A.M) {
-                for (int k = 0; k < A.K; ++k) A.Out[r * A.ldo + k] = A.alpha * (p[k] + bias[k]);
+            if (cpt >= 4) {
+                // butterfly with a transpose: the first step leaves each lane two of the four sums, the second one - 6 shuffles for the row instead of 20
+                const int h1 = cpt >> 1, h2 = cpt >> 2;
+                const bool up1 = (tc & h1) != 0, up2 = (tc & h2) != 0;
+                const float s01 = up1 ? p[0] : p[2], s23 = up1 ? p[1] : p[3];            // what this lane hands over: the pair it does not keep
+                float a = (up1 ? p[2] : p[0]) + __shfl_xor(s01, h1, 64);                  // lanes with bit h1 clear keep sums 0 and 1, the others 2 and 3
+                float b = (up1 ? p[3] : p[1]) + __shfl_xor(s23, h1, 64);
+                float v = (up2 ? b : a) + __shfl_xor(up2 ? a : b, h2, 64);                 // ... and of its pair: bit h2 clear keeps the first, set the second
+                for (int o = h2 >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+                const int k = (up1 ? 2 : 0) + (up2 ? 1 : 0);                               // which sum ended up here
+                if ((tc & (h2 - 1)) == 0 && r < A.M && k < A.K) A.Out[r * A.ldo + k] = A.alpha * (v + (k == 0 ? bias[0] : k == 1 ? bias[1] : k == 2 ? bias[2] : bias[3]));
+            } else {
+                for (int o = cpt >> 1; o > 0; o >>= 1) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) p[k] += __shfl_xor(p[k], o, 64);
+                }
+                if (tc == 0 && r < A.M) {
+                    for (int k = 0; k < A.K; ++k) A.Out[r * A.ldo + k] = A.alpha * (p[k] + bias[k]);
+                }
             }
         }
     }
